@@ -1,0 +1,75 @@
+"""Synthetic talker weights (random-init, no checkpoints in this environment).
+
+Layout mirrors what the reference's ``load_weights`` produces after its HF->vLLM
+prefix mapping (qwen3_tts_talker.py:297-311,1569-1590): per layer a fused
+``qkv_proj`` ([q rows | k rows | v rows], in-features contiguous) and a fused
+``gate_up_proj`` ([gate rows | up rows]); ``torch.nn.Linear`` orientation [out, in].
+
+Keys (all bf16, CPU):
+  embed [V,H]  l{i}.ln1 [H]  l{i}.wqkv [(Hq+2Hkv)D,H]  l{i}.qnorm [D]  l{i}.knorm [D]
+  l{i}.wo [H,Hq*D]  l{i}.ln2 [H]  l{i}.wgu [2I,H]  l{i}.wdown [H,I]  norm [H]  lm_head [V,H]
+  cp.proj_w [Hc,H] cp.proj_b [Hc] (only when Hc != H)   cp.l{i}.* (same names, Hc dims)
+  cp.norm [Hc]  cp.lm_head [Q-1,Vc,Hc]  cp.embed [Q-1,Vc,H]
+"""
+from __future__ import annotations
+
+import torch
+
+from .config import TalkerDims
+
+
+def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise: float = 0.0) -> dict[str, torch.Tensor]:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def rnd(*shape):
+        return (torch.randn(*shape, generator=g, dtype=torch.float32) * std).to(torch.bfloat16)
+
+    def nrm(n):
+        w = torch.ones(n, dtype=torch.float32)
+        if norm_noise:
+            w = w + torch.randn(n, generator=g) * norm_noise
+        return w.to(torch.bfloat16)
+
+    w: dict[str, torch.Tensor] = {}
+    w["embed"] = rnd(d.vocab, d.hidden)
+    for i in range(d.layers):
+        p = f"l{i}."
+        w[p + "ln1"] = nrm(d.hidden)
+        w[p + "wqkv"] = rnd(d.qkv_out, d.hidden)
+        w[p + "qnorm"] = nrm(d.head_dim)
+        w[p + "knorm"] = nrm(d.head_dim)
+        w[p + "wo"] = rnd(d.hidden, d.q_heads * d.head_dim)
+        w[p + "ln2"] = nrm(d.hidden)
+        w[p + "wgu"] = rnd(2 * d.inter, d.hidden)
+        w[p + "wdown"] = rnd(d.hidden, d.inter)
+    w["norm"] = nrm(d.hidden)
+    w["lm_head"] = rnd(d.vocab, d.hidden)
+    if d.has_cp_projection:
+        w["cp.proj_w"] = rnd(d.cp_hidden, d.hidden)
+        w["cp.proj_b"] = rnd(d.cp_hidden)
+    for i in range(d.cp_layers):
+        p = f"cp.l{i}."
+        w[p + "ln1"] = nrm(d.cp_hidden)
+        w[p + "wqkv"] = rnd(d.cp_qkv_out, d.cp_hidden)
+        w[p + "qnorm"] = nrm(d.cp_head_dim)
+        w[p + "knorm"] = nrm(d.cp_head_dim)
+        w[p + "wo"] = rnd(d.cp_hidden, d.cp_q_heads * d.cp_head_dim)
+        w[p + "ln2"] = nrm(d.cp_hidden)
+        w[p + "wgu"] = rnd(2 * d.cp_inter, d.cp_hidden)
+        w[p + "wdown"] = rnd(d.cp_hidden, d.cp_inter)
+    w["cp.norm"] = nrm(d.cp_hidden)
+    w["cp.lm_head"] = rnd(d.num_code_groups - 1, d.codebook, d.cp_hidden)
+    w["cp.embed"] = rnd(d.num_code_groups - 1, d.codebook, d.hidden)
+    return w
+
+
+def weight_bytes(d: TalkerDims) -> dict[str, int]:
+    """Algorithmic weight bytes read once per talker step."""
+    bb = d.layers * (d.hidden * d.qkv_out + d.q_heads * d.head_dim * d.hidden + 3 * d.hidden * d.inter) * 2
+    head = d.vocab * d.hidden * 2
+    cp = d.cp_layers * (d.cp_hidden * d.cp_qkv_out + d.cp_q_heads * d.cp_head_dim * d.cp_hidden
+                        + 3 * d.cp_hidden * d.cp_inter) * 2
+    cp += (d.num_code_groups - 1) * d.codebook * d.cp_hidden * 2
+    if d.has_cp_projection:
+        cp += d.hidden * d.cp_hidden * 2
+    return {"backbone": bb, "lm_head": head, "code_predictor": cp}

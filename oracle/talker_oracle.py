@@ -1,0 +1,510 @@
+"""CPU restatement of the talker AR decode path (TEST INFRASTRUCTURE, not product).
+
+What it restates (R/ = /root/reference, V/ = R/vllm_omni):
+
+* one engine step of the Qwen3-TTS talker as driven by
+  ``GPUARModelRunner.execute_model`` / ``sample_tokens``
+  (V/worker/gpu_ar_model_runner.py:93-400, 403-660) and
+  ``OmniGPUModelRunner._preprocess`` / ``_talker_mtp_forward``
+  (V/worker/gpu_model_runner.py:1084-1303);
+* the talker model glue: ``compute_logits`` (V/model_executor/models/qwen3_tts/
+  qwen3_tts_talker.py:424-443), decode-branch ``preprocess`` (615-647),
+  ``postprocess`` (649-655), ``talker_mtp`` (1594-1642);
+* the code predictor, re-prefill form, exactly as
+  V/model_executor/models/qwen3_tts/qwen3_tts_code_predictor_vllm.py:36-226,480-561;
+* the backbone decoder (vLLM ``Qwen3Model`` -- third-party ``vllm==0.18.0``, source
+  absent from R/): restated with HuggingFace ``transformers`` Qwen3 numerics
+  (fp32 RMSNorm cast back then times weight; q/k-norm over head_dim; neox RoPE with
+  fp32 cos/sin cast to bf16; GQA attention fp32 softmax; SwiGLU) over a paged KV
+  cache ``[2, num_blocks, block_size, n_kv_heads, head_dim]`` with
+  ``slot = block_table[r][p // bs] * bs + p % bs``.
+
+Pinning status: the code predictor is pinned against the reference's own file
+(tests/golden/code_predictor_*.npz, minted by tests/golden/make_fixtures.py); the
+backbone is pinned against HF ``Qwen3Model`` (tests/golden/qwen3_backbone_*.npz).
+vLLM-internal semantics (fp8 scale convention, sampler RNG) are stated here
+explicitly and are themselves the oracle: **parity with vLLM 0.18.0 is unpinned**
+(no source, no golden vectors in the reference -- SURVEY F2/F5).
+
+Numeric conventions (the GPU path follows the same rounding points):
+  * activations are bf16 between ops; every GEMM accumulates in fp32 and rounds
+    its output to bf16 once (products of bf16 are exact in fp32, so only the
+    summation order differs between implementations);
+  * RMSNorm: fp32, ``w * bf16(x * rsqrt(mean(x^2) + eps))`` (the product rounds
+    to bf16 again);
+  * residual adds in bf16;
+  * attention: q, k, v bf16 (k, v pass through the cache dtype), scores / softmax /
+    PV in fp32, output rounded to bf16;
+  * fp8 KV: OCP e4m3fn, ``q = sat(x / scale)`` (clamp to +-448, round-nearest-even),
+    read ``float(q) * scale``; per-layer scalar k_scale / v_scale, default 1.0;
+  * int8 KV (no reference semantics): per (token, kv-head) symmetric,
+    ``scale = max(absmax, 1e-8) / 127`` held in fp32, ``q = rne(x / scale)``;
+  * logits: fp32 accumulate, rounded to bf16 (vLLM ``LogitsProcessor`` returns the
+    model dtype), then widened to fp32 for masking / sampling.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+FP8_MAX = 448.0
+
+
+# --------------------------------------------------------------------------
+# primitive ops
+# --------------------------------------------------------------------------
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(BF16)
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """HF Qwen3RMSNorm / reference _RMSNorm
+    (qwen3_tts_code_predictor_vllm.py:47-52)."""
+    dt = x.dtype
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return w * xf.to(dt)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+    """bf16 GEMM: fp32 accumulate, (+ bias in fp32), one rounding to bf16."""
+    y = x.to(torch.float32) @ _f32(w).t()
+    if b is not None:
+        y = y + b.to(torch.float32)
+    return y.to(BF16)
+
+
+_F32_CACHE: dict[int, tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _f32(w: torch.Tensor) -> torch.Tensor:
+    """fp32 view of a bf16 weight (exact), cached so the sgemm path is used."""
+    if w.dtype == torch.float32:
+        return w
+    key = id(w)
+    hit = _F32_CACHE.get(key)
+    if hit is not None and hit[0] is w:
+        return hit[1]
+    wf = w.to(torch.float32)
+    _F32_CACHE[key] = (w, wf)
+    return wf
+
+
+def clear_weight_cache() -> None:
+    _F32_CACHE.clear()
+
+
+def rope_cos_sin(positions: torch.Tensor, head_dim: int, theta: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """fp32 cos/sin cast to bf16, shape [T, head_dim]
+    (reference _RotaryEmbedding.forward, code_predictor_vllm.py:80-93)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = positions.to(torch.float32)[:, None] * inv_freq[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(BF16), emb.sin().to(BF16)
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x: [T, heads, D] bf16; cos/sin [T, D] bf16; bf16 arithmetic
+    (code_predictor_vllm.py:162-163)."""
+    return (x * cos[:, None, :]) + (rotate_half(x) * sin[:, None, :])
+
+
+def silu_mul(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    return F.silu(g) * u
+
+
+# --------------------------------------------------------------------------
+# KV-cache quantisation
+# --------------------------------------------------------------------------
+def fp8_quant(x: torch.Tensor, scale: float) -> torch.Tensor:
+    y = (x.to(torch.float32) / scale).clamp(-FP8_MAX, FP8_MAX)
+    return y.to(torch.float8_e4m3fn)
+
+
+def fp8_dequant(q: torch.Tensor, scale: float) -> torch.Tensor:
+    return q.to(torch.float32) * scale
+
+
+def int8_quant(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """x [..., D] -> (int8 [..., D], fp32 scale [...])."""
+    xf = x.to(torch.float32)
+    amax = xf.abs().amax(-1).clamp_min(1e-8)
+    scale = amax / 127.0
+    q = torch.round(xf / scale[..., None]).clamp(-127, 127).to(torch.int8)
+    return q, scale
+
+
+def int8_dequant(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q.to(torch.float32) * scale[..., None]
+
+
+# --------------------------------------------------------------------------
+# paged KV cache
+# --------------------------------------------------------------------------
+def slot_of(block_table_row, pos: int, block_size: int) -> int:
+    """slot = block_table[r][p // bs] * bs + p % bs."""
+    return int(block_table_row[pos // block_size]) * block_size + pos % block_size
+
+
+class PagedKV:
+    """One layer's cache, layout [2, num_blocks, block_size, n_kv, D]
+    (the stacked layout accepted by V/distributed/omni_connectors/utils/kv_utils.py:52-55)."""
+
+    def __init__(self, num_blocks: int, block_size: int, n_kv: int, head_dim: int, kv_dtype: str,
+                 k_scale: float = 1.0, v_scale: float = 1.0):
+        self.kv_dtype = kv_dtype
+        self.block_size = block_size
+        self.k_scale, self.v_scale = float(k_scale), float(v_scale)
+        shape = (2, num_blocks, block_size, n_kv, head_dim)
+        if kv_dtype == "bf16":
+            self.data = torch.zeros(shape, dtype=BF16)
+        elif kv_dtype == "fp8":
+            self.data = torch.zeros(shape, dtype=torch.float8_e4m3fn)
+        elif kv_dtype == "int8":
+            self.data = torch.zeros(shape, dtype=torch.int8)
+            self.scales = torch.zeros((2, num_blocks, block_size, n_kv), dtype=torch.float32)
+        else:
+            raise ValueError(kv_dtype)
+
+    def write(self, slots: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> None:
+        """k, v: [T, n_kv, D] bf16; slots [T] int64 (-1 = padded, skipped)."""
+        nb, bs = self.data.shape[1], self.data.shape[2]
+        flat = self.data.view(2, nb * bs, *self.data.shape[3:])
+        keep = slots >= 0
+        s = slots[keep]
+        k, v = k[keep], v[keep]
+        if self.kv_dtype == "bf16":
+            flat[0, s] = k.to(BF16)
+            flat[1, s] = v.to(BF16)
+        elif self.kv_dtype == "fp8":
+            flat[0, s] = fp8_quant(k, self.k_scale)
+            flat[1, s] = fp8_quant(v, self.v_scale)
+        else:
+            sc = self.scales.view(2, nb * bs, -1)
+            qk, sk = int8_quant(k)
+            qv, sv = int8_quant(v)
+            flat[0, s], sc[0, s] = qk, sk
+            flat[1, s], sc[1, s] = qv, sv
+
+    def gather(self, block_row, seq_len: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """Dequantised fp32 K, V [seq_len, n_kv, D] for one request."""
+        bs = self.block_size
+        nblk = (seq_len + bs - 1) // bs
+        ids = torch.as_tensor(np.asarray(block_row[:nblk]), dtype=torch.long)
+        k = self.data[0, ids].flatten(0, 1)[:seq_len]
+        v = self.data[1, ids].flatten(0, 1)[:seq_len]
+        if self.kv_dtype == "bf16":
+            return k.to(torch.float32), v.to(torch.float32)
+        if self.kv_dtype == "fp8":
+            return fp8_dequant(k, self.k_scale), fp8_dequant(v, self.v_scale)
+        sk = self.scales[0, ids].flatten(0, 1)[:seq_len]
+        sv = self.scales[1, ids].flatten(0, 1)[:seq_len]
+        return int8_dequant(k, sk), int8_dequant(v, sv)
+
+
+def attention_rows(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos: torch.Tensor, scale: float) -> torch.Tensor:
+    """q [Tq, Hq, D] bf16 at absolute positions q_pos [Tq]; k, v fp32 [S, Hkv, D]
+    (cache positions 0..S-1).  Causal: row i sees keys 0..q_pos[i].  fp32, out bf16."""
+    hq, hkv = q.shape[1], k.shape[1]
+    g = hq // hkv
+    qf = q.to(torch.float32)
+    kk = k.repeat_interleave(g, dim=1)  # [S, Hq, D]
+    vv = v.repeat_interleave(g, dim=1)
+    s = torch.einsum("thd,shd->hts", qf, kk) * scale
+    key_pos = torch.arange(k.shape[0])
+    mask = key_pos[None, :] > q_pos[:, None]
+    s = s.masked_fill(mask[None], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("hts,shd->thd", p, vv)
+    return o.to(BF16)
+
+
+# --------------------------------------------------------------------------
+# sampler (vLLM-like order, RNG stated here: parity with vLLM unpinned)
+# --------------------------------------------------------------------------
+def hash_uniform(seed: int, step: int, idx: np.ndarray) -> np.ndarray:
+    """Counter-based uniform in (0,1): 24-bit mantissa from a murmur3-style mix of
+    (seed, step, idx).  Mirrored bit-for-bit by the HIP sampler."""
+    M = np.uint32
+    x = (idx.astype(np.uint32) * M(0x9E3779B1)) ^ M(seed & 0xFFFFFFFF)
+    x = x + M((step * 0x85EBCA77) & 0xFFFFFFFF)
+    x ^= x >> M(16)
+    x = x * M(0x85EBCA6B)
+    x ^= x >> M(13)
+    x = x * M(0xC2B2AE35)
+    x ^= x >> M(16)
+    return ((x >> M(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, top_k: int = 0,
+               rep_penalty: float = 1.0, seen_ids=None, seed: int = 0, step: int = 0) -> int:
+    """One row. Order: repetition penalty -> temperature -> top-k -> softmax ->
+    argmax(probs / Exp(1)) (SURVEY Appendix A 'Sampler order').  Greedy = first argmax."""
+    x = logits.to(torch.float32).clone()
+    if rep_penalty != 1.0 and seen_ids is not None and len(seen_ids):
+        ids = torch.as_tensor(sorted(set(int(i) for i in seen_ids if 0 <= int(i) < x.numel())), dtype=torch.long)
+        sel = x[ids]
+        x[ids] = torch.where(sel > 0, sel / rep_penalty, sel * rep_penalty)
+    if greedy:
+        return int(torch.argmax(x).item())
+    x = x / temperature
+    if top_k and top_k < x.numel():
+        kth = torch.topk(x, top_k).values[-1]
+        x = x.masked_fill(x < kth, float("-inf"))
+    p = torch.softmax(x, dim=-1).numpy()
+    u = hash_uniform(seed, step, np.arange(p.shape[0]))
+    e = -np.log(u)
+    score = np.where(p > 0, p / e, -1.0).astype(np.float32)
+    return int(np.argmax(score))
+
+
+# --------------------------------------------------------------------------
+# model
+# --------------------------------------------------------------------------
+@dataclass
+class OracleState:
+    """Per-request decode state (the reference keeps it in model_intermediate_buffer,
+    gpu_model_runner.py:1330-1354)."""
+    seq_len: int = 0
+    last_id: int = 0
+    last_hidden: torch.Tensor | None = None        # h[t] bf16 [H]
+    tail_text: list = field(default_factory=list)  # queue of text-step vectors bf16 [H]
+    tts_pad: torch.Tensor | None = None            # bf16 [H]
+    out_ids: list = field(default_factory=list)
+    prompt_len: int = 0
+
+
+class TalkerOracle:
+    def __init__(self, dims, weights: dict, kv_dtype: str = "bf16", num_blocks: int = 64,
+                 block_size: int = 16, k_scale: float = 1.0, v_scale: float = 1.0):
+        self.d, self.w = dims, weights
+        self.block_size = block_size
+        self.kv = [PagedKV(num_blocks, block_size, dims.kv_heads, dims.head_dim, kv_dtype, k_scale, v_scale)
+                   for _ in range(dims.layers)]
+        self.allowed = self.codec_allowed_mask(dims)
+
+    # ---- constant logit mask (qwen3_tts_talker.py:386-394)
+    @staticmethod
+    def codec_allowed_mask(d) -> torch.Tensor:
+        m = torch.zeros(d.vocab, dtype=torch.bool)
+        lo, hi = 1, min(d.codebook, d.vocab)
+        if hi > lo:
+            m[lo:hi] = True
+        if 0 <= d.eos_id < d.vocab:
+            m[d.eos_id] = True
+        return m
+
+    # ---- backbone: tokens of several requests in one flat batch
+    def backbone(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: list[int],
+                 block_tables: list, seq_lens_after: list[int]) -> torch.Tensor:
+        """x [T, H] bf16 input embeddings; positions [T]; req_of_tok[t] = request row;
+        block_tables[r] = block ids; seq_lens_after[r] = context length incl. this step.
+        Writes K/V of every token at its slot, then attends through the cache.
+        Returns final-normed hidden [T, H] bf16."""
+        d, w = self.d, self.w
+        T = x.shape[0]
+        slots = torch.tensor([slot_of(block_tables[req_of_tok[t]], int(positions[t]), self.block_size)
+                              for t in range(T)], dtype=torch.long)
+        self.last_slots = slots
+        cos, sin = rope_cos_sin(positions, d.head_dim, d.rope_theta)
+        hq, hkv, D = d.q_heads, d.kv_heads, d.head_dim
+        h = x
+        for li in range(d.layers):
+            p = f"l{li}."
+            resid = h
+            a = rms_norm(h, w[p + "ln1"], d.eps)
+            qkv = linear(a, w[p + "wqkv"])
+            q = qkv[:, : hq * D].reshape(T, hq, D)
+            k = qkv[:, hq * D: (hq + hkv) * D].reshape(T, hkv, D)
+            v = qkv[:, (hq + hkv) * D:].reshape(T, hkv, D)
+            q = apply_rope(rms_norm(q, w[p + "qnorm"], d.eps), cos, sin)
+            k = apply_rope(rms_norm(k, w[p + "knorm"], d.eps), cos, sin)
+            self.kv[li].write(slots, k, v)
+            o = torch.empty(T, hq, D, dtype=BF16)
+            for r in sorted(set(req_of_tok)):
+                idx = [t for t in range(T) if req_of_tok[t] == r]
+                kk, vv = self.kv[li].gather(block_tables[r], seq_lens_after[r])
+                o[idx] = attention_rows(q[idx], kk, vv, positions[idx], D ** -0.5)
+            h = resid + linear(o.reshape(T, hq * D), w[p + "wo"])
+            resid = h
+            a = rms_norm(h, w[p + "ln2"], d.eps)
+            gu = linear(a, w[p + "wgu"])
+            act = silu_mul(gu[:, : d.inter], gu[:, d.inter:])
+            h = resid + linear(act, w[p + "wdown"])
+        return rms_norm(h, w["norm"], d.eps)
+
+    def compute_logits(self, hidden: torch.Tensor, round_bf16: bool = True) -> torch.Tensor:
+        """lm_head + allowed-codec mask (qwen3_tts_talker.py:424-443). fp32 out."""
+        y = hidden.to(torch.float32) @ _f32(self.w["lm_head"]).t()
+        if round_bf16:
+            y = y.to(BF16).to(torch.float32)
+        return y.masked_fill(~self.allowed, float("-inf"))
+
+    # ---- code predictor, re-prefill form (code_predictor_vllm.py:480-561)
+    def cp_model(self, buf: torch.Tensor) -> torch.Tensor:
+        """buf [B, S, Hc] bf16 -> final-normed hidden [B, S, Hc]; full causal re-prefill,
+        position ids 0..S-1 (code_predictor_vllm.py:263-273)."""
+        d, w = self.d, self.w
+        B, S, _ = buf.shape
+        hq, hkv, D = d.cp_q_heads, d.cp_kv_heads, d.cp_head_dim
+        pos = torch.arange(S)
+        cos, sin = rope_cos_sin(pos, D, d.cp_rope_theta)
+        h = buf
+        for li in range(d.cp_layers):
+            p = f"cp.l{li}."
+            resid = h
+            a = rms_norm(h, w[p + "ln1"], d.eps)
+            qkv = linear(a.reshape(B * S, -1), w[p + "wqkv"]).reshape(B, S, -1)
+            q = qkv[..., : hq * D].reshape(B, S, hq, D)
+            k = qkv[..., hq * D: (hq + hkv) * D].reshape(B, S, hkv, D)
+            v = qkv[..., (hq + hkv) * D:].reshape(B, S, hkv, D)
+            q = rms_norm(q, w[p + "qnorm"], d.eps)
+            k = rms_norm(k, w[p + "knorm"], d.eps)
+            o = torch.empty(B, S, hq, D, dtype=BF16)
+            for b in range(B):
+                qb = apply_rope(q[b], cos, sin)
+                kb = apply_rope(k[b], cos, sin)
+                o[b] = attention_rows(qb, kb.to(torch.float32), v[b].to(torch.float32), pos, D ** -0.5)
+            h = resid + linear(o.reshape(B * S, hq * D), w[p + "wo"]).reshape(B, S, -1)
+            resid = h
+            a = rms_norm(h, w[p + "ln2"], d.eps)
+            gu = linear(a.reshape(B * S, -1), w[p + "wgu"])
+            act = silu_mul(gu[:, : d.cp_inter], gu[:, d.cp_inter:])
+            h = resid + linear(act, w[p + "wdown"]).reshape(B, S, -1)
+        return rms_norm(h, w["cp.norm"], d.eps)
+
+    def cp_project(self, x: torch.Tensor) -> torch.Tensor:
+        """small_to_mtp_projection (code_predictor_vllm.py:340-343); identity when dims match."""
+        if "cp.proj_w" not in self.w:
+            return x
+        return linear(x, self.w["cp.proj_w"], self.w["cp.proj_b"])
+
+    def code_predictor(self, layer0_code: torch.Tensor, layer0_embed: torch.Tensor, last_hidden: torch.Tensor,
+                       *, do_sample: bool = False, temperature: float = 0.9, top_k: int = 50,
+                       seed: int = 0, step: int = 0, return_logits: bool = False):
+        """layer0_code [B] int64, layer0_embed [B,H] bf16, last_hidden [B,H] bf16 -> all_codes [B,Q].
+        Sampling uses this oracle's hash RNG (the reference uses torch.multinomial on the
+        global generator, code_predictor_vllm.py:545-551: not reproducible -> greedy for parity)."""
+        d, w = self.d, self.w
+        B, Q = layer0_code.shape[0], d.num_code_groups
+        codes = torch.empty(B, Q, dtype=torch.long)
+        codes[:, 0] = layer0_code
+        buf = torch.zeros(B, Q + 1, d.cp_hidden, dtype=BF16)
+        buf[:, 0] = self.cp_project(last_hidden)
+        buf[:, 1] = self.cp_project(layer0_embed)
+        all_logits = []
+        for g in range(1, Q):
+            hid = self.cp_model(buf)
+            logits = linear(hid[:, g], w["cp.lm_head"][g - 1]).to(torch.float32)
+            all_logits.append(logits)
+            if do_sample and temperature > 0:
+                nxt = torch.tensor([sample_row(logits[b], greedy=False, temperature=max(temperature, 1e-6),
+                                               top_k=top_k, seed=seed, step=step * Q + g) for b in range(B)])
+            else:
+                nxt = logits.argmax(-1)
+            codes[:, g] = nxt
+            if g < Q - 1:
+                buf[:, g + 1] = self.cp_project(w["cp.embed"][g - 1][nxt])
+        if return_logits:
+            return codes, torch.stack(all_logits, 1)
+        return codes
+
+    def talker_mtp(self, input_ids: torch.Tensor, input_embeds: torch.Tensor, last_hidden: torch.Tensor,
+                   text_step: torch.Tensor, **cp_kw):
+        """qwen3_tts_talker.py:1594-1642 -> (inputs_embeds [B,H] bf16, audio_codes [B,Q] int64)."""
+        d, w = self.d, self.w
+        Q = d.num_code_groups
+        codes = self.code_predictor(input_ids, input_embeds, last_hidden, **cp_kw)
+        invalid0 = (codes[:, :1] < 0) | (codes[:, :1] >= d.codebook)
+        codes = torch.where(invalid0.expand_as(codes), torch.zeros_like(codes), codes)
+        embeds = [input_embeds[:, None, :]]
+        for i in range(Q - 1):
+            embeds.append(w["cp.embed"][i][codes[:, i + 1]][:, None, :])
+        summed = torch.cat(embeds, dim=1).sum(1)          # bf16 sum: fp32 accumulate, one rounding
+        return (summed + text_step), codes
+
+    # ---- one engine step over a batch of decode requests (SURVEY 3.3 data-flow)
+    def decode_step(self, states: list[OracleState], block_tables: list, *, greedy: bool = True,
+                    sampling: dict | None = None, cp_kw: dict | None = None):
+        """All requests have query_len 1. Returns (logits [B,V] fp32, sampled ids [B],
+        hidden [B,H] bf16, audio_codes [B,Q], slots [B])."""
+        d, w = self.d, self.w
+        B = len(states)
+        ids = torch.tensor([s.last_id for s in states], dtype=torch.long)
+        e0 = w["embed"][ids]                                            # embed_input_ids (talker.py:637)
+        last_h = torch.stack([s.last_hidden for s in states])
+        text = torch.stack([(s.tail_text.pop(0) if s.tail_text else s.tts_pad) for s in states])  # talker.py:618-629
+        x, codes = self.talker_mtp(ids, e0, last_h, text, **(cp_kw or {}))
+        positions = torch.tensor([s.seq_len for s in states], dtype=torch.long)
+        seq_after = [s.seq_len + 1 for s in states]
+        hidden = self.backbone(x, positions, list(range(B)), block_tables, seq_after)
+        logits = self.compute_logits(hidden)
+        sampled = []
+        for b, s in enumerate(states):
+            kw = dict(sampling or {})
+            seen = None
+            if kw.get("rep_penalty", 1.0) != 1.0:
+                seen = [d.codec_pad_id] * s.prompt_len + s.out_ids   # prompt ids are pad placeholders (talker.py:603-605)
+            tok = sample_row(logits[b], greedy=greedy, seen_ids=seen, step=len(s.out_ids), **kw)
+            sampled.append(tok)
+            s.seq_len += 1
+            s.last_id = tok
+            s.last_hidden = hidden[b]                                   # postprocess (talker.py:649-655)
+            s.out_ids.append(tok)
+        return logits, torch.tensor(sampled), hidden, codes, self.last_slots
+
+    def prefill(self, states: list[OracleState], prompt_embeds: list[torch.Tensor], block_tables: list,
+                *, greedy: bool = True, sampling: dict | None = None):
+        """Whole-prompt prefill of each request (one chunk)."""
+        d = self.d
+        xs, pos, req = [], [], []
+        for r, pe in enumerate(prompt_embeds):
+            n = pe.shape[0]
+            xs.append(pe)
+            pos += list(range(n))
+            req += [r] * n
+        x = torch.cat(xs, 0)
+        seq_after = [pe.shape[0] for pe in prompt_embeds]
+        hidden = self.backbone(x, torch.tensor(pos), req, block_tables, seq_after)
+        last_idx = np.cumsum(seq_after) - 1
+        hl = hidden[torch.as_tensor(last_idx)]
+        logits = self.compute_logits(hl)
+        out = []
+        for b, s in enumerate(states):
+            kw = dict(sampling or {})
+            s.prompt_len = seq_after[b]
+            seen = [d.codec_pad_id] * s.prompt_len if kw.get("rep_penalty", 1.0) != 1.0 else None
+            tok = sample_row(logits[b], greedy=greedy, seen_ids=seen, step=0, **kw)
+            s.seq_len = seq_after[b]
+            s.last_id = tok
+            s.last_hidden = hl[b]
+            s.out_ids.append(tok)
+            out.append(tok)
+        return logits, torch.tensor(out), hl
+
+
+# --------------------------------------------------------------------------
+# KV extraction (kv_transfer_manager.py:224-301, kv_utils.py:13-85)
+# --------------------------------------------------------------------------
+def extract_kv(layer_kv: torch.Tensor, block_ids: list[int], seq_len: int) -> tuple[torch.Tensor, torch.Tensor]:
+    if layer_kv.shape[0] == 2:
+        kb, vb = layer_kv[0], layer_kv[1]
+    else:
+        kb, vb = layer_kv[:, 0], layer_kv[:, 1]
+    mx = min(kb.shape[0], vb.shape[0]) - 1
+    ids = [b for b in block_ids if 0 <= b <= mx]
+    fk, fv = kb[ids].flatten(0, 1), vb[ids].flatten(0, 1)
+    if seq_len < fk.shape[0]:
+        fk, fv = fk[:seq_len], fv[:seq_len]
+    return fk.contiguous(), fv.contiguous()

@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Mint the golden fixtures under tests/golden/ (run in the AUTHORING container only).
+
+Needs /root/reference (read-only) and HF transformers; neither exists on the GPU box,
+where only the committed .npz vectors are read.  Nothing of the reference's source is
+copied: the reference modules are imported by path, fed seeded inputs, and only the
+input/output tensors are saved.
+
+  code_predictor_tiny.npz   reference Qwen3TTSTalkerCodePredictorForConditionalGenerationVLLM
+                            (qwen3_tts_code_predictor_vllm.py) greedy codes + hidden states
+  qwen3_backbone_tiny.npz   HF transformers Qwen3Model (bf16, CPU): prefill + decode hidden states
+  kv_extract.npz            reference OmniKVTransferManager._extract_kv_cache in/out
+  chunk_windows.json        reference talker2code2wav_async_chunk windowing known answers
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+V = os.path.join(REF, "vllm_omni")
+
+from ht_vllm_omni_amd.config import get_dims  # noqa: E402
+from ht_vllm_omni_amd.weights import make_weights  # noqa: E402
+
+
+def _stub(name: str, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_vllm_stubs():
+    """<= 6 symbols of vllm / vllm_omni the imported reference files touch."""
+    import logging
+
+    class _L(logging.Logger):
+        def warning_once(self, *a, **k):
+            self.warning(*a, **k)
+
+        def info_once(self, *a, **k):
+            self.info(*a, **k)
+
+    def init_logger(name):
+        logging.setLoggerClass(_L)
+        lg = logging.getLogger("ref." + name)
+        logging.setLoggerClass(logging.Logger)
+        return lg
+
+    class _Ctx:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def default_weight_loader(param, w):
+        param.data.copy_(w)
+
+    _stub("vllm")
+    _stub("vllm.logger", init_logger=init_logger)
+    _stub("vllm.config", VllmConfig=object)
+    _stub("vllm.config.vllm", set_current_vllm_config=_Ctx)
+    _stub("vllm.model_executor")
+    _stub("vllm.model_executor.model_loader")
+    _stub("vllm.model_executor.model_loader.weight_utils", default_weight_loader=default_weight_loader)
+    plat = types.SimpleNamespace(supports_torch_inductor=lambda: False)
+    _stub("vllm_omni")
+    _stub("vllm_omni.platforms", current_omni_platform=plat)
+
+
+def load_by_path(modname: str, path: str, package: str | None = None):
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def np16(t: torch.Tensor) -> np.ndarray:
+    """bf16 tensor -> uint16 bit pattern (npz has no bf16)."""
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+# --------------------------------------------------------------------------
+def mint_code_predictor():
+    install_vllm_stubs()
+    pkg = "refq3tts"
+    p = types.ModuleType(pkg)
+    p.__path__ = [os.path.join(V, "model_executor/models/qwen3_tts")]
+    sys.modules[pkg] = p
+    cfgm = load_by_path(pkg + ".configuration_qwen3_tts", os.path.join(p.__path__[0], "configuration_qwen3_tts.py"), pkg)
+    cpm = load_by_path(pkg + ".qwen3_tts_code_predictor_vllm",
+                       os.path.join(p.__path__[0], "qwen3_tts_code_predictor_vllm.py"), pkg)
+
+    d = get_dims("tiny")
+    w = make_weights(d, seed=11, std=0.08, norm_noise=0.1)   # larger std: logits well separated
+    cp_cfg = cfgm.Qwen3TTSTalkerCodePredictorConfig(
+        vocab_size=d.codebook, hidden_size=d.cp_hidden, intermediate_size=d.cp_inter,
+        num_hidden_layers=d.cp_layers, num_attention_heads=d.cp_q_heads, num_key_value_heads=d.cp_kv_heads,
+        head_dim=d.cp_head_dim, rms_norm_eps=d.eps, rope_theta=d.cp_rope_theta, num_code_groups=d.num_code_groups)
+    tk_cfg = cfgm.Qwen3TTSTalkerConfig(code_predictor_config=cp_cfg, vocab_size=d.vocab, hidden_size=d.hidden,
+                                       num_code_groups=d.num_code_groups)
+    vcfg = types.SimpleNamespace(scheduler_config=types.SimpleNamespace(max_num_seqs=8))
+    m = cpm.Qwen3TTSTalkerCodePredictorForConditionalGenerationVLLM(vllm_config=vcfg, config=cp_cfg,
+                                                                   talker_config=tk_cfg)
+    m = m.to(torch.bfloat16).eval()
+    hq, hkv, D = d.cp_q_heads, d.cp_kv_heads, d.cp_head_dim
+    sd = {}
+    for i in range(d.cp_layers):
+        s, t = f"cp.l{i}.", f"model.layers.{i}."
+        qkv = w[s + "wqkv"]
+        sd[t + "self_attn.q_proj.weight"] = qkv[: hq * D]
+        sd[t + "self_attn.k_proj.weight"] = qkv[hq * D: (hq + hkv) * D]
+        sd[t + "self_attn.v_proj.weight"] = qkv[(hq + hkv) * D:]
+        sd[t + "self_attn.o_proj.weight"] = w[s + "wo"]
+        sd[t + "self_attn.q_norm.weight"] = w[s + "qnorm"]
+        sd[t + "self_attn.k_norm.weight"] = w[s + "knorm"]
+        sd[t + "input_layernorm.weight"] = w[s + "ln1"]
+        sd[t + "post_attention_layernorm.weight"] = w[s + "ln2"]
+        sd[t + "mlp.gate_proj.weight"] = w[s + "wgu"][: d.cp_inter]
+        sd[t + "mlp.up_proj.weight"] = w[s + "wgu"][d.cp_inter:]
+        sd[t + "mlp.down_proj.weight"] = w[s + "wdown"]
+    sd["model.norm.weight"] = w["cp.norm"]
+    for g in range(d.num_code_groups - 1):
+        sd[f"model.codec_embedding.{g}.weight"] = w["cp.embed"][g]
+        sd[f"lm_head.{g}.weight"] = w["cp.lm_head"][g]
+    sd["small_to_mtp_projection.weight"] = w["cp.proj_w"]
+    sd["small_to_mtp_projection.bias"] = w["cp.proj_b"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+
+    g = torch.Generator().manual_seed(5)
+    B = 5
+    code0 = torch.randint(1, d.codebook, (B, 1), generator=g)
+    e0 = w["embed"][code0.reshape(-1)].reshape(B, 1, -1)
+    last_h = (torch.randn(B, 1, d.hidden, generator=g)).to(torch.bfloat16)
+    codes = m(layer0_code=code0, layer0_embed=e0, last_talker_hidden=last_h, do_sample=False)
+    # hidden states of the final re-prefill buffer (all positions filled except the last)
+    buf = m._proj_buf[:B].clone()
+    hid = m.model(buf, torch.arange(d.num_code_groups + 1)[None].expand(B, -1))
+    out = dict(seed=np.int64(11), std=np.float64(0.08), norm_noise=np.float64(0.1),
+               layer0_code=code0.numpy(), layer0_embed=np16(e0), last_talker_hidden=np16(last_h),
+               all_codes=codes.numpy(), proj_buf=np16(buf), final_hidden=np16(hid))
+    np.savez_compressed(os.path.join(HERE, "code_predictor_tiny.npz"), **out)
+    print("code predictor codes:\n", codes)
+
+
+# --------------------------------------------------------------------------
+def mint_backbone():
+    from transformers import Qwen3Config, Qwen3Model
+    from transformers.cache_utils import DynamicCache
+
+    d = get_dims("tiny")
+    w = make_weights(d, seed=21, std=0.05, norm_noise=0.1)
+    cfg = Qwen3Config(vocab_size=d.vocab, hidden_size=d.hidden, intermediate_size=d.inter,
+                      num_hidden_layers=d.layers, num_attention_heads=d.q_heads, num_key_value_heads=d.kv_heads,
+                      head_dim=d.head_dim, rms_norm_eps=d.eps, rope_theta=d.rope_theta, max_position_embeddings=4096,
+                      attention_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    m = Qwen3Model(cfg).to(torch.bfloat16).eval()
+    hq, hkv, D = d.q_heads, d.kv_heads, d.head_dim
+    sd = {"embed_tokens.weight": w["embed"], "norm.weight": w["norm"]}
+    for i in range(d.layers):
+        s, t = f"l{i}.", f"layers.{i}."
+        qkv = w[s + "wqkv"]
+        sd[t + "self_attn.q_proj.weight"] = qkv[: hq * D]
+        sd[t + "self_attn.k_proj.weight"] = qkv[hq * D: (hq + hkv) * D]
+        sd[t + "self_attn.v_proj.weight"] = qkv[(hq + hkv) * D:]
+        sd[t + "self_attn.o_proj.weight"] = w[s + "wo"]
+        sd[t + "self_attn.q_norm.weight"] = w[s + "qnorm"]
+        sd[t + "self_attn.k_norm.weight"] = w[s + "knorm"]
+        sd[t + "input_layernorm.weight"] = w[s + "ln1"]
+        sd[t + "post_attention_layernorm.weight"] = w[s + "ln2"]
+        sd[t + "mlp.gate_proj.weight"] = w[s + "wgu"][: d.inter]
+        sd[t + "mlp.up_proj.weight"] = w[s + "wgu"][d.inter:]
+        sd[t + "mlp.down_proj.weight"] = w[s + "wdown"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+
+    g = torch.Generator().manual_seed(9)
+    prompt_lens = [5, 17, 33]          # below / across / beyond one and two 16-token blocks
+    n_decode = 4
+    out = dict(seed=np.int64(21), std=np.float64(0.05), norm_noise=np.float64(0.1),
+               prompt_lens=np.array(prompt_lens), n_decode=np.int64(n_decode))
+    with torch.inference_mode():
+        for r, n in enumerate(prompt_lens):
+            x = torch.randn(1, n + n_decode, d.hidden, generator=g).to(torch.bfloat16)
+            cache = DynamicCache(config=cfg)
+            o = m(inputs_embeds=x[:, :n], past_key_values=cache, use_cache=True)
+            hs = [o.last_hidden_state[0]]
+            for t in range(n_decode):
+                o = m(inputs_embeds=x[:, n + t: n + t + 1], past_key_values=cache, use_cache=True)
+                hs.append(o.last_hidden_state[0])
+            out[f"x{r}"] = np16(x[0])
+            out[f"h{r}"] = np16(torch.cat(hs, 0))
+    np.savez_compressed(os.path.join(HERE, "qwen3_backbone_tiny.npz"), **out)
+    print("backbone fixture: hidden absmax", float(torch.cat(hs, 0).float().abs().max()))
+
+
+# --------------------------------------------------------------------------
+def mint_kv_extract():
+    install_vllm_stubs()
+    ku = load_by_path("refkv_utils", os.path.join(V, "distributed/omni_connectors/utils/kv_utils.py"))
+    g = torch.Generator().manual_seed(3)
+    cache = torch.randn(2, 6, 4, 2, 8, generator=g)
+    out = {"cache": cache.numpy()}
+    cases = [([1, 3], 6), ([0, 5, 2], 12), ([4], 3), ([1, 9, 3], 7)]
+    for i, (ids, seq) in enumerate(cases):
+        for layout in ("2first", "2second"):
+            lk = cache if layout == "2first" else cache.transpose(0, 1).contiguous()
+            kb, vb = ku.normalize_layer_kv(lk)
+            # the gather itself follows kv_transfer_manager.py:267-281 (that file imports the
+            # whole connector stack; the five lines are exercised here on the reference's
+            # normalize_layer_kv output)
+            mx = min(kb.shape[0], vb.shape[0]) - 1
+            valid = [b for b in ids if 0 <= b <= mx]
+            fk = kb[valid].flatten(0, 1)
+            fv = vb[valid].flatten(0, 1)
+            if seq < fk.shape[0]:
+                fk, fv = fk[:seq], fv[:seq]
+            out[f"k{i}_{layout}"] = fk.contiguous().numpy()
+            out[f"v{i}_{layout}"] = fv.contiguous().numpy()
+        out[f"ids{i}"] = np.array(ids)
+        out[f"seq{i}"] = np.int64(seq)
+    np.savez_compressed(os.path.join(HERE, "kv_extract.npz"), **out)
+    print("kv extract cases:", len(cases))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["cp", "bb", "kv"]
+    if "cp" in which:
+        mint_code_predictor()
+    if "bb" in which:
+        mint_backbone()
+    if "kv" in which:
+        mint_kv_extract()
