@@ -1,0 +1,123 @@
+"""ctypes binding of libomni_talker.so (the C-ABI of include/omni_talker.h).
+
+The product path has NO fallback: if the HIP library is missing or an entry point fails,
+this module raises.  `import torch` happens first so the library resolves libamdhip64.so.7
+to the HIP runtime PyTorch-ROCm already loaded (one runtime, shared streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below: shares torch's HIP runtime)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libomni_talker.so")
+
+KV_BF16, KV_FP8, KV_INT8 = 0, 1, 2
+KV_CODES = {"bf16": KV_BF16, "auto": KV_BF16, "fp8": KV_FP8, "fp8_e4m3": KV_FP8, "int8": KV_INT8}
+EPI_BF16, EPI_SILU_MUL, EPI_F32, EPI_F32_BF16RND = 0, 1, 2, 3
+
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+
+class OmniError(RuntimeError):
+    pass
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")]
+
+
+class TalkerDesc(C.Structure):
+    _fields_ = [
+        ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
+        ("vocab", i32), ("codebook", i32), ("num_code_groups", i32), ("eps", f32),
+        ("cp_hidden", i32), ("cp_layers", i32), ("cp_q_heads", i32), ("cp_kv_heads", i32), ("cp_head_dim", i32),
+        ("cp_inter", i32), ("has_cp_projection", i32),
+        ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
+        ("k_scale", f32), ("v_scale", f32),
+        ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),
+        ("cos_sin", vp), ("cp_proj_w", vp), ("cp_proj_b", vp), ("cp_layer", C.POINTER(LayerWeights)), ("cp_norm", vp),
+        ("cp_lm_head", vp), ("cp_embed", vp), ("cp_cos_sin", vp),
+        ("k_cache", C.POINTER(vp)), ("v_cache", C.POINTER(vp)), ("k_scales", C.POINTER(vp)), ("v_scales", C.POINTER(vp)),
+        ("scratch", vp), ("scratch_bytes", i64),
+    ]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("B", i32), ("input_ids", vp), ("positions", vp), ("seq_lens", vp), ("block_table", vp), ("slot_mapping", vp),
+        ("last_hidden", vp), ("text_step", vp), ("inputs_embeds", vp), ("audio_codes", vp), ("logits", vp),
+        ("seen", vp), ("steps", vp),
+        ("greedy", i32), ("temperature", f32), ("top_k", i32), ("rep_penalty", f32), ("seed", u32),
+        ("cp_greedy", i32), ("cp_temperature", f32), ("cp_top_k", i32),
+        ("advance", i32),
+    ]
+
+
+# every symbol include/omni_talker.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "omni_last_error": (C.c_char_p, []),
+    "omni_abi_version": (i32, []),
+    "omni_rmsnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_qknorm_rope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),
+    "omni_slot_mapping": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
+    "omni_paged_attn_decode": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, vp]),
+    "omni_paged_attn_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "omni_paged_attn_prefill": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp]),
+    "omni_embed": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "omni_sample": (i32, [vp, i32, i32, i32, i32, f32, i32, f32, vp, u32, vp, i32, i32, i32, vp, vp]),
+    "omni_talker_scratch_bytes": (i64, [C.POINTER(TalkerDesc)]),
+    "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
+    "omni_talker_destroy": (None, [vp]),
+    "omni_talker_mtp": (i32, [vp, C.POINTER(StepIO), vp]),
+    "omni_talker_layer_attn": (i32, [vp, C.POINTER(StepIO), i32, vp]),
+    "omni_talker_layer_mlp": (i32, [vp, C.POINTER(StepIO), i32, vp]),
+    "omni_talker_finish": (i32, [vp, C.POINTER(StepIO), vp]),
+    "omni_talker_decode_step": (i32, [vp, C.POINTER(StepIO), vp]),
+    "omni_talker_attn_out": (vp, [vp]),
+    "omni_talker_mlp_out": (vp, [vp]),
+    "omni_talker_prefill": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "omni_talker_logits": (i32, [vp, vp, vp, i32, i32, vp]),
+    "omni_talker_code_predictor": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, u32, vp, vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every declared symbol; raises OmniError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmniError(
+            f"{LIB_PATH} is missing: build it with `python -m ht_vllm_omni_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OmniError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().omni_last_error().decode(errors="replace")
+        raise OmniError(f"{what or 'omni call'} failed (rc={rc}): {msg}")
+
+
+def ptr(t) -> int | None:
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

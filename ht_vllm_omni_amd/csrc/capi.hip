@@ -1,0 +1,463 @@
+// Talker engine: the decode step of SURVEY 3.3 as a fixed sequence of kernel launches on one
+// HIP stream (no allocation, no host sync -> capturable into a hipGraph by the caller).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.cuh"
+#include "kernels.h"
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+void omni_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* omni_last_error(void) { return g_err; }
+extern "C" int omni_abi_version(void) { return 1; }
+
+#define TRY(expr)                    \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != OMNI_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------ small step kernels
+// x[t+1] = bf16( bf16( sum_fp32(e0, emb_1..emb_{Q-1}) ) + text_step ); invalid layer-0 id -> frame of zeros
+// (qwen3_tts_talker.py:1630-1641).  One block per row.
+__global__ void mtp_finalize_kernel(const int32_t* __restrict__ input_ids, int32_t* __restrict__ codes /*[B,Q]*/,
+                                    const uint16_t* __restrict__ e0, const uint16_t* __restrict__ cp_embed,
+                                    const uint16_t* __restrict__ text_step, uint16_t* __restrict__ x_out,
+                                    uint16_t* __restrict__ resid_out, int64_t* __restrict__ audio_codes, int H, int Q,
+                                    int codebook) {
+    const int b = blockIdx.x;
+    const int c0 = input_ids[b];
+    const bool invalid0 = c0 < 0 || c0 >= codebook;
+    __shared__ int cg[64];
+    if (threadIdx.x < Q) {
+        int c = threadIdx.x == 0 ? c0 : codes[(size_t)b * Q + threadIdx.x];
+        if (invalid0) c = 0;
+        cg[threadIdx.x] = c;
+        audio_codes[(size_t)b * Q + threadIdx.x] = (int64_t)c;
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        float s = bf2f(e0[(size_t)b * H + h]);
+        for (int g = 1; g < Q; ++g) s += bf2f(cp_embed[((size_t)(g - 1) * codebook + cg[g]) * H + h]);
+        const float y = bfround(bfround(s) + bf2f(text_step[(size_t)b * H + h]));
+        const uint16_t o = f2bf(y);
+        x_out[(size_t)b * H + h] = o;
+        resid_out[(size_t)b * H + h] = o;
+    }
+}
+
+__global__ void advance_kernel(int32_t* positions, int32_t* seq_lens, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        positions[i] += 1;
+        seq_lens[i] += 1;
+    }
+}
+
+__global__ void copy_i32_to_i64_kernel(const int32_t* src, int64_t* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------ engine
+struct omni_talker {
+    omni_talker_desc d;
+    std::vector<omni_layer_weights> layer, cp_layer;
+    std::vector<void*> k_cache, v_cache;
+    std::vector<float*> k_scales, v_scales;
+    int Bm, cp_bs;
+    // scratch carve
+    uint16_t *resid, *normed, *qkv, *q, *attn, *attn_out, *act, *mlp_out, *hidden, *e0;
+    float* attn_ws;
+    uint16_t *cp_resid, *cp_normed, *cp_qkv, *cp_q, *cp_attn, *cp_o, *cp_act, *cp_mlp, *cp_hidden, *cp_in, *cp_row;
+    float* cp_logits;
+    int32_t *codes, *cp_bt, *cp_pos, *cp_seq;
+    int64_t* cp_slots;
+    std::vector<uint16_t*> cp_k, cp_v;
+    int32_t* pf_seq;   // prefill scratch
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += align_up(n * sizeof(T));
+        return p;
+    }
+};
+
+static int carve(omni_talker* t, char* base, size_t* total) {
+    const omni_talker_desc& d = t->d;
+    const size_t B = d.max_batch, H = d.hidden, Hc = d.cp_hidden, Q = d.num_code_groups;
+    const size_t qkv_out = (size_t)(d.q_heads + 2 * d.kv_heads) * d.head_dim;
+    const size_t cp_qkv_out = (size_t)(d.cp_q_heads + 2 * d.cp_kv_heads) * d.cp_head_dim;
+    Carver c{base, 0};
+    t->resid = c.take<uint16_t>(B * H);
+    t->normed = c.take<uint16_t>(B * H);
+    t->qkv = c.take<uint16_t>(B * qkv_out);
+    t->q = c.take<uint16_t>(B * d.q_heads * d.head_dim);
+    t->attn = c.take<uint16_t>(B * d.q_heads * d.head_dim);
+    t->attn_out = c.take<uint16_t>(B * H);
+    t->act = c.take<uint16_t>(B * d.inter);
+    t->mlp_out = c.take<uint16_t>(B * H);
+    t->hidden = c.take<uint16_t>(B * H);
+    t->e0 = c.take<uint16_t>(B * H);
+    t->attn_ws = c.take<float>((size_t)omni_paged_attn_workspace_bytes(d.max_batch, d.q_heads, d.head_dim, d.max_model_len) / 4);
+    t->cp_resid = c.take<uint16_t>(B * Hc);
+    t->cp_normed = c.take<uint16_t>(B * Hc);
+    t->cp_qkv = c.take<uint16_t>(B * cp_qkv_out);
+    t->cp_q = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
+    t->cp_attn = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
+    t->cp_o = c.take<uint16_t>(B * Hc);
+    t->cp_act = c.take<uint16_t>(B * d.cp_inter);
+    t->cp_mlp = c.take<uint16_t>(B * Hc);
+    t->cp_hidden = c.take<uint16_t>(B * Hc);
+    t->cp_in = c.take<uint16_t>(B * Hc);
+    t->cp_row = c.take<uint16_t>(B * H);
+    t->cp_logits = c.take<float>(B * d.codebook);
+    t->codes = c.take<int32_t>(B * Q);
+    t->cp_bt = c.take<int32_t>(B);
+    t->cp_pos = c.take<int32_t>((Q + 1) * B);
+    t->cp_seq = c.take<int32_t>((Q + 1) * B);
+    t->cp_slots = c.take<int64_t>((Q + 1) * B);
+    t->pf_seq = c.take<int32_t>(8);
+    t->cp_k.resize(d.cp_layers);
+    t->cp_v.resize(d.cp_layers);
+    const size_t cpkv = B * t->cp_bs * d.cp_kv_heads * d.cp_head_dim;
+    for (int l = 0; l < d.cp_layers; ++l) {
+        t->cp_k[l] = c.take<uint16_t>(cpkv);
+        t->cp_v[l] = c.take<uint16_t>(cpkv);
+    }
+    *total = c.off;
+    return OMNI_OK;
+}
+
+static int check_desc(const omni_talker_desc* d) {
+    OMNI_CHECK_ARG(d, "omni_talker: null descriptor");
+    OMNI_CHECK_ARG(d->head_dim == 128 && d->cp_head_dim == 128, "omni_talker: head_dim must be 128");
+    OMNI_CHECK_ARG(d->max_batch >= 1 && d->max_batch <= 64, "omni_talker: max_batch=%d outside 1..64", d->max_batch);
+    OMNI_CHECK_ARG(d->num_code_groups >= 1 && d->num_code_groups <= 63, "omni_talker: num_code_groups=%d", d->num_code_groups);
+    OMNI_CHECK_ARG(d->hidden % 32 == 0 && d->inter % 32 == 0 && d->cp_hidden % 32 == 0 && d->cp_inter % 32 == 0,
+                   "omni_talker: hidden/intermediate sizes must be multiples of 32");
+    OMNI_CHECK_ARG(d->vocab % 16 == 0 && d->codebook % 16 == 0, "omni_talker: vocab/codebook must be multiples of 16");
+    OMNI_CHECK_ARG(d->kv_heads > 0 && d->q_heads % d->kv_heads == 0 && d->cp_kv_heads > 0 && d->cp_q_heads % d->cp_kv_heads == 0,
+                   "omni_talker: bad head counts");
+    return OMNI_OK;
+}
+
+extern "C" int64_t omni_talker_scratch_bytes(const omni_talker_desc* desc) {
+    if (check_desc(desc) != OMNI_OK) return -1;
+    omni_talker tmp;
+    tmp.d = *desc;
+    tmp.cp_bs = desc->num_code_groups + 1;
+    size_t total = 0;
+    carve(&tmp, nullptr, &total);
+    return (int64_t)total;
+}
+
+extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
+    if (check_desc(desc) != OMNI_OK) return nullptr;
+    if (!desc->layer || !desc->cp_layer || !desc->k_cache || !desc->v_cache || !desc->scratch) {
+        omni_set_error("omni_talker_create: null weight/cache/scratch pointer");
+        return nullptr;
+    }
+    if (desc->has_cp_projection && (!desc->cp_proj_w || !desc->cp_proj_b)) {
+        omni_set_error("omni_talker_create: projection weights missing");
+        return nullptr;
+    }
+    if (!desc->has_cp_projection && desc->cp_hidden != desc->hidden) {
+        omni_set_error("omni_talker_create: cp_hidden != hidden needs the projection");
+        return nullptr;
+    }
+    omni_talker* t = new omni_talker();
+    t->d = *desc;
+    t->Bm = desc->max_batch;
+    t->cp_bs = desc->num_code_groups + 1;
+    t->layer.assign(desc->layer, desc->layer + desc->layers);
+    t->cp_layer.assign(desc->cp_layer, desc->cp_layer + desc->cp_layers);
+    t->k_cache.assign(desc->k_cache, desc->k_cache + desc->layers);
+    t->v_cache.assign(desc->v_cache, desc->v_cache + desc->layers);
+    if (desc->kv_dtype == OMNI_KV_INT8) {
+        if (!desc->k_scales || !desc->v_scales) {
+            omni_set_error("omni_talker_create: int8 KV needs scale arrays");
+            delete t;
+            return nullptr;
+        }
+        t->k_scales.assign(desc->k_scales, desc->k_scales + desc->layers);
+        t->v_scales.assign(desc->v_scales, desc->v_scales + desc->layers);
+    } else {
+        t->k_scales.assign(desc->layers, nullptr);
+        t->v_scales.assign(desc->layers, nullptr);
+    }
+    size_t total = 0;
+    carve(t, reinterpret_cast<char*>(desc->scratch), &total);
+    if ((int64_t)total > desc->scratch_bytes) {
+        omni_set_error("omni_talker_create: scratch too small (%lld < %zu)", (long long)desc->scratch_bytes, total);
+        delete t;
+        return nullptr;
+    }
+    // constant code-predictor metadata: request b owns "block" b of cp_bs positions
+    const int B = t->Bm, Q = desc->num_code_groups;
+    std::vector<int32_t> bt(B), pos((Q + 1) * B), seq((Q + 1) * B);
+    std::vector<int64_t> slots((Q + 1) * B);
+    for (int b = 0; b < B; ++b) bt[b] = b;
+    for (int p = 0; p <= Q; ++p)
+        for (int b = 0; b < B; ++b) {
+            pos[p * B + b] = p;
+            seq[p * B + b] = p + 1;
+            slots[p * B + b] = (int64_t)b * t->cp_bs + p;
+        }
+    hipError_t e = hipMemcpy(t->cp_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->cp_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->cp_seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->cp_slots, slots.data(), slots.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        omni_set_error("omni_talker_create: hipMemcpy failed: %s", hipGetErrorString(e));
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+
+extern "C" void omni_talker_destroy(omni_talker* t) { delete t; }
+extern "C" void* omni_talker_attn_out(omni_talker* t) { return t ? t->attn_out : nullptr; }
+extern "C" void* omni_talker_mlp_out(omni_talker* t) { return t ? t->mlp_out : nullptr; }
+
+static int check_io(const omni_talker* t, const omni_step_io* io) {
+    OMNI_CHECK_ARG(t && io, "omni_talker: null engine/io");
+    OMNI_CHECK_ARG(io->B >= 1 && io->B <= t->Bm, "omni_talker: B=%d outside 1..%d", io->B, t->Bm);
+    OMNI_CHECK_ARG(io->input_ids && io->positions && io->seq_lens && io->block_table && io->slot_mapping &&
+                       io->last_hidden && io->text_step && io->inputs_embeds && io->audio_codes && io->logits,
+                   "omni_talker: null io buffer");
+    return OMNI_OK;
+}
+
+// ---- one code-predictor forward pass at buffer position p (input rows in t->cp_in)
+static int cp_forward(omni_talker* t, int B, int p, void* st) {
+    const omni_talker_desc& d = t->d;
+    const int Hc = d.cp_hidden, hq = d.cp_q_heads, hkv = d.cp_kv_heads, D = d.cp_head_dim;
+    const int Bm = t->Bm;
+    for (int l = 0; l < d.cp_layers; ++l) {
+        const omni_layer_weights& w = t->cp_layer[l];
+        if (l == 0)
+            TRY(omni_rmsnorm(t->cp_in, nullptr, nullptr, w.ln1, t->cp_normed, B, Hc, d.eps, st));
+        else
+            TRY(omni_rmsnorm(nullptr, t->cp_mlp, t->cp_resid, w.ln1, t->cp_normed, B, Hc, d.eps, st));
+        TRY(omni_gemm_bf16(t->cp_normed, Hc, w.wqkv, nullptr, t->cp_qkv, B, (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
+        TRY(omni_qknorm_rope_kvwrite(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin,
+                                     t->cp_slots + (size_t)p * Bm, t->cp_q, t->cp_k[l], t->cp_v[l], nullptr, nullptr, B,
+                                     hq, hkv, D, d.eps, OMNI_KV_BF16, 1.f, 1.f, st));
+        TRY(omni_paged_attn_decode(t->cp_q, t->cp_k[l], t->cp_v[l], nullptr, nullptr, t->cp_bt, 1,
+                                   t->cp_seq + (size_t)p * Bm, t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs,
+                                   OMNI_KV_BF16, 1.f, 1.f, 1.0f / sqrtf((float)D), t->cp_bs, st));
+        TRY(omni_gemm_bf16(t->cp_attn, hq * D, w.wo, nullptr, t->cp_o, B, Hc, hq * D, OMNI_EPI_BF16, nullptr, st));
+        if (l == 0) {
+            // residual stream starts as the projected input row
+            hipError_t e = hipMemcpyAsync(t->cp_resid, t->cp_in, (size_t)B * Hc * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
+            if (e != hipSuccess) { omni_set_error("cp_forward: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        }
+        TRY(omni_rmsnorm(nullptr, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, B, Hc, d.eps, st));
+        TRY(omni_gemm_bf16(t->cp_normed, Hc, w.wgu, nullptr, t->cp_act, B, d.cp_inter, Hc, OMNI_EPI_SILU_MUL, nullptr, st));
+        TRY(omni_gemm_bf16(t->cp_act, d.cp_inter, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, OMNI_EPI_BF16, nullptr, st));
+    }
+    TRY(omni_rmsnorm(nullptr, t->cp_mlp, t->cp_resid, d.cp_norm, t->cp_hidden, B, Hc, d.eps, st));
+    return OMNI_OK;
+}
+
+static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, void* st) {
+    const omni_talker_desc& d = t->d;
+    if (d.has_cp_projection)
+        return omni_gemm_bf16(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_in, B, d.cp_hidden, d.hidden, OMNI_EPI_BF16, nullptr, st);
+    hipError_t e = hipMemcpyAsync(t->cp_in, rows, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
+    if (e != hipSuccess) { omni_set_error("cp_project: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+    return OMNI_OK;
+}
+
+// codes int32 [B,Q] in t->codes (column 0 untouched); cp_logits fp32 [B,Q-1,codebook] optional
+static int run_code_predictor(omni_talker* t, const void* layer0_embed, const void* last_hidden, int B, int greedy,
+                              float temperature, int top_k, uint32_t seed, int32_t* steps, float* cp_logits_out, void* st) {
+    const omni_talker_desc& d = t->d;
+    const int Q = d.num_code_groups;
+    if (Q <= 1) return OMNI_OK;
+    TRY(cp_project(t, last_hidden, B, st));
+    TRY(cp_forward(t, B, 0, st));
+    TRY(cp_project(t, layer0_embed, B, st));
+    for (int g = 1; g < Q; ++g) {
+        TRY(cp_forward(t, B, g, st));
+        const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * d.cp_hidden;
+        TRY(omni_gemm_bf16(t->cp_hidden, d.cp_hidden, head, nullptr, t->cp_logits, B, d.codebook, d.cp_hidden,
+                           OMNI_EPI_F32_BF16RND, nullptr, st));
+        if (cp_logits_out) {
+            hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
+                                            t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,
+                                            hipMemcpyDeviceToDevice, (hipStream_t)st);
+            if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        }
+        // RNG key = steps[b] * Q + g (oracle: step * Q + g)
+        TRY(k_sample(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q, g,
+                     0, t->codes + g, Q, st));
+        if (g < Q - 1) {
+            const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
+            TRY(k_embed(t->codes + g, Q, tab, t->cp_row, B, d.hidden, d.codebook, st));
+            TRY(cp_project(t, t->cp_row, B, st));
+        }
+    }
+    return OMNI_OK;
+}
+
+extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed,
+                                          const void* last_hidden, int64_t* codes, float* cp_logits, int B, int greedy,
+                                          float temperature, int top_k, uint32_t seed, const int32_t* steps, void* stream) {
+    OMNI_CHECK_ARG(t && layer0_ids && layer0_embed && last_hidden && codes, "omni_talker_code_predictor: null pointer");
+    OMNI_CHECK_ARG(B >= 1 && B <= t->Bm, "omni_talker_code_predictor: B=%d", B);
+    const int Q = t->d.num_code_groups;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpy2DAsync(t->codes, (size_t)Q * 4, layer0_ids, 4, 4, B, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+    TRY(run_code_predictor(t, layer0_embed, last_hidden, B, greedy, temperature, top_k, seed, const_cast<int32_t*>(steps),
+                           cp_logits, stream));
+    hipLaunchKernelGGL(copy_i32_to_i64_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, st, t->codes, codes, B * Q);
+    OMNI_CHECK_LAUNCH("copy_i32_to_i64");
+    return OMNI_OK;
+}
+
+extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* stream) {
+    TRY(check_io(t, io));
+    const omni_talker_desc& d = t->d;
+    const int B = io->B, Q = d.num_code_groups;
+    hipStream_t st = (hipStream_t)stream;
+    // slots of the token computed this step (bit-exact parity output)
+    TRY(omni_slot_mapping(io->block_table, d.bt_stride, io->positions, io->slot_mapping, B, B, d.block_size, stream));
+    // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640)
+    TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
+    TRY(run_code_predictor(t, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->seed,
+                           io->steps, nullptr, stream));
+    hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, t->e0,
+                       (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds, t->resid,
+                       io->audio_codes, d.hidden, Q, d.codebook);
+    OMNI_CHECK_LAUNCH("mtp_finalize");
+    return OMNI_OK;
+}
+
+static int layer_attn_rows(omni_talker* t, int l, int rows, const int32_t* positions, const int64_t* slots,
+                           const int32_t* block_table, const int32_t* seq_lens, const int32_t* req_of_tok, void* st) {
+    const omni_talker_desc& d = t->d;
+    const omni_layer_weights& w = t->layer[l];
+    const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim;
+    if (l == 0)
+        TRY(omni_rmsnorm(nullptr, nullptr, t->resid, w.ln1, t->normed, rows, H, d.eps, st));
+    else
+        TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, w.ln1, t->normed, rows, H, d.eps, st));
+    TRY(omni_gemm_bf16(t->normed, H, w.wqkv, nullptr, t->qkv, rows, (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
+    TRY(omni_qknorm_rope_kvwrite(t->qkv, w.qnorm, w.knorm, positions, d.cos_sin, slots, t->q, t->k_cache[l], t->v_cache[l],
+                                 t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, d.k_scale, d.v_scale, st));
+    const float sm = 1.0f / sqrtf((float)D);
+    if (req_of_tok)
+        TRY(omni_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table,
+                                    d.bt_stride, req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype,
+                                    d.k_scale, d.v_scale, sm, st));
+    else
+        TRY(omni_paged_attn_decode(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table,
+                                   d.bt_stride, seq_lens, t->attn, t->attn_ws, rows, hq, hkv, D, d.block_size, d.kv_dtype,
+                                   d.k_scale, d.v_scale, sm, d.max_model_len, st));
+    TRY(omni_gemm_bf16(t->attn, hq * D, w.wo, nullptr, t->attn_out, rows, H, hq * D, OMNI_EPI_BF16, nullptr, st));
+    return OMNI_OK;
+}
+
+static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
+    const omni_talker_desc& d = t->d;
+    const omni_layer_weights& w = t->layer[l];
+    TRY(omni_rmsnorm(nullptr, t->attn_out, t->resid, w.ln2, t->normed, rows, d.hidden, d.eps, st));
+    TRY(omni_gemm_bf16(t->normed, d.hidden, w.wgu, nullptr, t->act, rows, d.inter, d.hidden, OMNI_EPI_SILU_MUL, nullptr, st));
+    TRY(omni_gemm_bf16(t->act, d.inter, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, OMNI_EPI_BF16, nullptr, st));
+    return OMNI_OK;
+}
+
+extern "C" int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
+    TRY(check_io(t, io));
+    OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_attn: layer=%d", layer);
+    return layer_attn_rows(t, layer, io->B, io->positions, io->slot_mapping, io->block_table, io->seq_lens, nullptr, stream);
+}
+
+extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
+    TRY(check_io(t, io));
+    OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_mlp: layer=%d", layer);
+    return layer_mlp_rows(t, layer, io->B, stream);
+}
+
+extern "C" int omni_talker_logits(omni_talker* t, const void* hidden, float* logits, int R, int round_bf16, void* stream) {
+    OMNI_CHECK_ARG(t && hidden && logits, "omni_talker_logits: null pointer");
+    const omni_talker_desc& d = t->d;
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        const int m = R - r0 < 64 ? R - r0 : 64;
+        TRY(omni_gemm_bf16(reinterpret_cast<const uint16_t*>(hidden) + (size_t)r0 * d.hidden, d.hidden, d.lm_head, nullptr,
+                           logits + (size_t)r0 * d.vocab, m, d.vocab, d.hidden,
+                           round_bf16 ? OMNI_EPI_F32_BF16RND : OMNI_EPI_F32, d.allowed_mask, stream));
+    }
+    return OMNI_OK;
+}
+
+extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* stream) {
+    TRY(check_io(t, io));
+    const omni_talker_desc& d = t->d;
+    const int B = io->B;
+    hipStream_t st = (hipStream_t)stream;
+    TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, d.final_norm, t->hidden, B, d.hidden, d.eps, stream));
+    TRY(omni_talker_logits(t, t->hidden, io->logits, B, 1, stream));
+    TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,
+                 io->steps, 1, 0, 1, io->input_ids, 1, stream));
+    // postprocess: keep h[t+1] for the next step's code predictor (qwen3_tts_talker.py:649-655)
+    hipError_t e = hipMemcpyAsync(io->last_hidden, t->hidden, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { omni_set_error("finish: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+    if (io->advance) {
+        hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, io->positions, io->seq_lens, B);
+        OMNI_CHECK_LAUNCH("advance");
+    }
+    return OMNI_OK;
+}
+
+extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
+    TRY(omni_talker_mtp(t, io, stream));
+    for (int l = 0; l < t->d.layers; ++l) {
+        TRY(omni_talker_layer_attn(t, io, l, stream));
+        TRY(omni_talker_layer_mlp(t, io, l, stream));
+    }
+    return omni_talker_finish(t, io, stream);
+}
+
+extern "C" int omni_talker_prefill(omni_talker* t, const void* x, const int32_t* positions, const int32_t* req_of_tok,
+                                   const int64_t* slot_mapping, const int32_t* block_table, void* hidden_out, int T,
+                                   void* stream) {
+    OMNI_CHECK_ARG(t && x && positions && req_of_tok && slot_mapping && block_table && hidden_out,
+                   "omni_talker_prefill: null pointer");
+    const omni_talker_desc& d = t->d;
+    hipStream_t st = (hipStream_t)stream;
+    // chunks of <= max_batch tokens through the skinny-GEMM path; KV of earlier chunks is already in the
+    // cache when later chunks attend (causal), so chunking does not change results.
+    for (int t0 = 0; t0 < T; t0 += t->Bm) {
+        const int rows = T - t0 < t->Bm ? T - t0 : t->Bm;
+        hipError_t e = hipMemcpyAsync(t->resid, reinterpret_cast<const uint16_t*>(x) + (size_t)t0 * d.hidden,
+                                      (size_t)rows * d.hidden * 2, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { omni_set_error("prefill: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        for (int l = 0; l < d.layers; ++l) {
+            TRY(layer_attn_rows(t, l, rows, positions + t0, slot_mapping + t0, block_table, nullptr, req_of_tok + t0, stream));
+            TRY(layer_mlp_rows(t, l, rows, stream));
+        }
+        TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, d.final_norm,
+                         reinterpret_cast<uint16_t*>(hidden_out) + (size_t)t0 * d.hidden, rows, d.hidden, d.eps, stream));
+    }
+    return OMNI_OK;
+}

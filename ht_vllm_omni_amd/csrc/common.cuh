@@ -1,0 +1,77 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) talker kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omni_talker.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ---- error plumbing (host)
+void omni_set_error(const char* fmt, ...);
+#define OMNI_CHECK_ARG(cond, ...)                \
+    do {                                         \
+        if (!(cond)) {                           \
+            omni_set_error(__VA_ARGS__);         \
+            return OMNI_EINVAL;                  \
+        }                                        \
+    } while (0)
+#define OMNI_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            omni_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return OMNI_EHIP;                                                     \
+        }                                                                         \
+    } while (0)
+
+// ---- bf16 <-> f32 (bit-exact RNE; v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (bf16_t)f); }
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+// ---- wave64 reductions (butterfly over all 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- OCP e4m3fn <-> f32 (saturating, round-nearest-even: clamp then hardware cvt)
+#define OMNI_FP8_MAX 448.0f
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -OMNI_FP8_MAX), OMNI_FP8_MAX);
+    b = fminf(fmaxf(b, -OMNI_FP8_MAX), OMNI_FP8_MAX);
+    c = fminf(fmaxf(c, -OMNI_FP8_MAX), OMNI_FP8_MAX);
+    d = fminf(fmaxf(d, -OMNI_FP8_MAX), OMNI_FP8_MAX);
+    int p = 0;
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
+}
+__device__ __forceinline__ void unpack_fp8x4(uint32_t w, float* o) {
+    f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+    f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+}
+
+// ---- the oracle's counter-based uniform (oracle/talker_oracle.py hash_uniform)
+__device__ __forceinline__ float hash_uniform(uint32_t seed, uint32_t step, uint32_t idx) {
+    uint32_t x = (idx * 0x9E3779B1u) ^ seed;
+    x += step * 0x85EBCA77u;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}

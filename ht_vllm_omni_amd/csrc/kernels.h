@@ -1,0 +1,9 @@
+// Internal (non-ABI) launchers shared between translation units.
+#pragma once
+#include <stdint.h>
+
+int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
+             uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
+             int out_stride, void* stream);
+int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
+            void* stream);

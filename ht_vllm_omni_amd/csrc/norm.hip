@@ -1,0 +1,120 @@
+// Fused residual-add + RMSNorm and small row-wise helpers (HBM/L2-bound elementwise work).
+// One wave per row, 16-byte loads, fp32 statistics, wave64 butterfly reduce.
+// Numerics follow HF Qwen3RMSNorm (oracle: talker_oracle.rms_norm):
+//   r = bf16(residual + delta);  out = w * bf16(r * rsqrt(mean(r^2) + eps))   (product rounds to bf16)
+#include "common.cuh"
+#include "kernels.h"
+
+#define NORM_ROWS_PER_BLOCK 4
+
+template <int MAXV>   // MAXV = max 8-element vectors per lane (hidden <= 64*8*MAXV)
+__global__ __launch_bounds__(64 * NORM_ROWS_PER_BLOCK) void rmsnorm_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta, uint16_t* __restrict__ residual,
+    const uint16_t* __restrict__ w, uint16_t* __restrict__ out, int rows, int hidden, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * NORM_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = hidden >> 3;
+    const uint16_t* src = (residual ? residual : x) + (size_t)row * hidden;
+    float v[MAXV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            uint4 a = *reinterpret_cast<const uint4*>(src + vi * 8);
+            const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a);
+            if (delta) {
+                uint4 d = *reinterpret_cast<const uint4*>(delta + (size_t)row * hidden + vi * 8);
+                const uint32_t* dw = reinterpret_cast<const uint32_t*>(&d);
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bfround(bf_lo(aw[j]) + bf_lo(dw[j]));
+                    const float hi = bfround(bf_hi(aw[j]) + bf_hi(dw[j]));
+                    v[i][2 * j] = lo;
+                    v[i][2 * j + 1] = hi;
+                    o[j] = pack_bf2(lo, hi);
+                }
+                *reinterpret_cast<uint4*>(residual + (size_t)row * hidden + vi * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[i][2 * j] = bf_lo(aw[j]);
+                    v[i][2 * j + 1] = bf_hi(aw[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            uint4 ww = *reinterpret_cast<const uint4*>(w + vi * 8);
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(&ww);
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = bf_lo(wp[j]) * bfround(v[i][2 * j] * rstd);
+                const float hi = bf_hi(wp[j]) * bfround(v[i][2 * j + 1] * rstd);
+                o[j] = pack_bf2(lo, hi);
+            }
+            *reinterpret_cast<uint4*>(out + (size_t)row * hidden + vi * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+extern "C" int omni_rmsnorm(const void* x, const void* delta, void* residual, const void* w, void* out, int rows,
+                            int hidden, float eps, void* stream) {
+    OMNI_CHECK_ARG(w && out && (x || residual), "omni_rmsnorm: null pointer");
+    OMNI_CHECK_ARG(!(delta && !residual), "omni_rmsnorm: delta needs residual");
+    OMNI_CHECK_ARG(rows >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 64 * 8 * 8,
+                   "omni_rmsnorm: hidden=%d unsupported (multiple of 8, <= 4096)", hidden);
+    if (rows == 0) return OMNI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + NORM_ROWS_PER_BLOCK - 1) / NORM_ROWS_PER_BLOCK), block(64 * NORM_ROWS_PER_BLOCK);
+    const int nvec = hidden / 8;
+    if (nvec <= 64 * 2)
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
+                           (uint16_t*)residual, (const uint16_t*)w, (uint16_t*)out, rows, hidden, eps);
+    else if (nvec <= 64 * 4)
+        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
+                           (uint16_t*)residual, (const uint16_t*)w, (uint16_t*)out, rows, hidden, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
+                           (uint16_t*)residual, (const uint16_t*)w, (uint16_t*)out, rows, hidden, eps);
+    OMNI_CHECK_LAUNCH("omni_rmsnorm");
+    return OMNI_OK;
+}
+
+// ---- embedding gather: out[t] = table[ids[t]] (ids outside [0,vocab) -> zeros)
+__global__ void embed_kernel(const int32_t* __restrict__ ids, int ids_stride, const uint16_t* __restrict__ table,
+                             uint16_t* __restrict__ out, int T, int hidden, int vocab) {
+    const int t = blockIdx.x;
+    const int id = ids[(size_t)t * ids_stride];
+    const bool ok = id >= 0 && id < vocab;
+    for (int v = threadIdx.x; v < hidden / 8; v += blockDim.x) {
+        uint4 a = ok ? *reinterpret_cast<const uint4*>(table + (size_t)id * hidden + v * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(out + (size_t)t * hidden + v * 8) = a;
+    }
+}
+
+int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
+            void* stream) {
+    OMNI_CHECK_ARG(ids && table && out, "omni_embed: null pointer");
+    OMNI_CHECK_ARG(hidden % 8 == 0, "omni_embed: hidden=%d not a multiple of 8", hidden);
+    if (T <= 0) return OMNI_OK;
+    hipLaunchKernelGGL(embed_kernel, dim3(T), dim3(128), 0, (hipStream_t)stream, ids, ids_stride, (const uint16_t*)table,
+                       (uint16_t*)out, T, hidden, vocab);
+    OMNI_CHECK_LAUNCH("omni_embed");
+    return OMNI_OK;
+}
+
+extern "C" int omni_embed(const int32_t* ids, const void* table, void* out, int T, int hidden, int vocab,
+                          void* stream) {
+    return k_embed(ids, 1, table, out, T, hidden, vocab, stream);
+}

@@ -1,0 +1,140 @@
+// Row sampler: repetition penalty -> temperature -> top-k (radix select, ties kept) -> Gumbel-max
+// with the oracle's counter-based RNG; greedy = first argmax.  One 256-thread workgroup per row,
+// the row (V <= 8192 floats) staged once in LDS.  Oracle: talker_oracle.sample_row.
+#include "common.cuh"
+#include "kernels.h"
+
+#define SMP_THREADS 256
+#define SMP_MAXV 8192
+
+__device__ __forceinline__ uint32_t ord_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// block-wide argmax with smallest-index tie-break; result broadcast to all threads
+__device__ __forceinline__ int block_argmax(float v, int idx, float* sval, int* sidx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sval[wave] = v; sidx[wave] = idx; }
+    __syncthreads();
+    float bv = sval[0];
+    int bi = sidx[0];
+#pragma unroll
+    for (int w = 1; w < SMP_THREADS / 64; ++w)
+        if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+    __syncthreads();
+    return bi;
+}
+
+__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __restrict__ logits, int ld, int V, int greedy,
+                                                             float temperature, int top_k, float rep_penalty,
+                                                             uint8_t* __restrict__ seen, uint32_t seed,
+                                                             int32_t* __restrict__ steps, int step_mul, int step_add,
+                                                             int inc_steps, int32_t* __restrict__ out_ids, int out_stride) {
+    __shared__ float row[SMP_MAXV];
+    __shared__ uint32_t hist[256];
+    __shared__ float sval[SMP_THREADS / 64];
+    __shared__ int sidx[SMP_THREADS / 64];
+    __shared__ uint32_t sel_prefix, sel_k;
+    const int b = blockIdx.x;
+    const float* src = logits + (size_t)b * ld;
+    uint8_t* sn = seen ? seen + (size_t)b * V : nullptr;
+    for (int i = threadIdx.x; i < V; i += SMP_THREADS) {
+        float x = src[i];
+        if (sn && rep_penalty != 1.0f && sn[i]) x = x > 0.f ? x / rep_penalty : x * rep_penalty;
+        if (!greedy) x = x / temperature;
+        row[i] = x;
+    }
+    __syncthreads();
+    int pick;
+    if (greedy) {
+        float bv = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        for (int i = threadIdx.x; i < V; i += SMP_THREADS) {
+            const float x = row[i];
+            if (x > bv || (x == bv && i < bi)) { bv = x; bi = i; }
+        }
+        if (bi == 0x7FFFFFFF) bi = threadIdx.x < V ? threadIdx.x : 0;   // all -inf / NaN row
+        pick = block_argmax(bv, bi, sval, sidx);
+    } else {
+        float kth = -INFINITY;
+        if (top_k > 0 && top_k < V) {
+            // radix select of the top_k-th largest ordered key, 8 bits per pass
+            uint32_t prefix = 0, mask = 0, krem = (uint32_t)top_k;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                for (int i = threadIdx.x; i < 256; i += SMP_THREADS) hist[i] = 0;
+                __syncthreads();
+                for (int i = threadIdx.x; i < V; i += SMP_THREADS) {
+                    const uint32_t k = ord_key(row[i]);
+                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1u);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t cum = 0;
+                    int bin = 255;
+                    for (; bin > 0; --bin) {
+                        if (cum + hist[bin] >= krem) break;
+                        cum += hist[bin];
+                    }
+                    sel_prefix = prefix | ((uint32_t)bin << shift);
+                    sel_k = krem - cum;
+                }
+                __syncthreads();
+                prefix = sel_prefix;
+                krem = sel_k;
+                mask |= 0xFFu << shift;
+                __syncthreads();
+            }
+            const uint32_t kb = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
+            kth = __uint_as_float(kb);
+        }
+        const uint32_t step = (uint32_t)(steps ? steps[b] * step_mul + step_add : step_add);
+        float bv = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        for (int i = threadIdx.x; i < V; i += SMP_THREADS) {
+            const float x = row[i];
+            float sc = -INFINITY;
+            if (x >= kth && x > -INFINITY) {
+                const float u = hash_uniform(seed, step, (uint32_t)i);
+                sc = x - logf(-logf(u));
+            }
+            if (sc > bv || (sc == bv && i < bi)) { bv = sc; bi = i; }
+        }
+        if (bi == 0x7FFFFFFF) bi = 0;
+        pick = block_argmax(bv, bi, sval, sidx);
+    }
+    if (threadIdx.x == 0) {
+        out_ids[(size_t)b * out_stride] = pick;
+        if (sn && pick >= 0 && pick < V) sn[pick] = 1;
+        if (steps && inc_steps) steps[b] += 1;
+    }
+}
+
+int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
+             uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
+             int out_stride, void* stream) {
+    OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
+    OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
+    OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
+    OMNI_CHECK_ARG(rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
+    if (B <= 0) return OMNI_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,
+                       temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids,
+                       out_stride);
+    OMNI_CHECK_LAUNCH("omni_sample");
+    return OMNI_OK;
+}
+
+extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+                           float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
+                           int inc_steps, int32_t* out_ids, void* stream) {
+    return k_sample(logits, ld, B, V, greedy, temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add,
+                    inc_steps, out_ids, 1, stream);
+}

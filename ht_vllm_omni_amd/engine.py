@@ -1,0 +1,271 @@
+"""TalkerEngine: device-resident weights + paged KV cache + the native decode step.
+
+Owns what the reference's ``GPUARModelRunner`` owns for the talker stage (weights, ``kv_caches``,
+persistent per-step input buffers; V/worker/gpu_ar_model_runner.py:62-72,
+V/worker/gpu_model_runner.py:90-119) and drives libomni_talker.so.  Tensor-parallel layout is
+Megatron-style as in vLLM: qkv / gate_up column-sharded by heads / intermediate,
+o_proj / down_proj row-sharded, KV cache sharded by KV head, embed / lm_head / code predictor
+replicated; one all-reduce(sum) of [B,H] bf16 after o_proj and after down_proj (RCCL).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .config import TalkerDims
+
+BF16 = torch.bfloat16
+
+
+def codec_allowed_mask(d: TalkerDims, allow_eos: bool = True) -> torch.Tensor:
+    """Constant logit mask (qwen3_tts_talker.py:386-394): ids [1, codebook) plus codec EOS."""
+    m = torch.zeros(d.vocab, dtype=torch.uint8)
+    lo, hi = 1, min(d.codebook, d.vocab)
+    if hi > lo:
+        m[lo:hi] = 1
+    if allow_eos and 0 <= d.eos_id < d.vocab:
+        m[d.eos_id] = 1
+    return m
+
+
+def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict:
+    """Per-rank slices of one backbone layer."""
+    D = d.head_dim
+    hq_l = d.q_heads // tp
+    if tp <= d.kv_heads:
+        hkv_l = d.kv_heads // tp
+        kv0 = rank * hkv_l
+    else:                       # more ranks than KV heads: replicate (vLLM QKVParallelLinear)
+        hkv_l = 1
+        kv0 = rank // (tp // d.kv_heads)
+    wqkv = w[prefix + "wqkv"]
+    qo, ko, vo = 0, d.q_heads * D, (d.q_heads + d.kv_heads) * D
+    q = wqkv[qo + rank * hq_l * D: qo + (rank + 1) * hq_l * D]
+    k = wqkv[ko + kv0 * D: ko + (kv0 + hkv_l) * D]
+    v = wqkv[vo + kv0 * D: vo + (kv0 + hkv_l) * D]
+    i_l = d.inter // tp
+    wgu = w[prefix + "wgu"]
+    return {
+        "ln1": w[prefix + "ln1"], "ln2": w[prefix + "ln2"], "qnorm": w[prefix + "qnorm"], "knorm": w[prefix + "knorm"],
+        "wqkv": torch.cat([q, k, v], 0).contiguous(),
+        "wo": w[prefix + "wo"][:, rank * hq_l * D:(rank + 1) * hq_l * D].contiguous(),
+        "wgu": torch.cat([wgu[rank * i_l:(rank + 1) * i_l], wgu[d.inter + rank * i_l: d.inter + (rank + 1) * i_l]], 0).contiguous(),
+        "wdown": w[prefix + "wdown"][:, rank * i_l:(rank + 1) * i_l].contiguous(),
+    }
+
+
+class TalkerEngine:
+    def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
+                 block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None):
+        if not torch.cuda.is_available():
+            raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
+        self.lib = L.load()
+        self.d, self.device = dims, torch.device(device)
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
+        self.kv_dtype = kv_dtype
+        self.kv_code = L.KV_CODES[kv_dtype]
+        self.block_size, self.num_blocks, self.max_batch = block_size, num_blocks, max_batch
+        self.hq_l = dims.q_heads // tp_size
+        self.hkv_l = max(dims.kv_heads // tp_size, 1)
+        self.inter_l = dims.inter // tp_size
+        self.bt_stride = (dims.max_model_len + block_size - 1) // block_size
+        dev = self.device
+        d = dims
+
+        # ---- weights -> HBM
+        self._keep: list[torch.Tensor] = []
+
+        def up(t: torch.Tensor) -> torch.Tensor:
+            t = t.to(dev).contiguous()
+            self._keep.append(t)
+            return t
+
+        self.embed = up(weights["embed"])
+        self.final_norm = up(weights["norm"])
+        self.lm_head = up(weights["lm_head"])
+        self.allowed = up(codec_allowed_mask(d, allow_eos))
+        self.cos_sin = up(ops.rope_table(d.max_model_len, d.head_dim, d.rope_theta))
+        self.cp_cos_sin = up(ops.rope_table(d.num_code_groups + 1, d.cp_head_dim, d.cp_rope_theta))
+        self.cp_norm = up(weights["cp.norm"])
+        self.cp_lm_head = up(weights["cp.lm_head"])
+        self.cp_embed = up(weights["cp.embed"])
+        self.cp_proj_w = up(weights["cp.proj_w"]) if d.has_cp_projection else None
+        self.cp_proj_b = up(weights["cp.proj_b"]) if d.has_cp_projection else None
+        names = ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")
+        self._layers = (L.LayerWeights * d.layers)()
+        self.layer_w: list[dict] = []
+        for i in range(d.layers):
+            sh = shard_layer(d, weights, f"l{i}.", tp_rank, tp_size)
+            lw = {n: up(sh[n]) for n in names}
+            self.layer_w.append(lw)
+            for n in names:
+                setattr(self._layers[i], n, lw[n].data_ptr())
+        self._cp_layers = (L.LayerWeights * d.cp_layers)()
+        self.cp_layer_w: list[dict] = []
+        for i in range(d.cp_layers):
+            lw = {n: up(weights[f"cp.l{i}.{n}"]) for n in names}
+            self.cp_layer_w.append(lw)
+            for n in names:
+                setattr(self._cp_layers[i], n, lw[n].data_ptr())
+
+        # ---- paged KV cache, one tensor per layer: [2, num_blocks, block_size, Hkv_local, D]
+        store = {"bf16": BF16, "auto": BF16, "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8}[kv_dtype]
+        shape = (2, num_blocks, block_size, self.hkv_l, d.head_dim)
+        self.kv_caches = [torch.zeros(shape, dtype=store, device=dev) for _ in range(d.layers)]
+        self.kv_scales = ([torch.zeros(shape[:-1], dtype=torch.float32, device=dev) for _ in range(d.layers)]
+                          if self.kv_code == L.KV_INT8 else None)
+        self._kc = (C.c_void_p * d.layers)(*[c[0].data_ptr() for c in self.kv_caches])
+        self._vc = (C.c_void_p * d.layers)(*[c[1].data_ptr() for c in self.kv_caches])
+        if self.kv_scales is not None:
+            self._ks = (C.c_void_p * d.layers)(*[s[0].data_ptr() for s in self.kv_scales])
+            self._vs = (C.c_void_p * d.layers)(*[s[1].data_ptr() for s in self.kv_scales])
+        else:
+            self._ks = self._vs = None
+
+        # ---- descriptor + scratch + native engine
+        desc = L.TalkerDesc()
+        desc.hidden, desc.layers, desc.q_heads, desc.kv_heads = d.hidden, d.layers, self.hq_l, self.hkv_l
+        desc.head_dim, desc.inter, desc.vocab, desc.codebook = d.head_dim, self.inter_l, d.vocab, d.codebook
+        desc.num_code_groups, desc.eps = d.num_code_groups, d.eps
+        desc.cp_hidden, desc.cp_layers, desc.cp_q_heads, desc.cp_kv_heads = d.cp_hidden, d.cp_layers, d.cp_q_heads, d.cp_kv_heads
+        desc.cp_head_dim, desc.cp_inter, desc.has_cp_projection = d.cp_head_dim, d.cp_inter, int(d.has_cp_projection)
+        desc.max_batch, desc.block_size, desc.kv_dtype = max_batch, block_size, self.kv_code
+        desc.max_model_len, desc.bt_stride = d.max_model_len, self.bt_stride
+        desc.k_scale, desc.v_scale = k_scale, v_scale
+        desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
+        desc.layer = C.cast(self._layers, C.POINTER(L.LayerWeights))
+        desc.lm_head, desc.allowed_mask, desc.cos_sin = self.lm_head.data_ptr(), self.allowed.data_ptr(), self.cos_sin.data_ptr()
+        desc.cp_proj_w, desc.cp_proj_b = L.ptr(self.cp_proj_w), L.ptr(self.cp_proj_b)
+        desc.cp_layer = C.cast(self._cp_layers, C.POINTER(L.LayerWeights))
+        desc.cp_norm, desc.cp_lm_head = self.cp_norm.data_ptr(), self.cp_lm_head.data_ptr()
+        desc.cp_embed, desc.cp_cos_sin = self.cp_embed.data_ptr(), self.cp_cos_sin.data_ptr()
+        pvp = C.POINTER(C.c_void_p)
+        desc.k_cache, desc.v_cache = C.cast(self._kc, pvp), C.cast(self._vc, pvp)
+        if self._ks is not None:
+            desc.k_scales, desc.v_scales = C.cast(self._ks, pvp), C.cast(self._vs, pvp)
+        nbytes = self.lib.omni_talker_scratch_bytes(C.byref(desc))
+        if nbytes < 0:
+            raise L.OmniError("omni_talker_scratch_bytes: " + self.lib.omni_last_error().decode())
+        self.scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        desc.scratch, desc.scratch_bytes = self.scratch.data_ptr(), nbytes
+        self._desc = desc
+        self.handle = self.lib.omni_talker_create(C.byref(desc))
+        if not self.handle:
+            raise L.OmniError("omni_talker_create: " + self.lib.omni_last_error().decode())
+
+        # ---- persistent per-step buffers (graph-stable addresses), row r = batch slot r
+        Bm, H, Q = max_batch, d.hidden, d.num_code_groups
+        z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        self.input_ids = z(Bm, dt=torch.int32)
+        self.positions = z(Bm, dt=torch.int32)
+        self.seq_lens = z(Bm, dt=torch.int32)
+        self.block_table = z(Bm, self.bt_stride, dt=torch.int32)
+        self.slot_mapping = z(Bm, dt=torch.int64)
+        self.last_hidden = z(Bm, H, dt=BF16)
+        self.text_step = z(Bm, H, dt=BF16)
+        self.inputs_embeds = z(Bm, H, dt=BF16)
+        self.audio_codes = z(Bm, Q, dt=torch.int64)
+        self.logits = z(Bm, d.vocab, dt=torch.float32)
+        self.seen = z(Bm, d.vocab, dt=torch.uint8)
+        self.steps = z(Bm, dt=torch.int32)
+        self.sampling = dict(greedy=1, temperature=1.0, top_k=0, rep_penalty=1.0, seed=0, cp_greedy=1,
+                             cp_temperature=0.9, cp_top_k=50)
+        self._attn_out = self._scratch_view(self.lib.omni_talker_attn_out(self.handle), Bm * H).view(Bm, H)
+        self._mlp_out = self._scratch_view(self.lib.omni_talker_mlp_out(self.handle), Bm * H).view(Bm, H)
+
+    def _scratch_view(self, p: int, n_bf16: int) -> torch.Tensor:
+        off = p - self.scratch.data_ptr()
+        return self.scratch[off: off + 2 * n_bf16].view(BF16)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.omni_talker_destroy(h)
+
+    # ------------------------------------------------------------------ step
+    def set_sampling(self, **kw) -> None:
+        self.sampling.update(kw)
+
+    def _io(self, B: int, advance: bool) -> L.StepIO:
+        io = L.StepIO()
+        io.B = B
+        for n in ("input_ids", "positions", "seq_lens", "block_table", "slot_mapping", "last_hidden", "text_step",
+                  "inputs_embeds", "audio_codes", "logits", "steps"):
+            setattr(io, n, getattr(self, n).data_ptr())
+        s = self.sampling
+        io.seen = self.seen.data_ptr() if s["rep_penalty"] != 1.0 else None
+        io.greedy, io.temperature, io.top_k = int(s["greedy"]), float(s["temperature"]), int(s["top_k"])
+        io.rep_penalty, io.seed = float(s["rep_penalty"]), int(s["seed"]) & 0xFFFFFFFF
+        io.cp_greedy, io.cp_temperature, io.cp_top_k = int(s["cp_greedy"]), float(s["cp_temperature"]), int(s["cp_top_k"])
+        io.advance = int(advance)
+        return io
+
+    def decode_step(self, B: int, advance: bool = True) -> None:
+        """One talker decode step for rows [0, B) on torch's current stream (capturable)."""
+        io = self._io(B, advance)
+        st = L.current_stream()
+        if self.tp_size == 1:
+            L.check(self.lib.omni_talker_decode_step(self.handle, C.byref(io), st), "omni_talker_decode_step")
+            return
+        import torch.distributed as dist
+        L.check(self.lib.omni_talker_mtp(self.handle, C.byref(io), st), "omni_talker_mtp")
+        for l in range(self.d.layers):
+            L.check(self.lib.omni_talker_layer_attn(self.handle, C.byref(io), l, st), "omni_talker_layer_attn")
+            dist.all_reduce(self._attn_out[:B], group=self.tp_group)
+            L.check(self.lib.omni_talker_layer_mlp(self.handle, C.byref(io), l, st), "omni_talker_layer_mlp")
+            dist.all_reduce(self._mlp_out[:B], group=self.tp_group)
+        L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
+
+    def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
+                block_table: torch.Tensor | None = None) -> torch.Tensor:
+        """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H]."""
+        if self.tp_size != 1:
+            raise L.OmniError("prefill under TP>1 is not wired yet")
+        bt = self.block_table if block_table is None else block_table
+        T = x.shape[0]
+        out = torch.empty_like(x)
+        L.check(self.lib.omni_talker_prefill(self.handle, L.ptr(x), L.ptr(positions), L.ptr(req_of_tok),
+                                             L.ptr(slot_mapping), L.ptr(bt), L.ptr(out), T, L.current_stream()),
+                "omni_talker_prefill")
+        return out
+
+    def compute_logits(self, hidden: torch.Tensor, round_bf16: bool = True) -> torch.Tensor:
+        """lm_head + codec mask (qwen3_tts_talker.py:424-443) -> fp32 [R, vocab]."""
+        R = hidden.shape[0]
+        out = torch.empty(R, self.d.vocab, dtype=torch.float32, device=self.device)
+        L.check(self.lib.omni_talker_logits(self.handle, L.ptr(hidden), L.ptr(out), R, int(round_bf16),
+                                            L.current_stream()), "omni_talker_logits")
+        return out
+
+    def code_predictor(self, layer0_ids, layer0_embed, last_hidden, *, greedy=True, temperature=0.9, top_k=50, seed=0,
+                       steps=None, return_logits=False):
+        B = layer0_ids.shape[0]
+        Q = self.d.num_code_groups
+        codes = torch.empty(B, Q, dtype=torch.int64, device=self.device)
+        lg = torch.empty(B, Q - 1, self.d.codebook, dtype=torch.float32, device=self.device) if return_logits else None
+        L.check(self.lib.omni_talker_code_predictor(
+            self.handle, L.ptr(layer0_ids), L.ptr(layer0_embed), L.ptr(last_hidden), L.ptr(codes), L.ptr(lg), B,
+            int(greedy), float(temperature), int(top_k), int(seed) & 0xFFFFFFFF, L.ptr(steps), L.current_stream()),
+            "omni_talker_code_predictor")
+        return (codes, lg) if return_logits else codes
+
+    # ------------------------------------------------------------------ roofline accounting
+    def step_bytes(self, ctx_lens) -> dict:
+        """Algorithmic HBM bytes of one decode step on this rank (each counted once)."""
+        from .weights import weight_bytes
+        d = self.d
+        wb = weight_bytes(d)
+        kvb = {"bf16": 2, "auto": 2}.get(self.kv_dtype, 1)
+        per_tok = d.layers * 2 * self.hkv_l * d.head_dim * kvb
+        if self.kv_code == L.KV_INT8:
+            per_tok += d.layers * 2 * self.hkv_l * 4
+        kv_rd = int(sum(int(c) for c in ctx_lens)) * per_tok
+        kv_wr = len(ctx_lens) * per_tok
+        return {"weights_backbone": wb["backbone"] // self.tp_size, "lm_head": wb["lm_head"],
+                "code_predictor": wb["code_predictor"], "kv_read": kv_rd, "kv_write": kv_wr,
+                "total": wb["backbone"] // self.tp_size + wb["lm_head"] + wb["code_predictor"] + kv_rd + kv_wr}

@@ -1,0 +1,122 @@
+"""Tensor-level wrappers over the per-op C-ABI entry points (device memory via PyTorch-ROCm,
+arithmetic in libomni_talker.so).  Every wrapper launches on torch's current stream."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.OmniError("omni ops need device tensors (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise L.OmniError("omni ops need contiguous tensors")
+
+
+def rmsnorm(x, w, eps, *, delta=None, residual=None):
+    """out = w * bf16(v * rstd); v = residual(+delta, updated in place) or x."""
+    src = residual if residual is not None else x
+    _chk_dev(x, w, delta, residual)
+    out = torch.empty_like(src)
+    rows, hidden = src.shape
+    L.check(L.load().omni_rmsnorm(L.ptr(x), L.ptr(delta), L.ptr(residual), L.ptr(w), L.ptr(out), rows, hidden,
+                                  float(eps), L.current_stream()), "omni_rmsnorm")
+    return out
+
+
+def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None):
+    """out[M,N] = x[M,K] . w[N,K]^T ; silu_mul: w = [gate|up] rows -> N = rows/2."""
+    _chk_dev(x, w, bias, mask)
+    M, K = x.shape
+    N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
+    dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
+    out = torch.empty(M, N, dtype=dt, device=x.device)
+    L.check(L.load().omni_gemm_bf16(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue,
+                                    L.ptr(mask), L.current_stream()), "omni_gemm_bf16")
+    return out
+
+
+def slot_mapping(block_table, positions, block_size, B_padded=None):
+    _chk_dev(block_table, positions)
+    B = positions.shape[0]
+    Bp = B if B_padded is None else B_padded
+    out = torch.empty(Bp, dtype=torch.int64, device=positions.device)
+    L.check(L.load().omni_slot_mapping(L.ptr(block_table), block_table.stride(0), L.ptr(positions), L.ptr(out), B, Bp,
+                                       block_size, L.current_stream()), "omni_slot_mapping")
+    return out
+
+
+def qknorm_rope_kvwrite(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cache, v_cache, *, q_heads, kv_heads,
+                        head_dim, eps, kv_dtype, k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None):
+    _chk_dev(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cache, v_cache, k_scales, v_scales)
+    T = qkv.shape[0]
+    q = torch.empty(T, q_heads * head_dim, dtype=BF16, device=qkv.device)
+    L.check(L.load().omni_qknorm_rope_kvwrite(
+        L.ptr(qkv), L.ptr(qnorm_w), L.ptr(knorm_w), L.ptr(positions), L.ptr(cos_sin), L.ptr(slots), L.ptr(q),
+        L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), T, q_heads, kv_heads, head_dim, float(eps),
+        kv_dtype, float(k_scale), float(v_scale), L.current_stream()), "omni_qknorm_rope_kvwrite")
+    return q
+
+
+def paged_attn_decode(q, k_cache, v_cache, block_table, seq_lens, *, q_heads, kv_heads, head_dim, block_size, kv_dtype,
+                      k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None, max_seq_len=4096, split=True):
+    _chk_dev(q, k_cache, v_cache, block_table, seq_lens, k_scales, v_scales)
+    B = q.shape[0]
+    out = torch.empty_like(q)
+    ws = None
+    if split:
+        nbytes = L.load().omni_paged_attn_workspace_bytes(B, q_heads, head_dim, max_seq_len)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    L.check(L.load().omni_paged_attn_decode(
+        L.ptr(q), L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), L.ptr(block_table),
+        block_table.stride(0), L.ptr(seq_lens), L.ptr(out), L.ptr(ws), B, q_heads, kv_heads, head_dim, block_size,
+        kv_dtype, float(k_scale), float(v_scale), 1.0 / math.sqrt(head_dim), max_seq_len, L.current_stream()),
+        "omni_paged_attn_decode")
+    return out
+
+
+def paged_attn_prefill(q, k_cache, v_cache, block_table, req_of_tok, positions, *, q_heads, kv_heads, head_dim,
+                       block_size, kv_dtype, k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None):
+    _chk_dev(q, k_cache, v_cache, block_table, req_of_tok, positions, k_scales, v_scales)
+    T = q.shape[0]
+    out = torch.empty_like(q)
+    L.check(L.load().omni_paged_attn_prefill(
+        L.ptr(q), L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), L.ptr(block_table),
+        block_table.stride(0), L.ptr(req_of_tok), L.ptr(positions), L.ptr(out), T, q_heads, kv_heads, head_dim,
+        block_size, kv_dtype, float(k_scale), float(v_scale), 1.0 / math.sqrt(head_dim), L.current_stream()),
+        "omni_paged_attn_prefill")
+    return out
+
+
+def embed(ids, table):
+    _chk_dev(ids, table)
+    T = ids.shape[0]
+    out = torch.empty(T, table.shape[1], dtype=BF16, device=table.device)
+    L.check(L.load().omni_embed(L.ptr(ids), L.ptr(table), L.ptr(out), T, table.shape[1], table.shape[0],
+                                L.current_stream()), "omni_embed")
+    return out
+
+
+def sample(logits, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0, steps=None, step_mul=1,
+           step_add=0, inc_steps=False):
+    _chk_dev(logits, seen, steps)
+    B, V = logits.shape
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    L.check(L.load().omni_sample(L.ptr(logits), logits.stride(0), B, V, int(greedy), float(temperature), int(top_k),
+                                 float(rep_penalty), L.ptr(seen), int(seed) & 0xFFFFFFFF, L.ptr(steps), step_mul,
+                                 step_add, int(inc_steps), L.ptr(out), L.current_stream()), "omni_sample")
+    return out
+
+
+def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
+    """Host-built cos/sin table, bf16 [max_pos][2][head_dim/2]: fp32 cos/sin cast to bf16, the
+    HF / reference numerics (qwen3_tts_code_predictor_vllm.py:80-93)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return torch.stack((freqs.cos(), freqs.sin()), dim=1).to(BF16).contiguous()

@@ -1,0 +1,239 @@
+/*
+ * omni_talker.h -- C-ABI of the MI355X-native talker AR decode path.
+ *
+ * Drop-in boundary for the hot path of heiervang-technologies/ht-vllm-omni
+ * (R/ = the reference tree, V/ = R/vllm_omni).  The reference has no native code
+ * (SURVEY F1): every arithmetic op on this path is reached through vllm==0.18.0
+ * Python call sites.  Each entry point below names the reference call site whose
+ * work it replaces.  Plain pointers and sizes only; all pointers are DEVICE
+ * pointers unless marked host; `stream` is a hipStream_t passed as void*.
+ * Every function is asynchronous on `stream`, performs no allocation and no host
+ * synchronisation (safe under hipStreamBeginCapture), and returns 0 on success or
+ * a negative OMNI_E* code (message via omni_last_error()).  Nothing aborts the
+ * process (V/worker error convention, SURVEY 8b "Error conventions").
+ *
+ * dtypes: bf16 = 16-bit brain float bit pattern; kv_dtype selects the KV-cache
+ * storage: OMNI_KV_BF16 (vLLM cache_dtype "auto"), OMNI_KV_FP8 (OCP e4m3fn,
+ * "fp8"), OMNI_KV_INT8 (build-defined, no reference semantics: SURVEY F3).
+ *
+ * KV cache layout (one allocation per layer), the stacked layout that
+ * V/distributed/omni_connectors/utils/kv_utils.py:52-55 accepts:
+ *     [2][num_blocks][block_size][n_kv_heads][head_dim]  (+ for INT8 a float
+ *     scale array [2][num_blocks][block_size][n_kv_heads])
+ * slot = block_table[row][pos / block_size] * block_size + pos % block_size.
+ */
+#ifndef OMNI_TALKER_H
+#define OMNI_TALKER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMNI_OK 0
+#define OMNI_EINVAL (-1)   /* bad argument / unsupported shape */
+#define OMNI_EHIP (-2)     /* HIP launch error */
+
+#define OMNI_KV_BF16 0
+#define OMNI_KV_FP8 1
+#define OMNI_KV_INT8 2
+
+/* GEMM epilogues */
+#define OMNI_EPI_BF16 0        /* out bf16 [M,N] = bf16(acc + bias)                         */
+#define OMNI_EPI_SILU_MUL 1    /* W = [gate rows | up rows] (2N rows); out bf16 [M,N]       */
+#define OMNI_EPI_F32 2         /* out fp32 [M,N]                                            */
+#define OMNI_EPI_F32_BF16RND 3 /* out fp32 [M,N] holding bf16-rounded values (logits)       */
+
+const char* omni_last_error(void);
+int omni_abi_version(void);
+
+/* ------------------------------------------------------------------ per-op entry points */
+
+/* Fused residual-add + RMSNorm (vLLM fused_add_rms_norm reached inside Qwen3Model layers,
+ * V/model_executor/models/qwen3_tts/qwen3_tts_talker.py:341; HF numerics, see oracle).
+ *   delta    : bf16 [rows,hidden] or NULL            (branch output to add)
+ *   residual : bf16 [rows,hidden] in/out or NULL     (residual <- bf16(residual + delta))
+ *   x        : bf16 [rows,hidden] input when residual == NULL
+ *   out      : bf16 [rows,hidden] = w * bf16(v * rsqrt(mean(v^2)+eps)), v = residual (or x)   */
+int omni_rmsnorm(const void* x, const void* delta, void* residual, const void* w, void* out,
+                 int rows, int hidden, float eps, void* stream);
+
+/* Skinny-M bf16 GEMM  out[M,N] = x[M,K] . W[N,K]^T (+bias[N]), fp32 accumulate on MFMA
+ * (vLLM QKVParallelLinear / RowParallelLinear / MergedColumnParallelLinear / ParallelLMHead
+ * apply(), reached from qwen3_tts_talker.py:341,344-351,431).  M <= 64.
+ *   ldx = row stride of x in elements; mask (EPI_F32*) = uint8 [N] allowed flags or NULL:
+ *   disallowed columns are written as -inf (qwen3_tts_talker.py:435).                        */
+int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out,
+                   int M, int N, int K, int epilogue, const uint8_t* mask, void* stream);
+
+/* Per-head q/k RMSNorm + neox RoPE + KV-cache write with quantisation
+ * (vLLM Qwen3Attention q_norm/k_norm + rotary_emb + reshape_and_cache; slot mapping built at
+ * V/worker/gpu_ar_model_runner.py:239-244, passed via set_forward_context 283-292).
+ *   qkv       : bf16 [T, (Hq+2Hkv)*D]      q_out : bf16 [T, Hq*D]
+ *   positions : int32 [T]                  cos_sin : bf16 [max_pos][2][D/2] (cos | sin, host-built)
+ *   slot_mapping : int64 [T], -1 = padded token (skipped)
+ *   k_cache/v_cache : base of the K / V half of one layer's cache; kv_scales: INT8 only.     */
+int omni_qknorm_rope_kvwrite(const void* qkv, const void* qnorm_w, const void* knorm_w,
+                             const int32_t* positions, const void* cos_sin, const int64_t* slot_mapping,
+                             void* q_out, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
+                             int T, int q_heads, int kv_heads, int head_dim, float eps,
+                             int kv_dtype, float k_scale, float v_scale, void* stream);
+
+/* Slot mapping for a uniform decode batch, computed on device (vLLM BlockTable.compute_slot_mapping,
+ * reached from gpu_ar_model_runner.py:239-244):  slot[r] = bt[r][pos/bs]*bs + pos%bs, -1 when r >= B. */
+int omni_slot_mapping(const int32_t* block_table, int bt_stride, const int32_t* positions,
+                      int64_t* slot_mapping, int B, int B_padded, int block_size, void* stream);
+
+/* Paged-attention decode, query_len = 1 (vLLM attention backend forward inside _model_forward,
+ * gpu_ar_model_runner.py:299-308; metadata built 246-258).
+ *   q : bf16 [B, Hq*D]   out : bf16 [B, Hq*D]   block_table : int32 [B, bt_stride]
+ *   seq_lens : int32 [B] (context length INCLUDING the current token)
+ *   workspace: fp32, >= omni_paged_attn_workspace_bytes(...)                                  */
+int omni_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                           const float* k_scales, const float* v_scales,
+                           const int32_t* block_table, int bt_stride, const int32_t* seq_lens,
+                           void* out, void* workspace, int B, int q_heads, int kv_heads, int head_dim,
+                           int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
+                           int max_seq_len, void* stream);
+int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_dim, int max_seq_len);
+
+/* Causal paged-attention for prefill / mixed batches (correctness path; the MFMA prefill
+ * kernel is the "next" row of SURVEY 8f).  Token t of request r = req_of_tok[t] at absolute
+ * position positions[t] attends cache positions 0..positions[t] of r.                         */
+int omni_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache,
+                            const float* k_scales, const float* v_scales,
+                            const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
+                            const int32_t* positions, void* out, int T, int q_heads, int kv_heads,
+                            int head_dim, int block_size, int kv_dtype, float k_scale, float v_scale,
+                            float sm_scale, void* stream);
+
+/* Embedding row gather  out[t] = table[ids[t]]  (embed_input_ids, qwen3_tts_talker.py:411-412,637). */
+int omni_embed(const int32_t* ids, const void* table, void* out, int T, int hidden, int vocab, void* stream);
+
+/* Sampler (vLLM Sampler reached at gpu_ar_model_runner.py:455; params
+ * V/model_executor/stage_configs/qwen3_tts.yaml:27-34).  logits fp32 [B, ld]; V columns used.
+ *   greedy != 0 : first argmax.  Otherwise: repetition penalty over seen[B,V] (uint8, may be
+ *   NULL) -> /temperature -> top-k (ties kept) -> Gumbel-max with the hash RNG of the oracle
+ *   keyed by (seed, steps[b], column).  out_ids int32 [B]; if seen != NULL the sampled id is
+ *   marked.  steps int32 [B] (device) is incremented when inc_steps != 0.                     */
+int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+                float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul,
+                int step_add, int inc_steps, int32_t* out_ids, void* stream);
+
+/* ------------------------------------------------------------------ talker engine */
+
+typedef struct omni_layer_weights {
+    const void* ln1;    /* bf16 [H]               */
+    const void* wqkv;   /* bf16 [(Hq+2Hkv)D, H]   */
+    const void* qnorm;  /* bf16 [D]               */
+    const void* knorm;  /* bf16 [D]               */
+    const void* wo;     /* bf16 [H, Hq*D]         */
+    const void* ln2;    /* bf16 [H]               */
+    const void* wgu;    /* bf16 [2I, H]           */
+    const void* wdown;  /* bf16 [H, I]            */
+} omni_layer_weights;
+
+typedef struct omni_talker_desc {
+    /* backbone dims (per TP rank) */
+    int hidden, layers, q_heads, kv_heads, head_dim, inter, vocab;
+    int codebook, num_code_groups;
+    float eps;
+    /* code predictor dims */
+    int cp_hidden, cp_layers, cp_q_heads, cp_kv_heads, cp_head_dim, cp_inter;
+    int has_cp_projection;
+    /* runtime */
+    int max_batch, block_size, kv_dtype, max_model_len, bt_stride;
+    float k_scale, v_scale;
+    /* weights (device) */
+    const void* embed;                 /* bf16 [vocab, H]                    */
+    const omni_layer_weights* layer;   /* HOST array [layers]                */
+    const void* final_norm;            /* bf16 [H]                           */
+    const void* lm_head;               /* bf16 [vocab, H]                    */
+    const uint8_t* allowed_mask;       /* uint8 [vocab]                      */
+    const void* cos_sin;               /* bf16 [max_model_len][2][D/2]       */
+    const void* cp_proj_w;             /* bf16 [Hc, H] or NULL               */
+    const void* cp_proj_b;             /* bf16 [Hc]   or NULL                */
+    const omni_layer_weights* cp_layer;/* HOST array [cp_layers]             */
+    const void* cp_norm;               /* bf16 [Hc]                          */
+    const void* cp_lm_head;            /* bf16 [Q-1][codebook][Hc]           */
+    const void* cp_embed;              /* bf16 [Q-1][codebook][H]            */
+    const void* cp_cos_sin;            /* bf16 [Q+1][2][Dc/2]                */
+    /* KV caches (device), HOST arrays [layers] of K-half / V-half base pointers */
+    void* const* k_cache;
+    void* const* v_cache;
+    float* const* k_scales;            /* INT8 only, else NULL               */
+    float* const* v_scales;
+    /* scratch (device), sized by omni_talker_scratch_bytes() */
+    void* scratch;
+    int64_t scratch_bytes;
+} omni_talker_desc;
+
+typedef struct omni_talker omni_talker;
+
+int64_t omni_talker_scratch_bytes(const omni_talker_desc* desc);
+omni_talker* omni_talker_create(const omni_talker_desc* desc);   /* copies the descriptor */
+void omni_talker_destroy(omni_talker* t);
+
+/* Per-step device buffers (persistent, graph-stable addresses).  Row r = batch slot r. */
+typedef struct omni_step_io {
+    int B;                        /* live decode rows, 1..max_batch                        */
+    int32_t* input_ids;           /* [B] in: last sampled layer-0 id; out: newly sampled    */
+    int32_t* positions;           /* [B] in: position of the token computed this step; +1   */
+    int32_t* seq_lens;            /* [B] in: context length incl. this token; +1            */
+    const int32_t* block_table;   /* [B, bt_stride]                                         */
+    int64_t* slot_mapping;        /* [B] out: slots written this step (bit-exact parity)    */
+    void* last_hidden;            /* bf16 [B,H] in: h[t]; out: h[t+1] (postprocess)         */
+    const void* text_step;        /* bf16 [B,H] text-step vector of this step               */
+    void* inputs_embeds;          /* bf16 [B,H] out: x[t+1] fed to the backbone             */
+    int64_t* audio_codes;         /* [B,Q] out: frame [c0..c15][t]                          */
+    float* logits;                /* [B,vocab] out                                          */
+    uint8_t* seen;                /* [B,vocab] repetition-penalty bitmap or NULL            */
+    int32_t* steps;               /* [B] per-request generated-token counters (RNG key)     */
+    /* sampling */
+    int greedy;                   /* talker layer-0 sampler                                 */
+    float temperature; int top_k; float rep_penalty; uint32_t seed;
+    int cp_greedy;                /* code predictor sub-steps                               */
+    float cp_temperature; int cp_top_k;
+    int advance;                  /* !=0: positions/seq_lens += 1 after the step (on device)*/
+} omni_step_io;
+
+/* The four phases of one decode step.  With TP > 1 the host
+ * all-reduces (RCCL) `omni_talker_attn_out` after layer_attn and `omni_talker_mlp_out`
+ * after layer_mlp; with TP == 1 omni_talker_decode_step runs everything.
+ *   mtp        : _preprocess decode branch + _talker_mtp_forward + talker_mtp
+ *                (gpu_model_runner.py:1211-1303, qwen3_tts_talker.py:615-647,1594-1642,
+ *                 qwen3_tts_code_predictor_vllm.py:480-561)
+ *   layer_attn : RMSNorm -> qkv_proj -> q/k-norm+RoPE+KV write -> paged attention -> o_proj
+ *   layer_mlp  : (+residual) RMSNorm -> gate_up_proj -> SiLU*mul -> down_proj
+ *   finish     : final norm, compute_logits (qwen3_tts_talker.py:424-443), sampler
+ *                (gpu_ar_model_runner.py:455), postprocess (qwen3_tts_talker.py:649-655)     */
+int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* stream);
+int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, int layer, void* stream);
+int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int layer, void* stream);
+int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* stream);
+int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream);
+void* omni_talker_attn_out(omni_talker* t);   /* bf16 [max_batch,H] (TP all-reduce buffer)  */
+void* omni_talker_mlp_out(omni_talker* t);    /* bf16 [max_batch,H]                         */
+
+/* Prefill / mixed batch through the backbone only (T tokens, several requests):
+ * x bf16 [T,H] -> hidden bf16 [T,H] (final-normed); writes KV at slot_mapping.
+ * Correctness path for TTFA head (SURVEY 8f rank 2 is its MFMA replacement).                */
+int omni_talker_prefill(omni_talker* t, const void* x, const int32_t* positions,
+                        const int32_t* req_of_tok, const int64_t* slot_mapping,
+                        const int32_t* block_table, void* hidden_out, int T, void* stream);
+
+/* compute_logits on arbitrary rows: hidden bf16 [R,H] -> logits fp32 [R,vocab] (masked). */
+int omni_talker_logits(omni_talker* t, const void* hidden, float* logits, int R, int round_bf16, void* stream);
+
+/* Code predictor alone (parity tests): layer0 ids + layer0 embeds + last hidden -> codes.
+ * (qwen3_tts_code_predictor_vllm.py:480-561).  cp_logits fp32 [B,Q-1,codebook] or NULL.     */
+int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed,
+                               const void* last_hidden, int64_t* codes, float* cp_logits, int B,
+                               int greedy, float temperature, int top_k, uint32_t seed,
+                               const int32_t* steps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNI_TALKER_H */

@@ -250,7 +250,8 @@ def hash_uniform(seed: int, step: int, idx: np.ndarray) -> np.ndarray:
 def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, top_k: int = 0,
                rep_penalty: float = 1.0, seen_ids=None, seed: int = 0, step: int = 0) -> int:
     """One row. Order: repetition penalty -> temperature -> top-k -> softmax ->
-    argmax(probs / Exp(1)) (SURVEY Appendix A 'Sampler order').  Greedy = first argmax."""
+    Gumbel-max, equivalent in distribution to vLLM's argmax(probs / Exp(1)) (SURVEY Appendix A
+    'Sampler order'; vLLM's generator stream is not reproducible here).  Greedy = first argmax."""
     x = logits.to(torch.float32).clone()
     if rep_penalty != 1.0 and seen_ids is not None and len(seen_ids):
         ids = torch.as_tensor(sorted(set(int(i) for i in seen_ids if 0 <= int(i) < x.numel())), dtype=torch.long)
@@ -262,11 +263,30 @@ def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, 
     if top_k and top_k < x.numel():
         kth = torch.topk(x, top_k).values[-1]
         x = x.masked_fill(x < kth, float("-inf"))
-    p = torch.softmax(x, dim=-1).numpy()
-    u = hash_uniform(seed, step, np.arange(p.shape[0]))
-    e = -np.log(u)
-    score = np.where(p > 0, p / e, -1.0).astype(np.float32)
+    # Gumbel-max: argmax(x + g), g = -log(-log u)  ==  argmax(softmax(x) / Exp(1)) in distribution
+    xn = x.numpy().astype(np.float32)
+    u = hash_uniform(seed, step, np.arange(xn.shape[0]))
+    score = np.where(np.isfinite(xn), xn - np.log(-np.log(u)).astype(np.float32), -np.inf).astype(np.float32)
     return int(np.argmax(score))
+
+
+def sample_row_margin(logits: torch.Tensor, **kw) -> float:
+    """Gap between the best and second-best Gumbel score (tests skip near-ties: logf differs
+    by ulps between numpy and the GPU)."""
+    x = logits.to(torch.float32).clone()
+    if kw.get("greedy"):
+        v = torch.topk(x, 2).values
+        return float(v[0] - v[1])
+    x = x / kw.get("temperature", 1.0)
+    top_k = kw.get("top_k", 0)
+    if top_k and top_k < x.numel():
+        kth = torch.topk(x, top_k).values[-1]
+        x = x.masked_fill(x < kth, float("-inf"))
+    xn = x.numpy().astype(np.float32)
+    u = hash_uniform(kw.get("seed", 0), kw.get("step", 0), np.arange(xn.shape[0]))
+    score = np.where(np.isfinite(xn), xn - np.log(-np.log(u)).astype(np.float32), -np.inf)
+    top = np.sort(score)[-2:]
+    return float(top[1] - top[0])
 
 
 # --------------------------------------------------------------------------
@@ -409,8 +429,9 @@ class TalkerOracle:
             logits = linear(hid[:, g], w["cp.lm_head"][g - 1]).to(torch.float32)
             all_logits.append(logits)
             if do_sample and temperature > 0:
+                st = step if hasattr(step, "__len__") else [step] * B
                 nxt = torch.tensor([sample_row(logits[b], greedy=False, temperature=max(temperature, 1e-6),
-                                               top_k=top_k, seed=seed, step=step * Q + g) for b in range(B)])
+                                               top_k=top_k, seed=seed, step=int(st[b]) * Q + g) for b in range(B)])
             else:
                 nxt = logits.argmax(-1)
             codes[:, g] = nxt
@@ -445,7 +466,9 @@ class TalkerOracle:
         e0 = w["embed"][ids]                                            # embed_input_ids (talker.py:637)
         last_h = torch.stack([s.last_hidden for s in states])
         text = torch.stack([(s.tail_text.pop(0) if s.tail_text else s.tts_pad) for s in states])  # talker.py:618-629
-        x, codes = self.talker_mtp(ids, e0, last_h, text, **(cp_kw or {}))
+        cp_kw = dict(cp_kw or {})
+        cp_kw.setdefault("step", [len(s.out_ids) for s in states])     # RNG key = tokens generated so far
+        x, codes = self.talker_mtp(ids, e0, last_h, text, **cp_kw)
         positions = torch.tensor([s.seq_len for s in states], dtype=torch.long)
         seq_after = [s.seq_len + 1 for s in states]
         hidden = self.backbone(x, positions, list(range(B)), block_tables, seq_after)

@@ -1,0 +1,277 @@
+"""Per-op parity: every HIP kernel, called through the C-ABI, against the CPU oracle on the same
+seeded inputs.  Bar: integer/index outputs bit-exact; bf16 outputs within 1 bf16 ulp (same rounding
+points, different fp32 summation order) and fp32 outputs within 1e-3 (north_star tolerance)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import talker_oracle as O
+from tests.util import BF16, assert_bf16_close, assert_f32_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ht_vllm_omni_amd import _lib, ops as _ops
+    _lib.load()
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return _ops
+
+
+def _rand(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(BF16)
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 256), (7, 1024), (64, 2048), (3, 4096), (5, 128)])
+def test_rmsnorm(ops, rows, hidden):
+    g = torch.Generator().manual_seed(rows * 1000 + hidden)
+    x, dl = _rand(g, rows, hidden), _rand(g, rows, hidden)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(BF16)
+    out = ops.rmsnorm(x.cuda(), w.cuda(), 1e-6)
+    assert_bf16_close(out, O.rms_norm(x, w, 1e-6), what="rmsnorm")
+    # fused residual add: residual <- residual + delta (bf16), out = norm(residual)
+    res = x.clone().cuda()
+    out2 = ops.rmsnorm(None, w.cuda(), 1e-6, delta=dl.cuda(), residual=res)
+    r_ref = x + dl
+    assert torch.equal(res.cpu().view(torch.int16), r_ref.view(torch.int16)), "residual add must be bit-exact"
+    assert_bf16_close(out2, O.rms_norm(r_ref, w, 1e-6), what="rmsnorm+residual")
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 33, 64])
+@pytest.mark.parametrize("N,K", [(256, 128), (4096, 2048), (2048, 6144), (3072, 1024), (48, 96)])
+def test_gemm(ops, M, N, K):
+    from ht_vllm_omni_amd import _lib as L
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x, w, b = _rand(g, M, K), _rand(g, N, K, scale=0.05), _rand(g, N, scale=0.1)
+    ref32 = x.float() @ w.float().t()
+    out32 = ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_F32)
+    assert_f32_close(out32, ref32, atol=1e-3 * max(1.0, ref32.abs().max().item() / 8), what="gemm f32")
+    out = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda())
+    assert_bf16_close(out, O.linear(x, w, b), what="gemm bf16+bias")
+    mask = (torch.rand(N, generator=g) > 0.3).to(torch.uint8)
+    outm = ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_F32_BF16RND, mask=mask.cuda())
+    refm = ref32.to(BF16).float().masked_fill(mask == 0, float("-inf"))
+    assert_bf16_close(outm.cpu().nan_to_num(neginf=-1e30), refm.nan_to_num(neginf=-1e30), what="gemm logits+mask")
+    assert torch.equal(torch.isinf(outm.cpu()), torch.isinf(refm))
+
+
+@pytest.mark.parametrize("M", [2, 64])
+@pytest.mark.parametrize("inter,K", [(512, 256), (6144, 2048), (3072, 1024)])
+def test_gemm_silu_mul(ops, M, inter, K):
+    from ht_vllm_omni_amd import _lib as L
+    g = torch.Generator().manual_seed(inter + K + M)
+    x, w = _rand(g, M, K), _rand(g, 2 * inter, K, scale=0.05)
+    out = ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_SILU_MUL)
+    gu = O.linear(x, w)
+    ref = O.silu_mul(gu[:, :inter], gu[:, inter:])
+    assert_bf16_close(out, ref, ulps=2, max_mismatch=0.03, what="gemm silu*mul")
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from ht_vllm_omni_amd import _lib as L
+    x = torch.zeros(65, 64, dtype=BF16, device="cuda")
+    w = torch.zeros(32, 64, dtype=BF16, device="cuda")
+    with pytest.raises(L.OmniError):
+        ops.gemm(x, w)
+    with pytest.raises(L.OmniError):
+        ops.gemm(x[:4, :40].contiguous(), w[:, :40].contiguous())
+
+
+def test_slot_mapping_bit_exact(ops):
+    bs, B = 16, 9
+    g = torch.Generator().manual_seed(1)
+    bt = torch.randint(1, 500, (B, 40), generator=g, dtype=torch.int32)
+    pos = torch.tensor([0, 1, 15, 16, 17, 255, 256, 300, 639], dtype=torch.int32)
+    got = ops.slot_mapping(bt.cuda(), pos.cuda(), bs, B_padded=12).cpu()
+    ref = [O.slot_of(bt[r].tolist(), int(pos[r]), bs) for r in range(B)] + [-1, -1, -1]
+    assert got.tolist() == ref
+
+
+@pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (2, 1)])
+def test_qknorm_rope_kvwrite(ops, kv, hq, hkv):
+    from ht_vllm_omni_amd import _lib as L
+    D, T, nb, bs = 128, 11, 6, 16
+    g = torch.Generator().manual_seed(hq * 10 + hkv)
+    qkv = _rand(g, T, (hq + 2 * hkv) * D, scale=2.0)
+    qn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    kn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    pos = torch.tensor([0, 1, 2, 3, 17, 40, 41, 95, 5, 6, 7], dtype=torch.int32)
+    slots = torch.tensor([16, 17, 18, 19, 33, 40, 41, -1, 85, 86, 95], dtype=torch.int64)  # one padded token
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    cos_sin = ops.rope_table(128, D, 1e6)
+    store = {"bf16": BF16, "fp8": torch.uint8, "int8": torch.int8}[kv]
+    cache = torch.zeros(2, nb, bs, hkv, D, dtype=store, device="cuda")
+    scales = torch.zeros(2, nb, bs, hkv, dtype=torch.float32, device="cuda") if kv == "int8" else None
+    q = ops.qknorm_rope_kvwrite(qkv.cuda(), qn.cuda(), kn.cuda(), pos.cuda(), cos_sin.cuda(), slots.cuda(), cache[0], cache[1],
+                                q_heads=hq, kv_heads=hkv, head_dim=D, eps=1e-6, kv_dtype=L.KV_CODES[kv], k_scale=k_scale,
+                                v_scale=v_scale, k_scales=None if scales is None else scales[0],
+                                v_scales=None if scales is None else scales[1])
+    # oracle
+    cos, sin = O.rope_cos_sin(pos.long(), D, 1e6)
+    qq = qkv[:, : hq * D].reshape(T, hq, D)
+    kk = qkv[:, hq * D:(hq + hkv) * D].reshape(T, hkv, D)
+    vv = qkv[:, (hq + hkv) * D:].reshape(T, hkv, D)
+    q_ref = O.apply_rope(O.rms_norm(qq, qn, 1e-6), cos, sin)
+    k_ref = O.apply_rope(O.rms_norm(kk, kn, 1e-6), cos, sin)
+    assert_bf16_close(q.view(T, hq, D), q_ref, what="q norm+rope")
+    pk = O.PagedKV(nb, bs, hkv, D, kv, k_scale, v_scale)
+    pk.write(slots, k_ref, vv)
+    got = cache.cpu()
+    if kv == "bf16":
+        assert torch.equal(got[1].view(torch.int16), pk.data[1].view(torch.int16)), "V rows are a pure copy"
+        assert_bf16_close(got[0], pk.data[0], what="K cache bf16")
+    elif kv == "fp8":
+        ref = pk.data.view(torch.uint8)
+        assert torch.equal(got[1], ref[1]), "V fp8 bytes must be bit-exact (same input, RNE + saturate)"
+        mism = (got[0] != ref[0]).float().mean().item()
+        assert mism < 0.01, f"K fp8 bytes differ in {mism:.3%}"
+        d = (got[0].view(torch.float8_e4m3fn).float() - ref[0].view(torch.float8_e4m3fn).float()).abs()
+        assert (d <= ref[0].view(torch.float8_e4m3fn).float().abs() * 0.126 + 2 ** -9).all(), "K fp8 beyond 1 ulp"
+    else:
+        assert torch.equal(got[1], pk.data[1]), "V int8 must be bit-exact"
+        assert torch.equal(scales.cpu()[1], pk.scales[1]), "V int8 scales must be bit-exact"
+        assert (got[0].int() - pk.data[0].int()).abs().max().item() <= 1
+        torch.testing.assert_close(scales.cpu()[0], pk.scales[0], rtol=1e-2, atol=0)
+    # padded token (slot -1) must not have been written anywhere: blocks 0 and 2's tail stay zero
+    assert got[:, 0].abs().sum().item() == 0
+
+
+def _fill_cache(kv, nb, bs, hkv, D, gen, k_scale, v_scale):
+    pk = O.PagedKV(nb, bs, hkv, D, kv, k_scale, v_scale)
+    slots = torch.arange(nb * bs)
+    k = _rand(gen, nb * bs, hkv, D, scale=1.5)
+    v = _rand(gen, nb * bs, hkv, D, scale=1.5)
+    pk.write(slots, k, v)
+    return pk
+
+
+@pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1)])
+@pytest.mark.parametrize("split", [False, True])
+def test_paged_attn_decode(ops, kv, hq, hkv, split):
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, nb = 128, 16, 128
+    g = torch.Generator().manual_seed(hq + hkv + len(kv))
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    pk = _fill_cache(kv, nb, bs, hkv, D, g, k_scale, v_scale)
+    seq_lens = [1, 15, 16, 17, 31, 33, 257, 700, 128, 1000]
+    B = len(seq_lens)
+    perm = torch.randperm(nb - 1, generator=g) + 1
+    bt = torch.zeros(B, 64, dtype=torch.int32)
+    ptr = 0
+    for r, n in enumerate(seq_lens):
+        need = (n + bs - 1) // bs
+        bt[r, :need] = perm[(ptr + torch.arange(need)) % (nb - 1)]
+        ptr += 7
+    q = _rand(g, B, hq * D, scale=1.0)
+    store = pk.data.view(torch.uint8) if kv == "fp8" else pk.data
+    cache = store.cuda()
+    sc = pk.scales.cuda() if kv == "int8" else None
+    out = ops.paged_attn_decode(q.cuda(), cache[0], cache[1], bt.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(),
+                                q_heads=hq, kv_heads=hkv, head_dim=D, block_size=bs, kv_dtype=L.KV_CODES[kv],
+                                k_scale=k_scale, v_scale=v_scale, k_scales=None if sc is None else sc[0],
+                                v_scales=None if sc is None else sc[1], max_seq_len=1024, split=split)
+    for r, n in enumerate(seq_lens):
+        kk, vv = pk.gather(bt[r].tolist(), n)
+        ref = O.attention_rows(q[r].view(1, hq, D), kk, vv, torch.tensor([n - 1]), D ** -0.5)
+        assert_bf16_close(out[r].view(1, hq, D), ref, ulps=1, max_mismatch=0.05, what=f"attn row {r} len {n}")
+
+
+def test_paged_attn_prefill_causal(ops):
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, nb, hq, hkv = 128, 16, 32, 4, 2
+    g = torch.Generator().manual_seed(77)
+    pk = _fill_cache("bf16", nb, bs, hkv, D, g, 1.0, 1.0)
+    lens = [5, 33]
+    bt = torch.tensor([[3, 0, 0, 0], [7, 9, 4, 0]], dtype=torch.int32)
+    req = torch.tensor([0] * lens[0] + [1] * lens[1], dtype=torch.int32)
+    pos = torch.tensor(list(range(lens[0])) + list(range(lens[1])), dtype=torch.int32)
+    T = req.numel()
+    q = _rand(g, T, hq * D)
+    cache = pk.data.cuda()
+    out = ops.paged_attn_prefill(q.cuda(), cache[0], cache[1], bt.cuda(), req.cuda(), pos.cuda(), q_heads=hq, kv_heads=hkv,
+                                 head_dim=D, block_size=bs, kv_dtype=L.KV_BF16)
+    o = 0
+    for r, n in enumerate(lens):
+        kk, vv = pk.gather(bt[r].tolist(), n)
+        ref = O.attention_rows(q[o:o + n].view(n, hq, D), kk, vv, torch.arange(n), D ** -0.5)
+        assert_bf16_close(out[o:o + n].view(n, hq, D), ref, max_mismatch=0.05, what=f"prefill req {r}")
+        o += n
+
+
+def test_attention_softmax_property_full_size(ops):
+    """BASELINE size (B=64, 16/8 heads, fp8, ctx U{96..608}): V == const -> output == const exactly,
+    whatever K, q and the block placement are (softmax weights sum to 1)."""
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, hq, hkv, B = 128, 16, 16, 8, 64
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(96, 609, (B,), generator=g)
+    nblk = int(((lens + bs - 1) // bs).sum()) + 1
+    cache = torch.zeros(2, nblk, bs, hkv, D, dtype=torch.uint8, device="cuda")
+    cache[0] = torch.randint(0, 120, cache[0].shape, dtype=torch.uint8, device="cuda")   # positive finite e4m3 patterns
+    cache[1] = 0x38                                                                    # e4m3fn 1.0
+    bt = torch.zeros(B, 64, dtype=torch.int32)
+    nxt = 1
+    for r in range(B):
+        need = int((lens[r] + bs - 1) // bs)
+        bt[r, :need] = torch.arange(nxt, nxt + need)
+        nxt += need
+    q = _rand(g, B, hq * D)
+    out = ops.paged_attn_decode(q.cuda(), cache[0], cache[1], bt.cuda(), lens.to(torch.int32).cuda(), q_heads=hq,
+                                kv_heads=hkv, head_dim=D, block_size=bs, kv_dtype=L.KV_FP8, k_scale=1.0, v_scale=0.75,
+                                max_seq_len=1024)
+    assert (out.float().cpu() - 0.75).abs().max().item() <= 2 ** -8
+
+
+def test_embed(ops):
+    g = torch.Generator().manual_seed(2)
+    tab = _rand(g, 50, 256)
+    ids = torch.tensor([0, 49, 7, 7, 50, -1], dtype=torch.int32)
+    out = ops.embed(ids.cuda(), tab.cuda()).cpu()
+    assert torch.equal(out[:4].view(torch.int16), tab[ids[:4].long()].view(torch.int16))
+    assert out[4:].abs().sum().item() == 0     # out-of-range ids -> zero rows
+
+
+def test_sampler_greedy_and_penalty(ops):
+    g = torch.Generator().manual_seed(3)
+    B, V = 6, 3072
+    logits = torch.randn(B, V, generator=g)
+    logits[:, 2048:] = float("-inf")
+    logits[2, 5] = logits[2, 9] = 50.0            # tie -> first index
+    out = ops.sample(logits.cuda(), greedy=True).cpu()
+    assert out.tolist() == [O.sample_row(logits[b], greedy=True) for b in range(B)]
+    assert out[2].item() == 5
+    seen = torch.zeros(B, V, dtype=torch.uint8)
+    best = logits.argmax(-1)
+    for b in range(B):
+        seen[b, best[b]] = 1
+    seen_d = seen.cuda()
+    out2 = ops.sample(logits.cuda(), greedy=True, rep_penalty=50.0, seen=seen_d).cpu()
+    ref2 = [O.sample_row(logits[b], greedy=True, rep_penalty=50.0, seen_ids=[int(best[b])]) for b in range(B)]
+    assert out2.tolist() == ref2
+    assert all(seen_d.cpu()[b, out2[b]] == 1 for b in range(B)), "sampled id must be marked seen"
+
+
+@pytest.mark.parametrize("V,top_k", [(3072, 50), (2048, 50), (192, 0), (2048, 1)])
+def test_sampler_topk_gumbel(ops, V, top_k):
+    g = torch.Generator().manual_seed(V + top_k)
+    B = 64
+    logits = torch.randn(B, V, generator=g) * 3
+    steps = torch.arange(B, dtype=torch.int32)
+    kw = dict(temperature=0.9, top_k=top_k, seed=42)
+    out = ops.sample(logits.cuda(), greedy=False, steps=steps.cuda(), step_mul=3, step_add=1, **kw).cpu()
+    n_checked = 0
+    for b in range(B):
+        okw = dict(greedy=False, step=int(steps[b]) * 3 + 1, **kw)
+        if O.sample_row_margin(logits[b], **okw) < 1e-4:
+            continue                                     # near-tie: logf ulps may decide
+        assert out[b].item() == O.sample_row(logits[b], **okw), b
+        n_checked += 1
+    assert n_checked >= B - 4
+    if top_k:
+        kth = torch.topk(logits, top_k, dim=-1).values[:, -1]
+        assert (logits[torch.arange(B), out.long()] >= kth).all(), "sample outside the top-k set"

@@ -1,0 +1,35 @@
+"""Shared helpers for the parity tests."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+BF16 = torch.bfloat16
+
+
+def bf16_from_u16(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(a.view(np.int16).copy()).view(BF16)
+
+
+def assert_bf16_close(got: torch.Tensor, ref: torch.Tensor, *, ulps: int = 1, max_mismatch: float = 0.02,
+                      atol: float = 1e-3, what: str = "") -> None:
+    """Both tensors hold bf16 values.  Same rounding points, different fp32 summation order:
+    values agree to `atol` or `ulps` bf16 ulps, and all but `max_mismatch` of them bit-exactly."""
+    g, r = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert g.shape == r.shape, (what, g.shape, r.shape)
+    diff = (g - r).abs()
+    tol = torch.maximum(torch.full_like(r, atol), r.abs() * (2.0 ** -7) * ulps * 1.01)
+    bad = diff > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} values beyond {ulps} ulp; max diff {diff.max().item():.4g}"
+    frac = (diff > 0).float().mean().item()
+    assert frac <= max_mismatch, f"{what}: {frac:.4%} values differ (> {max_mismatch:.2%})"
+
+
+def assert_f32_close(got: torch.Tensor, ref: torch.Tensor, *, atol: float = 1e-3, rtol: float = 0.0, what: str = "") -> None:
+    g, r = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert g.shape == r.shape, (what, g.shape, r.shape)
+    fin = torch.isfinite(r)
+    assert torch.equal(torch.isfinite(g), fin), f"{what}: -inf pattern differs"
+    diff = (g[fin] - r[fin]).abs()
+    lim = atol + rtol * r[fin].abs()
+    assert (diff <= lim).all(), f"{what}: max diff {diff.max().item():.4g} > {atol}"
