@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- talker AR decode throughput on MI355X (BASELINE.json metric).
+
+Workload W3 (BASELINE config #3): Qwen3-TTS-1.7B-shaped talker, random bf16 weights
+(seed 1234), fp8-e4m3fn KV (unit scales), B = 64 concurrent requests, prompt lengths U{32..160}
+(seed 7), KV block 16, sampling T=0.9 / top-k 50 / rep-penalty 1.05 / seed 42 with EOS masked, the
+whole decode step (code predictor + 28-layer backbone + lm_head + sampler) captured as ONE hipGraph.
+A "step" = one decode step of the batch = 64 speech tokens (64 codec frames of 16 codes).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run,
+                                                         tensor-parallel over RCCL, strong scaling)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_engine(args, rank, world):
+    from ht_vllm_omni_amd.config import get_dims
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    from ht_vllm_omni_amd.weights import make_weights
+    d = get_dims(args.model)
+    t0 = time.time()
+    w = make_weights(d, seed=1234, std=0.02)
+    log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
+    eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
+                       device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False)
+    return d, w, eng
+
+
+def setup_requests(d, eng, args):
+    """Prompt lengths, block tables for the whole run (all blocks allocated up front: no host work in
+    the timed loop), prefill through the native path; returns (lens, prefill_ms)."""
+    from ht_vllm_omni_amd.sched import BlockPool
+    B, bs = args.batch, 16
+    rng = np.random.default_rng(7)
+    lens = rng.integers(32, 161, size=B).tolist()
+    total_steps = args.warmup + args.steps + args.ttfa_steps + 2
+    pool = BlockPool(args.num_blocks, bs)
+    g = torch.Generator().manual_seed(7)
+    bt = torch.zeros(eng.max_batch, eng.bt_stride, dtype=torch.int32)
+    for r, n in enumerate(lens):
+        pool.allocate(f"r{r}", n + total_steps)
+        ids = pool.block_ids(f"r{r}")
+        bt[r, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    eng.block_table.copy_(bt)
+    x = (torch.randn(sum(lens), d.hidden, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32)
+    req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32)
+    slots = torch.tensor([int(bt[int(req[t]), int(pos[t]) // bs]) * bs + int(pos[t]) % bs for t in range(len(pos))])
+    pos, req, slots = pos.cuda(), req.cuda(), slots.cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hid = eng.prefill(x, pos, req, slots)
+    last = torch.tensor(np.cumsum(lens) - 1).cuda()
+    hl = hid[last]
+    logits = eng.compute_logits(hl)
+    from ht_vllm_omni_amd import ops
+    s = eng.sampling
+    eng.seen.zero_()
+    eng.seen[:B, d.codec_pad_id] = 1
+    eng.steps.zero_()
+    ids = ops.sample(logits, greedy=False, temperature=s["temperature"], top_k=s["top_k"], rep_penalty=s["rep_penalty"],
+                     seen=eng.seen, seed=s["seed"], steps=eng.steps, inc_steps=True)
+    torch.cuda.synchronize()
+    prefill_ms = (time.perf_counter() - t0) * 1e3
+    eng.input_ids[:B] = ids
+    eng.last_hidden[:B] = hl
+    eng.positions[:B] = torch.tensor(lens, dtype=torch.int32).cuda()
+    eng.seq_lens[:B] = torch.tensor(lens, dtype=torch.int32).cuda() + 1
+    eng.text_step[:B] = (torch.randn(B, d.hidden, generator=g) * 0.05).to(torch.bfloat16).cuda()   # tts_pad_embed rows
+    return lens, prefill_ms
+
+
+def cpu_baseline(d, w, args, lens):
+    """The oracle (CPU restatement of the reference's algorithm, kind 'port') timed on the host cores
+    on a bounded sample: B=64, fp8 KV pre-filled with random bytes at the W3 mean context, a few decode
+    steps (no prefill).  A reported baseline, not the optimisation target."""
+    from oracle import talker_oracle as O
+    B, bs = args.batch, 16
+    n_steps = args.cpu_steps
+    ctx = [n + args.warmup + args.steps // 2 for n in lens]
+    nblk = sum((c + n_steps + bs) // bs for c in ctx) + 1
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nblk, block_size=bs)
+    g = torch.Generator().manual_seed(11)
+    for kv in orc.kv:
+        kv.data.view(torch.uint8).copy_(torch.randint(0, 120, kv.data.shape, generator=g, dtype=torch.uint8))
+    bts, nxt = [], 1
+    for c in ctx:
+        need = (c + n_steps + bs) // bs
+        bts.append(list(range(nxt, nxt + need)))
+        nxt += need
+    pad = (torch.randn(d.hidden, generator=g) * 0.05).to(torch.bfloat16)
+    states = [O.OracleState(seq_len=c, last_id=int(torch.randint(1, d.codebook, (1,), generator=g)),
+                            last_hidden=torch.randn(d.hidden, generator=g).to(torch.bfloat16), tts_pad=pad, prompt_len=lens[i],
+                            out_ids=[1]) for i, c in enumerate(ctx)]
+    samp = dict(temperature=0.9, top_k=50, rep_penalty=1.05, seed=42)
+    cpk = dict(do_sample=True, temperature=0.9, top_k=50, seed=42)
+    orc.decode_step(states, bts, greedy=False, sampling=samp, cp_kw=cpk)      # untimed: fp32 weight views, page-in
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        orc.decode_step(states, bts, greedy=False, sampling=samp, cp_kw=cpk)
+    dt = time.perf_counter() - t0
+    O.clear_weight_cache()
+    return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} decode steps of the CPU oracle (re-prefill code predictor as in the reference), B={B}, "
+                      f"fp8 KV, mean ctx {int(np.mean(ctx))}, no prefill; {dt / n_steps * 1e3:.0f} ms/step"}
+
+
+def copy_probe_gbs():
+    """Achievable HBM bandwidth: device-to-device copy of 1 GiB (read + write bytes / time)."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="tts-1.7b")
+    ap.add_argument("--kv", default="fp8")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--num-blocks", type=int, default=8192)
+    ap.add_argument("--ttfa-steps", type=int, default=16, help="initial_chunk_size at full load (chunk_size_utils.py:12-33)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--greedy", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+
+    d, w, eng = build_engine(args, rank, world)
+    B = args.batch
+    if args.greedy:
+        eng.set_sampling(greedy=1, cp_greedy=1)
+    else:
+        eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9,
+                         cp_top_k=50)
+    lens, prefill_ms = setup_requests(d, eng, args)
+    log(f"[rank {rank}] prefill of {sum(lens)} prompt tokens: {prefill_ms:.1f} ms (correctness path, skinny-GEMM chunks)")
+
+    # ---- capture the whole decode step as one hipGraph
+    graph, use_graph = None, not args.no_graph
+    eng.decode_step(B)                       # eager warm-up step (also the first TTFA step)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.decode_step(B)
+            torch.cuda.synchronize()
+        except Exception as e:               # noqa: BLE001
+            log(f"[rank {rank}] hipGraph capture failed ({e!r}); falling back to eager launches")
+            graph = None
+    run = (graph.replay if graph is not None else (lambda: eng.decode_step(B)))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- TTFA: prefill + IC decode steps (IC = 16 at full load), vocoder / HTTP excluded
+    steps_done = 2 if graph is not None else 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(max(args.ttfa_steps - steps_done, 0)):
+        run()
+    sync()
+    ic_ms = (time.perf_counter() - t0) * 1e3 / max(args.ttfa_steps - steps_done, 1) * args.ttfa_steps
+    ttfa_ms = prefill_ms + ic_ms
+
+    for _ in range(args.warmup):
+        run()
+    sync()
+    ctx0 = eng.seq_lens[:B].cpu().numpy().astype(np.int64)          # context incl. the token of the next step
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        run()
+    e1.record()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ev_ms = e0.elapsed_time(e1) / args.steps
+
+    # ---- roofline: algorithmic bytes of one step (each counted once) / measured step time
+    mean_ctx = ctx0 + (args.steps - 1) / 2.0
+    by = eng.step_bytes(mean_ctx)
+    achieved = by["total"] / (ev_ms * 1e-3) / 1e9
+    out = {
+        "metric": "speech-tokens/sec", "value": B * args.steps / dt, "unit": "speech-tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"W3: Qwen3-TTS-1.7B-shaped talker decode, random bf16 weights, {args.kv} KV, B={B}, "
+                               f"prompts U{{32..160}} seed 7, KV block 16, T=0.9/top-k 50/rep 1.05 sampling"
+                               if args.model == "tts-1.7b" else f"{args.model} {args.kv} B={B}",
+                   "model": args.model, "kv_cache": args.kv, "batch": B, "mean_ctx": float(np.mean(mean_ctx)),
+                   "parallelism": f"tp{world}", "hipgraph": graph is not None,
+                   "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42"},
+        "p50_ttfa_ms": ttfa_ms, "ttfa": {"prefill_ms": prefill_ms, "ic_steps": args.ttfa_steps, "ic_ms": ic_ms},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "launch": "one hipGraph replay = one decode step (per TP rank)", "event_ms_per_step": ev_ms,
+                     "bytes_per_step": by},
+    }
+    if rank == 0:
+        try:
+            out["roofline"]["copy_probe_gbs"] = copy_probe_gbs()
+        except Exception as e:   # noqa: BLE001
+            log(f"copy probe failed: {e!r}")
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                del eng
+                torch.cuda.empty_cache()
+                out["cpu_baseline"] = cpu_baseline(d, w, args, lens)
+            except Exception as e:   # noqa: BLE001
+                log(f"cpu baseline failed: {e!r}")
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,3 +33,19 @@ def assert_f32_close(got: torch.Tensor, ref: torch.Tensor, *, atol: float = 1e-3
     diff = (g[fin] - r[fin]).abs()
     lim = atol + rtol * r[fin].abs()
     assert (diff <= lim).all(), f"{what}: max diff {diff.max().item():.4g} > {atol}"
+
+
+def assert_e2e_close(got: torch.Tensor, ref: torch.Tensor, *, mean_tol: float = 4e-3, what: str = "") -> None:
+    """End-to-end (multi-layer) comparison of bf16 activations / logits.  A 1-ulp rounding flip
+    upstream moves every downstream value by an absolute amount, so the bound is stated at the
+    tensor's scale: max |diff| <= 2 bf16 ulps of the largest magnitude, mean |diff| <= mean_tol
+    (1e-3, the north_star tolerance, at the BASELINE weight scale; see DESIGN.md 'Parity')."""
+    g, r = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert g.shape == r.shape, (what, g.shape, r.shape)
+    fin = torch.isfinite(r)
+    assert torch.equal(torch.isfinite(g), fin), f"{what}: -inf pattern differs"
+    d = (g[fin] - r[fin]).abs()
+    amax = r[fin].abs().max().item()
+    ulp = 2.0 ** (int(np.floor(np.log2(max(amax, 1e-30)))) - 7)
+    assert d.max().item() <= 2.02 * ulp, f"{what}: max diff {d.max().item():.4g} > 2 ulp ({2 * ulp:.4g}) at scale {amax:.3g}"
+    assert d.mean().item() <= mean_tol, f"{what}: mean diff {d.mean().item():.4g} > {mean_tol}"
