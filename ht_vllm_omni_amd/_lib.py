@@ -39,7 +39,7 @@ class TalkerDesc(C.Structure):
         ("k_scale", f32), ("v_scale", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),
         ("cos_sin", vp), ("cp_proj_w", vp), ("cp_proj_b", vp), ("cp_layer", C.POINTER(LayerWeights)), ("cp_norm", vp),
-        ("cp_lm_head", vp), ("cp_embed", vp), ("cp_cos_sin", vp),
+        ("cp_lm_head", vp), ("cp_embed", vp), ("cp_cos_sin", vp), ("cp_proj_table", vp), ("cp_e0_table", vp),
         ("k_cache", C.POINTER(vp)), ("v_cache", C.POINTER(vp)), ("k_scales", C.POINTER(vp)), ("v_scales", C.POINTER(vp)),
         ("scratch", vp), ("scratch_bytes", i64),
     ]
@@ -62,6 +62,9 @@ SIGNATURES = {
     "omni_abi_version": (i32, []),
     "omni_rmsnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_gemm_resid_norm": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                     f32, f32, f32, i32, vp]),
     "omni_qknorm_rope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),
     "omni_slot_mapping": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
     "omni_paged_attn_decode": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, vp]),

@@ -28,12 +28,11 @@ extern "C" int omni_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------ small step kernels
 // x[t+1] = bf16( bf16( sum_fp32(e0, emb_1..emb_{Q-1}) ) + text_step ); invalid layer-0 id -> frame of zeros
-// (qwen3_tts_talker.py:1630-1641).  One block per row.
-__global__ void mtp_finalize_kernel(const int32_t* __restrict__ input_ids, int32_t* __restrict__ codes /*[B,Q]*/,
-                                    const uint16_t* __restrict__ e0, const uint16_t* __restrict__ cp_embed,
-                                    const uint16_t* __restrict__ text_step, uint16_t* __restrict__ x_out,
-                                    uint16_t* __restrict__ resid_out, int64_t* __restrict__ audio_codes, int H, int Q,
-                                    int codebook) {
+// (qwen3_tts_talker.py:1630-1641).  One block per row, 8 elements (16 B) per thread, all gathers independent.
+__global__ __launch_bounds__(256) void mtp_finalize_kernel(
+    const int32_t* __restrict__ input_ids, const int32_t* __restrict__ codes /*[B,Q]*/, const uint16_t* __restrict__ embed,
+    int vocab, const uint16_t* __restrict__ cp_embed, const uint16_t* __restrict__ text_step, uint16_t* __restrict__ x_out,
+    uint16_t* __restrict__ resid_out, int64_t* __restrict__ audio_codes, int H, int Q, int codebook) {
     const int b = blockIdx.x;
     const int c0 = input_ids[b];
     const bool invalid0 = c0 < 0 || c0 >= codebook;
@@ -45,13 +44,32 @@ __global__ void mtp_finalize_kernel(const int32_t* __restrict__ input_ids, int32
         audio_codes[(size_t)b * Q + threadIdx.x] = (int64_t)c;
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < H; h += blockDim.x) {
-        float s = bf2f(e0[(size_t)b * H + h]);
-        for (int g = 1; g < Q; ++g) s += bf2f(cp_embed[((size_t)(g - 1) * codebook + cg[g]) * H + h]);
-        const float y = bfround(bfround(s) + bf2f(text_step[(size_t)b * H + h]));
-        const uint16_t o = f2bf(y);
-        x_out[(size_t)b * H + h] = o;
-        resid_out[(size_t)b * H + h] = o;
+    for (int v = threadIdx.x; v < H / 8; v += blockDim.x) {
+        float s[8];
+        {
+            // e0 = embed_input_ids(last sampled id): the id itself, not the zeroed code (talker.py:1636)
+            const bool ok = c0 >= 0 && c0 < vocab;
+            const uint4 e = ok ? *reinterpret_cast<const uint4*>(embed + (size_t)c0 * H + v * 8) : make_uint4(0, 0, 0, 0);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[2 * j] = bf_lo(w[j]); s[2 * j + 1] = bf_hi(w[j]); }
+        }
+#pragma unroll 4
+        for (int g = 1; g < Q; ++g) {
+            const uint4 e = *reinterpret_cast<const uint4*>(cp_embed + ((size_t)(g - 1) * codebook + cg[g]) * H + v * 8);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[2 * j] += bf_lo(w[j]); s[2 * j + 1] += bf_hi(w[j]); }
+        }
+        const uint4 tx = *reinterpret_cast<const uint4*>(text_step + (size_t)b * H + v * 8);
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(&tx);
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf2(bfround(s[2 * j]) + bf_lo(tw[j]), bfround(s[2 * j + 1]) + bf_hi(tw[j]));
+        const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(x_out + (size_t)b * H + v * 8) = ov;
+        *reinterpret_cast<uint4*>(resid_out + (size_t)b * H + v * 8) = ov;
     }
 }
 
@@ -245,71 +263,84 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
     return OMNI_OK;
 }
 
-// ---- one code-predictor forward pass at buffer position p (input rows in t->cp_in)
+// ---- fused-or-fallback building blocks --------------------------------------------------------
+// out = epilogue( rmsnorm(resid (+delta)) . W^T ); resid updated in place; one launch when K allows it
+static int norm_gemm(omni_talker* t, uint16_t* resid, const uint16_t* delta, const void* norm_w, uint16_t* normed_scratch,
+                     void* normed_out, const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask,
+                     void* st) {
+    const float eps = t->d.eps;
+    if (k_gemm_rn_supported(K))
+        return omni_gemm_resid_norm(resid, delta, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
+    uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
+    TRY(omni_rmsnorm(nullptr, delta, resid, norm_w, nx, rows, K, eps, st));
+    return omni_gemm_bf16(nx, K, w, nullptr, out, rows, N, K, epi, mask, st);
+}
+
+// ---- one code-predictor forward pass at buffer position p (input rows = residual stream in t->cp_resid)
+// leaves the last layer's MLP output in t->cp_mlp (the final norm is fused into the lm_head GEMM)
 static int cp_forward(omni_talker* t, int B, int p, void* st) {
     const omni_talker_desc& d = t->d;
     const int Hc = d.cp_hidden, hq = d.cp_q_heads, hkv = d.cp_kv_heads, D = d.cp_head_dim;
     const int Bm = t->Bm;
+    const float sm = 1.0f / sqrtf((float)D);
     for (int l = 0; l < d.cp_layers; ++l) {
         const omni_layer_weights& w = t->cp_layer[l];
-        if (l == 0)
-            TRY(omni_rmsnorm(t->cp_in, nullptr, nullptr, w.ln1, t->cp_normed, B, Hc, d.eps, st));
-        else
-            TRY(omni_rmsnorm(nullptr, t->cp_mlp, t->cp_resid, w.ln1, t->cp_normed, B, Hc, d.eps, st));
-        TRY(omni_gemm_bf16(t->cp_normed, Hc, w.wqkv, nullptr, t->cp_qkv, B, (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
-        TRY(omni_qknorm_rope_kvwrite(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin,
-                                     t->cp_slots + (size_t)p * Bm, t->cp_q, t->cp_k[l], t->cp_v[l], nullptr, nullptr, B,
-                                     hq, hkv, D, d.eps, OMNI_KV_BF16, 1.f, 1.f, st));
-        TRY(omni_paged_attn_decode(t->cp_q, t->cp_k[l], t->cp_v[l], nullptr, nullptr, t->cp_bt, 1,
-                                   t->cp_seq + (size_t)p * Bm, t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs,
-                                   OMNI_KV_BF16, 1.f, 1.f, 1.0f / sqrtf((float)D), t->cp_bs, st));
+        TRY(norm_gemm(t, t->cp_resid, l == 0 ? nullptr : t->cp_mlp, w.ln1, t->cp_normed, nullptr, w.wqkv, t->cp_qkv, B,
+                      (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
+        TRY(omni_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
+                                   t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
+                                   t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, st));
         TRY(omni_gemm_bf16(t->cp_attn, hq * D, w.wo, nullptr, t->cp_o, B, Hc, hq * D, OMNI_EPI_BF16, nullptr, st));
-        if (l == 0) {
-            // residual stream starts as the projected input row
-            hipError_t e = hipMemcpyAsync(t->cp_resid, t->cp_in, (size_t)B * Hc * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
-            if (e != hipSuccess) { omni_set_error("cp_forward: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
-        }
-        TRY(omni_rmsnorm(nullptr, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, B, Hc, d.eps, st));
-        TRY(omni_gemm_bf16(t->cp_normed, Hc, w.wgu, nullptr, t->cp_act, B, d.cp_inter, Hc, OMNI_EPI_SILU_MUL, nullptr, st));
+        TRY(norm_gemm(t, t->cp_resid, t->cp_o, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter, Hc,
+                      OMNI_EPI_SILU_MUL, nullptr, st));
         TRY(omni_gemm_bf16(t->cp_act, d.cp_inter, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, OMNI_EPI_BF16, nullptr, st));
     }
-    TRY(omni_rmsnorm(nullptr, t->cp_mlp, t->cp_resid, d.cp_norm, t->cp_hidden, B, Hc, d.eps, st));
     return OMNI_OK;
 }
 
+// small_to_mtp_projection of arbitrary rows into the residual stream (code_predictor_vllm.py:528-529)
 static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, void* st) {
     const omni_talker_desc& d = t->d;
     if (d.has_cp_projection)
-        return omni_gemm_bf16(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_in, B, d.cp_hidden, d.hidden, OMNI_EPI_BF16, nullptr, st);
-    hipError_t e = hipMemcpyAsync(t->cp_in, rows, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
+        return omni_gemm_bf16(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_resid, B, d.cp_hidden, d.hidden, OMNI_EPI_BF16, nullptr, st);
+    hipError_t e = hipMemcpyAsync(t->cp_resid, rows, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
     if (e != hipSuccess) { omni_set_error("cp_project: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
     return OMNI_OK;
 }
 
-// codes int32 [B,Q] in t->codes (column 0 untouched); cp_logits fp32 [B,Q-1,codebook] optional
-static int run_code_predictor(omni_talker* t, const void* layer0_embed, const void* last_hidden, int B, int greedy,
-                              float temperature, int top_k, uint32_t seed, int32_t* steps, float* cp_logits_out, void* st) {
+// codes int32 [B,Q] in t->codes (column 0 untouched); cp_logits fp32 [B,Q-1,codebook] optional.
+// layer0_ids != NULL and d.cp_e0_table: position-1 input is gathered from the folded table instead of projected.
+static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed, const void* last_hidden,
+                              int B, int greedy, float temperature, int top_k, uint32_t seed, int32_t* steps,
+                              float* cp_logits_out, void* st) {
     const omni_talker_desc& d = t->d;
-    const int Q = d.num_code_groups;
+    const int Q = d.num_code_groups, Hc = d.cp_hidden;
     if (Q <= 1) return OMNI_OK;
     TRY(cp_project(t, last_hidden, B, st));
     TRY(cp_forward(t, B, 0, st));
-    TRY(cp_project(t, layer0_embed, B, st));
+    if (layer0_ids && d.cp_e0_table)
+        TRY(k_embed(layer0_ids, 1, d.cp_e0_table, t->cp_resid, B, Hc, d.vocab, st));
+    else
+        TRY(cp_project(t, layer0_embed, B, st));
     for (int g = 1; g < Q; ++g) {
         TRY(cp_forward(t, B, g, st));
-        const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * d.cp_hidden;
-        TRY(omni_gemm_bf16(t->cp_hidden, d.cp_hidden, head, nullptr, t->cp_logits, B, d.codebook, d.cp_hidden,
-                           OMNI_EPI_F32_BF16RND, nullptr, st));
+        const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
+        TRY(norm_gemm(t, t->cp_resid, t->cp_mlp, d.cp_norm, t->cp_normed, nullptr, head, t->cp_logits, B, d.codebook, Hc,
+                      OMNI_EPI_F32_BF16RND, nullptr, st));
         if (cp_logits_out) {
             hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
                                             t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,
                                             hipMemcpyDeviceToDevice, (hipStream_t)st);
             if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         }
-        // RNG key = steps[b] * Q + g (oracle: step * Q + g)
-        TRY(k_sample(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q, g,
-                     0, t->codes + g, Q, st));
-        if (g < Q - 1) {
+        // RNG key = steps[b] * Q + g (oracle: step * Q + g); the sampled code's projected embedding row is
+        // gathered straight into the residual stream when the folded table exists
+        const bool more = g < Q - 1;
+        const uint16_t* ptab = (more && d.cp_proj_table)
+                                   ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
+        TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q,
+                            g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, st));
+        if (more && !ptab) {
             const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
             TRY(k_embed(t->codes + g, Q, tab, t->cp_row, B, d.hidden, d.codebook, st));
             TRY(cp_project(t, t->cp_row, B, st));
@@ -327,8 +358,9 @@ extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemcpy2DAsync(t->codes, (size_t)Q * 4, layer0_ids, 4, 4, B, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
-    TRY(run_code_predictor(t, layer0_embed, last_hidden, B, greedy, temperature, top_k, seed, const_cast<int32_t*>(steps),
-                           cp_logits, stream));
+    // explicit layer0_embed given: project it (parity entry point; the folded e0 table is the step path)
+    TRY(run_code_predictor(t, nullptr, layer0_embed, last_hidden, B, greedy, temperature, top_k, seed,
+                           const_cast<int32_t*>(steps), cp_logits, stream));
     hipLaunchKernelGGL(copy_i32_to_i64_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, st, t->codes, codes, B * Q);
     OMNI_CHECK_LAUNCH("copy_i32_to_i64");
     return OMNI_OK;
@@ -339,40 +371,45 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
     const omni_talker_desc& d = t->d;
     const int B = io->B, Q = d.num_code_groups;
     hipStream_t st = (hipStream_t)stream;
-    // slots of the token computed this step (bit-exact parity output)
-    TRY(omni_slot_mapping(io->block_table, d.bt_stride, io->positions, io->slot_mapping, B, B, d.block_size, stream));
-    // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640)
-    TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
-    TRY(run_code_predictor(t, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->seed,
-                           io->steps, nullptr, stream));
-    hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, t->e0,
-                       (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds, t->resid,
-                       io->audio_codes, d.hidden, Q, d.codebook);
+    // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640): gathered only when no folded table
+    if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
+    TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k,
+                           io->seed, io->steps, nullptr, stream));
+    hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, (const uint16_t*)d.embed,
+                       d.vocab, (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds,
+                       t->resid, io->audio_codes, d.hidden, Q, d.codebook);
     OMNI_CHECK_LAUNCH("mtp_finalize");
     return OMNI_OK;
 }
 
-static int layer_attn_rows(omni_talker* t, int l, int rows, const int32_t* positions, const int64_t* slots,
-                           const int32_t* block_table, const int32_t* seq_lens, const int32_t* req_of_tok, void* st) {
+// decode rows: fused norm+qkv, fused rope/kv-write/attention, o_proj
+static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st) {
+    const omni_talker_desc& d = t->d;
+    const omni_layer_weights& w = t->layer[l];
+    const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
+    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, B,
+                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
+    TRY(omni_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
+                               t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
+                               l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
+                               d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, st));
+    TRY(omni_gemm_bf16(t->attn, hq * D, w.wo, nullptr, t->attn_out, B, H, hq * D, OMNI_EPI_BF16, nullptr, st));
+    return OMNI_OK;
+}
+
+// prefill / mixed rows (correctness path): separate rope + KV write, causal attention through the cache
+static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* positions, const int64_t* slots,
+                              const int32_t* block_table, const int32_t* req_of_tok, void* st) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim;
-    if (l == 0)
-        TRY(omni_rmsnorm(nullptr, nullptr, t->resid, w.ln1, t->normed, rows, H, d.eps, st));
-    else
-        TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, w.ln1, t->normed, rows, H, d.eps, st));
-    TRY(omni_gemm_bf16(t->normed, H, w.wqkv, nullptr, t->qkv, rows, (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
+    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, rows,
+                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
     TRY(omni_qknorm_rope_kvwrite(t->qkv, w.qnorm, w.knorm, positions, d.cos_sin, slots, t->q, t->k_cache[l], t->v_cache[l],
                                  t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, d.k_scale, d.v_scale, st));
-    const float sm = 1.0f / sqrtf((float)D);
-    if (req_of_tok)
-        TRY(omni_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table,
-                                    d.bt_stride, req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype,
-                                    d.k_scale, d.v_scale, sm, st));
-    else
-        TRY(omni_paged_attn_decode(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table,
-                                   d.bt_stride, seq_lens, t->attn, t->attn_ws, rows, hq, hkv, D, d.block_size, d.kv_dtype,
-                                   d.k_scale, d.v_scale, sm, d.max_model_len, st));
+    TRY(omni_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table, d.bt_stride,
+                                req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale,
+                                d.v_scale, 1.0f / sqrtf((float)D), st));
     TRY(omni_gemm_bf16(t->attn, hq * D, w.wo, nullptr, t->attn_out, rows, H, hq * D, OMNI_EPI_BF16, nullptr, st));
     return OMNI_OK;
 }
@@ -380,8 +417,8 @@ static int layer_attn_rows(omni_talker* t, int l, int rows, const int32_t* posit
 static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
-    TRY(omni_rmsnorm(nullptr, t->attn_out, t->resid, w.ln2, t->normed, rows, d.hidden, d.eps, st));
-    TRY(omni_gemm_bf16(t->normed, d.hidden, w.wgu, nullptr, t->act, rows, d.inter, d.hidden, OMNI_EPI_SILU_MUL, nullptr, st));
+    TRY(norm_gemm(t, t->resid, t->attn_out, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
+                  OMNI_EPI_SILU_MUL, nullptr, st));
     TRY(omni_gemm_bf16(t->act, d.inter, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, OMNI_EPI_BF16, nullptr, st));
     return OMNI_OK;
 }
@@ -389,7 +426,7 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
 extern "C" int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
     TRY(check_io(t, io));
     OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_attn: layer=%d", layer);
-    return layer_attn_rows(t, layer, io->B, io->positions, io->slot_mapping, io->block_table, io->seq_lens, nullptr, stream);
+    return layer_attn_decode(t, layer, io, stream);
 }
 
 extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
@@ -415,13 +452,12 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     const omni_talker_desc& d = t->d;
     const int B = io->B;
     hipStream_t st = (hipStream_t)stream;
-    TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, d.final_norm, t->hidden, B, d.hidden, d.eps, stream));
-    TRY(omni_talker_logits(t, t->hidden, io->logits, B, 1, stream));
+    // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
+    // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
+    TRY(norm_gemm(t, t->resid, t->mlp_out, d.final_norm, reinterpret_cast<uint16_t*>(io->last_hidden), io->last_hidden,
+                  d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, stream));
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream));
-    // postprocess: keep h[t+1] for the next step's code predictor (qwen3_tts_talker.py:649-655)
-    hipError_t e = hipMemcpyAsync(io->last_hidden, t->hidden, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) { omni_set_error("finish: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
     if (io->advance) {
         hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, io->positions, io->seq_lens, B);
         OMNI_CHECK_LAUNCH("advance");
@@ -453,7 +489,7 @@ extern "C" int omni_talker_prefill(omni_talker* t, const void* x, const int32_t*
                                       (size_t)rows * d.hidden * 2, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { omni_set_error("prefill: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         for (int l = 0; l < d.layers; ++l) {
-            TRY(layer_attn_rows(t, l, rows, positions + t0, slot_mapping + t0, block_table, nullptr, req_of_tok + t0, stream));
+            TRY(layer_attn_prefill(t, l, rows, positions + t0, slot_mapping + t0, block_table, req_of_tok + t0, stream));
             TRY(layer_mlp_rows(t, l, rows, stream));
         }
         TRY(omni_rmsnorm(nullptr, t->mlp_out, t->resid, d.final_norm,

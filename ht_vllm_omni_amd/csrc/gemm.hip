@@ -1,46 +1,69 @@
-// Skinny-M (M <= 64) bf16 GEMM for the decode step: out[M,N] = x[M,K] . W[N,K]^T.
+// Skinny-M (M <= 64) bf16 GEMM for the decode step: out[M,N] = x[M,K] . W[N,K]^T, with the
+// residual-add + RMSNorm of the producing layer optionally fused into the prologue.
 //
 // HBM-bound weight streaming (64 FLOP/B << MFMA ridge): W is read exactly once, straight from
-// HBM into MFMA A-operand registers (no LDS round trip: each W element feeds one wave only);
-// x (<= 64 x K, L2-resident) is the B operand.  v_mfma_f32_16x16x32_bf16:
+// HBM into MFMA A-operand registers with non-temporal loads (each W element feeds one wave only,
+// and keeping it out of L2 leaves the activations and kernel code L2-resident); x (<= 64 x K,
+// L2-resident) is the B operand.  v_mfma_f32_16x16x32_bf16:
 //   A lane(r = l&15, q = l>>4) = W[n0 + r][k0 + 8q .. +8)      (16 rows x 64 B per load)
 //   B lane(c = l&15, q)        = x[m0 + c][k0 + 8q .. +8)
 //   D[n][m]: lane holds m = l&15, n = 4*(l>>4) + reg.
-// One workgroup = 8 waves = one group of NT 16-row n-tiles; the waves split K (k-steps
-// interleaved w, w+8, ...) and combine through LDS, so every CU has 8+ KB of W in flight per
-// load round.  fp32 accumulate, one rounding to bf16 (oracle: talker_oracle.linear).
+// Workgroup = 8 waves = one group of NT 16-row n-tiles x MT 16-row m-tiles; grid = (n groups,
+// m splits) sized to >= 256 workgroups.  The 8 waves split K (k-steps interleaved w, w+8, ...),
+// loads are software-pipelined two groups deep, partial sums combine through LDS.
+// fp32 accumulate, one rounding to bf16 (oracle: talker_oracle.linear / rms_norm).
+//
+// PRO_RN prologue (K = hidden <= 2048, K % 256 == 0): every workgroup rebuilds the normalised
+// activation rows it needs from the residual stream:
+//   r = bf16(resid + delta);  x = w * bf16(r * rsqrt(mean(r^2) + eps))
+// (64 x K elements, ~2 us of VALU, instead of a separate 5-6 us kernel launch); the workgroups
+// with blockIdx.x == 0 write r back (and x, when the caller wants the normalised rows).
 #include "common.cuh"
+#include "kernels.h"
 
 #define GEMM_WAVES 8
 #define GEMM_THREADS (GEMM_WAVES * 64)
+#define GEMM_U 4          // k-steps per pipelined load group
+#define RN_MAX_STEPS 8    // PRO_RN: k-steps per wave (K <= 32 * 8 * 8 = 2048)
 
-template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
-    const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-    void* __restrict__ out, int M, int N, int K, const uint8_t* __restrict__ mask) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 ld16(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 ld16_nt(const uint16_t* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+struct GemmArgs {
+    const uint16_t* x; int ldx;
+    const uint16_t* W; const uint16_t* bias; void* out;
+    int M, N, K;
+    const uint8_t* mask;
+    // PRO_RN
+    uint16_t* resid; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
+};
+
+template <int MT, int NT, int PRO, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [WAVES][NT*MT*4][64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
+    const int K = a.K, N = a.N;
+    const int m_base = blockIdx.y * (MT * 16);
+    const int Mloc = min(a.M - m_base, MT * 16);     // valid rows of this workgroup (>= 1)
 
-    // row base of each n-tile of this workgroup
     const uint16_t* wrow[NT];
     if (EPI == OMNI_EPI_SILU_MUL) {
-        // tile 0 = gate rows, tile 1 = the matching up rows (W = [gate | up], N = inter)
-        const int n0 = blockIdx.x * 16;
-        wrow[0] = W + (size_t)(n0 + r) * K + 8 * q;
-        if (NT > 1) wrow[NT - 1] = W + (size_t)(N + n0 + r) * K + 8 * q;
+        const int n0 = blockIdx.x * 16;               // tile 0 = gate rows, tile 1 = matching up rows
+        wrow[0] = a.W + (size_t)(n0 + r) * K + 8 * q;
+        if (NT > 1) wrow[NT - 1] = a.W + (size_t)(N + n0 + r) * K + 8 * q;
     } else {
         const int n0 = blockIdx.x * 16 * NT;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(n0 + j * 16 + r) * K + 8 * q;
-    }
-    const uint16_t* xrow[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = i * 16 + r;
-        m = m < M ? m : M - 1;   // rows past M: valid address, result discarded
-        xrow[i] = x + (size_t)m * ldx + 8 * q;
+        for (int j = 0; j < NT; ++j) wrow[j] = a.W + (size_t)(n0 + j * 16 + r) * K + 8 * q;
     }
 
     f32x4 acc[NT][MT];
@@ -49,41 +72,130 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = K >> 5;          // k-steps of 32
-    constexpr int U = 4;
-    int s = wave;
-    for (; s + (U - 1) * GEMM_WAVES < nsteps; s += U * GEMM_WAVES) {
-        uint4 a[U][NT], b[U][MT];
+    const int nsteps = K >> 5;                                    // k-steps of 32
+    const int ntw = (nsteps - wave + GEMM_WAVES - 1) / GEMM_WAVES; // k-steps of this wave (may be 0)
+
+    if (PRO == 1) {
+        // ---------------- fused residual-add + RMSNorm prologue -----------------
+        u32x4 wf[RN_MAX_STEPS][NT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k0 = (s + u * GEMM_WAVES) << 5;
+        for (int s = 0; s < RN_MAX_STEPS; ++s)
+            if (s < ntw) {
+                const int k0 = (wave + s * GEMM_WAVES) << 5;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) a[u][j] = *reinterpret_cast<const uint4*>(wrow[j] + k0);
+                for (int j = 0; j < NT; ++j) wf[s][j] = ld16_nt(wrow[j] + k0);
+            }
+        u32x4 xr[MT][RN_MAX_STEPS];
+        float ss[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) b[u][i] = *reinterpret_cast<const uint4*>(xrow[i] + k0);
+        for (int i = 0; i < MT; ++i) {
+            int m = i * 16 + r;
+            m = m_base + (m < Mloc ? m : Mloc - 1);
+            const uint16_t* rp = a.resid + (size_t)m * K + 8 * q;
+            const uint16_t* dp = a.delta ? a.delta + (size_t)m * K + 8 * q : nullptr;
+            float s2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < RN_MAX_STEPS; ++s)
+                if (s < ntw) {
+                    const int k0 = (wave + s * GEMM_WAVES) << 5;
+                    u32x4 v = ld16(rp + k0);
+                    if (dp) {
+                        const u32x4 d = ld16(dp + k0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bf_lo(v[e]) + bf_lo(d[e]), bf_hi(v[e]) + bf_hi(d[e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf_lo(v[e]), hi = bf_hi(v[e]);
+                        s2 = fmaf(lo, lo, s2);
+                        s2 = fmaf(hi, hi, s2);
+                    }
+                    xr[i][s] = v;
+                }
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            ss[i] = s2;
         }
+        // row sums across the 8 waves: lds[wave][MT*16]
+        if (q == 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int i = 0; i < MT; ++i) lds[wave * (MT * 16) + i * 16 + r] = ss[i];
+        }
+        __syncthreads();
+        float rstd[MT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MT; ++i) {
+            float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, a[u][j]), __builtin_bit_cast(bf16x8, b[u][i]), acc[j][i], 0, 0, 0);
+            for (int w = 0; w < GEMM_WAVES; ++w) t += lds[w * (MT * 16) + i * 16 + r];
+            rstd[i] = 1.0f / sqrtf(t / (float)K + a.eps);
+        }
+        __syncthreads();      // lds is reused by the epilogue
+        const bool writer = blockIdx.x == 0;
+#pragma unroll
+        for (int s = 0; s < RN_MAX_STEPS; ++s)
+            if (s < ntw) {
+                const int k0 = (wave + s * GEMM_WAVES) << 5;
+                const u32x4 nw = ld16(a.norm_w + k0 + 8 * q);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int ml = i * 16 + r;
+                    const bool row_ok = ml < Mloc;
+                    const size_t off = (size_t)(m_base + ml) * K + k0 + 8 * q;
+                    u32x4 v = xr[i][s];
+                    if (writer && row_ok && a.delta) *reinterpret_cast<u32x4*>(a.resid + off) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd[i]);
+                        const float hi = bf_hi(nw[e]) * bfround(bf_hi(v[e]) * rstd[i]);
+                        v[e] = pack_bf2(lo, hi);
+                    }
+                    if (writer && row_ok && a.normed_out) *reinterpret_cast<u32x4*>(a.normed_out + off) = v;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j][i] = mfma16(wf[s][j], v, acc[j][i]);
+                }
+            }
+    } else {
+        // ---------------- plain x operand, two-deep pipelined load groups -----------------
+        const uint16_t* xrow[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int m = i * 16 + r;
+            m = m_base + (m < Mloc ? m : Mloc - 1);   // rows past M: valid address, result discarded
+            xrow[i] = a.x + (size_t)m * a.ldx + 8 * q;
+        }
+        u32x4 A0[GEMM_U][NT], B0[GEMM_U][MT], A1[GEMM_U][NT], B1[GEMM_U][MT];
+#define LOAD_GROUP(A, B, T0)                                                            \
+    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                \
+        int t_ = (T0) + u;                                                              \
+        t_ = t_ < ntw ? t_ : ntw - 1;                                                   \
+        const int k0 = (wave + t_ * GEMM_WAVES) << 5;                                   \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) A[u][j] = ld16_nt(wrow[j] + k0); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) B[u][i] = ld16(xrow[i] + k0);    \
     }
-    for (; s < nsteps; s += GEMM_WAVES) {
-        const int k0 = s << 5;
-        uint4 a[NT], b[MT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const uint4*>(wrow[j] + k0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const uint4*>(xrow[i] + k0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[i]), acc[j][i], 0, 0, 0);
+#define MMA_GROUP(A, B, T0)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                            \
+        if ((T0) + u < ntw) {                                                                       \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                          \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(A[u][j], B[u][i], acc[j][i]); \
+        }                                                                                           \
+    }
+        if (ntw > 0) {
+            int t = 0;
+            LOAD_GROUP(A0, B0, 0)
+            while (true) {
+                if (t + GEMM_U < ntw) { LOAD_GROUP(A1, B1, t + GEMM_U) }
+                MMA_GROUP(A0, B0, t)
+                t += GEMM_U;
+                if (t >= ntw) break;
+                if (t + GEMM_U < ntw) { LOAD_GROUP(A0, B0, t + GEMM_U) }
+                MMA_GROUP(A1, B1, t)
+                t += GEMM_U;
+                if (t >= ntw) break;
+            }
+        }
+#undef LOAD_GROUP
+#undef MMA_GROUP
     }
 
     // ---- combine the 8 K-partials through LDS: lds[wave][e][lane], e = (j*MT+i)*4+reg
@@ -97,14 +209,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
     __syncthreads();
 
     // item = (m-tile i, [n-tile j], lane l): 4 consecutive n (reg 0..3) of one row m
-    constexpr int NTO = (EPI == OMNI_EPI_SILU_MUL) ? 1 : NT;      // output n-tiles per group
+    constexpr int NTO = (EPI == OMNI_EPI_SILU_MUL) ? 1 : NT;
     constexpr int ITEMS = NTO * MT * 64;
     for (int it = threadIdx.x; it < ITEMS; it += GEMM_THREADS) {
         const int l = it & 63;
         const int t = it >> 6;
         const int i = t % MT, j = t / MT;
-        const int m = i * 16 + (l & 15);
-        if (m >= M) continue;
+        const int ml = i * 16 + (l & 15);
+        if (ml >= Mloc) continue;
+        const int m = m_base + ml;
         float v[4], v2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -119,7 +232,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
         }
         if (EPI == OMNI_EPI_SILU_MUL) {
             const int n = blockIdx.x * 16 + 4 * (l >> 4);
-            uint32_t p[2];
             float o[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -129,17 +241,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
                 const float sl = bfround(gt / (1.0f + expf(-gt)));
                 o[g] = sl * up;
             }
-            p[0] = pack_bf2(o[0], o[1]);
-            p[1] = pack_bf2(o[2], o[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + (size_t)m * N + n) = make_uint2(p[0], p[1]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)m * N + n) =
+                make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
         } else {
             const int n = blockIdx.x * 16 * NT + j * 16 + 4 * (l >> 4);
-            if (bias) {
+            if (a.bias) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) v[g] += bf2f(bias[n + g]);
+                for (int g = 0; g < 4; ++g) v[g] += bf2f(a.bias[n + g]);
             }
             if (EPI == OMNI_EPI_BF16) {
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + (size_t)m * N + n) =
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)m * N + n) =
                     make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             } else {
                 float4 o;
@@ -147,55 +258,92 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float y = (EPI == OMNI_EPI_F32_BF16RND) ? bfround(v[g]) : v[g];
-                    if (mask && !mask[n + g]) y = -INFINITY;
+                    if (a.mask && !a.mask[n + g]) y = -INFINITY;
                     po[g] = y;
                 }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * N + n) = o;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * N + n) = o;
             }
         }
     }
 }
 
-template <int MT, int NT, int EPI>
-static int launch_gemm(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K,
-                       const uint8_t* mask, hipStream_t st) {
-    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? N / 16 : N / (16 * NT);
-    const size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, EPI>), dim3(groups), dim3(GEMM_THREADS), lds, st,
-                       (const uint16_t*)x, ldx, (const uint16_t*)w, (const uint16_t*)bias, out, M, N, K, mask);
+template <int MT, int NT, int PRO, int EPI>
+static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
+    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
+    size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_bf16");
     return OMNI_OK;
 }
 
-template <int NT, int EPI>
-static int dispatch_mt(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K,
-                       const uint8_t* mask, hipStream_t st) {
-    if (M <= 16) return launch_gemm<1, NT, EPI>(x, ldx, w, bias, out, M, N, K, mask, st);
-    if (M <= 32) return launch_gemm<2, NT, EPI>(x, ldx, w, bias, out, M, N, K, mask, st);
-    return launch_gemm<4, NT, EPI>(x, ldx, w, bias, out, M, N, K, mask, st);
+template <int NT, int PRO, int EPI>
+static int dispatch_mt(const GemmArgs& a, hipStream_t st) {
+    // m-tiles per workgroup: split M over grid.y until the grid has >= ~256 workgroups
+    const int mt_total = (a.M + 15) / 16;
+    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
+    int splits = (256 + groups - 1) / groups;
+    if (splits > mt_total) splits = mt_total;
+    if (splits < 1) splits = 1;
+    int mt = (mt_total + splits - 1) / splits;       // 1..4
+    if (mt == 3) mt = 4;
+    splits = (mt_total + mt - 1) / mt;
+    if (mt == 1) return launch_gemm<1, NT, PRO, EPI>(a, splits, st);
+    if (mt == 2) return launch_gemm<2, NT, PRO, EPI>(a, splits, st);
+    return launch_gemm<4, NT, PRO, EPI>(a, splits, st);
 }
 
-extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
-                              int K, int epilogue, const uint8_t* mask, void* stream) {
-    OMNI_CHECK_ARG(x && w && out, "omni_gemm_bf16: null pointer");
-    OMNI_CHECK_ARG(M >= 1 && M <= 64, "omni_gemm_bf16: M=%d outside 1..64", M);
-    OMNI_CHECK_ARG(N > 0 && N % 16 == 0, "omni_gemm_bf16: N=%d not a multiple of 16", N);
-    OMNI_CHECK_ARG(K > 0 && K % 32 == 0, "omni_gemm_bf16: K=%d not a multiple of 32", K);
-    OMNI_CHECK_ARG(ldx >= K && ldx % 8 == 0, "omni_gemm_bf16: ldx=%d (need >= K, multiple of 8)", ldx);
-    hipStream_t st = (hipStream_t)stream;
+static int check_common(const GemmArgs& a) {
+    OMNI_CHECK_ARG(a.W && a.out, "omni_gemm_bf16: null pointer");
+    OMNI_CHECK_ARG(a.M >= 1 && a.M <= 64, "omni_gemm_bf16: M=%d outside 1..64", a.M);
+    OMNI_CHECK_ARG(a.N > 0 && a.N % 16 == 0, "omni_gemm_bf16: N=%d not a multiple of 16", a.N);
+    OMNI_CHECK_ARG(a.K > 0 && a.K % 32 == 0, "omni_gemm_bf16: K=%d not a multiple of 32", a.K);
+    return OMNI_OK;
+}
+
+template <int PRO>
+static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
     switch (epilogue) {
         case OMNI_EPI_BF16:
-            OMNI_CHECK_ARG(mask == nullptr, "omni_gemm_bf16: mask needs an fp32 epilogue");
-            return dispatch_mt<1, OMNI_EPI_BF16>(x, ldx, w, bias, out, M, N, K, nullptr, st);
+            OMNI_CHECK_ARG(a.mask == nullptr, "omni_gemm_bf16: mask needs an fp32 epilogue");
+            return dispatch_mt<1, PRO, OMNI_EPI_BF16>(a, st);
         case OMNI_EPI_SILU_MUL:
-            OMNI_CHECK_ARG(bias == nullptr && mask == nullptr, "omni_gemm_bf16: silu_mul takes no bias/mask");
-            return dispatch_mt<2, OMNI_EPI_SILU_MUL>(x, ldx, w, nullptr, out, M, N, K, nullptr, st);
+            OMNI_CHECK_ARG(a.bias == nullptr && a.mask == nullptr, "omni_gemm_bf16: silu_mul takes no bias/mask");
+            return dispatch_mt<2, PRO, OMNI_EPI_SILU_MUL>(a, st);
         case OMNI_EPI_F32:
-            return dispatch_mt<1, OMNI_EPI_F32>(x, ldx, w, bias, out, M, N, K, mask, st);
+            return dispatch_mt<1, PRO, OMNI_EPI_F32>(a, st);
         case OMNI_EPI_F32_BF16RND:
-            return dispatch_mt<1, OMNI_EPI_F32_BF16RND>(x, ldx, w, bias, out, M, N, K, mask, st);
+            return dispatch_mt<1, PRO, OMNI_EPI_F32_BF16RND>(a, st);
         default:
             omni_set_error("omni_gemm_bf16: unknown epilogue %d", epilogue);
             return OMNI_EINVAL;
     }
+}
+
+extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
+                              int K, int epilogue, const uint8_t* mask, void* stream) {
+    GemmArgs a{};
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.mask = mask;
+    int rc = check_common(a);
+    if (rc != OMNI_OK) return rc;
+    OMNI_CHECK_ARG(x, "omni_gemm_bf16: null x");
+    OMNI_CHECK_ARG(ldx >= K && ldx % 8 == 0, "omni_gemm_bf16: ldx=%d (need >= K, multiple of 8)", ldx);
+    return dispatch_epi<0>(a, epilogue, (hipStream_t)stream);
+}
+
+bool k_gemm_rn_supported(int K) { return K % 256 == 0 && K <= 32 * GEMM_WAVES * RN_MAX_STEPS; }
+
+extern "C" int omni_gemm_resid_norm(void* resid, const void* delta, const void* norm_w, float eps, void* normed_out,
+                                    const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
+                                    const uint8_t* mask, void* stream) {
+    GemmArgs a{};
+    a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.mask = mask;
+    a.resid = (uint16_t*)resid; a.delta = (const uint16_t*)delta; a.norm_w = (const uint16_t*)norm_w; a.eps = eps;
+    a.normed_out = (uint16_t*)normed_out;
+    int rc = check_common(a);
+    if (rc != OMNI_OK) return rc;
+    OMNI_CHECK_ARG(resid && norm_w, "omni_gemm_resid_norm: null pointer");
+    OMNI_CHECK_ARG(k_gemm_rn_supported(K), "omni_gemm_resid_norm: K=%d unsupported (multiple of 256, <= 2048)", K);
+    return dispatch_epi<1>(a, epilogue, (hipStream_t)stream);
 }

@@ -1,26 +1,42 @@
-// Paged-attention decode (query_len = 1) over bf16 / fp8-e4m3fn / int8 KV blocks, head_dim 128.
+// Paged-attention decode (query_len = 1) over bf16 / fp8-e4m3fn / int8 KV blocks, head_dim 128,
+// optionally FUSED with the per-head q/k RMSNorm + neox RoPE + KV-cache write of the new token
+// (one launch instead of two per layer; the workgroup that owns a (row, kv-head) computes that
+// head's new K/V itself, so no cross-workgroup dependency is created).
 //
-// HBM-bound: every K and V byte of the context is read exactly once, 16 B per lane, each
-// 128-B (fp8/int8) or 256-B (bf16) token row fully consumed.  Workgroup = 4 waves = one
+// HBM-bound: every K and V byte of the context is read exactly once with non-temporal 16-B loads,
+// each 128-B (fp8/int8) or 256-B (bf16) token row fully consumed.  Workgroup = 4 waves = one
 // (row, kv-head[, KV split]); a wave walks 8-token groups (8 lanes per token, 16 elements per
-// lane); the G = Hq/Hkv query heads of the kv head share every K/V load.  Dequant in registers,
-// fp32 scores, online softmax per 8-lane group (running max/sum, no cross-wave traffic in the
-// loop), one LDS combine at the end; optional KV splits merged by a second tiny kernel.
-// Output = oracle attention_rows (fp32 softmax and PV, one rounding to bf16).
+// lane), loads software-pipelined one batch of PA_U groups ahead (the first batch is issued before
+// the sequence length is known: unallocated block-table entries point at the null block).  The
+// G = Hq/Hkv query heads share every K/V load.  Dequant in registers, fp32 scores, online softmax
+// per 8-lane group (no cross-wave traffic in the loop), one LDS combine at the end; optional KV
+// splits merged by a second tiny kernel.  Output = oracle attention_rows (fp32 softmax and PV, one
+// rounding to bf16); the fused prologue = oracle rms_norm / apply_rope / fp8_quant / int8_quant.
 #include "common.cuh"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
-#define PA_U 4                 // 8-token groups in flight per wave
+#define PA_U 4                 // 8-token groups per load batch per wave
 #define LOG2E 1.4426950408889634f
+#define PA_REC 130             // partial record: [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
 
-template <int KV>
-struct KVLoad {  // raw bytes of one lane's 16 elements of one token row
-    uint4 a;
-    uint4 b;     // bf16 only (second 8 elements)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct PAArgs {
+    const uint16_t* q;             // bf16 [rows, Hq*128]           (unfused)
+    const uint16_t* qkv;           // bf16 [rows, (Hq+2Hkv)*128]    (fused)
+    const uint16_t* qnorm_w; const uint16_t* knorm_w; const int32_t* positions; const uint16_t* cos_sin;
+    int64_t* slot_out; float eps;
+    void* k_cache; void* v_cache; float* k_scales; float* v_scales;
+    const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
+    uint16_t* out; float* partial;
+    int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
 };
 
-// element index (0..127) of the e-th value (0..15) a lane with sub = lane&7 holds
+template <int KV>
+struct KVRaw { u32x4 a, b; };   // b: bf16 only (second 8 elements)
+
+// element index (0..127) of the e-th value (0..15) held by a lane with sub = lane & 7
 template <int KV>
 __device__ __forceinline__ int elem_of(int sub, int e) {
     if (KV == OMNI_KV_BF16) return (e < 8) ? (sub * 8 + e) : (64 + sub * 8 + (e - 8));
@@ -28,76 +44,119 @@ __device__ __forceinline__ int elem_of(int sub, int e) {
 }
 
 template <int KV>
-__device__ __forceinline__ KVLoad<KV> load_row(const void* base, size_t row, int sub) {
-    KVLoad<KV> r;
+__device__ __forceinline__ KVRaw<KV> load_row(const void* base, size_t row, int sub) {
+    KVRaw<KV> r;
     if (KV == OMNI_KV_BF16) {
         const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + row * 128;
-        r.a = *reinterpret_cast<const uint4*>(p + sub * 8);
-        r.b = *reinterpret_cast<const uint4*>(p + 64 + sub * 8);
+        r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + sub * 8));
+        r.b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64 + sub * 8));
     } else {
         const uint8_t* p = reinterpret_cast<const uint8_t*>(base) + row * 128;
-        r.a = *reinterpret_cast<const uint4*>(p + sub * 16);
-        r.b = make_uint4(0, 0, 0, 0);
+        r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + sub * 16));
+        r.b = (u32x4){0, 0, 0, 0};
     }
     return r;
 }
 
 template <int KV>
-__device__ __forceinline__ void to_f32(const KVLoad<KV>& r, float* f) {
-    const uint32_t* a = reinterpret_cast<const uint32_t*>(&r.a);
+__device__ __forceinline__ void to_f32(const KVRaw<KV>& r, float* f) {
     if (KV == OMNI_KV_BF16) {
-        const uint32_t* b = reinterpret_cast<const uint32_t*>(&r.b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f[2 * j] = bf_lo(a[j]);
-            f[2 * j + 1] = bf_hi(a[j]);
-            f[8 + 2 * j] = bf_lo(b[j]);
-            f[8 + 2 * j + 1] = bf_hi(b[j]);
+            f[2 * j] = bf_lo(r.a[j]);
+            f[2 * j + 1] = bf_hi(r.a[j]);
+            f[8 + 2 * j] = bf_lo(r.b[j]);
+            f[8 + 2 * j + 1] = bf_hi(r.b[j]);
         }
     } else if (KV == OMNI_KV_FP8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) unpack_fp8x4(a[j], f + 4 * j);
+        for (int j = 0; j < 4; ++j) unpack_fp8x4(r.a[j], f + 4 * j);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f[4 * j + 0] = (float)(int8_t)(a[j] & 0xFF);
-            f[4 * j + 1] = (float)(int8_t)((a[j] >> 8) & 0xFF);
-            f[4 * j + 2] = (float)(int8_t)((a[j] >> 16) & 0xFF);
-            f[4 * j + 3] = (float)(int8_t)(a[j] >> 24);
+            const uint32_t w = r.a[j];
+            f[4 * j + 0] = (float)(int8_t)(w & 0xFF);
+            f[4 * j + 1] = (float)(int8_t)((w >> 8) & 0xFF);
+            f[4 * j + 2] = (float)(int8_t)((w >> 16) & 0xFF);
+            f[4 * j + 3] = (float)(int8_t)(w >> 24);
         }
     }
 }
 
-// partial record per (row, q-head, split): [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
-#define PA_REC 130
+// one wave: RMSNorm (optional) + RoPE (optional) of one 128-wide head; lane owns elements l, l+64
+__device__ __forceinline__ void head_norm_rope(const uint16_t* src, const uint16_t* nw, const uint16_t* cs, float eps,
+                                               int lane, float& y0, float& y1) {
+    float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
+    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
+    const float n0 = bfround(bf2f(nw[lane]) * bfround(x0 * rstd));
+    const float n1 = bfround(bf2f(nw[lane + 64]) * bfround(x1 * rstd));
+    const float c = bf2f(cs[lane]), s = bf2f(cs[64 + lane]);
+    y0 = bfround(bfround(n0 * c) + bfround(-n1 * s));
+    y1 = bfround(bfround(n1 * c) + bfround(n0 * s));
+}
 
-template <int KV, int G>
-__global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(
-    const uint16_t* __restrict__ q, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, const int32_t* __restrict__ block_table,
-    int bt_stride, const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ req_of_row, int seq_from_pos,
-    uint16_t* __restrict__ out, float* __restrict__ partial, int q_heads, int kv_heads, int bs, float k_scale,
-    float v_scale, float sm_scale, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PA_WAVES*8][G][PA_REC]
+template <int KV, int G, bool FUSED>
+__global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PA_WAVES*8][G][PA_REC] | q scratch | kv scratch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 7, tg = lane >> 3;
     const int kvh = blockIdx.x, row = blockIdx.y, sp = blockIdx.z;
-    const int req = req_of_row ? req_of_row[row] : row;
-    const int seq_len = seq_lens[row] + (seq_from_pos ? 1 : 0);
-    // token range of this split (multiple of 32 so 8-token groups never straddle splits)
-    int per = (seq_len + nsplit - 1) / nsplit;
-    per = (per + 31) & ~31;
-    const int t_begin = sp * per;
-    const int t_end = min(seq_len, t_begin + per);
+    const int req = a.req_of_row ? a.req_of_row[row] : row;
+    const int kv_heads = a.kv_heads, bs = a.bs;
+    const int32_t* bt = a.block_table + (size_t)req * a.bt_stride;
+    const int max_blk = a.bt_stride - 1;
 
-    // q for the G heads of this kv head, pre-scaled into the log2 domain
+    // ---- batch 0 of K/V loads goes out before anything else is known (speculative: tokens past the
+    // sequence end resolve to whatever block the table holds there -- block 0, the null block)
+    KVRaw<KV> k0[PA_U], v0[PA_U], k1[PA_U], v1[PA_U];
+    float ks0[PA_U], vs0[PA_U], ks1[PA_U], vs1[PA_U];
+#define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
+    _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                       \
+        const int t_ = (T0) + u * PA_WAVES * 8 + tg;                                         \
+        const int bi_ = min(t_ / bs, max_blk);                                               \
+        const size_t r_ = ((size_t)bt[bi_] * bs + t_ % bs) * kv_heads + kvh;                 \
+        KR[u] = load_row<KV>(a.k_cache, r_, sub);                                            \
+        VR[u] = load_row<KV>(a.v_cache, r_, sub);                                            \
+        if (KV == OMNI_KV_INT8) { KS[u] = a.k_scales[r_]; VS[u] = a.v_scales[r_]; }          \
+    }
+    const bool spec = (a.nsplit == 1);
+    if (spec) { PA_LOAD(k0, v0, ks0, vs0, wave * 8) }
+
+    const int seq_len = a.seq_lens[row] + (a.seq_from_pos ? 1 : 0);
+    int per = (seq_len + a.nsplit - 1) / a.nsplit;
+    per = (per + 31) & ~31;                       // 8-token groups never straddle splits
+    const int t_begin = sp * per;
+    const int cur = seq_len - 1;                  // the token computed this step
+    const int t_end = min(FUSED ? cur : seq_len, t_begin + per);
+    if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
+
+    // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
     float qf[G][16];
-    const float qs = sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
+    const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? a.k_scale : 1.0f);
+    const int nslots = a.q_heads + 2 * kv_heads;
+    float* wq = lds + PA_WAVES * 8 * G * PA_REC + wave * (G * 128);
+    if (FUSED) {
+        const int pos = a.positions[row];
+        const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const uint16_t* qp = q + ((size_t)row * q_heads + kvh * G + g) * 128;
+        for (int g = 0; g < G; ++g) {
+            float y0, y1;
+            head_norm_rope(a.qkv + ((size_t)row * nslots + kvh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
+            wq[g * 128 + lane] = y0;
+            wq[g * 128 + 64 + lane] = y1;
+        }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) qf[g][e] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) qf[g][e] = wq[g * 128 + elem_of<KV>(sub, e)] * qs;
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint16_t* qp = a.q + ((size_t)row * a.q_heads + kvh * G + g) * 128;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) qf[g][e] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
+        }
     }
     float m[G], l[G], acc[G][16];
 #pragma unroll
@@ -107,33 +166,112 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
     }
-    const int32_t* bt = block_table + (size_t)req * bt_stride;
 
-    for (int t0 = t_begin + wave * 8; t0 < t_end; t0 += PA_WAVES * 8 * PA_U) {
-        KVLoad<KV> kr[PA_U], vr[PA_U];
-        float ksc[PA_U], vsc[PA_U];
-        bool valid[PA_U];
-#pragma unroll
-        for (int u = 0; u < PA_U; ++u) {
-            const int t = t0 + u * PA_WAVES * 8 + tg;
-            valid[u] = t < t_end;
-            const int tc = valid[u] ? t : (t_end - 1);        // clamp: valid address, masked below
-            const size_t r = ((size_t)bt[tc / bs] * bs + tc % bs) * kv_heads + kvh;
-            kr[u] = load_row<KV>(k_cache, r, sub);
-            vr[u] = load_row<KV>(v_cache, r, sub);
-            if (KV == OMNI_KV_INT8) {
-                ksc[u] = k_scales[r];
-                vsc[u] = v_scales[r];
+#define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
+    {                                                                                                \
+        float s_[PA_U][G], mx_[G];                                                                   \
+        bool ok_[PA_U];                                                                              \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
+            float kf_[16];                                                                           \
+            to_f32<KV>(KR[u], kf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float d_ = 0.f;                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
+                d_ += __shfl_xor(d_, 1, 64);                                                         \
+                d_ += __shfl_xor(d_, 2, 64);                                                         \
+                d_ += __shfl_xor(d_, 4, 64);                                                         \
+                if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
+                d_ = ok_[u] ? d_ : -INFINITY;                                                        \
+                s_[u][g] = d_;                                                                       \
+                mx_[g] = fmaxf(mx_[g], d_);                                                          \
+            }                                                                                        \
+        }                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                              \
+            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx_[g]);                 \
+            m[g] = mx_[g];                                                                           \
+            l[g] *= corr_;                                                                           \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            float vf_[16];                                                                           \
+            to_f32<KV>(VR[u], vf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float p_ = ok_[u] ? exp2f(s_[u][g] - m[g]) : 0.f;                                    \
+                l[g] += p_;                                                                          \
+                if (KV == OMNI_KV_INT8) p_ *= VS[u];                                                 \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p_, vf_[e], acc[g][e]); \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    // ---- main loop, loads one batch ahead
+    constexpr int STRIDE = PA_WAVES * 8 * PA_U;
+    for (int t0 = t_begin + wave * 8; t0 < t_end;) {
+        if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
+        PA_COMPUTE(k0, v0, ks0, vs0, t0)
+        t0 += STRIDE;
+        if (t0 >= t_end) break;
+        if (t0 + STRIDE < t_end) { PA_LOAD(k0, v0, ks0, vs0, t0 + STRIDE) }
+        PA_COMPUTE(k1, v1, ks1, vs1, t0)
+        t0 += STRIDE;
+    }
+#undef PA_LOAD
+#undef PA_COMPUTE
+
+    // ---- fused: the new token's K/V (wave 0 of the split that owns position `cur`)
+    if (FUSED) {
+        const int sp_cur = cur / per;
+        if (wave == 0 && sp == sp_cur) {
+            const int pos = a.positions[row];
+            const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+            const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
+            if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+            const size_t crow = (size_t)slot * kv_heads + kvh;
+            float* kvs = lds + PA_WAVES * 8 * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
+            float kx0, kx1;
+            head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
+            const uint16_t* vsrc = a.qkv + ((size_t)row * nslots + a.q_heads + kv_heads + kvh) * 128;
+            float vx0 = bf2f(vsrc[lane]), vx1 = bf2f(vsrc[lane + 64]);
+            float ksc_new = 1.f, vsc_new = 1.f;
+            if (KV == OMNI_KV_BF16) {
+                uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
+                uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
+                kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
+                vd[lane] = f2bf(vx0); vd[lane + 64] = f2bf(vx1);
+            } else if (KV == OMNI_KV_FP8) {
+                const float ik = a.k_scale, iv = a.v_scale;
+                const uint32_t pk = pack_fp8x4(ik == 1.f ? kx0 : kx0 / ik, ik == 1.f ? kx1 : kx1 / ik, 0.f, 0.f);
+                const uint32_t pv = pack_fp8x4(iv == 1.f ? vx0 : vx0 / iv, iv == 1.f ? vx1 : vx1 / iv, 0.f, 0.f);
+                uint8_t* kd = reinterpret_cast<uint8_t*>(a.k_cache) + crow * 128;
+                uint8_t* vd = reinterpret_cast<uint8_t*>(a.v_cache) + crow * 128;
+                kd[lane] = (uint8_t)(pk & 0xFF); kd[lane + 64] = (uint8_t)((pk >> 8) & 0xFF);
+                vd[lane] = (uint8_t)(pv & 0xFF); vd[lane + 64] = (uint8_t)((pv >> 8) & 0xFF);
+                float t4[4];
+                unpack_fp8x4(pk, t4); kx0 = t4[0]; kx1 = t4[1];       // what the cache now holds (unscaled)
+                unpack_fp8x4(pv, t4); vx0 = t4[0]; vx1 = t4[1];
+            } else {
+                const float ka = fmaxf(wave_max(fmaxf(fabsf(kx0), fabsf(kx1))), 1e-8f);
+                const float va = fmaxf(wave_max(fmaxf(fabsf(vx0), fabsf(vx1))), 1e-8f);
+                ksc_new = ka / 127.0f; vsc_new = va / 127.0f;
+                kx0 = fminf(fmaxf(rintf(kx0 / ksc_new), -127.f), 127.f); kx1 = fminf(fmaxf(rintf(kx1 / ksc_new), -127.f), 127.f);
+                vx0 = fminf(fmaxf(rintf(vx0 / vsc_new), -127.f), 127.f); vx1 = fminf(fmaxf(rintf(vx1 / vsc_new), -127.f), 127.f);
+                int8_t* kd = reinterpret_cast<int8_t*>(a.k_cache) + crow * 128;
+                int8_t* vd = reinterpret_cast<int8_t*>(a.v_cache) + crow * 128;
+                kd[lane] = (int8_t)kx0; kd[lane + 64] = (int8_t)kx1;
+                vd[lane] = (int8_t)vx0; vd[lane + 64] = (int8_t)vx1;
+                if (lane == 0) { a.k_scales[crow] = ksc_new; a.v_scales[crow] = vsc_new; }
             }
-        }
-        float s[PA_U][G];
-        float mx[G];
+            kvs[lane] = kx0; kvs[64 + lane] = kx1;
+            kvs[128 + lane] = vx0; kvs[192 + lane] = vx1;
+            // token-group 0 of this wave folds the new token into its running softmax state
+            float kf[16], vf[16];
 #pragma unroll
-        for (int g = 0; g < G; ++g) mx[g] = m[g];
-#pragma unroll
-        for (int u = 0; u < PA_U; ++u) {
-            float kf[16];
-            to_f32<KV>(kr[u], kf);
+            for (int e = 0; e < 16; ++e) {
+                kf[e] = kvs[elem_of<KV>(sub, e)];
+                vf[e] = kvs[128 + elem_of<KV>(sub, e)];
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float d = 0.f;
@@ -142,32 +280,17 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
                 d += __shfl_xor(d, 4, 64);
-                if (KV == OMNI_KV_INT8) d *= ksc[u];
-                d = valid[u] ? d : -INFINITY;
-                s[u][g] = d;
-                mx[g] = fmaxf(mx[g], d);
-            }
-        }
-        // one rescale per batch of PA_U tokens (mx stays -inf only if nothing valid yet)
+                if (KV == OMNI_KV_INT8) d *= ksc_new;
+                if (tg == 0) {
+                    const float mn = fmaxf(m[g], d);
+                    const float corr = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mn);
+                    float p = exp2f(d - mn);
+                    m[g] = mn;
+                    l[g] = l[g] * corr + p;
+                    if (KV == OMNI_KV_INT8) p *= vsc_new;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float corr = (mx[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx[g]);
-            m[g] = mx[g];
-            l[g] *= corr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] *= corr;
-        }
-#pragma unroll
-        for (int u = 0; u < PA_U; ++u) {
-            float vf[16];
-            to_f32<KV>(vr[u], vf);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float p = valid[u] ? exp2f(s[u][g] - m[g]) : 0.f;
-                l[g] += p;
-                if (KV == OMNI_KV_INT8) p *= vsc[u];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
+                    for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e] * corr);
+                }
             }
         }
     }
@@ -199,11 +322,11 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(
             A = fmaf(rec[2 + d], w, A);
         }
         const int qh = kvh * G + g;
-        if (nsplit == 1) {
-            const float vs = (KV == OMNI_KV_FP8) ? v_scale : 1.0f;
-            out[((size_t)row * q_heads + qh) * 128 + d] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
+        if (a.nsplit == 1) {
+            const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
+            a.out[((size_t)row * a.q_heads + qh) * 128 + d] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
         } else {
-            float* rec = partial + (((size_t)row * q_heads + qh) * nsplit + sp) * PA_REC;
+            float* rec = a.partial + (((size_t)row * a.q_heads + qh) * a.nsplit + sp) * PA_REC;
             if (d == 0) {
                 rec[0] = M;
                 rec[1] = L;
@@ -232,9 +355,10 @@ __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __re
 }
 
 static int pick_nsplit(int rows, int kv_heads, int max_seq_len) {
-    int wgs = rows * kv_heads;
-    int ns = (1024 + wgs - 1) / wgs;                  // aim for >= ~1024 workgroups (4/CU)
-    int cap = (max_seq_len + 255) / 256;              // >= 256 tokens per split
+    const int wgs = rows * kv_heads;
+    if (wgs >= 512) return 1;                         // 2+ workgroups per CU already
+    int ns = (512 + wgs - 1) / wgs;
+    const int cap = (max_seq_len + 255) / 256;        // >= 256 tokens per split
     if (ns > cap) ns = cap;
     if (ns > 16) ns = 16;
     return ns < 1 ? 1 : ns;
@@ -246,18 +370,12 @@ extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_
     return (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
 }
 
-template <int KV>
-static int launch_pa(const void* q, const void* kc, const void* vc, const float* ks, const float* vs,
-                     const int32_t* bt, int bt_stride, const int32_t* seq_lens, const int32_t* req_of_row,
-                     int seq_from_pos, void* out, void* ws, int rows, int q_heads, int kv_heads, int bs, float k_scale,
-                     float v_scale, float sm_scale, int nsplit, hipStream_t st) {
-    const int G = q_heads / kv_heads;
-    dim3 grid(kv_heads, rows, nsplit), block(PA_THREADS);
-    const size_t lds = (size_t)PA_WAVES * 8 * G * PA_REC * sizeof(float);
-#define LAUNCH(GG)                                                                                                 \
-    hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG>), grid, block, lds, st, (const uint16_t*)q, kc, vc, ks, vs, \
-                       bt, bt_stride, seq_lens, req_of_row, seq_from_pos, (uint16_t*)out, (float*)ws, q_heads,      \
-                       kv_heads, bs, k_scale, v_scale, sm_scale, nsplit)
+template <int KV, bool FUSED>
+static int launch_pa(const PAArgs& a, int rows, hipStream_t st) {
+    const int G = a.q_heads / a.kv_heads;
+    dim3 grid(a.kv_heads, rows, a.nsplit), block(PA_THREADS);
+    const size_t lds = ((size_t)PA_WAVES * 8 * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
+#define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
     switch (G) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -266,40 +384,34 @@ static int launch_pa(const void* q, const void* kc, const void* vc, const float*
     }
 #undef LAUNCH
     OMNI_CHECK_LAUNCH("omni_paged_attn_decode");
-    if (nsplit > 1) {
-        hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(rows * q_heads), dim3(128), 0, st, (const float*)ws,
-                           (uint16_t*)out, nsplit, KV == OMNI_KV_FP8 ? v_scale : 1.0f);
+    if (a.nsplit > 1) {
+        hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(rows * a.q_heads), dim3(128), 0, st, (const float*)a.partial,
+                           a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f);
         OMNI_CHECK_LAUNCH("omni_paged_attn_merge");
     }
     return OMNI_OK;
 }
 
-static int pa_dispatch(const void* q, const void* kc, const void* vc, const float* ks, const float* vs,
-                       const int32_t* bt, int bt_stride, const int32_t* seq_lens, const int32_t* req_of_row,
-                       int seq_from_pos, void* out, void* ws, int rows, int q_heads, int kv_heads, int head_dim,
-                       int bs, int kv_dtype, float k_scale, float v_scale, float sm_scale, int nsplit, void* stream) {
-    OMNI_CHECK_ARG(q && kc && vc && bt && seq_lens && out, "omni_paged_attn: null pointer");
+static int pa_dispatch(PAArgs& a, int rows, int head_dim, int kv_dtype, bool fused, void* stream) {
+    OMNI_CHECK_ARG(a.k_cache && a.v_cache && a.block_table && a.seq_lens && a.out, "omni_paged_attn: null pointer");
+    OMNI_CHECK_ARG(fused ? (a.qkv && a.qnorm_w && a.knorm_w && a.positions && a.cos_sin) : (a.q != nullptr),
+                   "omni_paged_attn: null q / qkv inputs");
     OMNI_CHECK_ARG(head_dim == 128, "omni_paged_attn: head_dim=%d (only 128)", head_dim);
-    OMNI_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "omni_paged_attn: q_heads=%d kv_heads=%d", q_heads, kv_heads);
-    OMNI_CHECK_ARG(bs > 0, "omni_paged_attn: block_size=%d", bs);
-    OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (ks && vs), "omni_paged_attn: int8 needs scale arrays");
-    OMNI_CHECK_ARG(nsplit == 1 || ws, "omni_paged_attn: workspace required for KV splits");
+    OMNI_CHECK_ARG(a.kv_heads > 0 && a.q_heads % a.kv_heads == 0, "omni_paged_attn: q_heads=%d kv_heads=%d", a.q_heads, a.kv_heads);
+    OMNI_CHECK_ARG(a.bs > 0 && a.bt_stride > 0, "omni_paged_attn: block_size=%d bt_stride=%d", a.bs, a.bt_stride);
+    OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (a.k_scales && a.v_scales), "omni_paged_attn: int8 needs scale arrays");
+    OMNI_CHECK_ARG(a.nsplit == 1 || a.partial, "omni_paged_attn: workspace required for KV splits");
+    OMNI_CHECK_ARG(a.k_scale > 0.f && a.v_scale > 0.f, "omni_paged_attn: scales must be > 0");
     if (rows <= 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
+#define GO(KVT) (fused ? launch_pa<KVT, true>(a, rows, st) : launch_pa<KVT, false>(a, rows, st))
     switch (kv_dtype) {
-        case OMNI_KV_BF16:
-            return launch_pa<OMNI_KV_BF16>(q, kc, vc, ks, vs, bt, bt_stride, seq_lens, req_of_row, seq_from_pos, out, ws,
-                                           rows, q_heads, kv_heads, bs, k_scale, v_scale, sm_scale, nsplit, st);
-        case OMNI_KV_FP8:
-            return launch_pa<OMNI_KV_FP8>(q, kc, vc, ks, vs, bt, bt_stride, seq_lens, req_of_row, seq_from_pos, out, ws,
-                                          rows, q_heads, kv_heads, bs, k_scale, v_scale, sm_scale, nsplit, st);
-        case OMNI_KV_INT8:
-            return launch_pa<OMNI_KV_INT8>(q, kc, vc, ks, vs, bt, bt_stride, seq_lens, req_of_row, seq_from_pos, out, ws,
-                                           rows, q_heads, kv_heads, bs, k_scale, v_scale, sm_scale, nsplit, st);
-        default:
-            omni_set_error("omni_paged_attn: kv_dtype=%d", kv_dtype);
-            return OMNI_EINVAL;
+        case OMNI_KV_BF16: return GO(OMNI_KV_BF16);
+        case OMNI_KV_FP8: return GO(OMNI_KV_FP8);
+        case OMNI_KV_INT8: return GO(OMNI_KV_INT8);
+        default: omni_set_error("omni_paged_attn: kv_dtype=%d", kv_dtype); return OMNI_EINVAL;
     }
+#undef GO
 }
 
 extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
@@ -307,10 +419,31 @@ extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const 
                                       const int32_t* seq_lens, void* out, void* workspace, int B, int q_heads,
                                       int kv_heads, int head_dim, int block_size, int kv_dtype, float k_scale,
                                       float v_scale, float sm_scale, int max_seq_len, void* stream) {
-    const int nsplit = (workspace && kv_heads > 0 && B > 0) ? pick_nsplit(B, kv_heads, max_seq_len) : 1;
-    return pa_dispatch(q, k_cache, v_cache, k_scales, v_scales, block_table, bt_stride, seq_lens, nullptr, 0, out,
-                       workspace, B, q_heads, kv_heads, head_dim, block_size, kv_dtype, k_scale, v_scale, sm_scale,
-                       nsplit, stream);
+    PAArgs a{};
+    a.q = (const uint16_t*)q; a.k_cache = const_cast<void*>(k_cache); a.v_cache = const_cast<void*>(v_cache);
+    a.k_scales = const_cast<float*>(k_scales); a.v_scales = const_cast<float*>(v_scales);
+    a.block_table = block_table; a.bt_stride = bt_stride; a.seq_lens = seq_lens; a.out = (uint16_t*)out;
+    a.partial = (float*)workspace; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
+    a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale;
+    a.nsplit = (workspace && kv_heads > 0 && B > 0) ? pick_nsplit(B, kv_heads, max_seq_len) : 1;
+    return pa_dispatch(a, B, head_dim, kv_dtype, false, stream);
+}
+
+extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                                      const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales,
+                                      float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* seq_lens,
+                                      int64_t* slot_out, void* out, void* workspace, int B, int q_heads, int kv_heads,
+                                      int head_dim, int block_size, int kv_dtype, float k_scale, float v_scale,
+                                      float sm_scale, int max_seq_len, void* stream) {
+    PAArgs a{};
+    a.qkv = (const uint16_t*)qkv; a.qnorm_w = (const uint16_t*)qnorm_w; a.knorm_w = (const uint16_t*)knorm_w;
+    a.positions = positions; a.cos_sin = (const uint16_t*)cos_sin; a.eps = eps; a.slot_out = slot_out;
+    a.k_cache = k_cache; a.v_cache = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
+    a.block_table = block_table; a.bt_stride = bt_stride; a.seq_lens = seq_lens; a.out = (uint16_t*)out;
+    a.partial = (float*)workspace; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
+    a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale;
+    a.nsplit = (workspace && kv_heads > 0 && B > 0) ? pick_nsplit(B, kv_heads, max_seq_len) : 1;
+    return pa_dispatch(a, B, head_dim, kv_dtype, true, stream);
 }
 
 extern "C" int omni_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
@@ -320,7 +453,11 @@ extern "C" int omni_paged_attn_prefill(const void* q, const void* k_cache, const
                                        float k_scale, float v_scale, float sm_scale, void* stream) {
     OMNI_CHECK_ARG(req_of_tok && positions, "omni_paged_attn_prefill: null pointer");
     // every token is a decode row whose context is positions[t] + 1 keys of request req_of_tok[t]
-    return pa_dispatch(q, k_cache, v_cache, k_scales, v_scales, block_table, bt_stride, positions, req_of_tok, 1, out,
-                       nullptr, T, q_heads, kv_heads, head_dim, block_size, kv_dtype, k_scale, v_scale, sm_scale, 1,
-                       stream);
+    PAArgs a{};
+    a.q = (const uint16_t*)q; a.k_cache = const_cast<void*>(k_cache); a.v_cache = const_cast<void*>(v_cache);
+    a.k_scales = const_cast<float*>(k_scales); a.v_scales = const_cast<float*>(v_scales);
+    a.block_table = block_table; a.bt_stride = bt_stride; a.seq_lens = positions; a.req_of_row = req_of_tok;
+    a.seq_from_pos = 1; a.out = (uint16_t*)out; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
+    a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale; a.nsplit = 1;
+    return pa_dispatch(a, T, head_dim, kv_dtype, false, stream);
 }

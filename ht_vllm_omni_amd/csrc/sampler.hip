@@ -36,12 +36,14 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              float temperature, int top_k, float rep_penalty,
                                                              uint8_t* __restrict__ seen, uint32_t seed,
                                                              int32_t* __restrict__ steps, int step_mul, int step_add,
-                                                             int inc_steps, int32_t* __restrict__ out_ids, int out_stride) {
+                                                             int inc_steps, int32_t* __restrict__ out_ids, int out_stride,
+                                                             const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim) {
     __shared__ float row[SMP_MAXV];
     __shared__ uint32_t hist[256];
     __shared__ float sval[SMP_THREADS / 64];
     __shared__ int sidx[SMP_THREADS / 64];
     __shared__ uint32_t sel_prefix, sel_k;
+    __shared__ uint32_t wtot[SMP_THREADS / 64];
     const int b = blockIdx.x;
     const float* src = logits + (size_t)b * ld;
     uint8_t* sn = seen ? seen + (size_t)b * V : nullptr;
@@ -76,15 +78,22 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                     if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1u);
                 }
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    uint32_t cum = 0;
-                    int bin = 255;
-                    for (; bin > 0; --bin) {
-                        if (cum + hist[bin] >= krem) break;
-                        cum += hist[bin];
+                {
+                    // thread t owns bin t: inclusive suffix sum S[t] = sum_{b >= t} hist[b]
+                    const uint32_t cnt = hist[threadIdx.x];
+                    uint32_t sfx = cnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t up = __shfl_down(sfx, o, 64);
+                        if ((int)(threadIdx.x & 63) + o < 64) sfx += up;
                     }
-                    sel_prefix = prefix | ((uint32_t)bin << shift);
-                    sel_k = krem - cum;
+                    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = sfx;
+                    __syncthreads();
+                    for (int w = (threadIdx.x >> 6) + 1; w < SMP_THREADS / 64; ++w) sfx += wtot[w];
+                    if (sfx >= krem && sfx - cnt < krem) {          // exactly one bin satisfies this
+                        sel_prefix = prefix | ((uint32_t)threadIdx.x << shift);
+                        sel_k = krem - (sfx - cnt);
+                    }
                 }
                 __syncthreads();
                 prefix = sel_prefix;
@@ -110,6 +119,11 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
         if (bi == 0x7FFFFFFF) bi = 0;
         pick = block_argmax(bv, bi, sval, sidx);
     }
+    if (gtab) {
+        for (int v = threadIdx.x; v < gdim / 8; v += SMP_THREADS)
+            *reinterpret_cast<uint4*>(gout + (size_t)b * gdim + v * 8) =
+                *reinterpret_cast<const uint4*>(gtab + (size_t)pick * gdim + v * 8);
+    }
     if (threadIdx.x == 0) {
         out_ids[(size_t)b * out_stride] = pick;
         if (sn && pick >= 0 && pick < V) sn[pick] = 1;
@@ -117,19 +131,28 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     }
 }
 
-int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
-             uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream) {
+int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+                    float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
+                    int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
+                    int gather_dim, void* stream) {
     OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
     OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
     OMNI_CHECK_ARG(rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
+    OMNI_CHECK_ARG(!gather_table || (gather_out && gather_dim % 8 == 0), "omni_sample: bad gather arguments");
     if (B <= 0) return OMNI_OK;
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,
                        temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids,
-                       out_stride);
+                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim);
     OMNI_CHECK_LAUNCH("omni_sample");
     return OMNI_OK;
+}
+
+int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
+             uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
+             int out_stride, void* stream) {
+    return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add,
+                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,

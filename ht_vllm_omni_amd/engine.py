@@ -96,6 +96,19 @@ class TalkerEngine:
         self.cp_embed = up(weights["cp.embed"])
         self.cp_proj_w = up(weights["cp.proj_w"]) if d.has_cp_projection else None
         self.cp_proj_b = up(weights["cp.proj_b"]) if d.has_cp_projection else None
+        # constant-folded projections of the embedding tables (bit-identical to projecting at run time:
+        # the GEMM result of a row does not depend on which other rows share the launch)
+        if d.has_cp_projection:
+            def fold(table: torch.Tensor) -> torch.Tensor:
+                out = torch.empty(table.shape[0], d.cp_hidden, dtype=BF16, device=dev)
+                for r0 in range(0, table.shape[0], 64):
+                    out[r0:r0 + 64] = ops.gemm(table[r0:r0 + 64].contiguous(), self.cp_proj_w, bias=self.cp_proj_b)
+                return out
+            self.cp_proj_table = torch.stack([fold(self.cp_embed[g]) for g in range(d.num_code_groups - 1)]).contiguous()
+            self.cp_e0_table = fold(self.embed)
+            torch.cuda.synchronize()
+        else:
+            self.cp_proj_table, self.cp_e0_table = self.cp_embed, self.embed
         names = ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")
         self._layers = (L.LayerWeights * d.layers)()
         self.layer_w: list[dict] = []
@@ -144,6 +157,7 @@ class TalkerEngine:
         desc.cp_layer = C.cast(self._cp_layers, C.POINTER(L.LayerWeights))
         desc.cp_norm, desc.cp_lm_head = self.cp_norm.data_ptr(), self.cp_lm_head.data_ptr()
         desc.cp_embed, desc.cp_cos_sin = self.cp_embed.data_ptr(), self.cp_cos_sin.data_ptr()
+        desc.cp_proj_table, desc.cp_e0_table = self.cp_proj_table.data_ptr(), self.cp_e0_table.data_ptr()
         pvp = C.POINTER(C.c_void_p)
         desc.k_cache, desc.v_cache = C.cast(self._kc, pvp), C.cast(self._vc, pvp)
         if self._ks is not None:

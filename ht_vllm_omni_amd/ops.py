@@ -42,6 +42,40 @@ def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None):
     return out
 
 
+def gemm_resid_norm(resid, w, norm_w, eps, *, delta=None, bias=None, epilogue=L.EPI_BF16, mask=None, want_normed=False):
+    """out = epilogue(rmsnorm(resid + delta) . w^T); resid is updated in place. Returns out or (out, normed)."""
+    _chk_dev(resid, w, norm_w, delta, bias, mask)
+    M, K = resid.shape
+    N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
+    dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
+    out = torch.empty(M, N, dtype=dt, device=resid.device)
+    normed = torch.empty_like(resid) if want_normed else None
+    L.check(L.load().omni_gemm_resid_norm(L.ptr(resid), L.ptr(delta), L.ptr(norm_w), float(eps), L.ptr(normed), L.ptr(w),
+                                          L.ptr(bias), L.ptr(out), M, N, K, epilogue, L.ptr(mask), L.current_stream()),
+            "omni_gemm_resid_norm")
+    return (out, normed) if want_normed else out
+
+
+def attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, k_cache, v_cache, block_table, seq_lens, *, q_heads,
+                      kv_heads, head_dim, block_size, kv_dtype, eps, k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None,
+                      max_seq_len=4096, split=True):
+    """q/k-norm + RoPE + KV write of the new token + paged attention in one launch -> (out, slots)."""
+    _chk_dev(qkv, qnorm_w, knorm_w, positions, cos_sin, k_cache, v_cache, block_table, seq_lens, k_scales, v_scales)
+    B = qkv.shape[0]
+    out = torch.empty(B, q_heads * head_dim, dtype=BF16, device=qkv.device)
+    slots = torch.full((B,), -7, dtype=torch.int64, device=qkv.device)
+    ws = None
+    if split:
+        nbytes = L.load().omni_paged_attn_workspace_bytes(B, q_heads, head_dim, max_seq_len)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+    L.check(L.load().omni_attn_decode_fused(
+        L.ptr(qkv), L.ptr(qnorm_w), L.ptr(knorm_w), L.ptr(positions), L.ptr(cos_sin), float(eps), L.ptr(k_cache),
+        L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), L.ptr(block_table), block_table.stride(0), L.ptr(seq_lens),
+        L.ptr(slots), L.ptr(out), L.ptr(ws), B, q_heads, kv_heads, head_dim, block_size, kv_dtype, float(k_scale),
+        float(v_scale), 1.0 / math.sqrt(head_dim), max_seq_len, L.current_stream()), "omni_attn_decode_fused")
+    return out, slots
+
+
 def slot_mapping(block_table, positions, block_size, B_padded=None):
     _chk_dev(block_table, positions)
     B = positions.shape[0]

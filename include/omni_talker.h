@@ -67,6 +67,15 @@ int omni_rmsnorm(const void* x, const void* delta, void* residual, const void* w
 int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out,
                    int M, int N, int K, int epilogue, const uint8_t* mask, void* stream);
 
+/* The same GEMM with the producing layer's residual-add + RMSNorm fused into the prologue
+ * (replaces one fused_add_rms_norm launch + one linear launch of the reference's layer loop):
+ *   r = bf16(resid + delta)  (delta may be NULL; r is written back to resid)
+ *   x = norm_w * bf16(r * rsqrt(mean(r^2) + eps));  out = x . W^T (+bias), epilogue as above.
+ *   normed_out: bf16 [M,K] or NULL, receives x.  K % 256 == 0 and K <= 2048.                    */
+int omni_gemm_resid_norm(void* resid, const void* delta, const void* norm_w, float eps, void* normed_out,
+                         const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
+                         const uint8_t* mask, void* stream);
+
 /* Per-head q/k RMSNorm + neox RoPE + KV-cache write with quantisation
  * (vLLM Qwen3Attention q_norm/k_norm + rotary_emb + reshape_and_cache; slot mapping built at
  * V/worker/gpu_ar_model_runner.py:239-244, passed via set_forward_context 283-292).
@@ -97,6 +106,16 @@ int omni_paged_attn_decode(const void* q, const void* k_cache, const void* v_cac
                            int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
                            int max_seq_len, void* stream);
 int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_dim, int max_seq_len);
+
+/* omni_qknorm_rope_kvwrite + omni_paged_attn_decode in ONE launch for a uniform decode batch: takes the
+ * raw qkv projection, writes the new token's K/V into the cache (slot computed from block_table and
+ * positions, returned in slot_out[B] when non-NULL) and attends over seq_lens[b] keys incl. the new one. */
+int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                           const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales,
+                           float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* seq_lens,
+                           int64_t* slot_out, void* out, void* workspace, int B, int q_heads, int kv_heads,
+                           int head_dim, int block_size, int kv_dtype, float k_scale, float v_scale,
+                           float sm_scale, int max_seq_len, void* stream);
 
 /* Causal paged-attention for prefill / mixed batches (correctness path; the MFMA prefill
  * kernel is the "next" row of SURVEY 8f).  Token t of request r = req_of_tok[t] at absolute
@@ -159,6 +178,10 @@ typedef struct omni_talker_desc {
     const void* cp_lm_head;            /* bf16 [Q-1][codebook][Hc]           */
     const void* cp_embed;              /* bf16 [Q-1][codebook][H]            */
     const void* cp_cos_sin;            /* bf16 [Q+1][2][Dc/2]                */
+    /* optional constant-folded projections (bit-identical to projecting at run time):
+     * cp_proj_table[g][c] = small_to_mtp_projection(cp_embed[g][c]), cp_e0_table[c] = projection(embed[c]) */
+    const void* cp_proj_table;         /* bf16 [Q-1][codebook][Hc] or NULL   */
+    const void* cp_e0_table;           /* bf16 [vocab][Hc] or NULL           */
     /* KV caches (device), HOST arrays [layers] of K-half / V-half base pointers */
     void* const* k_cache;
     void* const* v_cache;

@@ -70,6 +70,39 @@ def test_gemm_silu_mul(ops, M, inter, K):
     assert_bf16_close(out, ref, ulps=2, max_mismatch=0.03, what="gemm silu*mul")
 
 
+@pytest.mark.parametrize("M", [1, 16, 40, 64])
+@pytest.mark.parametrize("N,K,epi", [(4096, 2048, "bf16"), (1024, 256, "bf16"), (6144, 2048, "silu"), (3072, 1024, "logits"),
+                                     (2048, 1024, "silu")])
+def test_gemm_resid_norm_fused(ops, M, N, K, epi):
+    """Residual add + RMSNorm fused into the GEMM prologue == separate rmsnorm then GEMM (oracle)."""
+    from ht_vllm_omni_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    resid, delta = _rand(g, M, K), _rand(g, M, K)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16)
+    rows = 2 * N if epi == "silu" else N
+    w = _rand(g, rows, K, scale=0.03)
+    r_ref = resid + delta
+    x_ref = O.rms_norm(r_ref, nw, 1e-6)
+    code = {"bf16": L.EPI_BF16, "silu": L.EPI_SILU_MUL, "logits": L.EPI_F32_BF16RND}[epi]
+    rd = resid.clone().cuda()
+    out, normed = ops.gemm_resid_norm(rd, w.cuda(), nw.cuda(), 1e-6, delta=delta.cuda(), epilogue=code, want_normed=True)
+    assert torch.equal(rd.cpu().view(torch.int16), r_ref.view(torch.int16)), "residual write-back must be bit-exact"
+    assert_bf16_close(normed, x_ref, what="fused normed rows")
+    y = O.linear(x_ref, w)
+    if epi == "silu":
+        ref = O.silu_mul(y[:, :N], y[:, N:])
+        assert_bf16_close(out, ref, ulps=2, max_mismatch=0.06, what="fused norm+gemm silu")
+    elif epi == "logits":
+        assert_bf16_close(out, y.float(), ulps=1, max_mismatch=0.06, what="fused norm+gemm logits")
+    else:
+        assert_bf16_close(out, y, ulps=1, max_mismatch=0.06, what="fused norm+gemm")
+    # no delta: residual untouched
+    rd2 = resid.clone().cuda()
+    out2 = ops.gemm_resid_norm(rd2, w.cuda(), nw.cuda(), 1e-6, epilogue=code)
+    assert torch.equal(rd2.cpu().view(torch.int16), resid.view(torch.int16))
+    assert out2.shape == out.shape
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from ht_vllm_omni_amd import _lib as L
     x = torch.zeros(65, 64, dtype=BF16, device="cuda")
@@ -179,6 +212,61 @@ def test_paged_attn_decode(ops, kv, hq, hkv, split):
         kk, vv = pk.gather(bt[r].tolist(), n)
         ref = O.attention_rows(q[r].view(1, hq, D), kk, vv, torch.tensor([n - 1]), D ** -0.5)
         assert_bf16_close(out[r].view(1, hq, D), ref, ulps=1, max_mismatch=0.05, what=f"attn row {r} len {n}")
+
+
+@pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8)])
+@pytest.mark.parametrize("split", [False, True])
+def test_attn_decode_fused(ops, kv, hq, hkv, split):
+    """Fused q/k-norm + RoPE + KV write + attention == the two separate ops (oracle), incl. slot indices."""
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, nb = 128, 16, 96
+    g = torch.Generator().manual_seed(hq * 3 + hkv + len(kv))
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    pk = _fill_cache(kv, nb, bs, hkv, D, g, k_scale, v_scale)
+    seq_lens = [1, 2, 16, 17, 33, 129, 400, 64]        # context incl. the new token
+    B = len(seq_lens)
+    perm = torch.randperm(nb - 1, generator=g) + 1
+    bt = torch.zeros(B, 32, dtype=torch.int32)
+    ptr = 0
+    for r, n in enumerate(seq_lens):
+        need = (n + bs - 1) // bs
+        bt[r, :need] = perm[(ptr + torch.arange(need)) % (nb - 1)]
+        ptr += 11
+    pos = torch.tensor([n - 1 for n in seq_lens], dtype=torch.int32)
+    qkv = _rand(g, B, (hq + 2 * hkv) * D, scale=2.0)
+    qn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    kn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    cos_sin = ops.rope_table(512, D, 1e6)
+    store = pk.data.view(torch.uint8) if kv == "fp8" else pk.data
+    cache = store.clone().cuda()
+    sc = pk.scales.clone().cuda() if kv == "int8" else None
+    out, slots = ops.attn_decode_fused(qkv.cuda(), qn.cuda(), kn.cuda(), pos.cuda(), cos_sin.cuda(), cache[0], cache[1],
+                                       bt.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(), q_heads=hq, kv_heads=hkv,
+                                       head_dim=D, block_size=bs, kv_dtype=L.KV_CODES[kv], eps=1e-6, k_scale=k_scale,
+                                       v_scale=v_scale, k_scales=None if sc is None else sc[0],
+                                       v_scales=None if sc is None else sc[1], max_seq_len=512, split=split)
+    # oracle: norm + rope, write through the cache, attend
+    ref_slots = torch.tensor([O.slot_of(bt[r].tolist(), int(pos[r]), bs) for r in range(B)])
+    assert torch.equal(slots.cpu(), ref_slots), "slot indices must be bit-exact"
+    cos, sin = O.rope_cos_sin(pos.long(), D, 1e6)
+    qq = O.apply_rope(O.rms_norm(qkv[:, : hq * D].reshape(B, hq, D), qn, 1e-6), cos, sin)
+    kk = O.apply_rope(O.rms_norm(qkv[:, hq * D:(hq + hkv) * D].reshape(B, hkv, D), kn, 1e-6), cos, sin)
+    vv = qkv[:, (hq + hkv) * D:].reshape(B, hkv, D)
+    pk.write(ref_slots, kk, vv)
+    for r, n in enumerate(seq_lens):
+        kf, vf = pk.gather(bt[r].tolist(), n)
+        ref = O.attention_rows(qq[r:r + 1], kf, vf, torch.tensor([n - 1]), D ** -0.5)
+        assert_bf16_close(out[r].view(1, hq, D), ref, ulps=1, max_mismatch=0.08, what=f"fused attn row {r} len {n}")
+    # the cache now holds the new token exactly as the oracle's write would
+    got = cache.cpu()
+    ref_store = pk.data.view(torch.uint8) if kv == "fp8" else pk.data
+    if kv == "bf16":
+        assert_bf16_close(got, ref_store, what="cache after fused write")
+    else:
+        assert (got != ref_store).float().mean().item() < 1e-3
+    if kv == "int8":
+        torch.testing.assert_close(sc.cpu(), pk.scales, rtol=1e-2, atol=0)
 
 
 def test_paged_attn_prefill_causal(ops):
