@@ -62,7 +62,7 @@ SIGNATURES = {
     "omni_abi_version": (i32, []),
     "omni_rmsnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
-    "omni_gemm_resid_norm": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_gemm_resid_norm": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                      f32, f32, f32, i32, vp]),
     "omni_qknorm_rope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),

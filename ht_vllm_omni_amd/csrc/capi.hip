@@ -94,9 +94,9 @@ struct omni_talker {
     std::vector<float*> k_scales, v_scales;
     int Bm, cp_bs;
     // scratch carve
-    uint16_t *resid, *normed, *qkv, *q, *attn, *attn_out, *act, *mlp_out, *hidden, *e0;
+    uint16_t *resid, *resid_b, *normed, *qkv, *q, *attn, *attn_out, *act, *mlp_out, *hidden, *e0;
     float* attn_ws;
-    uint16_t *cp_resid, *cp_normed, *cp_qkv, *cp_q, *cp_attn, *cp_o, *cp_act, *cp_mlp, *cp_hidden, *cp_in, *cp_row;
+    uint16_t *cp_resid, *cp_resid_b, *cp_normed, *cp_qkv, *cp_q, *cp_attn, *cp_o, *cp_act, *cp_mlp, *cp_hidden, *cp_in, *cp_row;
     float* cp_logits;
     int32_t *codes, *cp_bt, *cp_pos, *cp_seq;
     int64_t* cp_slots;
@@ -124,6 +124,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     const size_t cp_qkv_out = (size_t)(d.cp_q_heads + 2 * d.cp_kv_heads) * d.cp_head_dim;
     Carver c{base, 0};
     t->resid = c.take<uint16_t>(B * H);
+    t->resid_b = c.take<uint16_t>(B * H);
     t->normed = c.take<uint16_t>(B * H);
     t->qkv = c.take<uint16_t>(B * qkv_out);
     t->q = c.take<uint16_t>(B * d.q_heads * d.head_dim);
@@ -135,6 +136,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->e0 = c.take<uint16_t>(B * H);
     t->attn_ws = c.take<float>((size_t)omni_paged_attn_workspace_bytes(d.max_batch, d.q_heads, d.head_dim, d.max_model_len) / 4);
     t->cp_resid = c.take<uint16_t>(B * Hc);
+    t->cp_resid_b = c.take<uint16_t>(B * Hc);
     t->cp_normed = c.take<uint16_t>(B * Hc);
     t->cp_qkv = c.take<uint16_t>(B * cp_qkv_out);
     t->cp_q = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
@@ -264,15 +266,23 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
 }
 
 // ---- fused-or-fallback building blocks --------------------------------------------------------
-// out = epilogue( rmsnorm(resid (+delta)) . W^T ); resid updated in place; one launch when K allows it
-static int norm_gemm(omni_talker* t, uint16_t* resid, const uint16_t* delta, const void* norm_w, uint16_t* normed_scratch,
-                     void* normed_out, const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask,
-                     void* st) {
+// out = epilogue( rmsnorm(resid_in (+delta)) . W^T ); r = resid_in + delta -> resid_out (ping-pong: the fused
+// kernel's workgroups all re-read resid_in, so it cannot be updated in place); one launch when K allows it
+static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* delta, uint16_t* resid_out, const void* norm_w,
+                     uint16_t* normed_scratch, void* normed_out, const void* w, void* out, int rows, int N, int K, int epi,
+                     const uint8_t* mask, void* st) {
     const float eps = t->d.eps;
     if (k_gemm_rn_supported(K))
-        return omni_gemm_resid_norm(resid, delta, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
+        return omni_gemm_resid_norm(resid_in, delta, resid_out, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
     uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
-    TRY(omni_rmsnorm(nullptr, delta, resid, norm_w, nx, rows, K, eps, st));
+    if (resid_out) {
+        hipError_t e = hipMemcpyAsync(resid_out, resid_in, (size_t)rows * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
+        if (e != hipSuccess) { omni_set_error("norm_gemm: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        TRY(omni_rmsnorm(nullptr, delta, resid_out, norm_w, nx, rows, K, eps, st));
+    } else {
+        OMNI_CHECK_ARG(delta == nullptr, "norm_gemm: delta without resid_out");
+        TRY(omni_rmsnorm(resid_in, nullptr, nullptr, norm_w, nx, rows, K, eps, st));
+    }
     return omni_gemm_bf16(nx, K, w, nullptr, out, rows, N, K, epi, mask, st);
 }
 
@@ -285,14 +295,15 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
     const float sm = 1.0f / sqrtf((float)D);
     for (int l = 0; l < d.cp_layers; ++l) {
         const omni_layer_weights& w = t->cp_layer[l];
-        TRY(norm_gemm(t, t->cp_resid, l == 0 ? nullptr : t->cp_mlp, w.ln1, t->cp_normed, nullptr, w.wqkv, t->cp_qkv, B,
-                      (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
+        // residual stream ping-pongs cp_resid -> cp_resid_b (attention half) -> cp_resid (MLP half)
+        TRY(norm_gemm(t, t->cp_resid, l == 0 ? nullptr : t->cp_mlp, t->cp_resid_b, w.ln1, t->cp_normed, nullptr, w.wqkv,
+                      t->cp_qkv, B, (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
         TRY(omni_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
                                    t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
                                    t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, st));
         TRY(omni_gemm_bf16(t->cp_attn, hq * D, w.wo, nullptr, t->cp_o, B, Hc, hq * D, OMNI_EPI_BF16, nullptr, st));
-        TRY(norm_gemm(t, t->cp_resid, t->cp_o, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter, Hc,
-                      OMNI_EPI_SILU_MUL, nullptr, st));
+        TRY(norm_gemm(t, t->cp_resid_b, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter,
+                      Hc, OMNI_EPI_SILU_MUL, nullptr, st));
         TRY(omni_gemm_bf16(t->cp_act, d.cp_inter, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, OMNI_EPI_BF16, nullptr, st));
     }
     return OMNI_OK;
@@ -325,8 +336,8 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
     for (int g = 1; g < Q; ++g) {
         TRY(cp_forward(t, B, g, st));
         const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
-        TRY(norm_gemm(t, t->cp_resid, t->cp_mlp, d.cp_norm, t->cp_normed, nullptr, head, t->cp_logits, B, d.codebook, Hc,
-                      OMNI_EPI_F32_BF16RND, nullptr, st));
+        TRY(norm_gemm(t, t->cp_resid, t->cp_mlp, t->cp_resid_b, d.cp_norm, t->cp_normed, nullptr, head, t->cp_logits, B,
+                      d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, st));
         if (cp_logits_out) {
             hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
                                             t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,
@@ -387,7 +398,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
-    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, B,
+    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, B,
                   (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
     TRY(omni_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
                                t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
@@ -403,7 +414,7 @@ static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* po
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim;
-    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, rows,
+    TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, rows,
                   (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
     TRY(omni_qknorm_rope_kvwrite(t->qkv, w.qnorm, w.knorm, positions, d.cos_sin, slots, t->q, t->k_cache[l], t->v_cache[l],
                                  t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, d.k_scale, d.v_scale, st));
@@ -417,7 +428,7 @@ static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* po
 static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
-    TRY(norm_gemm(t, t->resid, t->attn_out, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
+    TRY(norm_gemm(t, t->resid_b, t->attn_out, t->resid, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
                   OMNI_EPI_SILU_MUL, nullptr, st));
     TRY(omni_gemm_bf16(t->act, d.inter, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, OMNI_EPI_BF16, nullptr, st));
     return OMNI_OK;
@@ -454,8 +465,8 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     hipStream_t st = (hipStream_t)stream;
     // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
-    TRY(norm_gemm(t, t->resid, t->mlp_out, d.final_norm, reinterpret_cast<uint16_t*>(io->last_hidden), io->last_hidden,
-                  d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, stream));
+    TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, reinterpret_cast<uint16_t*>(io->last_hidden),
+                  io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, stream));
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream));
     if (io->advance) {

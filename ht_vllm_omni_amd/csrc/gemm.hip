@@ -17,7 +17,8 @@
 // activation rows it needs from the residual stream:
 //   r = bf16(resid + delta);  x = w * bf16(r * rsqrt(mean(r^2) + eps))
 // (64 x K elements, ~2 us of VALU, instead of a separate 5-6 us kernel launch); the workgroups
-// with blockIdx.x == 0 write r back (and x, when the caller wants the normalised rows).
+// with blockIdx.x == 0 write r to resid_out -- a DIFFERENT buffer than resid: other workgroups are
+// still reading the input -- and x to normed_out when the caller wants the normalised rows.
 #include "common.cuh"
 #include "kernels.h"
 
@@ -42,10 +43,11 @@ struct GemmArgs {
     int M, N, K;
     const uint8_t* mask;
     // PRO_RN
-    uint16_t* resid; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
+    const uint16_t* resid; uint16_t* resid_out; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
+    int dbg;   // ablation bits (diagnostics): 1 = no x loads, 2 = no W loads, 4 = no MFMA, 8 = no LDS combine
 };
 
-template <int MT, int NT, int PRO, int EPI>
+template <int MT, int NT, int PRO, int EPI, bool NTL>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [WAVES][NT*MT*4][64]
     const int lane = threadIdx.x & 63;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             if (s < ntw) {
                 const int k0 = (wave + s * GEMM_WAVES) << 5;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wf[s][j] = ld16_nt(wrow[j] + k0);
+                for (int j = 0; j < NT; ++j) wf[s][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
             }
         u32x4 xr[MT][RN_MAX_STEPS];
         float ss[MT];
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     const bool row_ok = ml < Mloc;
                     const size_t off = (size_t)(m_base + ml) * K + k0 + 8 * q;
                     u32x4 v = xr[i][s];
-                    if (writer && row_ok && a.delta) *reinterpret_cast<u32x4*>(a.resid + off) = v;
+                    if (writer && row_ok && a.resid_out) *reinterpret_cast<u32x4*>(a.resid_out + off) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd[i]);
@@ -156,7 +158,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 }
             }
     } else {
-        // ---------------- plain x operand, two-deep pipelined load groups -----------------
+        // ---------------- plain x operand: deep W prefetch ring, x one step ahead -----------------
+        // Every wave keeps DEPTH k-steps (DEPTH KB) of W outstanding (Little's law at ~3 us loaded HBM latency);
+        // x is L2-resident and fetched one k-step ahead.  (Measured alternatives, scripts/bench_ops.py: issuing a
+        // whole chunk of x fragments up front -- 218 VGPRs -- was 10-40 % slower; see DESIGN.md.)
         const uint16_t* xrow[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -164,40 +169,51 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             m = m_base + (m < Mloc ? m : Mloc - 1);   // rows past M: valid address, result discarded
             xrow[i] = a.x + (size_t)m * a.ldx + 8 * q;
         }
-        u32x4 A0[GEMM_U][NT], B0[GEMM_U][MT], A1[GEMM_U][NT], B1[GEMM_U][MT];
-#define LOAD_GROUP(A, B, T0)                                                            \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                \
-        int t_ = (T0) + u;                                                              \
-        t_ = t_ < ntw ? t_ : ntw - 1;                                                   \
-        const int k0 = (wave + t_ * GEMM_WAVES) << 5;                                   \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) A[u][j] = ld16_nt(wrow[j] + k0); \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) B[u][i] = ld16(xrow[i] + k0);    \
-    }
-#define MMA_GROUP(A, B, T0)                                                                         \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                            \
-        if ((T0) + u < ntw) {                                                                       \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                          \
-                _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(A[u][j], B[u][i], acc[j][i]); \
-        }                                                                                           \
-    }
+        constexpr int DEPTH = (NT == 1) ? 16 : 8;
+        u32x4 Wr[DEPTH][NT];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < ntw) {
+                const int k0 = (wave + d * GEMM_WAVES) << 5;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Wr[d][j] = (a.dbg & 2) ? (u32x4){(unsigned)k0, 1u, 2u, 3u} : (NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0));
+            }
+        u32x4 X[2][MT];
         if (ntw > 0) {
-            int t = 0;
-            LOAD_GROUP(A0, B0, 0)
-            while (true) {
-                if (t + GEMM_U < ntw) { LOAD_GROUP(A1, B1, t + GEMM_U) }
-                MMA_GROUP(A0, B0, t)
-                t += GEMM_U;
-                if (t >= ntw) break;
-                if (t + GEMM_U < ntw) { LOAD_GROUP(A0, B0, t + GEMM_U) }
-                MMA_GROUP(A1, B1, t)
-                t += GEMM_U;
-                if (t >= ntw) break;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) X[0][i] = (a.dbg & 1) ? (u32x4){1u, 2u, 3u, 4u} : ld16(xrow[i] + (wave << 5));
+        }
+        for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int t = t0 + d;
+                if (t < ntw) {
+                    if (t + 1 < ntw) {
+                        const int k1 = (wave + (t + 1) * GEMM_WAVES) << 5;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = (a.dbg & 1) ? (u32x4){(unsigned)k1, 2u, 3u, 4u} : ld16(xrow[i] + k1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            if (a.dbg & 4) acc[j][i][0] += __uint_as_float(Wr[d][j][0] ^ X[d & 1][i][0]);
+                            else acc[j][i] = mfma16(Wr[d][j], X[d & 1][i], acc[j][i]);
+                        }
+                    if (t + DEPTH < ntw) {
+                        const int k2 = (wave + (t + DEPTH) * GEMM_WAVES) << 5;
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) Wr[d][j] = (a.dbg & 2) ? (u32x4){(unsigned)k2, 1u, 2u, 3u} : (NTL ? ld16_nt(wrow[j] + k2) : ld16(wrow[j] + k2));
+                    }
+                }
             }
         }
-#undef LOAD_GROUP
-#undef MMA_GROUP
     }
 
+    if (a.dbg & 8) {
+        if (wave == 0) reinterpret_cast<float*>(a.out)[threadIdx.x] = acc[0][0][0] + acc[NT - 1][MT - 1][3];
+        return;
+    }
     // ---- combine the 8 K-partials through LDS: lds[wave][e][lane], e = (j*MT+i)*4+reg
     constexpr int E = NT * MT * 4;
 #pragma unroll
@@ -267,11 +283,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
+static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_dbg = 0;
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt; g_gemm_rn = rn; g_gemm_wgs = wgs; }
+extern "C" void omni_debug_ablate(int bits) { g_gemm_dbg = bits; }
+
 template <int MT, int NT, int PRO, int EPI>
 static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
     const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+    // non-temporal W loads only when each W byte is read by exactly one workgroup (no m-split)
+    if (m_splits == 1 && g_gemm_nt)
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, false>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_bf16");
     return OMNI_OK;
 }
@@ -281,7 +305,7 @@ static int dispatch_mt(const GemmArgs& a, hipStream_t st) {
     // m-tiles per workgroup: split M over grid.y until the grid has >= ~256 workgroups
     const int mt_total = (a.M + 15) / 16;
     const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
-    int splits = (256 + groups - 1) / groups;
+    int splits = (g_gemm_wgs + groups - 1) / groups;
     if (splits > mt_total) splits = mt_total;
     if (splits < 1) splits = 1;
     int mt = (mt_total + splits - 1) / splits;       // 1..4
@@ -323,7 +347,7 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
                               int K, int epilogue, const uint8_t* mask, void* stream) {
     GemmArgs a{};
     a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
-    a.M = M; a.N = N; a.K = K; a.mask = mask;
+    a.M = M; a.N = N; a.K = K; a.mask = mask; a.dbg = g_gemm_dbg;
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_ARG(x, "omni_gemm_bf16: null x");
@@ -331,19 +355,24 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
     return dispatch_epi<0>(a, epilogue, (hipStream_t)stream);
 }
 
-bool k_gemm_rn_supported(int K) { return K % 256 == 0 && K <= 32 * GEMM_WAVES * RN_MAX_STEPS; }
+// the fused prologue multiplies the activation traffic by the number of workgroups (every workgroup re-reads
+// resid + delta: 2 x 64 x K x 2 B): measured 2-3x SLOWER than a separate norm launch at B = 64 -> off by default
+static bool rn_shape_ok(int K) { return K % 256 == 0 && K <= 32 * GEMM_WAVES * RN_MAX_STEPS; }
+bool k_gemm_rn_supported(int K) { return g_gemm_rn && rn_shape_ok(K); }
 
-extern "C" int omni_gemm_resid_norm(void* resid, const void* delta, const void* norm_w, float eps, void* normed_out,
-                                    const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
-                                    const uint8_t* mask, void* stream) {
+extern "C" int omni_gemm_resid_norm(const void* resid, const void* delta, void* resid_out, const void* norm_w, float eps,
+                                    void* normed_out, const void* w, const void* bias, void* out, int M, int N, int K,
+                                    int epilogue, const uint8_t* mask, void* stream) {
     GemmArgs a{};
     a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
     a.M = M; a.N = N; a.K = K; a.mask = mask;
-    a.resid = (uint16_t*)resid; a.delta = (const uint16_t*)delta; a.norm_w = (const uint16_t*)norm_w; a.eps = eps;
+    a.resid = (const uint16_t*)resid; a.resid_out = (uint16_t*)resid_out; a.delta = (const uint16_t*)delta; a.norm_w = (const uint16_t*)norm_w; a.eps = eps;
     a.normed_out = (uint16_t*)normed_out;
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_ARG(resid && norm_w, "omni_gemm_resid_norm: null pointer");
-    OMNI_CHECK_ARG(k_gemm_rn_supported(K), "omni_gemm_resid_norm: K=%d unsupported (multiple of 256, <= 2048)", K);
+    OMNI_CHECK_ARG(resid_out != resid && (normed_out == nullptr || normed_out != resid),
+                   "omni_gemm_resid_norm: outputs must not alias resid (other workgroups still read it)");
+    OMNI_CHECK_ARG(rn_shape_ok(K), "omni_gemm_resid_norm: K=%d unsupported (multiple of 256, <= 2048)", K);
     return dispatch_epi<1>(a, epilogue, (hipStream_t)stream);
 }

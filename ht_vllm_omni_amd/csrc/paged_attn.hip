@@ -98,7 +98,7 @@ __device__ __forceinline__ void head_norm_rope(const uint16_t* src, const uint16
 
 template <int KV, int G, bool FUSED>
 __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PA_WAVES*8][G][PA_REC] | q scratch | kv scratch
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [PA_WAVES][G][PA_REC] | q scratch | kv scratch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 7, tg = lane >> 3;
     const int kvh = blockIdx.x, row = blockIdx.y, sp = blockIdx.z;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     float qf[G][16];
     const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? a.k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;
-    float* wq = lds + PA_WAVES * 8 * G * PA_REC + wave * (G * 128);
+    float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
     if (FUSED) {
         const int pos = a.positions[row];
         const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
             if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
             const size_t crow = (size_t)slot * kv_heads + kvh;
-            float* kvs = lds + PA_WAVES * 8 * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
+            float* kvs = lds + PA_WAVES * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
             float kx0, kx1;
             head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
             const uint16_t* vsrc = a.qkv + ((size_t)row * nslots + a.q_heads + kv_heads + kvh) * 128;
@@ -295,27 +295,51 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         }
     }
 
-    // ---- combine: every (wave, token-group) publishes (m, l, acc) per head through LDS
-    const int part = wave * 8 + tg;
+    // ---- combine: the 8 token-groups of a wave merge in registers (xor-shuffles over lane bits 3..5),
+    // then the 4 wave partials go through LDS
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float* rec = lds + ((size_t)part * G + g) * PA_REC;
-        if (sub == 0) {
-            rec[0] = m[g];
-            rec[1] = l[g];
-        }
+        float mw = m[g];
+        mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+        mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
+        float lw = l[g] * sc;
+        lw += __shfl_xor(lw, 8, 64);
+        lw += __shfl_xor(lw, 16, 64);
+        lw += __shfl_xor(lw, 32, 64);
+        m[g] = mw;
+        l[g] = lw;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rec[2 + elem_of<KV>(sub, e)] = acc[g][e];
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[g][e] * sc;
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[g][e] = v;
+        }
+    }
+    if (tg == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float* rec = lds + ((size_t)wave * G + g) * PA_REC;
+            if (sub == 0) {
+                rec[0] = m[g];
+                rec[1] = l[g];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rec[2 + elem_of<KV>(sub, e)] = acc[g][e];
+        }
     }
     __syncthreads();
     for (int it = threadIdx.x; it < G * 128; it += PA_THREADS) {
         const int g = it >> 7, d = it & 127;
         float M = -INFINITY;
-#pragma unroll 8
-        for (int p = 0; p < PA_WAVES * 8; ++p) M = fmaxf(M, lds[((size_t)p * G + g) * PA_REC]);
+#pragma unroll
+        for (int p = 0; p < PA_WAVES; ++p) M = fmaxf(M, lds[((size_t)p * G + g) * PA_REC]);
         float L = 0.f, A = 0.f;
-#pragma unroll 8
-        for (int p = 0; p < PA_WAVES * 8; ++p) {
+#pragma unroll
+        for (int p = 0; p < PA_WAVES; ++p) {
             const float* rec = lds + ((size_t)p * G + g) * PA_REC;
             const float w = (rec[0] == -INFINITY) ? 0.f : exp2f(rec[0] - M);
             L = fmaf(rec[1], w, L);
@@ -374,7 +398,7 @@ template <int KV, bool FUSED>
 static int launch_pa(const PAArgs& a, int rows, hipStream_t st) {
     const int G = a.q_heads / a.kv_heads;
     dim3 grid(a.kv_heads, rows, a.nsplit), block(PA_THREADS);
-    const size_t lds = ((size_t)PA_WAVES * 8 * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
+    const size_t lds = ((size_t)PA_WAVES * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
 #define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
     switch (G) {
         case 1: LAUNCH(1); break;

@@ -43,17 +43,18 @@ def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None):
 
 
 def gemm_resid_norm(resid, w, norm_w, eps, *, delta=None, bias=None, epilogue=L.EPI_BF16, mask=None, want_normed=False):
-    """out = epilogue(rmsnorm(resid + delta) . w^T); resid is updated in place. Returns out or (out, normed)."""
+    """out = epilogue(rmsnorm(resid + delta) . w^T). Returns (out, new_resid) or (out, new_resid, normed)."""
     _chk_dev(resid, w, norm_w, delta, bias, mask)
     M, K = resid.shape
     N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
     dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
     out = torch.empty(M, N, dtype=dt, device=resid.device)
     normed = torch.empty_like(resid) if want_normed else None
-    L.check(L.load().omni_gemm_resid_norm(L.ptr(resid), L.ptr(delta), L.ptr(norm_w), float(eps), L.ptr(normed), L.ptr(w),
-                                          L.ptr(bias), L.ptr(out), M, N, K, epilogue, L.ptr(mask), L.current_stream()),
-            "omni_gemm_resid_norm")
-    return (out, normed) if want_normed else out
+    new_resid = torch.empty_like(resid)
+    L.check(L.load().omni_gemm_resid_norm(L.ptr(resid), L.ptr(delta), L.ptr(new_resid), L.ptr(norm_w), float(eps),
+                                          L.ptr(normed), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue, L.ptr(mask),
+                                          L.current_stream()), "omni_gemm_resid_norm")
+    return (out, new_resid, normed) if want_normed else (out, new_resid)
 
 
 def attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, k_cache, v_cache, block_table, seq_lens, *, q_heads,

@@ -69,12 +69,13 @@ int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void
 
 /* The same GEMM with the producing layer's residual-add + RMSNorm fused into the prologue
  * (replaces one fused_add_rms_norm launch + one linear launch of the reference's layer loop):
- *   r = bf16(resid + delta)  (delta may be NULL; r is written back to resid)
+ *   r = bf16(resid + delta)  (delta may be NULL); r -> resid_out (bf16 [M,K] or NULL; must not alias
+ *   resid: every workgroup re-reads resid)
  *   x = norm_w * bf16(r * rsqrt(mean(r^2) + eps));  out = x . W^T (+bias), epilogue as above.
  *   normed_out: bf16 [M,K] or NULL, receives x.  K % 256 == 0 and K <= 2048.                    */
-int omni_gemm_resid_norm(void* resid, const void* delta, const void* norm_w, float eps, void* normed_out,
-                         const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
-                         const uint8_t* mask, void* stream);
+int omni_gemm_resid_norm(const void* resid, const void* delta, void* resid_out, const void* norm_w, float eps,
+                         void* normed_out, const void* w, const void* bias, void* out, int M, int N, int K,
+                         int epilogue, const uint8_t* mask, void* stream);
 
 /* Per-head q/k RMSNorm + neox RoPE + KV-cache write with quantisation
  * (vLLM Qwen3Attention q_norm/k_norm + rotary_emb + reshape_and_cache; slot mapping built at

@@ -25,12 +25,13 @@ def timeit(name, mode, blocks, threads, arg=0, reps=500):
     torch.cuda.synchronize(); gr = (time.perf_counter() - t0) / reps / 5 * 1e6
     print(f"{name:40s} eager {eager:6.2f} us/kernel   graph {gr:6.2f} us/kernel")
 
-timeit("empty 1x64", 0, 1, 64)
-timeit("empty 256x256", 0, 256, 256)
-timeit("empty 1024x512", 0, 1024, 512)
-timeit("touch 1x64", 1, 1, 64)
-timeit("touch 256x256", 1, 256, 256)
-timeit("chase depth1 16x256", 2, 16, 256, 1)
-timeit("chase depth2 16x256", 2, 16, 256, 2)
-timeit("chase depth4 16x256", 2, 16, 256, 4)
-timeit("chase depth8 16x256", 2, 16, 256, 8)
+timeit("empty 256x512", 0, 256, 512)
+timeit("lds 0KB 256x512", 3, 256, 512, 0)
+timeit("lds 32KB 256x512", 3, 256, 512, 32768)
+timeit("lds 64KB 256x512", 3, 256, 512, 65536)
+timeit("lds 64KB 384x512", 3, 384, 512, 65536)
+timeit("lds 64KB 512x512", 3, 512, 512, 65536)
+timeit("vgpr32 256x512 n=1", 4, 256, 512, 1)
+timeit("vgpr120 256x512 n=1", 5, 256, 512, 1)
+timeit("vgpr120 384x512 n=1", 5, 384, 512, 1)
+timeit("vgpr120 256x512 n=20", 5, 256, 512, 20)

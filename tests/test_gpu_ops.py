@@ -85,8 +85,9 @@ def test_gemm_resid_norm_fused(ops, M, N, K, epi):
     x_ref = O.rms_norm(r_ref, nw, 1e-6)
     code = {"bf16": L.EPI_BF16, "silu": L.EPI_SILU_MUL, "logits": L.EPI_F32_BF16RND}[epi]
     rd = resid.clone().cuda()
-    out, normed = ops.gemm_resid_norm(rd, w.cuda(), nw.cuda(), 1e-6, delta=delta.cuda(), epilogue=code, want_normed=True)
-    assert torch.equal(rd.cpu().view(torch.int16), r_ref.view(torch.int16)), "residual write-back must be bit-exact"
+    out, new_r, normed = ops.gemm_resid_norm(rd, w.cuda(), nw.cuda(), 1e-6, delta=delta.cuda(), epilogue=code, want_normed=True)
+    assert torch.equal(rd.cpu().view(torch.int16), resid.view(torch.int16)), "input residual must stay untouched"
+    assert torch.equal(new_r.cpu().view(torch.int16), r_ref.view(torch.int16)), "residual add must be bit-exact"
     assert_bf16_close(normed, x_ref, what="fused normed rows")
     y = O.linear(x_ref, w)
     if epi == "silu":
@@ -97,9 +98,8 @@ def test_gemm_resid_norm_fused(ops, M, N, K, epi):
     else:
         assert_bf16_close(out, y, ulps=1, max_mismatch=0.06, what="fused norm+gemm")
     # no delta: residual untouched
-    rd2 = resid.clone().cuda()
-    out2 = ops.gemm_resid_norm(rd2, w.cuda(), nw.cuda(), 1e-6, epilogue=code)
-    assert torch.equal(rd2.cpu().view(torch.int16), resid.view(torch.int16))
+    out2, new_r2 = ops.gemm_resid_norm(resid.cuda(), w.cuda(), nw.cuda(), 1e-6, epilogue=code)
+    assert torch.equal(new_r2.cpu().view(torch.int16), resid.view(torch.int16))
     assert out2.shape == out.shape
 
 
@@ -229,10 +229,10 @@ def test_attn_decode_fused(ops, kv, hq, hkv, split):
     perm = torch.randperm(nb - 1, generator=g) + 1
     bt = torch.zeros(B, 32, dtype=torch.int32)
     ptr = 0
-    for r, n in enumerate(seq_lens):
+    for r, n in enumerate(seq_lens):                   # disjoint blocks: this op WRITES the new token
         need = (n + bs - 1) // bs
-        bt[r, :need] = perm[(ptr + torch.arange(need)) % (nb - 1)]
-        ptr += 11
+        bt[r, :need] = perm[ptr:ptr + need]
+        ptr += need
     pos = torch.tensor([n - 1 for n in seq_lens], dtype=torch.int32)
     qkv = _rand(g, B, (hq + 2 * hkv) * D, scale=2.0)
     qn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
