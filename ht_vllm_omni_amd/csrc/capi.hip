@@ -275,14 +275,8 @@ static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* d
     if (k_gemm_rn_supported(K))
         return omni_gemm_resid_norm(resid_in, delta, resid_out, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
     uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
-    if (resid_out) {
-        hipError_t e = hipMemcpyAsync(resid_out, resid_in, (size_t)rows * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
-        if (e != hipSuccess) { omni_set_error("norm_gemm: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
-        TRY(omni_rmsnorm(nullptr, delta, resid_out, norm_w, nx, rows, K, eps, st));
-    } else {
-        OMNI_CHECK_ARG(delta == nullptr, "norm_gemm: delta without resid_out");
-        TRY(omni_rmsnorm(resid_in, nullptr, nullptr, norm_w, nx, rows, K, eps, st));
-    }
+    OMNI_CHECK_ARG(resid_out || delta == nullptr, "norm_gemm: delta without resid_out");
+    TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, nx, rows, K, eps, st));
     return omni_gemm_bf16(nx, K, w, nullptr, out, rows, N, K, epi, mask, st);
 }
 

@@ -13,3 +13,6 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, void* stream);
+// rmsnorm with out-of-place residual update: residual_out = bf16(residual + delta) (may alias residual)
+int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,
+              int rows, int hidden, float eps, void* stream);

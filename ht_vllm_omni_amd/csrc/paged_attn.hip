@@ -360,6 +360,150 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     }
 }
 
+// ---- short-context variant (code predictor: <= 17 keys): ONE wave per (row, kv-head), bf16 KV, fused
+// norm + RoPE + KV write.  The general kernel spends ~12 us of instructions (4 waves x q prologue, batch
+// loop, 32-way combine) on a context that fits one 8-token pass or two; this one is ~4x lighter.
+template <int G>
+__global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, int npairs) {
+    constexpr int KV = OMNI_KV_BF16;
+    __shared__ float sm[4][G * 128 + 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= npairs) return;                       // no workgroup barrier below
+    const int kv_heads = a.kv_heads, bs = a.bs;
+    const int row = pair / kv_heads, kvh = pair - row * kv_heads;
+    const int sub = lane & 7, tg = lane >> 3;
+    const int32_t* bt = a.block_table + (size_t)row * a.bt_stride;
+    const int max_blk = a.bt_stride - 1;
+    const int nslots = a.q_heads + 2 * kv_heads;
+    // first 8-token group: issued before the sequence length is known
+    const size_t r0 = ((size_t)bt[min(tg / bs, max_blk)] * bs + tg % bs) * kv_heads + kvh;
+    KVRaw<KV> kr = load_row<KV>(a.k_cache, r0, sub), vr = load_row<KV>(a.v_cache, r0, sub);
+    const int cur = a.seq_lens[row] - 1;
+    const int pos = a.positions[row];
+    const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+    float* wq = sm[wave];
+    float* kvs = sm[wave] + G * 128;
+    const float qs = a.sm_scale * LOG2E;
+    float qf[G][16];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float y0, y1;
+        head_norm_rope(a.qkv + ((size_t)row * nslots + kvh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
+        wq[g * 128 + lane] = y0;
+        wq[g * 128 + 64 + lane] = y1;
+    }
+    {   // new token: K (norm + rope) and V -> cache and LDS
+        const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
+        if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+        const size_t crow = (size_t)slot * kv_heads + kvh;
+        float kx0, kx1;
+        head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
+        const uint16_t* vsrc = a.qkv + ((size_t)row * nslots + a.q_heads + kv_heads + kvh) * 128;
+        const uint16_t v0 = vsrc[lane], v1 = vsrc[lane + 64];
+        uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
+        uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
+        kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
+        vd[lane] = v0; vd[lane + 64] = v1;
+        kvs[lane] = kx0; kvs[64 + lane] = kx1;
+        kvs[128 + lane] = bf2f(v0); kvs[192 + lane] = bf2f(v1);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qf[g][e] = wq[g * 128 + elem_of<KV>(sub, e)] * qs;
+    float m[G], l[G], acc[G][16];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    }
+    for (int t0 = 0; t0 < cur; t0 += 8) {
+        if (t0 > 0) {
+            const int t = t0 + tg;
+            const size_t r_ = ((size_t)bt[min(t / bs, max_blk)] * bs + t % bs) * kv_heads + kvh;
+            kr = load_row<KV>(a.k_cache, r_, sub);
+            vr = load_row<KV>(a.v_cache, r_, sub);
+        }
+        const bool ok = t0 + tg < cur;
+        float kf[16], vf[16];
+        to_f32<KV>(kr, kf);
+        to_f32<KV>(vr, vf);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            d = ok ? d : -INFINITY;
+            const float mn = fmaxf(m[g], d);
+            const float corr = (mn == -INFINITY) ? 1.0f : exp2f(m[g] - mn);
+            const float p = ok ? exp2f(d - mn) : 0.f;
+            m[g] = mn;
+            l[g] = l[g] * corr + p;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e] * corr);
+        }
+    }
+    {   // fold the new token into token-group 0
+        float kf[16], vf[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            kf[e] = kvs[elem_of<KV>(sub, e)];
+            vf[e] = kvs[128 + elem_of<KV>(sub, e)];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (tg == 0) {
+                const float mn = fmaxf(m[g], d);
+                const float corr = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mn);
+                const float p = exp2f(d - mn);
+                m[g] = mn;
+                l[g] = l[g] * corr + p;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e] * corr);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float mw = m[g];
+        mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+        mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
+        float lw = l[g] * sc;
+        lw += __shfl_xor(lw, 8, 64);
+        lw += __shfl_xor(lw, 16, 64);
+        lw += __shfl_xor(lw, 32, 64);
+        const float inv = 1.0f / lw;                  // >= the new token's weight, never 0
+        uint16_t* op = a.out + ((size_t)row * a.q_heads + kvh * G + g) * 128;
+        uint32_t packed[8];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            float v0 = acc[g][e] * sc, v1 = acc[g][e + 1] * sc;
+            v0 += __shfl_xor(v0, 8, 64); v1 += __shfl_xor(v1, 8, 64);
+            v0 += __shfl_xor(v0, 16, 64); v1 += __shfl_xor(v1, 16, 64);
+            v0 += __shfl_xor(v0, 32, 64); v1 += __shfl_xor(v1, 32, 64);
+            packed[e >> 1] = pack_bf2(v0 * inv, v1 * inv);
+        }
+        if (tg == 0) {   // bf16 layout: elements [8 sub, +8) and [64 + 8 sub, +8): two 16-B stores
+            *reinterpret_cast<uint4*>(op + sub * 8) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            *reinterpret_cast<uint4*>(op + 64 + sub * 8) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+        }
+    }
+}
+
 // merge KV splits: one 128-thread block per (row, q-head)
 __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ partial,
                                                                uint16_t* __restrict__ out, int nsplit, float v_mul) {
@@ -467,6 +611,21 @@ extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, cons
     a.partial = (float*)workspace; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
     a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale;
     a.nsplit = (workspace && kv_heads > 0 && B > 0) ? pick_nsplit(B, kv_heads, max_seq_len) : 1;
+    if (kv_dtype == OMNI_KV_BF16 && max_seq_len <= 64 && head_dim == 128 && kv_heads > 0 && q_heads % kv_heads == 0 && B > 0 &&
+        qkv && qnorm_w && knorm_w && positions && cos_sin && k_cache && v_cache && block_table && seq_lens && out &&
+        block_size > 0 && bt_stride > 0) {
+        const int G = q_heads / kv_heads, npairs = B * kv_heads;
+        dim3 grid((npairs + 3) / 4), block(256);
+        hipStream_t st = (hipStream_t)stream;
+        a.nsplit = 1;
+        if (G == 1) hipLaunchKernelGGL(attn_small_fused_kernel<1>, grid, block, 0, st, a, npairs);
+        else if (G == 2) hipLaunchKernelGGL(attn_small_fused_kernel<2>, grid, block, 0, st, a, npairs);
+        else if (G == 4) hipLaunchKernelGGL(attn_small_fused_kernel<4>, grid, block, 0, st, a, npairs);
+        if (G == 1 || G == 2 || G == 4) {
+            OMNI_CHECK_LAUNCH("omni_attn_decode_fused(small)");
+            return OMNI_OK;
+        }
+    }
     return pa_dispatch(a, B, head_dim, kv_dtype, true, stream);
 }
 

@@ -269,6 +269,38 @@ def test_attn_decode_fused(ops, kv, hq, hkv, split):
         torch.testing.assert_close(sc.cpu(), pk.scales, rtol=1e-2, atol=0)
 
 
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (2, 2)])
+def test_attn_decode_fused_short_context(ops, hq, hkv):
+    """Code-predictor geometry: block = one request's 17 positions, contexts 1..17 (one-wave kernel)."""
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, B = 128, 17, 17
+    g = torch.Generator().manual_seed(hq + hkv)
+    pk = _fill_cache("bf16", B, bs, hkv, D, g, 1.0, 1.0)
+    seq_lens = list(range(1, 18))
+    bt = torch.arange(B, dtype=torch.int32).view(B, 1)
+    pos = torch.tensor([n - 1 for n in seq_lens], dtype=torch.int32)
+    qkv = _rand(g, B, (hq + 2 * hkv) * D, scale=2.0)
+    qn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    kn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    cos_sin = ops.rope_table(32, D, 1e4)
+    cache = pk.data.clone().cuda()
+    out, slots = ops.attn_decode_fused(qkv.cuda(), qn.cuda(), kn.cuda(), pos.cuda(), cos_sin.cuda(), cache[0], cache[1],
+                                       bt.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(), q_heads=hq, kv_heads=hkv,
+                                       head_dim=D, block_size=bs, kv_dtype=L.KV_BF16, eps=1e-6, max_seq_len=bs, split=False)
+    ref_slots = torch.tensor([r * bs + int(pos[r]) for r in range(B)])
+    assert torch.equal(slots.cpu(), ref_slots)
+    cos, sin = O.rope_cos_sin(pos.long(), D, 1e4)
+    qq = O.apply_rope(O.rms_norm(qkv[:, : hq * D].reshape(B, hq, D), qn, 1e-6), cos, sin)
+    kk = O.apply_rope(O.rms_norm(qkv[:, hq * D:(hq + hkv) * D].reshape(B, hkv, D), kn, 1e-6), cos, sin)
+    vv = qkv[:, (hq + hkv) * D:].reshape(B, hkv, D)
+    pk.write(ref_slots, kk, vv)
+    for r, n in enumerate(seq_lens):
+        kf, vf = pk.gather(bt[r].tolist(), n)
+        ref = O.attention_rows(qq[r:r + 1], kf, vf, torch.tensor([n - 1]), D ** -0.5)
+        assert_bf16_close(out[r].view(1, hq, D), ref, ulps=1, max_mismatch=0.08, what=f"short ctx row {r} len {n}")
+    assert_bf16_close(cache.cpu(), pk.data, what="cache after fused write (short)")
+
+
 def test_paged_attn_prefill_causal(ops):
     from ht_vllm_omni_amd import _lib as L
     D, bs, nb, hq, hkv = 128, 16, 32, 4, 2
