@@ -83,6 +83,10 @@ SIGNATURES = {
     "omni_talker_attn_out": (vp, [vp]),
     "omni_talker_mlp_out": (vp, [vp]),
     "omni_talker_prefill": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "omni_talker_rows_begin": (i32, [vp, vp, i32, vp]),
+    "omni_talker_rows_attn": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
+    "omni_talker_rows_mlp": (i32, [vp, i32, i32, vp]),
+    "omni_talker_rows_end": (i32, [vp, vp, i32, vp]),
     "omni_talker_logits": (i32, [vp, vp, vp, i32, i32, vp]),
     "omni_talker_code_predictor": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, u32, vp, vp]),
 }

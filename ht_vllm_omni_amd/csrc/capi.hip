@@ -502,3 +502,25 @@ extern "C" int omni_talker_prefill(omni_talker* t, const void* x, const int32_t*
     }
     return OMNI_OK;
 }
+
+// ---- the prefill path one phase at a time (tensor-parallel hosts all-reduce between the phases)
+extern "C" int omni_talker_rows_begin(omni_talker* t, const void* x, int rows, void* stream) {
+    OMNI_CHECK_ARG(t && x && rows >= 1 && rows <= t->Bm, "omni_talker_rows_begin: bad arguments");
+    hipError_t e = hipMemcpyAsync(t->resid, x, (size_t)rows * t->d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { omni_set_error("rows_begin: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+    return OMNI_OK;
+}
+extern "C" int omni_talker_rows_attn(omni_talker* t, int layer, int rows, const int32_t* positions, const int64_t* slot_mapping,
+                                     const int32_t* block_table, const int32_t* req_of_tok, void* stream) {
+    OMNI_CHECK_ARG(t && positions && slot_mapping && block_table && req_of_tok && rows >= 1 && rows <= t->Bm &&
+                       layer >= 0 && layer < t->d.layers, "omni_talker_rows_attn: bad arguments");
+    return layer_attn_prefill(t, layer, rows, positions, slot_mapping, block_table, req_of_tok, stream);
+}
+extern "C" int omni_talker_rows_mlp(omni_talker* t, int layer, int rows, void* stream) {
+    OMNI_CHECK_ARG(t && rows >= 1 && rows <= t->Bm && layer >= 0 && layer < t->d.layers, "omni_talker_rows_mlp: bad arguments");
+    return layer_mlp_rows(t, layer, rows, stream);
+}
+extern "C" int omni_talker_rows_end(omni_talker* t, void* hidden_out, int rows, void* stream) {
+    OMNI_CHECK_ARG(t && hidden_out && rows >= 1 && rows <= t->Bm, "omni_talker_rows_end: bad arguments");
+    return omni_rmsnorm(nullptr, t->mlp_out, t->resid, t->d.final_norm, hidden_out, rows, t->d.hidden, t->d.eps, stream);
+}

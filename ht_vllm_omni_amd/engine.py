@@ -238,14 +238,27 @@ class TalkerEngine:
     def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
                 block_table: torch.Tensor | None = None) -> torch.Tensor:
         """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H]."""
-        if self.tp_size != 1:
-            raise L.OmniError("prefill under TP>1 is not wired yet")
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
         out = torch.empty_like(x)
-        L.check(self.lib.omni_talker_prefill(self.handle, L.ptr(x), L.ptr(positions), L.ptr(req_of_tok),
-                                             L.ptr(slot_mapping), L.ptr(bt), L.ptr(out), T, L.current_stream()),
-                "omni_talker_prefill")
+        st = L.current_stream()
+        if self.tp_size == 1:
+            L.check(self.lib.omni_talker_prefill(self.handle, L.ptr(x), L.ptr(positions), L.ptr(req_of_tok),
+                                                 L.ptr(slot_mapping), L.ptr(bt), L.ptr(out), T, st), "omni_talker_prefill")
+            return out
+        import torch.distributed as dist
+        Bm = self.max_batch
+        for t0 in range(0, T, Bm):
+            rows = min(Bm, T - t0)
+            L.check(self.lib.omni_talker_rows_begin(self.handle, x[t0:].data_ptr(), rows, st), "rows_begin")
+            for l in range(self.d.layers):
+                L.check(self.lib.omni_talker_rows_attn(self.handle, l, rows, positions[t0:].data_ptr(),
+                                                       slot_mapping[t0:].data_ptr(), L.ptr(bt), req_of_tok[t0:].data_ptr(), st),
+                        "rows_attn")
+                dist.all_reduce(self._attn_out[:rows], group=self.tp_group)
+                L.check(self.lib.omni_talker_rows_mlp(self.handle, l, rows, st), "rows_mlp")
+                dist.all_reduce(self._mlp_out[:rows], group=self.tp_group)
+            L.check(self.lib.omni_talker_rows_end(self.handle, out[t0:].data_ptr(), rows, st), "rows_end")
         return out
 
     def compute_logits(self, hidden: torch.Tensor, round_bf16: bool = True) -> torch.Tensor:
@@ -255,6 +268,12 @@ class TalkerEngine:
         L.check(self.lib.omni_talker_logits(self.handle, L.ptr(hidden), L.ptr(out), R, int(round_bf16),
                                             L.current_stream()), "omni_talker_logits")
         return out
+
+    def sample(self, logits: torch.Tensor, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0,
+               steps=None) -> torch.Tensor:
+        """Sampler on arbitrary logits rows (first token after prefill); marks `seen`, increments `steps`."""
+        return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, rep_penalty=rep_penalty, seen=seen,
+                          seed=seed, steps=steps, inc_steps=steps is not None)
 
     def code_predictor(self, layer0_ids, layer0_embed, last_hidden, *, greedy=True, temperature=0.9, top_k=50, seed=0,
                        steps=None, return_logits=False):

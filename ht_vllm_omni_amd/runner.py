@@ -1,0 +1,335 @@
+"""MI355XARModelRunner: the reference's two-phase AR runner contract over the native engine.
+
+Mirrors ``GPUARModelRunner`` / ``OmniGPUModelRunner`` for the talker stage:
+  execute_model(scheduler_output) -> None      V/worker/gpu_ar_model_runner.py:93-400
+  sample_tokens(grammar_output) -> OmniModelRunnerOutput                   ...:403-660
+  _update_states (persistent batch + block table maintenance)   V/worker/gpu_model_runner.py:246-514
+  _preprocess decode branch / talker_mtp staging                 ...:1084-1303  (batched on device here:
+      the per-request Python loop with 4 D2D copies per request and the O(B^2) list.index scatter are gone;
+      the text-step queue is one index_select, everything else lives in the native step)
+  KV transfer on finish + ack via kv_extracted_req_ids           gpu_ar_model_runner.py:106-124,639
+
+Persistent-batch invariant: rows [0, n_decode) of the engine's per-step buffers are the requests in decode
+phase (prompt fully computed), in arrival order; rows are swapped when a later request finishes its prefill
+first.  Freed / padded rows point at the null block (block 0), so graph buckets larger than the live batch
+are inert.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+import torch
+
+from .connectors import OmniKVTransferManager
+from .payloads import (EMPTY_MODEL_RUNNER_OUTPUT, OmniModelRunnerOutput, OmniSchedulerOutput, SamplingParams,
+                       decode_additional_information)
+
+logger = logging.getLogger("ht_vllm_omni_amd.runner")
+BF16 = torch.bfloat16
+
+
+@dataclass
+class RequestState:
+    req_id: str
+    prompt_embeds: torch.Tensor            # [prompt_len, H] bf16 (CPU; prefill-only, like talker_prompt_embeds)
+    block_ids: list[int]
+    sampling: SamplingParams
+    num_computed: int = 0
+    output_ids: list[int] = field(default_factory=list)
+    tail: torch.Tensor | None = None       # tailing_text_hidden [n, H] (device resident, gpu_resident_buffer_keys)
+    tail_pos: int = 0
+    tts_pad: torch.Tensor | None = None    # [H] device
+    info: dict[str, Any] = field(default_factory=dict)
+
+    @property
+    def prompt_len(self) -> int:
+        return int(self.prompt_embeds.shape[0])
+
+    @property
+    def in_decode(self) -> bool:
+        return self.num_computed >= self.prompt_len
+
+
+@dataclass
+class _StepState:
+    scheduler_output: OmniSchedulerOutput
+    decode_rows: list[int]
+    prefill_done: dict[int, torch.Tensor]      # row -> hidden [H] of the last prompt token
+    prefill_sampled: torch.Tensor | None       # ids for prefill_done rows (device)
+    prefill_spans: dict[int, tuple[int, int, torch.Tensor]]  # row -> (start, n, hidden[n,H])
+
+
+_ROW_BUFFERS = ("input_ids", "positions", "seq_lens", "block_table", "last_hidden", "seen", "steps")
+
+
+class MI355XARModelRunner:
+    def __init__(self, engine, *, kv_transfer: OmniKVTransferManager | None = None, use_graphs: bool = True,
+                 engine_output_type: str = "latent"):
+        self.engine = engine
+        self.d = engine.d
+        self.max_num_seqs = engine.max_batch
+        self.kv_caches = engine.kv_caches               # runner-owned list, one [2,nb,bs,h,d] tensor per layer
+        self.kv_transfer_manager = kv_transfer or OmniKVTransferManager(None)
+        self.requests: dict[str, RequestState] = {}
+        self.rows: list[str] = []                       # input_batch.req_ids (row order)
+        self.execute_model_state: _StepState | None = None
+        self.kv_extracted_req_ids: list[str] | None = None
+        self.use_graphs = use_graphs
+        self.graphs: dict[int, Any] = {}
+        self.engine_output_type = engine_output_type
+        self.cudagraph_stats = {"replays": 0, "eager_steps": 0}
+
+    # ------------------------------------------------------------------ persistent batch
+    def _reset_row(self, r: int) -> None:
+        e = self.engine
+        e.block_table[r].zero_()          # null block
+        e.positions[r] = 0
+        e.seq_lens[r] = 1
+        e.input_ids[r] = 0
+        e.steps[r] = 0
+        e.seen[r].zero_()
+
+    def _permute_rows(self, perm: list[int]) -> None:
+        n = len(perm)
+        if perm == list(range(n)):
+            return
+        idx = torch.as_tensor(perm, device=self.engine.input_ids.device)
+        for name in _ROW_BUFFERS:
+            buf = getattr(self.engine, name)
+            buf[:n] = buf[:n].index_select(0, idx)
+        self.rows = [self.rows[i] for i in perm]
+
+    def _update_states(self, so: OmniSchedulerOutput) -> None:
+        e = self.engine
+        # drop finished / preempted requests, closing holes with the last row (condense)
+        for rid in list(so.finished_req_ids) + list(so.preempted_req_ids):
+            if rid not in self.requests:
+                continue
+            r = self.rows.index(rid)
+            last = len(self.rows) - 1
+            if r != last:
+                for name in _ROW_BUFFERS:
+                    buf = getattr(e, name)
+                    buf[r] = buf[last]
+                self.rows[r] = self.rows[last]
+            self.rows.pop()
+            self._reset_row(last)
+            del self.requests[rid]
+        # new requests
+        for nr in so.scheduled_new_reqs:
+            if len(self.rows) >= self.max_num_seqs:
+                raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
+            info = decode_additional_information(nr.additional_information)
+            pe = nr.prompt_embeds if nr.prompt_embeds is not None else info.get("talker_prompt_embeds")
+            if pe is None or pe.ndim != 2 or pe.shape[1] != self.d.hidden:
+                raise ValueError(f"request {nr.req_id}: missing talker_prompt_embeds [T,{self.d.hidden}]")
+            dev = e.input_ids.device
+            tail = info.get("tailing_text_hidden")
+            pad = info.get("tts_pad_embed")
+            if pad is None:
+                raise ValueError(f"request {nr.req_id}: missing tts_pad_embed (prefill must initialise it)")
+            st = RequestState(req_id=nr.req_id, prompt_embeds=pe.to(BF16).cpu().contiguous(),
+                              block_ids=list(nr.block_ids[0]), sampling=nr.sampling_params or SamplingParams(),
+                              num_computed=int(nr.num_computed_tokens),
+                              tail=None if tail is None else tail.to(device=dev, dtype=BF16).reshape(-1, self.d.hidden),
+                              tts_pad=pad.to(device=dev, dtype=BF16).reshape(-1), info=info)
+            self.requests[nr.req_id] = st
+            r = len(self.rows)
+            self.rows.append(nr.req_id)
+            self._reset_row(r)
+            e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=dev)
+        # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489)
+        c = so.scheduled_cached_reqs
+        for i, rid in enumerate(c.req_ids):
+            st = self.requests[rid]
+            nb = c.new_block_ids[i] if i < len(c.new_block_ids) else None
+            if nb:
+                new = list(nb[0])
+                r = self.rows.index(rid)
+                dev = e.block_table.device
+                e.block_table[r, len(st.block_ids):len(st.block_ids) + len(new)] = torch.as_tensor(new, dtype=torch.int32, device=dev)
+                st.block_ids.extend(new)
+
+    # ------------------------------------------------------------------ phase 1
+    @torch.inference_mode()
+    def execute_model(self, scheduler_output: OmniSchedulerOutput, intermediate_tensors=None):
+        if self.execute_model_state is not None:
+            raise RuntimeError("State error: sample_tokens() must be called after execute_model() returns None.")
+        e = self.engine
+        # [Omni] KV transfer BEFORE updating states (which removes finished requests)
+        self.kv_extracted_req_ids = self.kv_transfer_manager.handle_finished_requests_kv_transfer(
+            finished_reqs=scheduler_output.finished_requests_needing_kv_transfer, kv_caches=self.kv_caches,
+            block_size=e.block_size, cache_dtype=str(e.kv_dtype)) or None
+        self._update_states(scheduler_output)
+        if not scheduler_output.total_num_scheduled_tokens:
+            return EMPTY_MODEL_RUNNER_OUTPUT
+
+        sched = scheduler_output.num_scheduled_tokens
+        # decode-first row order
+        dec = [i for i, rid in enumerate(self.rows) if rid in sched and self.requests[rid].in_decode]
+        rest = [i for i in range(len(self.rows)) if i not in set(dec)]
+        self._permute_rows(dec + rest)
+        nd = len(dec)
+        for i in range(nd):
+            if sched[self.rows[i]] != 1:
+                raise RuntimeError("decode requests are scheduled one token per step (no spec decode on this path)")
+
+        # ---- prefill spans (chunked prefill: a span is any slice of the prompt)
+        prefill_done: dict[int, torch.Tensor] = {}
+        spans: dict[int, tuple[int, int, torch.Tensor]] = {}
+        xs, pos, req, slots, meta = [], [], [], [], []
+        bs = e.block_size
+        for r in range(nd, len(self.rows)):
+            rid = self.rows[r]
+            n = sched.get(rid, 0)
+            if n <= 0:
+                continue
+            st = self.requests[rid]
+            s0 = st.num_computed
+            take = st.prompt_embeds[s0:s0 + n]
+            if take.shape[0] < n:   # placeholder longer than the embeddings: pad with tts_pad (talker.py:573-578)
+                take = torch.cat([take, st.tts_pad.cpu().reshape(1, -1).expand(n - take.shape[0], -1)], 0)
+            xs.append(take)
+            p = np.arange(s0, s0 + n)
+            pos.append(p)
+            req.append(np.full(n, r))
+            slots.append(np.asarray(st.block_ids)[p // bs] * bs + p % bs)
+            meta.append((r, s0, n))
+        sampled = None
+        if xs:
+            dev = e.input_ids.device
+            x = torch.cat(xs, 0).to(dev)
+            hid = e.prefill(x, torch.as_tensor(np.concatenate(pos), dtype=torch.int32, device=dev),
+                            torch.as_tensor(np.concatenate(req), dtype=torch.int32, device=dev),
+                            torch.as_tensor(np.concatenate(slots), dtype=torch.int64, device=dev))
+            o = 0
+            for r, s0, n in meta:
+                st = self.requests[self.rows[r]]
+                spans[r] = (s0, n, hid[o:o + n])
+                st.num_computed = s0 + n
+                if st.in_decode:
+                    prefill_done[r] = hid[o + n - 1]
+                o += n
+            if prefill_done:
+                rows_done = sorted(prefill_done)
+                hl = torch.stack([prefill_done[r] for r in rows_done])
+                logits = e.compute_logits(hl)
+                sampled = self._sample_prefill(rows_done, logits)
+                for j, r in enumerate(rows_done):
+                    st = self.requests[self.rows[r]]
+                    e.last_hidden[r] = hl[j]
+                    e.positions[r] = st.prompt_len
+                    e.seq_lens[r] = st.prompt_len + 1
+                e.input_ids[torch.as_tensor(rows_done, device=dev)] = sampled
+
+        # ---- decode rows: text-step queue pop (talker.py:618-629), then the native step
+        if nd:
+            text = []
+            for i in range(nd):
+                st = self.requests[self.rows[i]]
+                if st.tail is not None and st.tail_pos < st.tail.shape[0]:
+                    text.append(st.tail[st.tail_pos])
+                    st.tail_pos += 1
+                else:
+                    text.append(st.tts_pad)
+            e.text_step[:nd] = torch.stack(text)
+            self._apply_sampling(self.requests[self.rows[0]].sampling)
+            self._run_decode(nd)
+        self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans)
+        return None
+
+    def _apply_sampling(self, sp: SamplingParams) -> None:
+        self.engine.set_sampling(greedy=int(sp.greedy), temperature=sp.temperature or 1.0, top_k=sp.top_k,
+                                 rep_penalty=sp.repetition_penalty, seed=sp.seed or 0)
+
+    def _sample_prefill(self, rows: list[int], logits: torch.Tensor) -> torch.Tensor:
+        e = self.engine
+        sp = self.requests[self.rows[rows[0]]].sampling
+        idx = torch.as_tensor(rows, device=logits.device)
+        seen = e.seen.index_select(0, idx)
+        seen[:, self.d.codec_pad_id] = 1       # prompt ids are codec_pad placeholders (talker.py:603-605)
+        steps = torch.zeros(len(rows), dtype=torch.int32, device=logits.device)
+        ids = e.sample(logits, greedy=sp.greedy, temperature=sp.temperature or 1.0, top_k=sp.top_k,
+                       rep_penalty=sp.repetition_penalty, seen=seen, seed=sp.seed or 0, steps=steps)
+        e.seen[idx] = seen
+        e.steps[idx] = steps
+        return ids
+
+    def _bucket(self, n: int) -> int:
+        b = 1
+        while b < n:
+            b *= 2
+        return min(b, self.max_num_seqs)
+
+    def capture_graphs(self, sizes=None) -> None:
+        """hipGraph per padded batch bucket (reference: _dummy_run capture, gpu_model_runner.py:536-876).
+        Capture records the launches without running them, so live state is untouched."""
+        if not self.use_graphs or not torch.cuda.is_available():
+            return
+        sizes = sizes or sorted({self._bucket(n) for n in range(1, self.max_num_seqs + 1)})
+        self.engine.decode_step(min(sizes), advance=False)        # one eager pass loads code objects
+        torch.cuda.synchronize()
+        self._graph_sampling = dict(self.engine.sampling)      # sampling params are baked into the captured launches
+        for b in sizes:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.engine.decode_step(b)
+            self.graphs[b] = g
+
+    def _run_decode(self, nd: int) -> None:
+        g = self.graphs.get(self._bucket(nd)) if self.use_graphs else None
+        if g is not None and self.engine.sampling == getattr(self, "_graph_sampling", None):
+            g.replay()
+            self.cudagraph_stats["replays"] += 1
+        else:
+            self.engine.decode_step(nd)
+            self.cudagraph_stats["eager_steps"] += 1
+
+    # ------------------------------------------------------------------ phase 2
+    @torch.inference_mode()
+    def sample_tokens(self, grammar_output=None) -> OmniModelRunnerOutput | None:
+        kv_extracted = self.kv_extracted_req_ids
+        self.kv_extracted_req_ids = None
+        if self.execute_model_state is None:
+            return None
+        stt, self.execute_model_state = self.execute_model_state, None
+        e = self.engine
+        nd = len(stt.decode_rows)
+        Q = self.d.num_code_groups
+        # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550)
+        ids_cpu = e.input_ids[:len(self.rows)].cpu()
+        hid_cpu = e.last_hidden[:len(self.rows)].cpu()
+        codes_cpu = e.audio_codes[:nd].cpu() if nd else None
+        sched = stt.scheduler_output.num_scheduled_tokens
+        req_ids, sampled, pooler = [], [], []
+        for r, rid in enumerate(self.rows):
+            if rid not in sched or sched[rid] <= 0:
+                continue
+            st = self.requests[rid]
+            payload: dict[str, Any] = {}
+            if r < nd:
+                tok = int(ids_cpu[r])
+                st.num_computed += 1
+                st.output_ids.append(tok)
+                sampled.append([tok])
+                payload["hidden"] = hid_cpu[r:r + 1].clone()
+                payload["audio_codes"] = codes_cpu[r:r + 1].clone()      # frame [c0..c15][t] (talker.py:1642)
+            else:
+                s0, n, hid = stt.prefill_spans[r]
+                payload["hidden"] = hid.cpu()
+                payload["audio_codes"] = torch.zeros(n, Q, dtype=torch.long)   # prefill rows: zero codes (607-612)
+                if r in stt.prefill_done:
+                    tok = int(ids_cpu[r])
+                    st.output_ids.append(tok)
+                    sampled.append([tok])
+                else:
+                    sampled.append([])
+            req_ids.append(rid)
+            pooler.append(payload)
+        return OmniModelRunnerOutput(
+            req_ids=req_ids, req_id_to_index={rid: i for i, rid in enumerate(req_ids)}, sampled_token_ids=sampled,
+            pooler_output=pooler if self.engine_output_type != "text" else None, kv_extracted_req_ids=kv_extracted,
+            cudagraph_stats=dict(self.cudagraph_stats))

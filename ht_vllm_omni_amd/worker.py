@@ -1,0 +1,132 @@
+"""MI355XARWorker: the worker surface vLLM's executor drives, one process per GPU / TP rank.
+
+Mirrors ``GPUARWorker`` + ``OmniGPUWorkerBase`` (V/worker/gpu_ar_worker.py:22-106, V/worker/base.py:49-156) and the
+minimal-backend template ``XPUARWorker`` (V/platforms/xpu/worker/xpu_ar_worker.py:1-15):
+  __init__(vllm_config, local_rank, rank, distributed_init_method, ...)  init_device()  load_model()
+  determine_available_memory() -> bytes   initialize_from_config(kv_cache_config)   compile_or_warm_up_model()
+  execute_model(scheduler_output)   sample_tokens(grammar_output)   profile(is_start, profile_prefix)
+``vllm_config`` is duck-typed: a namespace with the handful of fields the talker stage reads
+(model dims preset or TalkerDims, cache dtype / block size, max_num_seqs, tensor_parallel_size, gpu_memory_utilization).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from types import SimpleNamespace
+from typing import Any
+
+import torch
+
+from .config import TalkerDims, get_dims
+from .connectors import OmniConnectorFactory, OmniKVTransferManager
+from .weights import make_weights, weight_bytes
+
+logger = logging.getLogger("ht_vllm_omni_amd.worker")
+
+
+def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "fp8", block_size: int = 16,
+                max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
+                num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
+                connector: str | None = None, enforce_eager: bool = False) -> SimpleNamespace:
+    return SimpleNamespace(model=model, kv_cache_dtype=kv_cache_dtype, block_size=block_size, max_num_seqs=max_num_seqs,
+                           tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
+                           num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
+                           enforce_eager=enforce_eager)
+
+
+class MI355XARWorker:
+    def __init__(self, vllm_config, local_rank: int = 0, rank: int = 0, distributed_init_method: str | None = None,
+                 is_driver_worker: bool = True, **_: Any):
+        self.vllm_config = vllm_config
+        self.local_rank, self.rank = local_rank, rank
+        self.distributed_init_method = distributed_init_method
+        self.is_driver_worker = is_driver_worker
+        self.tp_size = int(getattr(vllm_config, "tensor_parallel_size", 1))
+        self.dims: TalkerDims = vllm_config.model if isinstance(vllm_config.model, TalkerDims) else get_dims(vllm_config.model)
+        self.device: torch.device | None = None
+        self.model_runner = None
+        self.engine = None
+        self._weights = None
+        self._profiler = None
+
+    # ---- device + distributed (gpu_ar_worker.py:29-106)
+    def init_device(self) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("MI355XARWorker.init_device: no MI355X visible (torch.cuda unavailable)")
+        self.device = torch.device(f"cuda:{self.local_rank}")
+        torch.cuda.set_device(self.device)
+        if self.tp_size > 1 and not torch.distributed.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.distributed.init_process_group("nccl", init_method=self.distributed_init_method or "env://",
+                                                 rank=self.rank, world_size=self.tp_size, device_id=self.device)
+        torch.cuda.empty_cache()
+        self.init_free, self.init_total = torch.cuda.mem_get_info(self.device)
+
+    def load_model(self) -> None:
+        w = getattr(self.vllm_config, "weights", None)
+        self._weights = w if w is not None else make_weights(self.dims, seed=getattr(self.vllm_config, "seed", 1234))
+
+    # ---- memory (base.py:78-156): bytes available for the KV cache after weights and step scratch
+    def determine_available_memory(self) -> int:
+        wb = weight_bytes(self.dims)
+        resident = wb["backbone"] // self.tp_size + wb["lm_head"] + 2 * wb["code_predictor"] + (1 << 30)
+        budget = int(self.init_total * float(getattr(self.vllm_config, "gpu_memory_utilization", 0.9)))
+        return max(budget - resident - (self.init_total - self.init_free), 0)
+
+    def kv_bytes_per_block(self) -> int:
+        d = self.dims
+        per_elem = 2 if self.vllm_config.kv_cache_dtype in ("bf16", "auto") else 1
+        hkv = max(d.kv_heads // self.tp_size, 1)
+        b = d.layers * 2 * self.vllm_config.block_size * hkv * d.head_dim * per_elem
+        if self.vllm_config.kv_cache_dtype == "int8":
+            b += d.layers * 2 * self.vllm_config.block_size * hkv * 4
+        return b
+
+    def initialize_from_config(self, kv_cache_config: Any = None) -> None:
+        from .engine import TalkerEngine
+        from .runner import MI355XARModelRunner
+        cfg = self.vllm_config
+        nb = getattr(kv_cache_config, "num_blocks", None) or cfg.num_gpu_blocks_override
+        if nb is None:
+            nb = max(self.determine_available_memory() // self.kv_bytes_per_block(), 2)
+        self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(nb),
+                                   block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
+                                   tp_rank=self.rank, tp_size=self.tp_size)
+        self._weights = None
+        conn = OmniConnectorFactory.create_connector(cfg.connector) if getattr(cfg, "connector", None) else None
+        self.model_runner = MI355XARModelRunner(self.engine, kv_transfer=OmniKVTransferManager(conn),
+                                                use_graphs=not getattr(cfg, "enforce_eager", False))
+
+    def compile_or_warm_up_model(self) -> None:
+        self.model_runner.capture_graphs()
+
+    # ---- step (executor RPC targets)
+    def execute_model(self, scheduler_output, intermediate_tensors=None):
+        return self.model_runner.execute_model(scheduler_output, intermediate_tensors)
+
+    def sample_tokens(self, grammar_output=None):
+        return self.model_runner.sample_tokens(grammar_output)
+
+    # ---- profiling (base.py:49-76; range names of gpu_ar_model_runner.py:138,293,314,454,514 via torch.profiler)
+    def profile(self, is_start: bool = True, profile_prefix: str | None = None):
+        if is_start:
+            self._profiler = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU,
+                                                                torch.profiler.ProfilerActivity.CUDA])
+            self._profiler.__enter__()
+            return None
+        if self._profiler is None:
+            return None
+        self._profiler.__exit__(None, None, None)
+        path = f"{profile_prefix or 'stage0'}_rank{self.rank}.json"
+        self._profiler.export_chrome_trace(path)
+        self._profiler = None
+        return path
+
+    def check_health(self) -> None:
+        return None
+
+    def shutdown(self) -> None:
+        self.model_runner = None
+        self.engine = None
+        if torch.distributed.is_initialized() and self.tp_size > 1:
+            torch.distributed.destroy_process_group()

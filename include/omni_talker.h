@@ -247,6 +247,14 @@ int omni_talker_prefill(omni_talker* t, const void* x, const int32_t* positions,
                         const int32_t* req_of_tok, const int64_t* slot_mapping,
                         const int32_t* block_table, void* hidden_out, int T, void* stream);
 
+/* The same prefill path one phase at a time for <= max_batch rows (tensor-parallel hosts all-reduce
+ * omni_talker_attn_out / omni_talker_mlp_out between the phases, exactly as in the decode step). */
+int omni_talker_rows_begin(omni_talker* t, const void* x, int rows, void* stream);
+int omni_talker_rows_attn(omni_talker* t, int layer, int rows, const int32_t* positions, const int64_t* slot_mapping,
+                          const int32_t* block_table, const int32_t* req_of_tok, void* stream);
+int omni_talker_rows_mlp(omni_talker* t, int layer, int rows, void* stream);
+int omni_talker_rows_end(omni_talker* t, void* hidden_out, int rows, void* stream);
+
 /* compute_logits on arbitrary rows: hidden bf16 [R,H] -> logits fp32 [R,vocab] (masked). */
 int omni_talker_logits(omni_talker* t, const void* hidden, float* logits, int R, int round_bf16, void* stream);
 

@@ -1,0 +1,64 @@
+"""CPU stand-in for TalkerEngine so the runner's host logic is testable without a GPU (the reference tests its
+runner the same way: object.__new__ + dummy buffers + a fake talker_mtp, T/worker/test_omni_gpu_model_runner.py:41-92)."""
+import torch
+
+BF16 = torch.bfloat16
+
+
+class FakeEngine:
+    def __init__(self, dims, max_batch=8, block_size=16, num_blocks=64):
+        d = self.d = dims
+        self.max_batch, self.block_size, self.num_blocks = max_batch, block_size, num_blocks
+        self.kv_dtype = "bf16"
+        self.bt_stride = d.max_model_len // block_size
+        z = torch.zeros
+        self.input_ids = z(max_batch, dtype=torch.int32)
+        self.positions = z(max_batch, dtype=torch.int32)
+        self.seq_lens = z(max_batch, dtype=torch.int32)
+        self.block_table = z(max_batch, self.bt_stride, dtype=torch.int32)
+        self.slot_mapping = z(max_batch, dtype=torch.int64)
+        self.last_hidden = z(max_batch, d.hidden, dtype=BF16)
+        self.text_step = z(max_batch, d.hidden, dtype=BF16)
+        self.inputs_embeds = z(max_batch, d.hidden, dtype=BF16)
+        self.audio_codes = z(max_batch, d.num_code_groups, dtype=torch.int64)
+        self.logits = z(max_batch, d.vocab)
+        self.seen = z(max_batch, d.vocab, dtype=torch.uint8)
+        self.steps = z(max_batch, dtype=torch.int32)
+        self.kv_caches = [torch.arange(2 * num_blocks * block_size * d.kv_heads * 4, dtype=torch.float32)
+                          .reshape(2, num_blocks, block_size, d.kv_heads, 4) + 1000 * l for l in range(d.layers)]
+        self.sampling = {}
+        self.calls = []
+
+    def set_sampling(self, **kw):
+        self.sampling.update(kw)
+
+    def prefill(self, x, positions, req_of_tok, slot_mapping, block_table=None):
+        self.calls.append(("prefill", x.shape[0], positions.tolist(), req_of_tok.tolist(), slot_mapping.tolist()))
+        return (x.float() * 2).to(BF16)                       # "hidden" = 2 * embedding
+
+    def compute_logits(self, hidden, round_bf16=True):
+        lg = torch.full((hidden.shape[0], self.d.vocab), float("-inf"))
+        for i in range(hidden.shape[0]):                       # deterministic "argmax" id from the hidden state
+            lg[i, 1 + int(hidden[i, 0].float().abs().item() * 8) % (self.d.codebook - 1)] = 0.0
+        return lg
+
+    def sample(self, logits, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0, steps=None):
+        ids = logits.argmax(-1).to(torch.int32)
+        if seen is not None:
+            seen[torch.arange(len(ids)), ids.long()] = 1
+        if steps is not None:
+            steps += 1
+        return ids
+
+    def decode_step(self, B, advance=True):
+        self.calls.append(("decode", B, self.input_ids[:B].tolist(), self.positions[:B].tolist()))
+        self.inputs_embeds[:B] = self.text_step[:B]
+        self.audio_codes[:B] = self.input_ids[:B].long()[:, None] + torch.arange(self.d.num_code_groups)[None]
+        self.slot_mapping[:B] = torch.tensor([int(self.block_table[r, int(self.positions[r]) // self.block_size]) * self.block_size
+                                              + int(self.positions[r]) % self.block_size for r in range(B)])
+        self.last_hidden[:B] = (self.last_hidden[:B].float() + 1).to(BF16)
+        self.input_ids[:B] = (self.input_ids[:B] % (self.d.codebook - 2)) + 1
+        self.steps[:B] += 1
+        if advance:
+            self.positions[:B] += 1
+            self.seq_lens[:B] += 1

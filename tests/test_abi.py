@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/omni_talker.h declares; ctypes mirrors of the
+structs have the C layout (no compute calls: runs without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "omni_talker.h")
+
+
+def header_functions():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from ht_vllm_omni_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in omni_talker.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.omni_abi_version() == 1
+    assert lib.omni_last_error() is not None
+
+
+def test_struct_layout_matches_c(tmp_path):
+    from ht_vllm_omni_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+                   'sizeof(omni_talker_desc),sizeof(omni_step_io),sizeof(omni_layer_weights),offsetof(omni_talker_desc,scratch_bytes),'
+                   'offsetof(omni_step_io,advance),offsetof(omni_talker_desc,k_cache));return 0;}\n' % HDR)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == C.sizeof(_lib.TalkerDesc)
+    assert got[1] == C.sizeof(_lib.StepIO)
+    assert got[2] == C.sizeof(_lib.LayerWeights)
+    assert got[3] == _lib.TalkerDesc.scratch_bytes.offset
+    assert got[4] == _lib.StepIO.advance.offset
+    assert got[5] == _lib.TalkerDesc.k_cache.offset
+
+
+def test_argument_errors_do_not_abort():
+    """Bad arguments come back as error codes + message (host-side checks run before any launch)."""
+    from ht_vllm_omni_amd import _lib
+    lib = _lib.load()
+    rc = lib.omni_gemm_bf16(None, 0, None, None, None, 4, 16, 32, 0, None, None)
+    assert rc == -1 and b"null" in lib.omni_last_error()
+    rc = lib.omni_rmsnorm(None, None, None, None, None, 1, 8, 1e-6, None)
+    assert rc == -1
+    with pytest.raises(_lib.OmniError):
+        _lib.check(rc, "omni_rmsnorm")
+    assert lib.omni_talker_scratch_bytes(None) == -1
+
+
+def test_engine_refuses_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ht_vllm_omni_amd import _lib
+    from ht_vllm_omni_amd.config import get_dims
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    with pytest.raises(_lib.OmniError):
+        TalkerEngine(get_dims("tiny"), {})
+    from ht_vllm_omni_amd import ops
+    with pytest.raises(_lib.OmniError):
+        ops.rmsnorm(torch.zeros(1, 8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16), 1e-6)

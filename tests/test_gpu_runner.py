@@ -1,0 +1,132 @@
+"""The worker/runner contract end to end on the GPU: a mini scheduler (block pool, chunked prefill, staggered
+arrivals, finish + KV transfer, hipGraph buckets) drives MI355XARWorker; every step is checked against the CPU
+oracle driven the same way."""
+import pytest
+import torch
+
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.connectors import InProcConnector, OmniKVTransferManager
+from ht_vllm_omni_amd.payloads import (OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams,
+                                       encode_tensor)
+from ht_vllm_omni_amd.sched import BlockPool, truncate_blocks
+from ht_vllm_omni_amd.weights import make_weights
+from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
+from oracle import talker_oracle as O
+from tests.util import assert_e2e_close
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_worker_runner_matches_oracle(graphs):
+    d = get_dims("tiny")
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 64
+    cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w,
+                      enforce_eager=not graphs)
+    wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+    wk.init_device(); wk.load_model()
+    assert wk.determine_available_memory() > 0
+    wk.initialize_from_config(None)
+    conn = InProcConnector()
+    wk.model_runner.kv_transfer_manager = OmniKVTransferManager(conn)
+    wk.engine.set_sampling(greedy=1, cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    run, eng = wk.model_runner, wk.engine
+    assert (len(run.graphs) > 0) == graphs
+
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    pool = BlockPool(nb, bs)
+    g = torch.Generator().manual_seed(3)
+    spec = {"a": 5, "b": 40, "c": 12}
+    prompts = {k: torch.randn(n, d.hidden, generator=g).to(BF16) for k, n in spec.items()}
+    tails = {k: torch.randn(t, d.hidden, generator=g).to(BF16) for k, t in (("a", 2), ("b", 0), ("c", 4))}
+    pads = {k: torch.randn(d.hidden, generator=g).to(BF16) for k in spec}
+    ostate = {k: O.OracleState(tail_text=list(tails[k]), tts_pad=pads[k]) for k in spec}
+    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
+
+    def new_req(k):
+        pool.allocate(k, spec[k] + 1)
+        info = {"talker_prompt_embeds": encode_tensor(prompts[k]), "tts_pad_embed": encode_tensor(pads[k])}
+        if tails[k].shape[0]:
+            info["tailing_text_hidden"] = encode_tensor(tails[k])
+        return OmniNewRequestData(req_id=k, prompt_token_ids=[d.codec_pad_id] * spec[k], block_ids=(pool.block_ids(k),),
+                                  sampling_params=sp, additional_information=info)
+
+    def cached(keys):
+        new_blocks = []
+        for k in keys:
+            st = run.requests[k]
+            nb_new = pool.allocate(k, st.num_computed + 2)
+            new_blocks.append((nb_new,) if nb_new else None)
+        return OmniCachedRequestData(req_ids=list(keys), new_block_ids=new_blocks)
+
+    def oracle_prefill(k):
+        _, ids, h = orc.prefill([ostate[k]], [prompts[k]], [pool.block_ids(k)])
+        return int(ids[0]), h[0]
+
+    def force(k, tok, h):            # keep the GPU on the oracle's trajectory (1-ulp logit flips must not fork the run)
+        r = run.rows.index(k)
+        eng.input_ids[r] = tok
+        eng.last_hidden[r] = h.cuda()
+
+    def check_decode(keys, out):
+        ol, oi, oh, oc, osl = orc.decode_step([ostate[k] for k in keys], [pool.block_ids(k) for k in keys])
+        for j, k in enumerate(keys):
+            i = out.req_id_to_index[k]
+            assert torch.equal(out.pooler_output[i]["audio_codes"], oc[j:j + 1]), f"{k}: audio codes"
+            assert_e2e_close(out.pooler_output[i]["hidden"], oh[j:j + 1], mean_tol=6e-3, what=f"{k} hidden")
+            got = out.sampled_token_ids[i][0]
+            if got != int(oi[j]):
+                top = torch.topk(ol[j], 2).values
+                assert (top[0] - top[1]).item() <= 2 ** -6, f"{k}: sampled id differs without a near-tie"
+            force(k, int(oi[j]), oh[j])
+
+    # step 1: a whole prompt, b first chunk of 32
+    so = OmniSchedulerOutput(scheduled_new_reqs=[new_req("a"), new_req("b")], num_scheduled_tokens={"a": 5, "b": 32},
+                             total_num_scheduled_tokens=37)
+    assert wk.execute_model(so) is None
+    out = wk.sample_tokens(None)
+    tok, h = oracle_prefill("a")
+    assert out.sampled_token_ids[out.req_id_to_index["a"]] == [tok] and out.sampled_token_ids[out.req_id_to_index["b"]] == []
+    assert_e2e_close(out.pooler_output[out.req_id_to_index["a"]]["hidden"][-1:], h[None], mean_tol=6e-3, what="a prefill hidden")
+    force("a", tok, h)
+    # step 2: a decodes, b finishes its prompt
+    so = OmniSchedulerOutput(scheduled_cached_reqs=cached(["a", "b"]), num_scheduled_tokens={"a": 1, "b": 8}, total_num_scheduled_tokens=9)
+    wk.execute_model(so); out = wk.sample_tokens(None)
+    check_decode(["a"], out)
+    tok, h = oracle_prefill("b")
+    assert out.sampled_token_ids[out.req_id_to_index["b"]] == [tok]
+    force("b", tok, h)
+    # step 3: a, b decode; c arrives
+    so = OmniSchedulerOutput(scheduled_new_reqs=[new_req("c")], scheduled_cached_reqs=cached(["a", "b"]),
+                             num_scheduled_tokens={"a": 1, "b": 1, "c": 12}, total_num_scheduled_tokens=14)
+    wk.execute_model(so); out = wk.sample_tokens(None)
+    check_decode(["a", "b"], out)
+    tok, h = oracle_prefill("c")
+    assert out.sampled_token_ids[out.req_id_to_index["c"]] == [tok]
+    force("c", tok, h)
+    # steps 4-6: all decode
+    for _ in range(3):
+        so = OmniSchedulerOutput(scheduled_cached_reqs=cached(["a", "b", "c"]), num_scheduled_tokens={"a": 1, "b": 1, "c": 1},
+                                 total_num_scheduled_tokens=3)
+        wk.execute_model(so); out = wk.sample_tokens(None)
+        check_decode(["a", "b", "c"], out)
+    # step 7: a finishes -> KV transfer, ack, row reuse; b, c keep decoding (batch condensed)
+    seq_a = ostate["a"].seq_len
+    fin = {"a": {"seq_len": seq_a, "block_ids": truncate_blocks(pool.block_ids("a"), seq_a, bs)}}
+    so = OmniSchedulerOutput(finished_req_ids={"a"}, finished_requests_needing_kv_transfer=fin,
+                             scheduled_cached_reqs=cached(["b", "c"]), num_scheduled_tokens={"b": 1, "c": 1}, total_num_scheduled_tokens=2)
+    wk.execute_model(so); out = wk.sample_tokens(None)
+    assert out.kv_extracted_req_ids == ["a"]
+    check_decode(["b", "c"], out)
+    kv, _ = conn.get("0", "1", "omni_0_to_1_kv_cache_a")
+    k0 = kv["layer_blocks"]["key_cache"][0]
+    assert k0.shape == (seq_a, d.kv_heads, d.head_dim) and k0.dtype == torch.uint8       # fp8 blocks travel as raw bytes
+    ref_k, _ = O.extract_kv(orc.kv[0].data.view(torch.uint8), fin["a"]["block_ids"], seq_a)
+    assert (k0 != ref_k).float().mean().item() < 0.1
+    pool.free_request("a")
+    if graphs:
+        assert out.cudagraph_stats["replays"] >= 5 and out.cudagraph_stats["eager_steps"] == 0
+    wk.shutdown()

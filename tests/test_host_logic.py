@@ -1,0 +1,228 @@
+"""Host-side logic on CPU: block pool, payloads, connectors + KV extraction (reference known answers),
+the two-phase runner contract over a fake engine, platform plugin selection, TP weight sharding."""
+import os
+import uuid
+
+import numpy as np
+import pytest
+import torch
+
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.connectors import (InProcConnector, OmniConnectorFactory, OmniKVTransferManager, SharedMemoryConnector,
+                                         normalize_layer_kv)
+from ht_vllm_omni_amd.payloads import (OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams,
+                                       decode_additional_information, encode_tensor)
+from ht_vllm_omni_amd.runner import MI355XARModelRunner
+from ht_vllm_omni_amd.sched import BlockPool, slot_of, truncate_blocks
+from tests.fakes import FakeEngine
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------ block pool / slots
+def test_block_pool_allocation_order():
+    p = BlockPool(8, 16)
+    assert p.null_block == 0 and p.num_free == 7
+    assert p.allocate("a", 17) == [1, 2]            # head of the queue, id order, block 0 never handed out
+    assert p.allocate("b", 1) == [3]
+    assert p.allocate("a", 32) == []                # still covered
+    assert p.allocate("a", 33) == [4]
+    p.free_request("a")                             # appended to the tail in reverse order
+    assert list(p.free) == [5, 6, 7, 4, 2, 1]
+    assert p.allocate("c", 16 * 3) == [5, 6, 7]
+    with pytest.raises(MemoryError):
+        p.allocate("d", 16 * 4)
+    assert slot_of([5, 6, 7], 0, 16) == 80 and slot_of([5, 6, 7], 17, 16) == 97
+    assert truncate_blocks([5, 6, 7], 17, 16) == [5, 6] and truncate_blocks([5, 6, 7], 16, 16) == [5]
+
+
+# ------------------------------------------------------------------ payloads
+def test_additional_information_roundtrip():
+    t = (torch.randn(3, 8) * 2).to(BF16)
+    info = {"talker_prompt_embeds": encode_tensor(t), "text": ["hi"], "n": 3}
+    out = decode_additional_information(info)
+    assert torch.equal(out["talker_prompt_embeds"].view(torch.int16), t.view(torch.int16)) and out["text"] == ["hi"] and out["n"] == 3
+
+
+# ------------------------------------------------------------------ connectors
+def test_connector_factory_and_inproc():
+    assert {"SharedMemoryConnector", "InProcConnector"} <= set(OmniConnectorFactory.list_registered_connectors())
+    with pytest.raises(ValueError):
+        OmniConnectorFactory.create_connector("nope")
+    c = OmniConnectorFactory.create_connector("InProcConnector")
+    ok, n, meta = c.put("0", "1", "k", {"x": torch.arange(4), "s": "t"})
+    assert ok and n > 0 and meta is None
+    obj, n2 = c.get("0", "1", "k")
+    assert torch.equal(obj["x"], torch.arange(4)) and obj["s"] == "t" and n2 == n
+    assert c.get("0", "1", "k") is None
+    c.close(); c.close()                                           # idempotent
+
+
+def test_shm_connector_roundtrip_raw_bytes_dtypes():
+    c = SharedMemoryConnector({})
+    key = "omni_test_" + uuid.uuid4().hex[:12]
+    fp8 = (torch.randn(5, 2, 8).clamp(-3, 3)).to(torch.float8_e4m3fn)
+    payload = {"k": fp8, "b": (torch.randn(4, 3)).to(BF16), "i8": torch.randint(-127, 127, (7,), dtype=torch.int8), "meta": {"seq_len": 5}}
+    ok, size, meta = c.put("0", "1", key, payload)
+    assert ok and size > 0 and meta["shm"]["name"] == key and meta["size"] == size
+    got, n = c.get("0", "1", key, metadata=meta)
+    assert n == size and got["meta"] == {"seq_len": 5}
+    assert torch.equal(got["k"].view(torch.uint8), fp8.view(torch.uint8)) and got["k"].dtype == torch.float8_e4m3fn
+    assert torch.equal(got["b"].view(torch.int16), payload["b"].view(torch.int16)) and torch.equal(got["i8"], payload["i8"])
+    assert c.get("0", "1", key, metadata=meta) is None             # consumer read and unlinked
+    assert not os.path.exists(f"/dev/shm/shm_{key}_lockfile.lock")
+    h = c.health()
+    assert h["status"] == "healthy" and h["puts"] == 1 and h["gets"] == 1
+    assert c.get("0", "1", "missing_" + key) is None               # errors -> None, never raise
+
+
+def test_kv_extract_matches_reference_golden(golden_dir):
+    """Known answers minted from the reference's normalize_layer_kv + gather (tests/golden/make_fixtures.py)."""
+    z = np.load(os.path.join(golden_dir, "kv_extract.npz"))
+    cache = torch.from_numpy(z["cache"])
+    mgr = OmniKVTransferManager(None)
+    i = 0
+    while f"ids{i}" in z:
+        ids, seq = z[f"ids{i}"].tolist(), int(z[f"seq{i}"])
+        for layout, lk in (("2first", cache), ("2second", cache.transpose(0, 1).contiguous()),
+                           ("tuple", (cache[0], cache[1]))):
+            out = mgr.extract_kv_cache("r", ids, seq, [lk, lk], block_size=4, cache_dtype="float32")
+            ref = "2first" if layout == "tuple" else layout
+            for li in range(2):
+                assert torch.equal(out["layer_blocks"]["key_cache"][li], torch.from_numpy(z[f"k{i}_{ref}"]))
+                assert torch.equal(out["layer_blocks"]["value_cache"][li], torch.from_numpy(z[f"v{i}_{ref}"]))
+            assert out["metadata"]["seq_len"] == seq and out["metadata"]["num_layers"] == 2
+        i += 1
+    assert normalize_layer_kv(torch.zeros(3, 3)) is None and normalize_layer_kv((torch.zeros(2, 2),)) is None
+
+
+def test_kv_transfer_keys_and_retries():
+    class Flaky(InProcConnector):
+        fails = 2
+
+        def put(self, *a, **k):
+            if self.fails > 0:
+                self.fails -= 1
+                return False, 0, None
+            return super().put(*a, **k)
+    c = Flaky()
+    mgr = OmniKVTransferManager(c, from_stage="0", to_stage="1", backoff_s=0.0)
+    cache = torch.randn(2, 6, 4, 2, 8)
+    done = mgr.handle_finished_requests_kv_transfer({"req7": {"seq_len": 6, "block_ids": [1, 3]}}, [cache], 4, "bf16")
+    assert done == ["req7"]
+    obj, _ = c.get("0", "1", "omni_0_to_1_kv_cache_req7")          # key format kv_transfer_manager.py:303-361
+    assert obj["layer_blocks"]["key_cache"][0].shape == (6, 2, 8) and obj["block_ids"] == [1, 3]
+    assert OmniKVTransferManager(None).handle_finished_requests_kv_transfer({"a": {}}, [cache], 4, "bf16") == ["a"]
+
+
+# ------------------------------------------------------------------ runner contract
+def _new_req(d, rid, n_prompt, blocks, tail=2, g=None):
+    g = g or torch.Generator().manual_seed(hash(rid) % 1000)
+    info = {"talker_prompt_embeds": encode_tensor(torch.randn(n_prompt, d.hidden, generator=g).to(BF16)),
+            "tailing_text_hidden": encode_tensor(torch.randn(tail, d.hidden, generator=g).to(BF16)),
+            "tts_pad_embed": encode_tensor(torch.zeros(d.hidden).to(BF16))}
+    return OmniNewRequestData(req_id=rid, prompt_token_ids=[d.codec_pad_id] * n_prompt, block_ids=(blocks,),
+                              sampling_params=SamplingParams(temperature=0.0), additional_information=info)
+
+
+def test_runner_two_phase_contract_and_state():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    conn = InProcConnector()
+    run = MI355XARModelRunner(eng, kv_transfer=OmniKVTransferManager(conn), use_graphs=False)
+    assert run.sample_tokens(None) is None                               # nothing pending
+    so = OmniSchedulerOutput(scheduled_new_reqs=[_new_req(d, "a", 5, [1]), _new_req(d, "b", 20, [2, 3])],
+                             num_scheduled_tokens={"a": 5, "b": 16}, total_num_scheduled_tokens=21)   # b: chunked prefill
+    assert run.execute_model(so) is None
+    with pytest.raises(RuntimeError, match="sample_tokens"):
+        run.execute_model(so)                                            # gpu_ar_model_runner.py:98-99
+    out = run.sample_tokens(None)
+    assert out.req_ids == ["a", "b"] and out.req_id_to_index == {"a": 0, "b": 1}
+    assert len(out.sampled_token_ids[0]) == 1 and out.sampled_token_ids[1] == []      # b still prefilling
+    assert out.pooler_output[0]["hidden"].shape == (5, d.hidden) and out.pooler_output[0]["audio_codes"].shape == (5, d.num_code_groups)
+    assert int(out.pooler_output[0]["audio_codes"].abs().sum()) == 0                  # prefill rows: zero codes
+    kind, n, pos, req, slots = eng.calls[0]
+    assert kind == "prefill" and n == 21 and pos == list(range(5)) + list(range(16))
+    assert slots[:5] == [16 + i for i in range(5)] and slots[5:] == [32 + i for i in range(16)]   # slot = block*bs + off
+    assert int(eng.positions[0]) == 5 and int(eng.seq_lens[0]) == 6 and int(eng.steps[0]) == 1
+    # step 2: a decodes, b finishes its prompt (4 tokens) -> decode rows first
+    so2 = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a", "b"], new_block_ids=[None, None]),
+                              num_scheduled_tokens={"a": 1, "b": 4}, total_num_scheduled_tokens=5)
+    run.execute_model(so2)
+    out2 = run.sample_tokens(None)
+    assert [c[0] for c in eng.calls[1:]] == ["prefill", "decode"] and eng.calls[2][1] == 1
+    assert out2.pooler_output[0]["audio_codes"].shape == (1, d.num_code_groups) and len(out2.sampled_token_ids[1]) == 1
+    assert run.requests["a"].tail_pos == 1                              # one text-step vector popped
+    # step 3: both decode; a gets a new block; then a finishes with KV transfer
+    so3 = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a", "b"], new_block_ids=[([9],), None]),
+                              num_scheduled_tokens={"a": 1, "b": 1}, total_num_scheduled_tokens=2)
+    run.execute_model(so3)
+    out3 = run.sample_tokens(None)
+    assert eng.calls[-1][:2] == ("decode", 2) and run.requests["a"].block_ids == [1, 9]
+    assert int(eng.block_table[run.rows.index("a"), 1]) == 9
+    assert out3.cudagraph_stats["eager_steps"] == 2
+    so4 = OmniSchedulerOutput(finished_req_ids={"a"}, finished_requests_needing_kv_transfer={"a": {"seq_len": 7, "block_ids": [1]}},
+                              scheduled_cached_reqs=OmniCachedRequestData(req_ids=["b"], new_block_ids=[None]),
+                              num_scheduled_tokens={"b": 1}, total_num_scheduled_tokens=1)
+    run.execute_model(so4)
+    out4 = run.sample_tokens(None)
+    assert out4.kv_extracted_req_ids == ["a"] and run.rows == ["b"] and "a" not in run.requests
+    kv, _ = conn.get("0", "1", "omni_0_to_1_kv_cache_a")
+    assert kv["layer_blocks"]["key_cache"][0].shape[0] == 7 and kv["metadata"]["block_size"] == eng.block_size
+    assert int(eng.block_table[1].abs().sum()) == 0                      # freed row points at the null block
+    # no work scheduled
+    from ht_vllm_omni_amd.payloads import EMPTY_MODEL_RUNNER_OUTPUT
+    assert run.execute_model(OmniSchedulerOutput()) is EMPTY_MODEL_RUNNER_OUTPUT
+
+
+def test_runner_rejects_missing_prompt_embeds_and_overflow():
+    d = get_dims("tiny")
+    run = MI355XARModelRunner(FakeEngine(d, max_batch=1), use_graphs=False)
+    bad = OmniNewRequestData(req_id="x", prompt_token_ids=[1], block_ids=([1],), additional_information={})
+    with pytest.raises(ValueError, match="talker_prompt_embeds"):
+        run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[bad], num_scheduled_tokens={"x": 1}, total_num_scheduled_tokens=1))
+    run = MI355XARModelRunner(FakeEngine(d, max_batch=1), use_graphs=False)
+    so = OmniSchedulerOutput(scheduled_new_reqs=[_new_req(d, "a", 3, [1]), _new_req(d, "b", 3, [2])],
+                             num_scheduled_tokens={"a": 3, "b": 3}, total_num_scheduled_tokens=6)
+    with pytest.raises(RuntimeError, match="overflow"):
+        run.execute_model(so)
+
+
+# ------------------------------------------------------------------ platform plugin
+def test_platform_plugin_selection(monkeypatch):
+    from ht_vllm_omni_amd import platform as P
+    monkeypatch.delenv("HT_OMNI_FORCE_MI355X", raising=False)
+    if not torch.cuda.is_available():
+        assert P.register() is None                                      # inactive off-target
+    monkeypatch.setenv("HT_OMNI_FORCE_MI355X", "1")
+    assert P.register() == "ht_vllm_omni_amd.platform.MI355XOmniPlatform"
+    assert P.resolve_worker_cls({"worker_type": "ar"})["worker_cls"] == "ht_vllm_omni_amd.worker.MI355XARWorker"
+    assert P.resolve_worker_cls({"worker_type": "ar", "worker_cls": "x.Y"})["worker_cls"] == "x.Y"   # YAML override wins
+    with pytest.raises(ValueError):
+        P.resolve_worker_cls({"worker_type": "bogus"})
+    import importlib
+    mod, cls = P.MI355XOmniPlatform.get_omni_ar_worker_cls().rsplit(".", 1)
+    assert hasattr(importlib.import_module(mod), cls)
+    assert P.MI355XOmniPlatform.dist_backend == "nccl" and not P.MI355XOmniPlatform.supports_torch_inductor()
+
+
+# ------------------------------------------------------------------ TP sharding (single process; gloo run in test_tp_gloo.py)
+def test_shard_layer_partitions_weights():
+    from ht_vllm_omni_amd.engine import shard_layer
+    from ht_vllm_omni_amd.weights import make_weights
+    d = get_dims("tiny")
+    w = make_weights(d, seed=0)
+    for tp in (1, 2):
+        parts = [shard_layer(d, w, "l0.", r, tp) for r in range(tp)]
+        D, hq, hkv = d.head_dim, d.q_heads // tp, d.kv_heads // tp
+        q = torch.cat([p["wqkv"][: hq * D] for p in parts]); k = torch.cat([p["wqkv"][hq * D:(hq + hkv) * D] for p in parts])
+        v = torch.cat([p["wqkv"][(hq + hkv) * D:] for p in parts])
+        assert torch.equal(torch.cat([q, k, v]), w["l0.wqkv"])
+        assert torch.equal(torch.cat([p["wo"] for p in parts], 1), w["l0.wo"])
+        i = d.inter // tp
+        assert torch.equal(torch.cat([p["wgu"][:i] for p in parts] + [p["wgu"][i:] for p in parts]), w["l0.wgu"])
+        assert torch.equal(torch.cat([p["wdown"] for p in parts], 1), w["l0.wdown"])
+    # more ranks than KV heads: heads replicate (vLLM QKVParallelLinear)
+    parts = [shard_layer(d, w, "l0.", r, 4) for r in range(4)]
+    D = d.head_dim
+    assert torch.equal(parts[0]["wqkv"][D:2 * D], parts[1]["wqkv"][D:2 * D]) and not torch.equal(parts[0]["wqkv"][D:2 * D], parts[2]["wqkv"][D:2 * D])
