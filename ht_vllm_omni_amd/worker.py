@@ -27,11 +27,11 @@ logger = logging.getLogger("ht_vllm_omni_amd.worker")
 def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "fp8", block_size: int = 16,
                 max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
                 num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
-                connector: str | None = None, enforce_eager: bool = False) -> SimpleNamespace:
+                connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None) -> SimpleNamespace:
     return SimpleNamespace(model=model, kv_cache_dtype=kv_cache_dtype, block_size=block_size, max_num_seqs=max_num_seqs,
                            tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
                            num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
-                           enforce_eager=enforce_eager)
+                           enforce_eager=enforce_eager, default_sampling_params=default_sampling_params)
 
 
 class MI355XARWorker:
@@ -98,6 +98,11 @@ class MI355XARWorker:
                                                 use_graphs=not getattr(cfg, "enforce_eager", False))
 
     def compile_or_warm_up_model(self) -> None:
+        # the stage's default_sampling_params (stage_configs/qwen3_tts.yaml:27-34) are baked into the captured step;
+        # a request with other parameters falls back to eager launches
+        from .payloads import SamplingParams
+        sp = getattr(self.vllm_config, "default_sampling_params", None) or SamplingParams()
+        self.model_runner._apply_sampling(sp)
         self.model_runner.capture_graphs()
 
     # ---- step (executor RPC targets)

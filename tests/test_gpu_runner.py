@@ -23,15 +23,16 @@ def test_worker_runner_matches_oracle(graphs):
     d = get_dims("tiny")
     w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
     bs, nb = 16, 64
+    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
     cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w,
-                      enforce_eager=not graphs)
+                      enforce_eager=not graphs, default_sampling_params=sp)
     wk = MI355XARWorker(cfg, local_rank=0, rank=0)
     wk.init_device(); wk.load_model()
     assert wk.determine_available_memory() > 0
     wk.initialize_from_config(None)
     conn = InProcConnector()
     wk.model_runner.kv_transfer_manager = OmniKVTransferManager(conn)
-    wk.engine.set_sampling(greedy=1, cp_greedy=1)
+    wk.engine.set_sampling(cp_greedy=1)
     wk.compile_or_warm_up_model()
     run, eng = wk.model_runner, wk.engine
     assert (len(run.graphs) > 0) == graphs
@@ -44,8 +45,6 @@ def test_worker_runner_matches_oracle(graphs):
     tails = {k: torch.randn(t, d.hidden, generator=g).to(BF16) for k, t in (("a", 2), ("b", 0), ("c", 4))}
     pads = {k: torch.randn(d.hidden, generator=g).to(BF16) for k in spec}
     ostate = {k: O.OracleState(tail_text=list(tails[k]), tts_pad=pads[k]) for k in spec}
-    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
-
     def new_req(k):
         pool.allocate(k, spec[k] + 1)
         info = {"talker_prompt_embeds": encode_tensor(prompts[k]), "tts_pad_embed": encode_tensor(pads[k])}
