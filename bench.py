@@ -42,7 +42,8 @@ def build_engine(args, rank, world):
     w = make_weights(d, seed=1234, std=0.02)
     log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
-                       device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False)
+                       device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False,
+                       n_sub=args.sub_batches)
     return d, w, eng
 
 
@@ -159,6 +160,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
     args = ap.parse_args()
 
@@ -176,6 +178,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
 
     d, w, eng = build_engine(args, rank, world)
+    if os.environ.get("OMNI_EXTRA_TRIVIAL"):        # diagnostics: price of a trivial launch inside the real step
+        import ctypes
+        eng.lib.omni_debug_extra_trivial.argtypes = [ctypes.c_int]
+        eng.lib.omni_debug_extra_trivial(int(os.environ["OMNI_EXTRA_TRIVIAL"]))
     B = args.batch
     if args.greedy:
         eng.set_sampling(greedy=1, cp_greedy=1)
@@ -246,7 +252,7 @@ def main():
                                f"prompts U{{32..160}} seed 7, KV block 16, T=0.9/top-k 50/rep 1.05 sampling"
                                if args.model == "tts-1.7b" else f"{args.model} {args.kv} B={B}",
                    "model": args.model, "kv_cache": args.kv, "batch": B, "mean_ctx": float(np.mean(mean_ctx)),
-                   "parallelism": f"tp{world}", "hipgraph": graph is not None,
+                   "parallelism": f"tp{world}", "hipgraph": graph is not None, "sub_batches": args.sub_batches,
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42"},
         "p50_ttfa_ms": ttfa_ms, "ttfa": {"prefill_ms": prefill_ms, "ic_steps": args.ttfa_steps, "ic_ms": ic_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -470,10 +470,17 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     return OMNI_OK;
 }
 
+// diagnostics: append N trivial launches after every layer phase to price a launch inside the real step
+static int g_extra_trivial = 0;
+__global__ void dbg_nop_kernel(int32_t* p) { if (threadIdx.x == 9999) p[0] = 0; }
+extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
+
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(omni_talker_mtp(t, io, stream));
     for (int l = 0; l < t->d.layers; ++l) {
         TRY(omni_talker_layer_attn(t, io, l, stream));
+        for (int k = 0; k < g_extra_trivial; ++k)
+            hipLaunchKernelGGL(dbg_nop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, io->steps);
         TRY(omni_talker_layer_mlp(t, io, l, stream));
     }
     return omni_talker_finish(t, io, stream);

@@ -33,6 +33,75 @@ __global__ __launch_bounds__(512) void dbg_vgpr_kernel(float* p, int n) {
     if (s == 12345.678f) p[0] = s;
 }
 
+// distinct trivial kernels (different code objects) to separate code-fetch cost from data coldness
+template <int ID>
+__global__ void dbg_distinct_kernel(float* p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = p[i + ID * 4096];
+#pragma unroll
+    for (int k = 0; k < 8 + ID; ++k) v = v * 1.0001f + (float)(ID + k);
+    p[i + ID * 4096] = v;
+}
+// streams `n` floats (L2 thrash between the small kernels)
+__global__ void dbg_stream_kernel(const float4* __restrict__ src, float* dst, size_t n4) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) dst[0] = acc;
+}
+extern "C" int omni_debug_mix(int pattern, float* small, const void* big, size_t big_bytes, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < reps; ++r) {
+        if (pattern & 2) hipLaunchKernelGGL(dbg_stream_kernel, dim3(2048), dim3(256), 0, st, (const float4*)big, small, big_bytes / 16);
+        if (pattern & 1) {
+            hipLaunchKernelGGL(dbg_distinct_kernel<0>, dim3(16), dim3(256), 0, st, small);
+            hipLaunchKernelGGL(dbg_distinct_kernel<1>, dim3(16), dim3(256), 0, st, small);
+            hipLaunchKernelGGL(dbg_distinct_kernel<2>, dim3(16), dim3(256), 0, st, small);
+            hipLaunchKernelGGL(dbg_distinct_kernel<3>, dim3(16), dim3(256), 0, st, small);
+        } else if (!(pattern & 4)) {
+            for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(dbg_distinct_kernel<0>, dim3(16), dim3(256), 0, st, small);
+        }
+    }
+    OMNI_CHECK_LAUNCH("omni_debug_mix");
+    return OMNI_OK;
+}
+
+__global__ __launch_bounds__(512) void dbg_cfg_a_kernel(float* p) {   // 512 threads, dynamic LDS
+    extern __shared__ float sm[];
+    sm[threadIdx.x] = p[threadIdx.x];
+    __syncthreads();
+    p[blockIdx.x * 512 + threadIdx.x] = sm[(threadIdx.x + 1) & 511];
+}
+__global__ __launch_bounds__(256) void dbg_cfg_b_kernel(float* p) {   // 256 threads, no LDS
+    p[blockIdx.x * 256 + threadIdx.x] += 1.0f;
+}
+__global__ __launch_bounds__(64) void dbg_cfg_c_kernel(float* p) {    // 1 wave
+    p[threadIdx.x] += 1.0f;
+}
+// alternate kernels with different launch configurations (threads / LDS size / grid)
+extern "C" int omni_debug_cfgmix(int mode, float* p, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < reps; ++r) {
+        if (mode == 0) { for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(dbg_cfg_b_kernel, dim3(64), dim3(256), 0, st, p); }
+        else if (mode == 1) { for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(256), dim3(512), 65536, st, p); }
+        else if (mode == 2) {
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(256), dim3(512), 65536, st, p);
+            hipLaunchKernelGGL(dbg_cfg_b_kernel, dim3(64), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(256), dim3(512), 32768, st, p);
+            hipLaunchKernelGGL(dbg_cfg_c_kernel, dim3(1), dim3(64), 0, st, p);
+        } else {
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(256), dim3(512), 65536, st, p);
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(256), dim3(512), 32768, st, p);
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(128), dim3(512), 16384, st, p);
+            hipLaunchKernelGGL(dbg_cfg_a_kernel, dim3(384), dim3(512), 65536, st, p);
+        }
+    }
+    OMNI_CHECK_LAUNCH("omni_debug_cfgmix");
+    return OMNI_OK;
+}
+
 extern "C" int omni_debug_launch(int mode, int blocks, int threads, void* p0, void* p1, int arg, int reps, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (int r = 0; r < reps; ++r) {

@@ -44,10 +44,9 @@ struct GemmArgs {
     const uint8_t* mask;
     // PRO_RN
     const uint16_t* resid; uint16_t* resid_out; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
-    int dbg;   // ablation bits (diagnostics): 1 = no x loads, 2 = no W loads, 4 = no MFMA, 8 = no LDS combine
 };
 
-template <int MT, int NT, int PRO, int EPI, bool NTL>
+template <int MT, int NT, int PRO, int EPI, bool NTL, int KS>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [WAVES][NT*MT*4][64]
     const int lane = threadIdx.x & 63;
@@ -158,6 +157,42 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 }
             }
     } else {
+        // ---------------- plain x operand, K known at compile time (KS = k-steps per wave = K / 256) --------------
+        // Fully static schedule: every W load of the wave goes out first (KS KB in flight), x fragments run XW k-steps
+        // ahead in a register ring; no runtime guard anywhere, so hipcc keeps counted vmcnt waits.
+        if constexpr (KS > 0) {
+            const uint16_t* xr_[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int m = i * 16 + r;
+                m = m_base + (m < Mloc ? m : Mloc - 1);
+                xr_[i] = a.x + (size_t)m * a.ldx + 8 * q + (wave << 5);
+            }
+            constexpr int XW = (MT == 4) ? 4 : 8;
+            constexpr int XWe = XW < KS ? XW : KS;
+            u32x4 Wr[KS][NT], X[XWe][MT];
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    Wr[t][j] = NTL ? ld16_nt(wrow[j] + (wave << 5) + t * (GEMM_WAVES << 5)) : ld16(wrow[j] + (wave << 5) + t * (GEMM_WAVES << 5));
+#pragma unroll
+            for (int t = 0; t < XWe; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) X[t][i] = ld16(xr_[i] + t * (GEMM_WAVES << 5));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wr[t][j], X[t % XWe][i], acc[j][i]);
+                if (t + XWe < KS) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) X[t % XWe][i] = ld16(xr_[i] + (t + XWe) * (GEMM_WAVES << 5));
+                }
+            }
+        } else {
         // ---------------- plain x operand: deep W prefetch ring, x one step ahead -----------------
         // Every wave keeps DEPTH k-steps (DEPTH KB) of W outstanding (Little's law at ~3 us loaded HBM latency);
         // x is L2-resident and fetched one k-step ahead.  (Measured alternatives, scripts/bench_ops.py: issuing a
@@ -176,12 +211,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             if (d < ntw) {
                 const int k0 = (wave + d * GEMM_WAVES) << 5;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) Wr[d][j] = (a.dbg & 2) ? (u32x4){(unsigned)k0, 1u, 2u, 3u} : (NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0));
+                for (int j = 0; j < NT; ++j) Wr[d][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
             }
         u32x4 X[2][MT];
         if (ntw > 0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) X[0][i] = (a.dbg & 1) ? (u32x4){1u, 2u, 3u, 4u} : ld16(xrow[i] + (wave << 5));
+            for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + (wave << 5));
         }
         for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
 #pragma unroll
@@ -191,29 +226,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     if (t + 1 < ntw) {
                         const int k1 = (wave + (t + 1) * GEMM_WAVES) << 5;
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = (a.dbg & 1) ? (u32x4){(unsigned)k1, 2u, 3u, 4u} : ld16(xrow[i] + k1);
+                        for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = ld16(xrow[i] + k1);
                     }
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) {
-                            if (a.dbg & 4) acc[j][i][0] += __uint_as_float(Wr[d][j][0] ^ X[d & 1][i][0]);
-                            else acc[j][i] = mfma16(Wr[d][j], X[d & 1][i], acc[j][i]);
-                        }
+                        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wr[d][j], X[d & 1][i], acc[j][i]);
                     if (t + DEPTH < ntw) {
                         const int k2 = (wave + (t + DEPTH) * GEMM_WAVES) << 5;
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) Wr[d][j] = (a.dbg & 2) ? (u32x4){(unsigned)k2, 1u, 2u, 3u} : (NTL ? ld16_nt(wrow[j] + k2) : ld16(wrow[j] + k2));
+                        for (int j = 0; j < NT; ++j) Wr[d][j] = NTL ? ld16_nt(wrow[j] + k2) : ld16(wrow[j] + k2);
                     }
                 }
             }
         }
+        }   // KS == 0
     }
 
-    if (a.dbg & 8) {
-        if (wave == 0) reinterpret_cast<float*>(a.out)[threadIdx.x] = acc[0][0][0] + acc[NT - 1][MT - 1][3];
-        return;
-    }
     // ---- combine the 8 K-partials through LDS: lds[wave][e][lane], e = (j*MT+i)*4+reg
     constexpr int E = NT * MT * 4;
 #pragma unroll
@@ -283,21 +312,34 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
-static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_dbg = 0;
-extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt; g_gemm_rn = rn; g_gemm_wgs = wgs; }
-extern "C" void omni_debug_ablate(int bits) { g_gemm_dbg = bits; }
+static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 1;
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = !(nt & 2); g_gemm_rn = rn; g_gemm_wgs = wgs; }
 
-template <int MT, int NT, int PRO, int EPI>
-static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
+template <int MT, int NT, int PRO, int EPI, int KS>
+static int launch_gemm_ks(const GemmArgs& a, int m_splits, hipStream_t st) {
     const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
     // non-temporal W loads only when each W byte is read by exactly one workgroup (no m-split)
     if (m_splits == 1 && g_gemm_nt)
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     else
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, false>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_bf16");
     return OMNI_OK;
+}
+
+template <int MT, int NT, int PRO, int EPI>
+static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
+    if (PRO == 0 && g_gemm_static && a.K % 256 == 0) {
+        switch (a.K / 256) {       // hidden / intermediate sizes of the talker shapes (and their TP shards)
+            case 4: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 4 : 0)>(a, m_splits, st);
+            case 8: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 8 : 0)>(a, m_splits, st);
+            case 12: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 12 : 0)>(a, m_splits, st);
+            case 24: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? (MT * NT <= 2 ? 24 : 0) : 0)>(a, m_splits, st);
+            default: break;
+        }
+    }
+    return launch_gemm_ks<MT, NT, PRO, EPI, 0>(a, m_splits, st);
 }
 
 template <int NT, int PRO, int EPI>
@@ -347,7 +389,7 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
                               int K, int epilogue, const uint8_t* mask, void* stream) {
     GemmArgs a{};
     a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
-    a.M = M; a.N = N; a.K = K; a.mask = mask; a.dbg = g_gemm_dbg;
+    a.M = M; a.N = N; a.K = K; a.mask = mask;
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_ARG(x, "omni_gemm_bf16: null x");

@@ -18,6 +18,12 @@ __global__ __launch_bounds__(64 * NORM_ROWS_PER_BLOCK) void rmsnorm_kernel(
     const uint16_t* src = (residual ? residual : x) + (size_t)row * hidden;
     float v[MAXV][8];
     float ss = 0.f;
+    uint4 wv[MAXV];                       // norm weights: issued up front, consumed after the reduction
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        wv[i] = (vi < nvec) ? *reinterpret_cast<const uint4*>(w + vi * 8) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int vi = lane + i * 64;
@@ -56,8 +62,7 @@ __global__ __launch_bounds__(64 * NORM_ROWS_PER_BLOCK) void rmsnorm_kernel(
     for (int i = 0; i < MAXV; ++i) {
         const int vi = lane + i * 64;
         if (vi < nvec) {
-            uint4 ww = *reinterpret_cast<const uint4*>(w + vi * 8);
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(&ww);
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(&wv[i]);
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

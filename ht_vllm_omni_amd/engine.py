@@ -60,7 +60,7 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
 class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
-                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None):
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -171,6 +171,24 @@ class TalkerEngine:
         self.handle = self.lib.omni_talker_create(C.byref(desc))
         if not self.handle:
             raise L.OmniError("omni_talker_create: " + self.lib.omni_last_error().decode())
+        # ---- sub-batch engines: the decode step is latency-bound (dependent small launches), so independent row ranges
+        # of the batch run as concurrent branches of the same hipGraph on separate HIP streams; they share weights and
+        # the KV pool and differ only in their scratch (activations, code-predictor KV) and row offset.
+        self.n_sub = max(1, int(n_sub)) if tp_size == 1 else 1
+        self.sub_rows = (max_batch + self.n_sub - 1) // self.n_sub
+        self._sub = []
+        if self.n_sub > 1:
+            for k in range(self.n_sub):
+                dk = L.TalkerDesc.from_buffer_copy(desc)
+                dk.max_batch = self.sub_rows
+                nb2 = self.lib.omni_talker_scratch_bytes(C.byref(dk))
+                sc = torch.zeros(nb2, dtype=torch.uint8, device=dev)
+                dk.scratch, dk.scratch_bytes = sc.data_ptr(), nb2
+                h = self.lib.omni_talker_create(C.byref(dk))
+                if not h:
+                    raise L.OmniError("omni_talker_create(sub): " + self.lib.omni_last_error().decode())
+                self._sub.append((h, sc, dk))
+            self._sub_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_sub)]
 
         # ---- persistent per-step buffers (graph-stable addresses), row r = batch slot r
         Bm, H, Q = max_batch, d.hidden, d.num_code_groups
@@ -200,19 +218,22 @@ class TalkerEngine:
         h, self.handle = getattr(self, "handle", None), None
         if h:
             self.lib.omni_talker_destroy(h)
+        for hk, _, _ in getattr(self, "_sub", []):
+            self.lib.omni_talker_destroy(hk)
+        self._sub = []
 
     # ------------------------------------------------------------------ step
     def set_sampling(self, **kw) -> None:
         self.sampling.update(kw)
 
-    def _io(self, B: int, advance: bool) -> L.StepIO:
+    def _io(self, B: int, advance: bool, row0: int = 0) -> L.StepIO:
         io = L.StepIO()
         io.B = B
         for n in ("input_ids", "positions", "seq_lens", "block_table", "slot_mapping", "last_hidden", "text_step",
                   "inputs_embeds", "audio_codes", "logits", "steps"):
-            setattr(io, n, getattr(self, n).data_ptr())
+            setattr(io, n, getattr(self, n)[row0:].data_ptr())
         s = self.sampling
-        io.seen = self.seen.data_ptr() if s["rep_penalty"] != 1.0 else None
+        io.seen = self.seen[row0:].data_ptr() if s["rep_penalty"] != 1.0 else None
         io.greedy, io.temperature, io.top_k = int(s["greedy"]), float(s["temperature"]), int(s["top_k"])
         io.rep_penalty, io.seed = float(s["rep_penalty"]), int(s["seed"]) & 0xFFFFFFFF
         io.cp_greedy, io.cp_temperature, io.cp_top_k = int(s["cp_greedy"]), float(s["cp_temperature"]), int(s["cp_top_k"])
@@ -221,8 +242,29 @@ class TalkerEngine:
 
     def decode_step(self, B: int, advance: bool = True) -> None:
         """One talker decode step for rows [0, B) on torch's current stream (capturable)."""
-        io = self._io(B, advance)
         st = L.current_stream()
+        if self.n_sub > 1 and B > self.sub_rows:
+            # fork: one branch per row range (works eagerly and under stream capture -> parallel graph branches)
+            cur = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            joins = []
+            for k in range(self.n_sub):
+                r0 = k * self.sub_rows
+                rows = min(self.sub_rows, B - r0)
+                if rows <= 0:
+                    break
+                sk = self._sub_streams[k]
+                sk.wait_event(fork)
+                io = self._io(rows, advance, r0)
+                L.check(self.lib.omni_talker_decode_step(self._sub[k][0], C.byref(io), sk.cuda_stream), "omni_talker_decode_step(sub)")
+                ev = torch.cuda.Event()
+                ev.record(sk)
+                joins.append(ev)
+            for ev in joins:
+                cur.wait_event(ev)
+            return
+        io = self._io(B, advance)
         if self.tp_size == 1:
             L.check(self.lib.omni_talker_decode_step(self.handle, C.byref(io), st), "omni_talker_decode_step")
             return
