@@ -188,8 +188,9 @@ def main():
     else:
         eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9,
                          cp_top_k=50)
+    setup_requests(d, eng, args)                 # untimed: hipBLASLt handle / heuristics, code objects
     lens, prefill_ms = setup_requests(d, eng, args)
-    log(f"[rank {rank}] prefill of {sum(lens)} prompt tokens: {prefill_ms:.1f} ms (correctness path, skinny-GEMM chunks)")
+    log(f"[rank {rank}] prefill of {sum(lens)} prompt tokens: {prefill_ms:.1f} ms (hipBLASLt GEMMs + native norm/rope/attention)")
 
     # ---- capture the whole decode step as one hipGraph
     graph, use_graph = None, not args.no_graph

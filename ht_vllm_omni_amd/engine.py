@@ -60,12 +60,13 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
 class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
-                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1):
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
         self.d, self.device = dims, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        self.tp_path = tp_size > 1 or tp_force      # tp_force: run the collective path on a 1-rank group (tests)
         assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
         self.kv_dtype = kv_dtype
         self.kv_code = L.KV_CODES[kv_dtype]
@@ -174,7 +175,7 @@ class TalkerEngine:
         # ---- sub-batch engines: the decode step is latency-bound (dependent small launches), so independent row ranges
         # of the batch run as concurrent branches of the same hipGraph on separate HIP streams; they share weights and
         # the KV pool and differ only in their scratch (activations, code-predictor KV) and row offset.
-        self.n_sub = max(1, int(n_sub)) if tp_size == 1 else 1
+        self.n_sub = max(1, int(n_sub)) if not self.tp_path else 1
         self.sub_rows = (max_batch + self.n_sub - 1) // self.n_sub
         self._sub = []
         if self.n_sub > 1:
@@ -265,7 +266,7 @@ class TalkerEngine:
                 cur.wait_event(ev)
             return
         io = self._io(B, advance)
-        if self.tp_size == 1:
+        if not self.tp_path:
             L.check(self.lib.omni_talker_decode_step(self.handle, C.byref(io), st), "omni_talker_decode_step")
             return
         import torch.distributed as dist
@@ -277,14 +278,55 @@ class TalkerEngine:
             dist.all_reduce(self._mlp_out[:B], group=self.tp_group)
         L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
 
+    def prefill_blas(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
+                     block_table: torch.Tensor | None = None) -> torch.Tensor:
+        """Prefill with the four plain per-layer GEMMs on hipBLASLt (torch.nn.functional.linear; bf16 in, fp32
+        accumulate, one rounding -- the same convention as the skinny kernel) and everything else on the native
+        kernels (norm, q/k-norm + RoPE + KV write, causal paged attention).  All T tokens in one pass per layer
+        instead of max_batch-row chunks that each re-stream the weights."""
+        import torch.nn.functional as F
+        d = self.d
+        bt = self.block_table if block_table is None else block_table
+        D, hq, hkv = d.head_dim, self.hq_l, self.hkv_l
+        resid = x.clone()
+        delta = None
+        for l in range(d.layers):
+            w = self.layer_w[l]
+            a = ops.rmsnorm(None, w["ln1"], d.eps, delta=delta, residual=resid)
+            qkv = F.linear(a, w["wqkv"])
+            kc, vc = self.kv_caches[l][0], self.kv_caches[l][1]
+            ks = self.kv_scales[l] if self.kv_scales is not None else None
+            q = ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], positions, self.cos_sin, slot_mapping, kc, vc,
+                                        q_heads=hq, kv_heads=hkv, head_dim=D, eps=d.eps, kv_dtype=self.kv_code,
+                                        k_scale=self._desc.k_scale, v_scale=self._desc.v_scale,
+                                        k_scales=None if ks is None else ks[0], v_scales=None if ks is None else ks[1])
+            o = ops.paged_attn_prefill(q, kc, vc, bt, req_of_tok, positions, q_heads=hq, kv_heads=hkv, head_dim=D,
+                                       block_size=self.block_size, kv_dtype=self.kv_code, k_scale=self._desc.k_scale,
+                                       v_scale=self._desc.v_scale, k_scales=None if ks is None else ks[0],
+                                       v_scales=None if ks is None else ks[1])
+            o = F.linear(o, w["wo"])
+            if self.tp_path:
+                torch.distributed.all_reduce(o, group=self.tp_group)
+            a = ops.rmsnorm(None, w["ln2"], d.eps, delta=o, residual=resid)
+            gu = F.linear(a, w["wgu"])
+            act = F.silu(gu[:, : self.inter_l]) * gu[:, self.inter_l:]
+            delta = F.linear(act, w["wdown"])
+            if self.tp_path:
+                torch.distributed.all_reduce(delta, group=self.tp_group)
+        return ops.rmsnorm(None, self.final_norm, d.eps, delta=delta, residual=resid)
+
     def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
-                block_table: torch.Tensor | None = None) -> torch.Tensor:
+                block_table: torch.Tensor | None = None, use_blas: bool | None = None) -> torch.Tensor:
         """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H]."""
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
+        if use_blas is None:
+            use_blas = T > self.max_batch
+        if use_blas:
+            return self.prefill_blas(x, positions, req_of_tok, slot_mapping, bt)
         out = torch.empty_like(x)
         st = L.current_stream()
-        if self.tp_size == 1:
+        if not self.tp_path:
             L.check(self.lib.omni_talker_prefill(self.handle, L.ptr(x), L.ptr(positions), L.ptr(req_of_tok),
                                                  L.ptr(slot_mapping), L.ptr(bt), L.ptr(out), T, st), "omni_talker_prefill")
             return out

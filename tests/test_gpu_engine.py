@@ -220,3 +220,89 @@ def test_real_dims_one_layer():
     lens = torch.randint(4, 40, (64,), generator=g).tolist()
     rec = _scenario(d, w, "fp8", prompt_lens=lens, n_steps=2, num_blocks=300, mean_tol=1e-3)
     _check(rec, mean_tol=1e-3)      # BASELINE weight scale: logits within 1e-3 in the mean, 1-2 bf16 ulp max
+
+
+def test_prefill_blas_path_matches_native_and_oracle():
+    """Prefill with hipBLASLt GEMMs (all tokens per layer at once) == native skinny-GEMM chunks == oracle."""
+    d = get_dims("tiny")
+    w = make_weights(d, seed=12, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 64
+    lens = [5, 40, 17, 64]
+    for kv in ("bf16", "fp8"):
+        engs = [_engine(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs, max_batch=8) for _ in range(2)]
+        orc = O.TalkerOracle(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs)
+        pool = BlockPool(nb, bs)
+        g = torch.Generator().manual_seed(1)
+        prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in lens]
+        for r, n in enumerate(lens):
+            pool.allocate(f"r{r}", n)
+        bts = [pool.block_ids(f"r{r}") for r in range(len(lens))]
+        states = [O.OracleState() for _ in lens]
+        _, _, o_h = orc.prefill(states, prompts, bts)
+        x = torch.cat(prompts).cuda()
+        pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32).cuda()
+        req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32).cuda()
+        outs = []
+        for e, blas in zip(engs, (False, True)):
+            for r in range(len(lens)):
+                e.block_table[r, :len(bts[r])] = torch.tensor(bts[r], dtype=torch.int32)
+            outs.append(e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=blas))
+        last = torch.tensor(np.cumsum(lens) - 1)
+        for h in outs:
+            assert_e2e_close(h[last.cuda()], o_h, mean_tol=6e-3, max_ulps=3, what=f"prefill hidden {kv}")
+        assert_e2e_close(outs[0], outs[1], mean_tol=6e-3, max_ulps=3, what="blas vs native prefill")
+        for li in range(d.layers):
+            a, b = engs[0].kv_caches[li].cpu(), engs[1].kv_caches[li].cpu()
+            assert (a != b).float().mean().item() < 0.1, "KV written by both prefill paths"
+
+
+def test_tp_collective_path_captured_in_hipgraph():
+    """The tensor-parallel step (phase calls + RCCL all-reduce after o_proj and down_proj) on a 1-rank nccl group:
+    eager and hipGraph replay reproduce the single-call step bit for bit.  (N > 1 needs the driver's 8-GPU node.)"""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        d = get_dims("tiny")
+        w = make_weights(d, seed=13, std=0.06, norm_noise=0.1)
+        outs = []
+        for mode in ("single", "tp_eager", "tp_graph"):
+            eng = _engine(d, w, kv_dtype="fp8", num_blocks=32, max_batch=4, tp_force=(mode != "single"))
+            g = torch.Generator().manual_seed(2)
+            B = 3
+            eng.block_table[:B, :2] = torch.tensor([[1, 2], [3, 4], [5, 6]], dtype=torch.int32)
+            eng.positions[:B] = torch.tensor([3, 9, 17], dtype=torch.int32)
+            eng.seq_lens[:B] = eng.positions[:B] + 1
+            eng.input_ids[:B] = torch.tensor([5, 9, 77], dtype=torch.int32)
+            eng.last_hidden[:B] = torch.randn(B, d.hidden, generator=g).to(BF16).cuda()
+            eng.text_step[:B] = torch.randn(B, d.hidden, generator=g).to(BF16).cuda()
+            for c in eng.kv_caches:
+                c.copy_(torch.randint(0, 100, c.shape, generator=g, dtype=torch.uint8))
+            if mode == "tp_graph":
+                keep = {n: getattr(eng, n).clone() for n in ("input_ids", "positions", "seq_lens", "last_hidden", "steps")}
+                kvk = [c.clone() for c in eng.kv_caches]
+                eng.decode_step(B)                       # warm-up (RCCL communicator, code objects)
+                torch.cuda.synchronize()
+                for n, v in keep.items():
+                    getattr(eng, n).copy_(v)
+                for c, v in zip(eng.kv_caches, kvk):
+                    c.copy_(v)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    eng.decode_step(B)
+                gr.replay()
+            else:
+                eng.decode_step(B)
+            torch.cuda.synchronize()
+            outs.append((eng.logits[:B].cpu(), eng.audio_codes[:B].cpu(), eng.input_ids[:B].cpu(), eng.slot_mapping[:B].cpu()))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
