@@ -39,7 +39,7 @@ def build_engine(args, rank, world):
     from ht_vllm_omni_amd.weights import make_weights
     d = get_dims(args.model)
     t0 = time.time()
-    w = make_weights(d, seed=1234, std=0.02)
+    w = make_weights(d, seed=1234, std=0.02, device="cuda" if args.device_weights else "cpu")
     log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
                        device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False,
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--device-weights", action="store_true", help="profiler runs only: draw weights on the GPU (no H2D copy)")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
     args = ap.parse_args()
@@ -262,6 +263,16 @@ def main():
                      "bytes_per_step": by},
     }
     if rank == 0:
+        # HBM bytes per step from the PMC passes (rocprofv3 cannot ride along with a timed run: separate
+        # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary committed under profiles/)
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
+        if world == 1 and args.model == "tts-1.7b" and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                out["roofline"]["traffic"] = tj["traffic_bytes_per_step"]
+                out["roofline"]["traffic_note"] = "bytes/step, PMC FETCH_SIZE x2 + WRITE_SIZE at mean ctx ~105 (profiles/r01_pmc_step_traffic.json)"
+            except Exception as e:   # noqa: BLE001
+                log(f"traffic file unreadable: {e!r}")
         try:
             out["roofline"]["copy_probe_gbs"] = copy_probe_gbs()
         except Exception as e:   # noqa: BLE001

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
-static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 1;
-extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = !(nt & 2); g_gemm_rn = rn; g_gemm_wgs = wgs; }
+static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 0;   // static-K schedule: same time, +20 % fetch (profiles/r01_pmc_gemm_traffic.csv)
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = (nt >> 1) & 1; g_gemm_rn = rn; g_gemm_wgs = wgs; }
 
 template <int MT, int NT, int PRO, int EPI, int KS>
 static int launch_gemm_ks(const GemmArgs& a, int m_splits, hipStream_t st) {

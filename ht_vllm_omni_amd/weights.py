@@ -18,16 +18,19 @@ import torch
 from .config import TalkerDims
 
 
-def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise: float = 0.0) -> dict[str, torch.Tensor]:
-    g = torch.Generator(device="cpu").manual_seed(seed)
+def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise: float = 0.0,
+                 device: str = "cpu") -> dict[str, torch.Tensor]:
+    """device='cpu' is the reproducible stream every parity test and the bench use; device='cuda' draws from the device
+    generator (different values, same shapes) -- only for profiler runs that must avoid the 3.4 GB host-to-device copy."""
+    g = torch.Generator(device=device).manual_seed(seed)
 
     def rnd(*shape):
-        return (torch.randn(*shape, generator=g, dtype=torch.float32) * std).to(torch.bfloat16)
+        return (torch.randn(*shape, generator=g, dtype=torch.float32, device=device) * std).to(torch.bfloat16)
 
     def nrm(n):
-        w = torch.ones(n, dtype=torch.float32)
+        w = torch.ones(n, dtype=torch.float32, device=device)
         if norm_noise:
-            w = w + torch.randn(n, generator=g) * norm_noise
+            w = w + torch.randn(n, generator=g, device=device) * norm_noise
         return w.to(torch.bfloat16)
 
     w: dict[str, torch.Tensor] = {}
