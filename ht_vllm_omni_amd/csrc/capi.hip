@@ -295,6 +295,8 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
         TRY(omni_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
                                    t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
                                    t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, st));
+        // position 0 only feeds later positions through its K/V: nothing after the last layer's KV write is used
+        if (p == 0 && l == d.cp_layers - 1) break;
         TRY(omni_gemm_bf16(t->cp_attn, hq * D, w.wo, nullptr, t->cp_o, B, Hc, hq * D, OMNI_EPI_BF16, nullptr, st));
         TRY(norm_gemm(t, t->cp_resid_b, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter,
                       Hc, OMNI_EPI_SILU_MUL, nullptr, st));

@@ -58,9 +58,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 
     const uint16_t* wrow[NT];
     if (EPI == OMNI_EPI_SILU_MUL) {
-        const int n0 = blockIdx.x * 16;               // tile 0 = gate rows, tile 1 = matching up rows
-        wrow[0] = a.W + (size_t)(n0 + r) * K + 8 * q;
-        if (NT > 1) wrow[NT - 1] = a.W + (size_t)(N + n0 + r) * K + 8 * q;
+        // tiles [0, NT/2) = gate rows, tiles [NT/2, NT) = the matching up rows (W = [gate | up], N = inter)
+        const int n0 = blockIdx.x * 16 * (NT / 2);
+#pragma unroll
+        for (int j = 0; j < NT / 2; ++j) {
+            wrow[j] = a.W + (size_t)(n0 + j * 16 + r) * K + 8 * q;
+            wrow[NT / 2 + j] = a.W + (size_t)(N + n0 + j * 16 + r) * K + 8 * q;
+        }
     } else {
         const int n0 = blockIdx.x * 16 * NT;
 #pragma unroll
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             m = m_base + (m < Mloc ? m : Mloc - 1);   // rows past M: valid address, result discarded
             xrow[i] = a.x + (size_t)m * a.ldx + 8 * q;
         }
-        constexpr int DEPTH = (NT == 1) ? 16 : 8;
+        constexpr int DEPTH = (NT == 1) ? 16 : (NT == 2 ? 8 : 4);
         u32x4 Wr[DEPTH][NT];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     __syncthreads();
 
     // item = (m-tile i, [n-tile j], lane l): 4 consecutive n (reg 0..3) of one row m
-    constexpr int NTO = (EPI == OMNI_EPI_SILU_MUL) ? 1 : NT;
+    constexpr int NTO = (EPI == OMNI_EPI_SILU_MUL) ? NT / 2 : NT;
     constexpr int ITEMS = NTO * MT * 64;
     for (int it = threadIdx.x; it < ITEMS; it += GEMM_THREADS) {
         const int l = it & 63;
@@ -270,13 +274,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
             for (int w = 0; w < GEMM_WAVES; ++w) {
                 sum += lds[(w * E + (j * MT + i) * 4 + g) * 64 + l];
-                if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds[(w * E + ((NT - 1) * MT + i) * 4 + g) * 64 + l];
+                if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds[(w * E + ((NT / 2 + j) * MT + i) * 4 + g) * 64 + l];
             }
             v[g] = sum;
             v2[g] = sum2;
         }
         if (EPI == OMNI_EPI_SILU_MUL) {
-            const int n = blockIdx.x * 16 + 4 * (l >> 4);
+            const int n = blockIdx.x * 16 * (NT / 2) + j * 16 + 4 * (l >> 4);
             float o[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -312,13 +316,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
+static int g_gemm_silu_nt4 = 1;
 static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 0;   // static-K schedule: same time, +20 % fetch (profiles/r01_pmc_gemm_traffic.csv)
-extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = (nt >> 1) & 1; g_gemm_rn = rn; g_gemm_wgs = wgs; }
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = (nt >> 1) & 1; g_gemm_silu_nt4 = !((nt >> 2) & 1); g_gemm_rn = rn; g_gemm_wgs = wgs; }
 
 template <int MT, int NT, int PRO, int EPI, int KS>
 static int launch_gemm_ks(const GemmArgs& a, int m_splits, hipStream_t st) {
-    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
+    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / (8 * NT) : a.N / (16 * NT);
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
+    if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)
+        static bool done_t = false, done_f = false;
+        if (!done_t) { hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
+        if (!done_f) { hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_f = true; }
+    }
     // non-temporal W loads only when each W byte is read by exactly one workgroup (no m-split)
     if (m_splits == 1 && g_gemm_nt)
         hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
@@ -346,7 +356,7 @@ template <int NT, int PRO, int EPI>
 static int dispatch_mt(const GemmArgs& a, hipStream_t st) {
     // m-tiles per workgroup: split M over grid.y until the grid has >= ~256 workgroups
     const int mt_total = (a.M + 15) / 16;
-    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / 16 : a.N / (16 * NT);
+    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / (8 * NT) : a.N / (16 * NT);
     int splits = (g_gemm_wgs + groups - 1) / groups;
     if (splits > mt_total) splits = mt_total;
     if (splits < 1) splits = 1;
@@ -374,6 +384,8 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
             return dispatch_mt<1, PRO, OMNI_EPI_BF16>(a, st);
         case OMNI_EPI_SILU_MUL:
             OMNI_CHECK_ARG(a.bias == nullptr && a.mask == nullptr, "omni_gemm_bf16: silu_mul takes no bias/mask");
+            if (g_gemm_silu_nt4 && a.N % 32 == 0 && a.M > 32 && a.N / 32 >= 160)
+                return dispatch_mt<4, PRO, OMNI_EPI_SILU_MUL>(a, st);
             return dispatch_mt<2, PRO, OMNI_EPI_SILU_MUL>(a, st);
         case OMNI_EPI_F32:
             return dispatch_mt<1, PRO, OMNI_EPI_F32>(a, st);

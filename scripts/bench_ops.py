@@ -31,7 +31,7 @@ def bench_gemm(name, N, K, epi, M=64, hot=False):
         for i in range(n_launch):
             ops.gemm(x, Ws[i % R], epilogue=epi)
     res = []
-    for nt, wgs in ((1, 256), (3, 256)):   # nt bit0 = non-temporal W, bit1 = static-K schedule
+    for nt, wgs in ((1, 256), (5, 256)):   # nt bit0 = non-temporal W, bit1 = static-K schedule, bit2 = silu NT=2 instead of 4
         lib.omni_debug_set(nt, 0, wgs)
         us = graph_time(fn) / n_launch
         res.append(f"nt={nt} wgs={wgs}: {us:6.2f} us {wbytes / us / 1e6:5.2f} TB/s")
