@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libomni_talker.so")
 KV_BF16, KV_FP8, KV_INT8 = 0, 1, 2
 KV_CODES = {"bf16": KV_BF16, "auto": KV_BF16, "fp8": KV_FP8, "fp8_e4m3": KV_FP8, "int8": KV_INT8}
 EPI_BF16, EPI_SILU_MUL, EPI_F32, EPI_F32_BF16RND = 0, 1, 2, 3
+LAYOUT_W_FRAG, LAYOUT_X_FRAG, LAYOUT_OUT_FRAG = 1, 2, 4
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -34,7 +35,7 @@ class TalkerDesc(C.Structure):
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
         ("vocab", i32), ("codebook", i32), ("num_code_groups", i32), ("eps", f32),
         ("cp_hidden", i32), ("cp_layers", i32), ("cp_q_heads", i32), ("cp_kv_heads", i32), ("cp_head_dim", i32),
-        ("cp_inter", i32), ("has_cp_projection", i32),
+        ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32),
         ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
         ("k_scale", f32), ("v_scale", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "omni_abi_version": (i32, []),
     "omni_rmsnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_gemm_bf16_ex": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_gemm_resid_norm": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                      f32, f32, f32, i32, vp]),

@@ -123,26 +123,27 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     const size_t qkv_out = (size_t)(d.q_heads + 2 * d.kv_heads) * d.head_dim;
     const size_t cp_qkv_out = (size_t)(d.cp_q_heads + 2 * d.cp_kv_heads) * d.cp_head_dim;
     Carver c{base, 0};
+    const size_t B16 = (B + 15) & ~(size_t)15;      // fragment-major activation buffers hold whole 16-row tiles
     t->resid = c.take<uint16_t>(B * H);
     t->resid_b = c.take<uint16_t>(B * H);
-    t->normed = c.take<uint16_t>(B * H);
+    t->normed = c.take<uint16_t>(B16 * H);
     t->qkv = c.take<uint16_t>(B * qkv_out);
     t->q = c.take<uint16_t>(B * d.q_heads * d.head_dim);
-    t->attn = c.take<uint16_t>(B * d.q_heads * d.head_dim);
+    t->attn = c.take<uint16_t>(B16 * d.q_heads * d.head_dim);
     t->attn_out = c.take<uint16_t>(B * H);
-    t->act = c.take<uint16_t>(B * d.inter);
+    t->act = c.take<uint16_t>(B16 * d.inter);
     t->mlp_out = c.take<uint16_t>(B * H);
     t->hidden = c.take<uint16_t>(B * H);
     t->e0 = c.take<uint16_t>(B * H);
     t->attn_ws = c.take<float>((size_t)omni_paged_attn_workspace_bytes(d.max_batch, d.q_heads, d.head_dim, d.max_model_len) / 4);
     t->cp_resid = c.take<uint16_t>(B * Hc);
     t->cp_resid_b = c.take<uint16_t>(B * Hc);
-    t->cp_normed = c.take<uint16_t>(B * Hc);
+    t->cp_normed = c.take<uint16_t>(B16 * Hc);
     t->cp_qkv = c.take<uint16_t>(B * cp_qkv_out);
     t->cp_q = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
-    t->cp_attn = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
+    t->cp_attn = c.take<uint16_t>(B16 * d.cp_q_heads * d.cp_head_dim);
     t->cp_o = c.take<uint16_t>(B * Hc);
-    t->cp_act = c.take<uint16_t>(B * d.cp_inter);
+    t->cp_act = c.take<uint16_t>(B16 * d.cp_inter);
     t->cp_mlp = c.take<uint16_t>(B * Hc);
     t->cp_hidden = c.take<uint16_t>(B * Hc);
     t->cp_in = c.take<uint16_t>(B * Hc);
@@ -270,14 +271,28 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
 // kernel's workgroups all re-read resid_in, so it cannot be updated in place); one launch when K allows it
 static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* delta, uint16_t* resid_out, const void* norm_w,
                      uint16_t* normed_scratch, void* normed_out, const void* w, void* out, int rows, int N, int K, int epi,
-                     const uint8_t* mask, void* st) {
+                     const uint8_t* mask, int out_frag, void* st) {
     const float eps = t->d.eps;
-    if (k_gemm_rn_supported(K))
+    const int F = t->d.frag_layout;
+    if (!F && k_gemm_rn_supported(K))
         return omni_gemm_resid_norm(resid_in, delta, resid_out, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
-    uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
     OMNI_CHECK_ARG(resid_out || delta == nullptr, "norm_gemm: delta without resid_out");
-    TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, nx, rows, K, eps, st));
+    if (F) {
+        // normalised rows go out fragment-major for the GEMM (and row-major too when the caller wants them)
+        TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, normed_out, normed_scratch, rows, K, eps, st));
+        return omni_gemm_bf16_ex(normed_scratch, K, w, nullptr, out, rows, N, K, epi, mask,
+                                 OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | (out_frag ? OMNI_LAYOUT_OUT_FRAG : 0), st);
+    }
+    uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
+    TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, nx, nullptr, rows, K, eps, st));
     return omni_gemm_bf16(nx, K, w, nullptr, out, rows, N, K, epi, mask, st);
+}
+
+// plain GEMM on an activation buffer produced by one of our kernels (fragment-major when the engine runs that layout)
+static int act_gemm(omni_talker* t, const void* x, const void* w, const void* bias, void* out, int rows, int N, int K, void* st) {
+    const int F = t->d.frag_layout;
+    return omni_gemm_bf16_ex(x, K, w, bias, out, rows, N, K, OMNI_EPI_BF16, nullptr,
+                             F ? (OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG) : 0, st);
 }
 
 // ---- one code-predictor forward pass at buffer position p (input rows = residual stream in t->cp_resid)
@@ -291,16 +306,17 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
         const omni_layer_weights& w = t->cp_layer[l];
         // residual stream ping-pongs cp_resid -> cp_resid_b (attention half) -> cp_resid (MLP half)
         TRY(norm_gemm(t, t->cp_resid, l == 0 ? nullptr : t->cp_mlp, t->cp_resid_b, w.ln1, t->cp_normed, nullptr, w.wqkv,
-                      t->cp_qkv, B, (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, st));
-        TRY(omni_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
-                                   t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
-                                   t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, st));
+                      t->cp_qkv, B, (hq + 2 * hkv) * D, Hc, OMNI_EPI_BF16, nullptr, 0, st));
+        TRY(k_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
+                                t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
+                                t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs,
+                                d.frag_layout, st));
         // position 0 only feeds later positions through its K/V: nothing after the last layer's KV write is used
         if (p == 0 && l == d.cp_layers - 1) break;
-        TRY(omni_gemm_bf16(t->cp_attn, hq * D, w.wo, nullptr, t->cp_o, B, Hc, hq * D, OMNI_EPI_BF16, nullptr, st));
+        TRY(act_gemm(t, t->cp_attn, w.wo, nullptr, t->cp_o, B, Hc, hq * D, st));
         TRY(norm_gemm(t, t->cp_resid_b, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter,
-                      Hc, OMNI_EPI_SILU_MUL, nullptr, st));
-        TRY(omni_gemm_bf16(t->cp_act, d.cp_inter, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, OMNI_EPI_BF16, nullptr, st));
+                      Hc, OMNI_EPI_SILU_MUL, nullptr, d.frag_layout, st));
+        TRY(act_gemm(t, t->cp_act, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, st));
     }
     return OMNI_OK;
 }
@@ -309,7 +325,8 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
 static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, void* st) {
     const omni_talker_desc& d = t->d;
     if (d.has_cp_projection)
-        return omni_gemm_bf16(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_resid, B, d.cp_hidden, d.hidden, OMNI_EPI_BF16, nullptr, st);
+        return omni_gemm_bf16_ex(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_resid, B, d.cp_hidden, d.hidden, OMNI_EPI_BF16,
+                                 nullptr, d.frag_layout ? OMNI_LAYOUT_W_FRAG : 0, st);
     hipError_t e = hipMemcpyAsync(t->cp_resid, rows, (size_t)B * d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st);
     if (e != hipSuccess) { omni_set_error("cp_project: memcpy: %s", hipGetErrorString(e)); return OMNI_EHIP; }
     return OMNI_OK;
@@ -333,7 +350,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         TRY(cp_forward(t, B, g, st));
         const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
         TRY(norm_gemm(t, t->cp_resid, t->cp_mlp, t->cp_resid_b, d.cp_norm, t->cp_normed, nullptr, head, t->cp_logits, B,
-                      d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, st));
+                      d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, 0, st));
         if (cp_logits_out) {
             hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
                                             t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,
@@ -395,12 +412,12 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
     TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, B,
-                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
-    TRY(omni_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
-                               t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
-                               l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
-                               d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, st));
-    TRY(omni_gemm_bf16(t->attn, hq * D, w.wo, nullptr, t->attn_out, B, H, hq * D, OMNI_EPI_BF16, nullptr, st));
+                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, 0, st));
+    TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
+                            t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
+                            l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
+                            d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, st));
+    TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, B, H, hq * D, st));
     return OMNI_OK;
 }
 
@@ -411,13 +428,13 @@ static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* po
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim;
     TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, rows,
-                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, st));
+                  (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, 0, st));
     TRY(omni_qknorm_rope_kvwrite(t->qkv, w.qnorm, w.knorm, positions, d.cos_sin, slots, t->q, t->k_cache[l], t->v_cache[l],
                                  t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, d.k_scale, d.v_scale, st));
-    TRY(omni_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table, d.bt_stride,
-                                req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale,
-                                d.v_scale, 1.0f / sqrtf((float)D), st));
-    TRY(omni_gemm_bf16(t->attn, hq * D, w.wo, nullptr, t->attn_out, rows, H, hq * D, OMNI_EPI_BF16, nullptr, st));
+    TRY(k_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table, d.bt_stride,
+                             req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale,
+                             d.v_scale, 1.0f / sqrtf((float)D), d.frag_layout, st));
+    TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, rows, H, hq * D, st));
     return OMNI_OK;
 }
 
@@ -425,8 +442,8 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     TRY(norm_gemm(t, t->resid_b, t->attn_out, t->resid, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
-                  OMNI_EPI_SILU_MUL, nullptr, st));
-    TRY(omni_gemm_bf16(t->act, d.inter, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, OMNI_EPI_BF16, nullptr, st));
+                  OMNI_EPI_SILU_MUL, nullptr, d.frag_layout, st));
+    TRY(act_gemm(t, t->act, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, st));
     return OMNI_OK;
 }
 
@@ -447,9 +464,10 @@ extern "C" int omni_talker_logits(omni_talker* t, const void* hidden, float* log
     const omni_talker_desc& d = t->d;
     for (int r0 = 0; r0 < R; r0 += 64) {
         const int m = R - r0 < 64 ? R - r0 : 64;
-        TRY(omni_gemm_bf16(reinterpret_cast<const uint16_t*>(hidden) + (size_t)r0 * d.hidden, d.hidden, d.lm_head, nullptr,
-                           logits + (size_t)r0 * d.vocab, m, d.vocab, d.hidden,
-                           round_bf16 ? OMNI_EPI_F32_BF16RND : OMNI_EPI_F32, d.allowed_mask, stream));
+        TRY(omni_gemm_bf16_ex(reinterpret_cast<const uint16_t*>(hidden) + (size_t)r0 * d.hidden, d.hidden, d.lm_head, nullptr,
+                              logits + (size_t)r0 * d.vocab, m, d.vocab, d.hidden,
+                              round_bf16 ? OMNI_EPI_F32_BF16RND : OMNI_EPI_F32, d.allowed_mask,
+                              d.frag_layout ? OMNI_LAYOUT_W_FRAG : 0, stream));
     }
     return OMNI_OK;
 }
@@ -461,8 +479,8 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     hipStream_t st = (hipStream_t)stream;
     // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
-    TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, reinterpret_cast<uint16_t*>(io->last_hidden),
-                  io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, stream));
+    TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
+                  io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream));
     if (io->advance) {

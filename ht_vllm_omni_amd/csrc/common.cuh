@@ -75,3 +75,10 @@ __device__ __forceinline__ float hash_uniform(uint32_t seed, uint32_t step, uint
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
+
+// ---- fragment-major layout of a [rows, K] bf16 matrix (rows padded to 16, K % 32 == 0): the 16-row x 32-k tile an
+// MFMA 16x16x32 operand consumes is 512 contiguous elements in LANE order (lane = 16 * kchunk + row % 16, 8 elements per
+// lane), tiles ordered [row tile][k step].  One wave-level 16-B load of a fragment = 1 KB contiguous.
+__host__ __device__ __forceinline__ size_t frag_off(int row, int k, int K) {
+    return ((((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 4 + ((k & 31) >> 3)) * 16 + (row & 15)) * 8 + (k & 7);
+}

@@ -44,6 +44,7 @@ struct GemmArgs {
     const uint8_t* mask;
     // PRO_RN
     const uint16_t* resid; uint16_t* resid_out; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
+    int wshuf, xshuf, oshuf;   // fragment-major layouts (OMNI_LAYOUT_*), see common.cuh frag_off
 };
 
 template <int MT, int NT, int PRO, int EPI, bool NTL, int KS>
@@ -56,19 +57,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     const int m_base = blockIdx.y * (MT * 16);
     const int Mloc = min(a.M - m_base, MT * 16);     // valid rows of this workgroup (>= 1)
 
+    // Operand addressing.  Row-major: lane (r, q) reads 16 B of row r at k-offset 8q, k-step stride 32 elements -- 64
+    // separate cache accesses per wave-level load (adjacent lanes sit on different 2K-byte-strided rows: measured
+    // 64.8 TCP accesses per load, texture addresser 71 % busy at M = 64).  Fragment-major (frag_off): the 16 x 32 tile
+    // of one MFMA operand is 1 KB contiguous in lane order, one wave-level load = 8 full lines, k-step stride 512.
+    const int nsteps = K >> 5;                                    // k-steps of 32
+    const int wstep = a.wshuf ? 512 : 32;
+    const int xstep = a.xshuf ? 512 : 32;
     const uint16_t* wrow[NT];
-    if (EPI == OMNI_EPI_SILU_MUL) {
-        // tiles [0, NT/2) = gate rows, tiles [NT/2, NT) = the matching up rows (W = [gate | up], N = inter)
-        const int n0 = blockIdx.x * 16 * (NT / 2);
+    {
+        int row0[NT];
+        if (EPI == OMNI_EPI_SILU_MUL) {
+            // tiles [0, NT/2) = gate rows, tiles [NT/2, NT) = the matching up rows (W = [gate | up], N = inter)
+            const int n0 = blockIdx.x * 16 * (NT / 2);
 #pragma unroll
-        for (int j = 0; j < NT / 2; ++j) {
-            wrow[j] = a.W + (size_t)(n0 + j * 16 + r) * K + 8 * q;
-            wrow[NT / 2 + j] = a.W + (size_t)(N + n0 + j * 16 + r) * K + 8 * q;
+            for (int j = 0; j < NT / 2; ++j) {
+                row0[j] = n0 + j * 16;
+                row0[NT / 2 + j] = N + n0 + j * 16;
+            }
+        } else {
+            const int n0 = blockIdx.x * 16 * NT;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) row0[j] = n0 + j * 16;
         }
-    } else {
-        const int n0 = blockIdx.x * 16 * NT;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wrow[j] = a.W + (size_t)(n0 + j * 16 + r) * K + 8 * q;
+        for (int j = 0; j < NT; ++j)
+            wrow[j] = a.wshuf ? a.W + ((size_t)(row0[j] >> 4) * nsteps) * 512 + lane * 8
+                              : a.W + (size_t)(row0[j] + r) * K + 8 * q;
     }
 
     f32x4 acc[NT][MT];
@@ -77,7 +92,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = K >> 5;                                    // k-steps of 32
     const int ntw = (nsteps - wave + GEMM_WAVES - 1) / GEMM_WAVES; // k-steps of this wave (may be 0)
 
     if (PRO == 1) {
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
         for (int s = 0; s < RN_MAX_STEPS; ++s)
             if (s < ntw) {
-                const int k0 = (wave + s * GEMM_WAVES) << 5;
+                const int k0 = (wave + s * GEMM_WAVES) * wstep;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wf[s][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
             }
@@ -170,7 +184,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             for (int i = 0; i < MT; ++i) {
                 int m = i * 16 + r;
                 m = m_base + (m < Mloc ? m : Mloc - 1);
-                xr_[i] = a.x + (size_t)m * a.ldx + 8 * q + (wave << 5);
+                xr_[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8 + wave * xstep
+                                 : a.x + (size_t)m * a.ldx + 8 * q + wave * xstep;
             }
             constexpr int XW = (MT == 4) ? 4 : 8;
             constexpr int XWe = XW < KS ? XW : KS;
@@ -179,11 +194,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             for (int t = 0; t < KS; ++t)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    Wr[t][j] = NTL ? ld16_nt(wrow[j] + (wave << 5) + t * (GEMM_WAVES << 5)) : ld16(wrow[j] + (wave << 5) + t * (GEMM_WAVES << 5));
+                    Wr[t][j] = NTL ? ld16_nt(wrow[j] + (wave + t * GEMM_WAVES) * wstep) : ld16(wrow[j] + (wave + t * GEMM_WAVES) * wstep);
 #pragma unroll
             for (int t = 0; t < XWe; ++t)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) X[t][i] = ld16(xr_[i] + t * (GEMM_WAVES << 5));
+                for (int i = 0; i < MT; ++i) X[t][i] = ld16(xr_[i] + t * GEMM_WAVES * xstep);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wr[t][j], X[t % XWe][i], acc[j][i]);
                 if (t + XWe < KS) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) X[t % XWe][i] = ld16(xr_[i] + (t + XWe) * (GEMM_WAVES << 5));
+                    for (int i = 0; i < MT; ++i) X[t % XWe][i] = ld16(xr_[i] + (t + XWe) * GEMM_WAVES * xstep);
                 }
             }
         } else {
@@ -206,21 +221,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         for (int i = 0; i < MT; ++i) {
             int m = i * 16 + r;
             m = m_base + (m < Mloc ? m : Mloc - 1);   // rows past M: valid address, result discarded
-            xrow[i] = a.x + (size_t)m * a.ldx + 8 * q;
+            xrow[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8
+                              : a.x + (size_t)m * a.ldx + 8 * q;
         }
         constexpr int DEPTH = (NT == 1) ? 16 : (NT == 2 ? 8 : 4);
         u32x4 Wr[DEPTH][NT];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (d < ntw) {
-                const int k0 = (wave + d * GEMM_WAVES) << 5;
+                const int k0 = (wave + d * GEMM_WAVES) * wstep;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Wr[d][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
             }
         u32x4 X[2][MT];
         if (ntw > 0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + (wave << 5));
+            for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + wave * xstep);
         }
         for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
 #pragma unroll
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 const int t = t0 + d;
                 if (t < ntw) {
                     if (t + 1 < ntw) {
-                        const int k1 = (wave + (t + 1) * GEMM_WAVES) << 5;
+                        const int k1 = (wave + (t + 1) * GEMM_WAVES) * xstep;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = ld16(xrow[i] + k1);
                     }
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
                         for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wr[d][j], X[d & 1][i], acc[j][i]);
                     if (t + DEPTH < ntw) {
-                        const int k2 = (wave + (t + DEPTH) * GEMM_WAVES) << 5;
+                        const int k2 = (wave + (t + DEPTH) * GEMM_WAVES) * wstep;
 #pragma unroll
                         for (int j = 0; j < NT; ++j) Wr[d][j] = NTL ? ld16_nt(wrow[j] + k2) : ld16(wrow[j] + k2);
                     }
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 const float sl = bfround(gt / (1.0f + expf(-gt)));
                 o[g] = sl * up;
             }
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)m * N + n) =
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (a.oshuf ? frag_off(m, n, N) : (size_t)m * N + n)) =
                 make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
         } else {
             const int n = blockIdx.x * 16 * NT + j * 16 + 4 * (l >> 4);
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 for (int g = 0; g < 4; ++g) v[g] += bf2f(a.bias[n + g]);
             }
             if (EPI == OMNI_EPI_BF16) {
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)m * N + n) =
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (a.oshuf ? frag_off(m, n, N) : (size_t)m * N + n)) =
                     make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             } else {
                 float4 o;
@@ -397,16 +413,27 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
     }
 }
 
-extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
-                              int K, int epilogue, const uint8_t* mask, void* stream) {
+extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
+                                 int K, int epilogue, const uint8_t* mask, int layout, void* stream) {
     GemmArgs a{};
+    a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
+    a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
+    a.oshuf = (layout & OMNI_LAYOUT_OUT_FRAG) != 0;
+    OMNI_CHECK_ARG(!a.oshuf || epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL,
+                   "omni_gemm_bf16: fragment-major output needs a bf16 epilogue");
+    OMNI_CHECK_ARG(!a.oshuf || N % 32 == 0, "omni_gemm_bf16: fragment-major output needs N %% 32 == 0");
     a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
     a.M = M; a.N = N; a.K = K; a.mask = mask;
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_ARG(x, "omni_gemm_bf16: null x");
-    OMNI_CHECK_ARG(ldx >= K && ldx % 8 == 0, "omni_gemm_bf16: ldx=%d (need >= K, multiple of 8)", ldx);
+    OMNI_CHECK_ARG(a.xshuf || (ldx >= K && ldx % 8 == 0), "omni_gemm_bf16: ldx=%d (need >= K, multiple of 8)", ldx);
     return dispatch_epi<0>(a, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
+                              int K, int epilogue, const uint8_t* mask, void* stream) {
+    return omni_gemm_bf16_ex(x, ldx, w, bias, out, M, N, K, epilogue, mask, 0, stream);
 }
 
 // the fused prologue multiplies the activation traffic by the number of workgroups (every workgroup re-reads

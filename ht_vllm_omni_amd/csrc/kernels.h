@@ -14,5 +14,16 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, void* stream);
 // rmsnorm with out-of-place residual update: residual_out = bf16(residual + delta) (may alias residual)
+// out (row-major) and/or out_frag (fragment-major, common.cuh frag_off) receive the normalised rows
 int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,
-              int rows, int hidden, float eps, void* stream);
+              void* out_frag, int rows, int hidden, float eps, void* stream);
+// internal attention entry points with a fragment-major output option
+int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                        const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
+                        const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
+                        void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
+                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, void* stream);
+int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
+                         const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
+                         const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,
+                         int kv_dtype, float k_scale, float v_scale, float sm_scale, int out_frag, void* stream);

@@ -13,6 +13,7 @@
 // splits merged by a second tiny kernel.  Output = oracle attention_rows (fp32 softmax and PV, one
 // rounding to bf16); the fused prologue = oracle rms_norm / apply_rope / fp8_quant / int8_quant.
 #include "common.cuh"
+#include "kernels.h"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
@@ -31,6 +32,7 @@ struct PAArgs {
     const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
     uint16_t* out; float* partial;
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
+    int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
 };
 
 template <int KV>
@@ -348,7 +350,8 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         const int qh = kvh * G + g;
         if (a.nsplit == 1) {
             const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
-            a.out[((size_t)row * a.q_heads + qh) * 128 + d] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
+            const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
+            a.out[oo] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
         } else {
             float* rec = a.partial + (((size_t)row * a.q_heads + qh) * a.nsplit + sp) * PA_REC;
             if (d == 0) {
@@ -487,7 +490,9 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         lw += __shfl_xor(lw, 16, 64);
         lw += __shfl_xor(lw, 32, 64);
         const float inv = 1.0f / lw;                  // >= the new token's weight, never 0
-        uint16_t* op = a.out + ((size_t)row * a.q_heads + kvh * G + g) * 128;
+        const int kq = (kvh * G + g) * 128;
+        uint16_t* op0 = a.out_frag ? a.out + frag_off(row, kq + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + sub * 8;
+        uint16_t* op1 = a.out_frag ? a.out + frag_off(row, kq + 64 + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + 64 + sub * 8;
         uint32_t packed[8];
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
@@ -498,15 +503,16 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
             packed[e >> 1] = pack_bf2(v0 * inv, v1 * inv);
         }
         if (tg == 0) {   // bf16 layout: elements [8 sub, +8) and [64 + 8 sub, +8): two 16-B stores
-            *reinterpret_cast<uint4*>(op + sub * 8) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-            *reinterpret_cast<uint4*>(op + 64 + sub * 8) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+            *reinterpret_cast<uint4*>(op0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            *reinterpret_cast<uint4*>(op1) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
         }
     }
 }
 
 // merge KV splits: one 128-thread block per (row, q-head)
 __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ partial,
-                                                               uint16_t* __restrict__ out, int nsplit, float v_mul) {
+                                                               uint16_t* __restrict__ out, int nsplit, float v_mul,
+                                                               int q_heads, int out_frag) {
     const size_t rh = blockIdx.x;
     const int d = threadIdx.x;
     const float* base = partial + rh * nsplit * PA_REC;
@@ -519,7 +525,8 @@ __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __re
         L = fmaf(rec[1], w, L);
         A = fmaf(rec[2 + d], w, A);
     }
-    out[rh * 128 + d] = f2bf(L > 0.f ? (A / L) * v_mul : 0.f);
+    const int row = (int)(rh / q_heads), qh = (int)(rh % q_heads);
+    out[out_frag ? frag_off(row, qh * 128 + d, q_heads * 128) : rh * 128 + d] = f2bf(L > 0.f ? (A / L) * v_mul : 0.f);
 }
 
 static int pick_nsplit(int rows, int kv_heads, int max_seq_len) {
@@ -554,7 +561,7 @@ static int launch_pa(const PAArgs& a, int rows, hipStream_t st) {
     OMNI_CHECK_LAUNCH("omni_paged_attn_decode");
     if (a.nsplit > 1) {
         hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(rows * a.q_heads), dim3(128), 0, st, (const float*)a.partial,
-                           a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f);
+                           a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f, a.q_heads, a.out_frag);
         OMNI_CHECK_LAUNCH("omni_paged_attn_merge");
     }
     return OMNI_OK;
@@ -597,13 +604,13 @@ extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const 
     return pa_dispatch(a, B, head_dim, kv_dtype, false, stream);
 }
 
-extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
-                                      const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales,
-                                      float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* seq_lens,
-                                      int64_t* slot_out, void* out, void* workspace, int B, int q_heads, int kv_heads,
-                                      int head_dim, int block_size, int kv_dtype, float k_scale, float v_scale,
-                                      float sm_scale, int max_seq_len, void* stream) {
+int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                        const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
+                        const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
+                        void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
+                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, void* stream) {
     PAArgs a{};
+    a.out_frag = out_frag;
     a.qkv = (const uint16_t*)qkv; a.qnorm_w = (const uint16_t*)qnorm_w; a.knorm_w = (const uint16_t*)knorm_w;
     a.positions = positions; a.cos_sin = (const uint16_t*)cos_sin; a.eps = eps; a.slot_out = slot_out;
     a.k_cache = k_cache; a.v_cache = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
@@ -629,18 +636,38 @@ extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, cons
     return pa_dispatch(a, B, head_dim, kv_dtype, true, stream);
 }
 
-extern "C" int omni_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
-                                       const float* v_scales, const int32_t* block_table, int bt_stride,
-                                       const int32_t* req_of_tok, const int32_t* positions, void* out, int T,
-                                       int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
-                                       float k_scale, float v_scale, float sm_scale, void* stream) {
+extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                                      const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales,
+                                      float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* seq_lens,
+                                      int64_t* slot_out, void* out, void* workspace, int B, int q_heads, int kv_heads,
+                                      int head_dim, int block_size, int kv_dtype, float k_scale, float v_scale,
+                                      float sm_scale, int max_seq_len, void* stream) {
+    return k_attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, eps, k_cache, v_cache, k_scales, v_scales,
+                               block_table, bt_stride, seq_lens, slot_out, out, workspace, B, q_heads, kv_heads, head_dim,
+                               block_size, kv_dtype, k_scale, v_scale, sm_scale, max_seq_len, 0, stream);
+}
+
+int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
+                         const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
+                         const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,
+                         int kv_dtype, float k_scale, float v_scale, float sm_scale, int out_frag, void* stream) {
     OMNI_CHECK_ARG(req_of_tok && positions, "omni_paged_attn_prefill: null pointer");
     // every token is a decode row whose context is positions[t] + 1 keys of request req_of_tok[t]
     PAArgs a{};
+    a.out_frag = out_frag;
     a.q = (const uint16_t*)q; a.k_cache = const_cast<void*>(k_cache); a.v_cache = const_cast<void*>(v_cache);
     a.k_scales = const_cast<float*>(k_scales); a.v_scales = const_cast<float*>(v_scales);
     a.block_table = block_table; a.bt_stride = bt_stride; a.seq_lens = positions; a.req_of_row = req_of_tok;
     a.seq_from_pos = 1; a.out = (uint16_t*)out; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
     a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale; a.nsplit = 1;
     return pa_dispatch(a, T, head_dim, kv_dtype, false, stream);
+}
+
+extern "C" int omni_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
+                                       const float* v_scales, const int32_t* block_table, int bt_stride,
+                                       const int32_t* req_of_tok, const int32_t* positions, void* out, int T,
+                                       int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
+                                       float k_scale, float v_scale, float sm_scale, void* stream) {
+    return k_paged_attn_prefill(q, k_cache, v_cache, k_scales, v_scales, block_table, bt_stride, req_of_tok, positions, out, T,
+                                q_heads, kv_heads, head_dim, block_size, kv_dtype, k_scale, v_scale, sm_scale, 0, stream);
 }

@@ -31,6 +31,27 @@ def codec_allowed_mask(d: TalkerDims, allow_eos: bool = True) -> torch.Tensor:
     return m
 
 
+def frag_shuffle(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] row-major -> fragment-major (include/omni_talker.h OMNI_LAYOUT_W_FRAG): the 16-row x 32-k tile of one MFMA
+    operand becomes 1 KB contiguous in lane order.  Same bytes, same shape; done once at load."""
+    N, K = w.shape[-2], w.shape[-1]
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    lead = w.shape[:-2]
+    v = w.reshape(*lead, N // 16, 16, K // 32, 4, 8)
+    nd = len(lead)
+    v = v.permute(*range(nd), nd, nd + 2, nd + 3, nd + 1, nd + 4)
+    return v.contiguous().reshape(*lead, N, K)
+
+
+def frag_unshuffle(w: torch.Tensor) -> torch.Tensor:
+    N, K = w.shape[-2], w.shape[-1]
+    lead = w.shape[:-2]
+    v = w.reshape(*lead, N // 16, K // 32, 4, 16, 8)
+    nd = len(lead)
+    v = v.permute(*range(nd), nd, nd + 3, nd + 1, nd + 2, nd + 4)
+    return v.contiguous().reshape(*lead, N, K)
+
+
 def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict:
     """Per-rank slices of one backbone layer."""
     D = d.head_dim
@@ -60,7 +81,7 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
 class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
-                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False):
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -69,6 +90,7 @@ class TalkerEngine:
         self.tp_path = tp_size > 1 or tp_force      # tp_force: run the collective path on a 1-rank group (tests)
         assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
         self.kv_dtype = kv_dtype
+        self.frag_layout = bool(frag_layout)
         self.kv_code = L.KV_CODES[kv_dtype]
         self.block_size, self.num_blocks, self.max_batch = block_size, num_blocks, max_batch
         self.hq_l = dims.q_heads // tp_size
@@ -116,13 +138,19 @@ class TalkerEngine:
         for i in range(d.layers):
             sh = shard_layer(d, weights, f"l{i}.", tp_rank, tp_size)
             lw = {n: up(sh[n]) for n in names}
-            self.layer_w.append(lw)
+            self.layer_w.append(lw)                 # row-major: hipBLASLt prefill path
             for n in names:
-                setattr(self._layers[i], n, lw[n].data_ptr())
+                t_ = lw[n]
+                if self.frag_layout and n in ("wqkv", "wo", "wgu", "wdown"):
+                    t_ = up(frag_shuffle(lw[n]))    # fragment-major copy for the native decode GEMMs
+                setattr(self._layers[i], n, t_.data_ptr())
         self._cp_layers = (L.LayerWeights * d.cp_layers)()
         self.cp_layer_w: list[dict] = []
         for i in range(d.cp_layers):
             lw = {n: up(weights[f"cp.l{i}.{n}"]) for n in names}
+            if self.frag_layout:
+                for n in ("wqkv", "wo", "wgu", "wdown"):
+                    lw[n] = up(frag_shuffle(lw[n]))
             self.cp_layer_w.append(lw)
             for n in names:
                 setattr(self._cp_layers[i], n, lw[n].data_ptr())
@@ -148,15 +176,23 @@ class TalkerEngine:
         desc.num_code_groups, desc.eps = d.num_code_groups, d.eps
         desc.cp_hidden, desc.cp_layers, desc.cp_q_heads, desc.cp_kv_heads = d.cp_hidden, d.cp_layers, d.cp_q_heads, d.cp_kv_heads
         desc.cp_head_dim, desc.cp_inter, desc.has_cp_projection = d.cp_head_dim, d.cp_inter, int(d.has_cp_projection)
+        desc.frag_layout = int(self.frag_layout)
+        if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
+            self._lm_head_f = up(frag_shuffle(self.lm_head))
+            self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
+            self._cp_proj_w_f = up(frag_shuffle(self.cp_proj_w)) if self.cp_proj_w is not None else None
         desc.max_batch, desc.block_size, desc.kv_dtype = max_batch, block_size, self.kv_code
         desc.max_model_len, desc.bt_stride = d.max_model_len, self.bt_stride
         desc.k_scale, desc.v_scale = k_scale, v_scale
         desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
         desc.layer = C.cast(self._layers, C.POINTER(L.LayerWeights))
-        desc.lm_head, desc.allowed_mask, desc.cos_sin = self.lm_head.data_ptr(), self.allowed.data_ptr(), self.cos_sin.data_ptr()
-        desc.cp_proj_w, desc.cp_proj_b = L.ptr(self.cp_proj_w), L.ptr(self.cp_proj_b)
+        desc.lm_head = (self._lm_head_f if self.frag_layout else self.lm_head).data_ptr()
+        desc.allowed_mask, desc.cos_sin = self.allowed.data_ptr(), self.cos_sin.data_ptr()
+        desc.cp_proj_w = L.ptr(self._cp_proj_w_f if self.frag_layout else self.cp_proj_w)
+        desc.cp_proj_b = L.ptr(self.cp_proj_b)
         desc.cp_layer = C.cast(self._cp_layers, C.POINTER(L.LayerWeights))
-        desc.cp_norm, desc.cp_lm_head = self.cp_norm.data_ptr(), self.cp_lm_head.data_ptr()
+        desc.cp_norm = self.cp_norm.data_ptr()
+        desc.cp_lm_head = (self._cp_lm_head_f if self.frag_layout else self.cp_lm_head).data_ptr()
         desc.cp_embed, desc.cp_cos_sin = self.cp_embed.data_ptr(), self.cp_cos_sin.data_ptr()
         desc.cp_proj_table, desc.cp_e0_table = self.cp_proj_table.data_ptr(), self.cp_e0_table.data_ptr()
         pvp = C.POINTER(C.c_void_p)

@@ -30,15 +30,19 @@ def rmsnorm(x, w, eps, *, delta=None, residual=None):
     return out
 
 
-def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None):
-    """out[M,N] = x[M,K] . w[N,K]^T ; silu_mul: w = [gate|up] rows -> N = rows/2."""
+def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None, layout=0, M=None):
+    """out[M,N] = x[M,K] . w[N,K]^T ; silu_mul: w = [gate|up] rows -> N = rows/2.
+    layout bits (LAYOUT_*_FRAG): w / x given, out produced in fragment-major order (x, out then have 16-row padding;
+    pass the true M)."""
     _chk_dev(x, w, bias, mask)
-    M, K = x.shape
+    Mx, K = x.shape
+    M = Mx if M is None else M
     N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
     dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
-    out = torch.empty(M, N, dtype=dt, device=x.device)
-    L.check(L.load().omni_gemm_bf16(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue,
-                                    L.ptr(mask), L.current_stream()), "omni_gemm_bf16")
+    rows_out = (M + 15) // 16 * 16 if layout & L.LAYOUT_OUT_FRAG else M
+    out = torch.zeros(rows_out, N, dtype=dt, device=x.device)
+    L.check(L.load().omni_gemm_bf16_ex(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue,
+                                       L.ptr(mask), layout, L.current_stream()), "omni_gemm_bf16")
     return out
 
 

@@ -67,6 +67,17 @@ int omni_rmsnorm(const void* x, const void* delta, void* residual, const void* w
 int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out,
                    int M, int N, int K, int epilogue, const uint8_t* mask, void* stream);
 
+/* Operand layouts for omni_gemm_bf16_ex.  FRAG = fragment-major: the 16-row x 32-k tile of one MFMA operand is 512
+ * contiguous elements in lane order (element (row,k) at
+ *   ((((row/16) * (K/32) + k/32) * 4 + (k%32)/8) * 16 + row%16) * 8 + k%8 ),
+ * so one wave-level load is 1 KB contiguous instead of 64 scattered 16-B accesses.  Weights are shuffled once at
+ * load time; activations are written in this layout by the producing kernel (norm, attention, SiLU epilogue). */
+#define OMNI_LAYOUT_W_FRAG 1
+#define OMNI_LAYOUT_X_FRAG 2     /* x rows padded to a multiple of 16 (ldx ignored)                 */
+#define OMNI_LAYOUT_OUT_FRAG 4   /* bf16 epilogues only: out is the next GEMM's x (K' = N)          */
+int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K,
+                      int epilogue, const uint8_t* mask, int layout, void* stream);
+
 /* The same GEMM with the producing layer's residual-add + RMSNorm fused into the prologue
  * (replaces one fused_add_rms_norm launch + one linear launch of the reference's layer loop):
  *   r = bf16(resid + delta)  (delta may be NULL); r -> resid_out (bf16 [M,K] or NULL; must not alias
@@ -162,6 +173,7 @@ typedef struct omni_talker_desc {
     /* code predictor dims */
     int cp_hidden, cp_layers, cp_q_heads, cp_kv_heads, cp_head_dim, cp_inter;
     int has_cp_projection;
+    int frag_layout;   /* != 0: every GEMM weight below is fragment-major (OMNI_LAYOUT_W_FRAG); activations follow */
     /* runtime */
     int max_batch, block_size, kv_dtype, max_model_len, bt_stride;
     float k_scale, v_scale;

@@ -103,6 +103,34 @@ def test_gemm_resid_norm_fused(ops, M, N, K, epi):
     assert out2.shape == out.shape
 
 
+@pytest.mark.parametrize("M", [1, 16, 37, 64])
+@pytest.mark.parametrize("N,K,epi", [(4096, 2048, "bf16"), (2048, 6144, "bf16"), (6144, 2048, "silu"), (3072, 1024, "silu"),
+                                     (3072, 2048, "logits"), (96, 64, "bf16")])
+def test_gemm_fragment_major_layouts(ops, M, N, K, epi):
+    """Fragment-major W / x / out (one wave-level load = 1 KB contiguous) is a pure re-addressing: results are
+    bit-identical to the row-major launch of the same kernel."""
+    from ht_vllm_omni_amd import _lib as L
+    from ht_vllm_omni_amd.engine import frag_shuffle, frag_unshuffle
+    g = torch.Generator().manual_seed(M + N + K)
+    rows = 2 * N if epi == "silu" else N
+    x, w = _rand(g, M, K), _rand(g, rows, K, scale=0.05)
+    code = {"bf16": L.EPI_BF16, "silu": L.EPI_SILU_MUL, "logits": L.EPI_F32_BF16RND}[epi]
+    ref = ops.gemm(x.cuda(), w.cuda(), epilogue=code)
+    wf = frag_shuffle(w).cuda()
+    out_w = ops.gemm(x.cuda(), wf, epilogue=code, layout=L.LAYOUT_W_FRAG)
+    assert torch.equal(out_w, ref), "W fragment-major"
+    Mp = (M + 15) // 16 * 16
+    xp = torch.zeros(Mp, K, dtype=BF16)
+    xp[:M] = x
+    xf = frag_shuffle(xp).cuda()
+    out_wx = ops.gemm(xf, wf, epilogue=code, layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG, M=M)
+    assert torch.equal(out_wx, ref), "W + x fragment-major"
+    if epi != "logits" and N % 32 == 0:
+        out_f = ops.gemm(xf, wf, epilogue=code, layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG | L.LAYOUT_OUT_FRAG, M=M)
+        assert torch.equal(frag_unshuffle(out_f.cpu())[:M], ref.cpu()), "fragment-major output"
+    assert torch.equal(frag_unshuffle(frag_shuffle(w)), w)
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from ht_vllm_omni_amd import _lib as L
     x = torch.zeros(65, 64, dtype=BF16, device="cuda")
