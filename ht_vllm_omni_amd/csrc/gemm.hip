@@ -332,7 +332,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
-static int g_gemm_silu_nt4 = 1;
+static int g_gemm_silu_nt4 = 0;   // 32+32-column SiLU tiles: measured slower than 16+16 once the layouts are fragment-major
 static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 0;   // static-K schedule: same time, +20 % fetch (profiles/r01_pmc_gemm_traffic.csv)
 extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = (nt >> 1) & 1; g_gemm_silu_nt4 = !((nt >> 2) & 1); g_gemm_rn = rn; g_gemm_wgs = wgs; }
 
@@ -342,8 +342,8 @@ static int launch_gemm_ks(const GemmArgs& a, int m_splits, hipStream_t st) {
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
     if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)
         static bool done_t = false, done_f = false;
-        if (!done_t) { hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
-        if (!done_f) { hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_f = true; }
+        if (!done_t) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
+        if (!done_f) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_f = true; }
     }
     // non-temporal W loads only when each W byte is read by exactly one workgroup (no m-split)
     if (m_splits == 1 && g_gemm_nt)

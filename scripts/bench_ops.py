@@ -27,11 +27,19 @@ def bench_gemm(name, N, K, epi, M=64, hot=False):
     Ws = [torch.randn(rows, K, device=dev, dtype=BF16) * 0.02 for _ in range(R)]
     x = torch.randn(M, K, device=dev, dtype=BF16)
     n_launch = R if not hot else 20
+    frag = os.environ.get("OMNI_BENCH_FRAG", "1") == "1"
+    lay = 0
+    if frag:
+        from ht_vllm_omni_amd.engine import frag_shuffle
+        Ws = [frag_shuffle(w_) for w_ in Ws]
+        xp = torch.zeros((M + 15) // 16 * 16, K, device=dev, dtype=BF16); xp[:M] = x
+        x = frag_shuffle(xp)
+        lay = L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG
     def fn():
         for i in range(n_launch):
-            ops.gemm(x, Ws[i % R], epilogue=epi)
+            ops.gemm(x, Ws[i % R], epilogue=epi, layout=lay, M=M)
     res = []
-    for nt, wgs in ((1, 256), (5, 256)):   # nt bit0 = non-temporal W, bit1 = static-K schedule, bit2 = silu NT=2 instead of 4
+    for nt, wgs in ((5, 256), (5, 128), (5, 512), (4, 256)):   # nt bit0 = non-temporal W, bit1 = static-K, bit2 = silu NT=2
         lib.omni_debug_set(nt, 0, wgs)
         us = graph_time(fn) / n_launch
         res.append(f"nt={nt} wgs={wgs}: {us:6.2f} us {wbytes / us / 1e6:5.2f} TB/s")
