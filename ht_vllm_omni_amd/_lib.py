@@ -35,7 +35,7 @@ class TalkerDesc(C.Structure):
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
         ("vocab", i32), ("codebook", i32), ("num_code_groups", i32), ("eps", f32),
         ("cp_hidden", i32), ("cp_layers", i32), ("cp_q_heads", i32), ("cp_kv_heads", i32), ("cp_head_dim", i32),
-        ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32),
+        ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32), ("fused_norm", i32),
         ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
         ("k_scale", f32), ("v_scale", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),
@@ -64,7 +64,8 @@ SIGNATURES = {
     "omni_rmsnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "omni_gemm_bf16_ex": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
-    "omni_gemm_resid_norm": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "omni_gemm_resid": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "omni_gemm_xnorm": (i32, [vp, vp, i32, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                      f32, f32, f32, i32, vp]),
     "omni_qknorm_rope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),

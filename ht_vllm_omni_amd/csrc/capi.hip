@@ -32,7 +32,8 @@ extern "C" int omni_abi_version(void) { return 1; }
 __global__ __launch_bounds__(256) void mtp_finalize_kernel(
     const int32_t* __restrict__ input_ids, const int32_t* __restrict__ codes /*[B,Q]*/, const uint16_t* __restrict__ embed,
     int vocab, const uint16_t* __restrict__ cp_embed, const uint16_t* __restrict__ text_step, uint16_t* __restrict__ x_out,
-    uint16_t* __restrict__ resid_out, int64_t* __restrict__ audio_codes, int H, int Q, int codebook) {
+    uint16_t* __restrict__ resid_out, float* __restrict__ part_out /* != NULL: resid_out fragment-major + sum(x^2) slab 0 */,
+    int64_t* __restrict__ audio_codes, int H, int Q, int codebook) {
     const int b = blockIdx.x;
     const int c0 = input_ids[b];
     const bool invalid0 = c0 < 0 || c0 >= codebook;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void mtp_finalize_kernel(
         audio_codes[(size_t)b * Q + threadIdx.x] = (int64_t)c;
     }
     __syncthreads();
+    float ss = 0.f;
     for (int v = threadIdx.x; v < H / 8; v += blockDim.x) {
         float s[8];
         {
@@ -69,7 +71,20 @@ __global__ __launch_bounds__(256) void mtp_finalize_kernel(
             o[j] = pack_bf2(bfround(s[2 * j]) + bf_lo(tw[j]), bfround(s[2 * j + 1]) + bf_hi(tw[j]));
         const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<uint4*>(x_out + (size_t)b * H + v * 8) = ov;
-        *reinterpret_cast<uint4*>(resid_out + (size_t)b * H + v * 8) = ov;
+        if (part_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += bf_lo(o[j]) * bf_lo(o[j]) + bf_hi(o[j]) * bf_hi(o[j]);
+            *reinterpret_cast<uint4*>(resid_out + frag_off(b, v * 8, H)) = ov;
+        } else {
+            *reinterpret_cast<uint4*>(resid_out + (size_t)b * H + v * 8) = ov;
+        }
+    }
+    if (part_out) {
+        __shared__ float red[4];
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) part_out[b] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -95,7 +110,7 @@ struct omni_talker {
     int Bm, cp_bs;
     // scratch carve
     uint16_t *resid, *resid_b, *normed, *qkv, *q, *attn, *attn_out, *act, *mlp_out, *hidden, *e0;
-    float* attn_ws;
+    float *attn_ws, *part, *cp_part;   // sum-of-squares slabs of the fused-norm residual streams
     uint16_t *cp_resid, *cp_resid_b, *cp_normed, *cp_qkv, *cp_q, *cp_attn, *cp_o, *cp_act, *cp_mlp, *cp_hidden, *cp_in, *cp_row;
     float* cp_logits;
     int32_t *codes, *cp_bt, *cp_pos, *cp_seq;
@@ -124,8 +139,10 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     const size_t cp_qkv_out = (size_t)(d.cp_q_heads + 2 * d.cp_kv_heads) * d.cp_head_dim;
     Carver c{base, 0};
     const size_t B16 = (B + 15) & ~(size_t)15;      // fragment-major activation buffers hold whole 16-row tiles
-    t->resid = c.take<uint16_t>(B * H);
+    t->resid = c.take<uint16_t>(B16 * H);          // fragment-major in the fused-norm step
     t->resid_b = c.take<uint16_t>(B * H);
+    t->part = c.take<float>(H / 16 * 64);
+    t->cp_part = c.take<float>(Hc / 16 * 64);
     t->normed = c.take<uint16_t>(B16 * H);
     t->qkv = c.take<uint16_t>(B * qkv_out);
     t->q = c.take<uint16_t>(B * d.q_heads * d.head_dim);
@@ -136,7 +153,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->hidden = c.take<uint16_t>(B * H);
     t->e0 = c.take<uint16_t>(B * H);
     t->attn_ws = c.take<float>((size_t)omni_paged_attn_workspace_bytes(d.max_batch, d.q_heads, d.head_dim, d.max_model_len) / 4);
-    t->cp_resid = c.take<uint16_t>(B * Hc);
+    t->cp_resid = c.take<uint16_t>(B16 * Hc);
     t->cp_resid_b = c.take<uint16_t>(B * Hc);
     t->cp_normed = c.take<uint16_t>(B16 * Hc);
     t->cp_qkv = c.take<uint16_t>(B * cp_qkv_out);
@@ -203,6 +220,10 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
         omni_set_error("omni_talker_create: cp_hidden != hidden needs the projection");
         return nullptr;
     }
+    if (desc->fused_norm && !desc->frag_layout) {
+        omni_set_error("omni_talker_create: fused_norm needs frag_layout");
+        return nullptr;
+    }
     omni_talker* t = new omni_talker();
     t->d = *desc;
     t->Bm = desc->max_batch;
@@ -267,15 +288,13 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
 }
 
 // ---- fused-or-fallback building blocks --------------------------------------------------------
-// out = epilogue( rmsnorm(resid_in (+delta)) . W^T ); r = resid_in + delta -> resid_out (ping-pong: the fused
-// kernel's workgroups all re-read resid_in, so it cannot be updated in place); one launch when K allows it
+// separate-norm path (tensor-parallel ranks, prefill rows): out = epilogue( rmsnorm(resid_in (+delta)) . W^T );
+// r = resid_in + delta -> resid_out
 static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* delta, uint16_t* resid_out, const void* norm_w,
                      uint16_t* normed_scratch, void* normed_out, const void* w, void* out, int rows, int N, int K, int epi,
                      const uint8_t* mask, int out_frag, void* st) {
     const float eps = t->d.eps;
     const int F = t->d.frag_layout;
-    if (!F && k_gemm_rn_supported(K))
-        return omni_gemm_resid_norm(resid_in, delta, resid_out, norm_w, eps, normed_out, w, nullptr, out, rows, N, K, epi, mask, st);
     OMNI_CHECK_ARG(resid_out || delta == nullptr, "norm_gemm: delta without resid_out");
     if (F) {
         // normalised rows go out fragment-major for the GEMM (and row-major too when the caller wants them)
@@ -293,6 +312,51 @@ static int act_gemm(omni_talker* t, const void* x, const void* w, const void* bi
     const int F = t->d.frag_layout;
     return omni_gemm_bf16_ex(x, K, w, bias, out, rows, N, K, OMNI_EPI_BF16, nullptr,
                              F ? (OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG) : 0, st);
+}
+
+// ---- fused-norm building blocks (desc.fused_norm): the residual stream r stays fragment-major, every RMSNorm is folded
+// into the GEMM that consumes it (omni_gemm_xnorm) and every residual add into the GEMM that produces it (omni_gemm_resid)
+static int xnorm_gemm(omni_talker* t, const uint16_t* r, const float* part, int np, const void* norm_w, void* normed_out,
+                      const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask, int out_frag, void* st) {
+    return omni_gemm_xnorm(r, part, np, norm_w, t->d.eps, normed_out, w, out, rows, N, K, epi, mask, out_frag, st);
+}
+static int resid_gemm(const void* x_frag, const void* w, uint16_t* r, float* part, int rows, int N, int K, void* st) {
+    return omni_gemm_resid(x_frag, K, w, nullptr, r, 1, part, nullptr, rows, N, K, OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG, st);
+}
+
+// code-predictor pass at position p on the fused stream (r = t->cp_resid, slabs = t->cp_part); returns the slab count
+static int cp_forward_fused(omni_talker* t, int B, int p, int* np, void* st) {
+    const omni_talker_desc& d = t->d;
+    const int Hc = d.cp_hidden, hq = d.cp_q_heads, hkv = d.cp_kv_heads, D = d.cp_head_dim;
+    const int Bm = t->Bm;
+    const float sm = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < d.cp_layers; ++l) {
+        const omni_layer_weights& w = t->cp_layer[l];
+        TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, *np, w.ln1, nullptr, w.wqkv, t->cp_qkv, B, (hq + 2 * hkv) * D, Hc,
+                       OMNI_EPI_BF16, nullptr, 0, st));
+        TRY(k_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
+                                t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
+                                t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, 1, st));
+        if (p == 0 && l == d.cp_layers - 1) break;
+        TRY(resid_gemm(t->cp_attn, w.wo, t->cp_resid, t->cp_part, B, Hc, hq * D, st));
+        *np = Hc / 16;
+        TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, *np, w.ln2, nullptr, w.wgu, t->cp_act, B, d.cp_inter, Hc, OMNI_EPI_SILU_MUL,
+                       nullptr, 1, st));
+        TRY(resid_gemm(t->cp_act, w.wdown, t->cp_resid, t->cp_part, B, Hc, d.cp_inter, st));
+    }
+    return OMNI_OK;
+}
+
+// small_to_mtp_projection of row-major rows into the fused stream
+static int cp_project_fused(omni_talker* t, const void* rows, int B, int* np, void* st) {
+    const omni_talker_desc& d = t->d;
+    if (d.has_cp_projection) {
+        *np = d.cp_hidden / 16;
+        return omni_gemm_resid(rows, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_resid, 0, t->cp_part, nullptr, B, d.cp_hidden,
+                               d.hidden, OMNI_LAYOUT_W_FRAG, st);
+    }
+    *np = 1;
+    return k_gather_frag(nullptr, 0, rows, t->cp_resid, t->cp_part, B, d.hidden, 0, st);
 }
 
 // ---- one code-predictor forward pass at buffer position p (input rows = residual stream in t->cp_resid)
@@ -340,6 +404,41 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
     const omni_talker_desc& d = t->d;
     const int Q = d.num_code_groups, Hc = d.cp_hidden;
     if (Q <= 1) return OMNI_OK;
+    if (d.fused_norm) {
+        int np = 1;
+        TRY(cp_project_fused(t, last_hidden, B, &np, st));
+        TRY(cp_forward_fused(t, B, 0, &np, st));
+        if (layer0_ids && d.cp_e0_table) {
+            TRY(k_gather_frag(layer0_ids, 1, d.cp_e0_table, t->cp_resid, t->cp_part, B, Hc, d.vocab, st));
+            np = 1;
+        } else {
+            TRY(cp_project_fused(t, layer0_embed, B, &np, st));
+        }
+        for (int g = 1; g < Q; ++g) {
+            TRY(cp_forward_fused(t, B, g, &np, st));
+            const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
+            TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, np, d.cp_norm, nullptr, head, t->cp_logits, B, d.codebook, Hc,
+                           OMNI_EPI_F32_BF16RND, nullptr, 0, st));
+            if (cp_logits_out) {
+                hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
+                                                t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,
+                                                hipMemcpyDeviceToDevice, (hipStream_t)st);
+                if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+            }
+            const bool more = g < Q - 1;
+            const uint16_t* ptab = (more && d.cp_proj_table)
+                                       ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
+            TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q,
+                                g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, ptab ? t->cp_part : nullptr, st));
+            if (ptab) np = 1;
+            if (more && !ptab) {
+                const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
+                TRY(k_embed(t->codes + g, Q, tab, t->cp_row, B, d.hidden, d.codebook, st));
+                TRY(cp_project_fused(t, t->cp_row, B, &np, st));
+            }
+        }
+        return OMNI_OK;
+    }
     TRY(cp_project(t, last_hidden, B, st));
     TRY(cp_forward(t, B, 0, st));
     if (layer0_ids && d.cp_e0_table)
@@ -363,7 +462,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         const uint16_t* ptab = (more && d.cp_proj_table)
                                    ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
         TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q,
-                            g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, st));
+                            g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, nullptr, st));
         if (more && !ptab) {
             const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
             TRY(k_embed(t->codes + g, Q, tab, t->cp_row, B, d.hidden, d.codebook, st));
@@ -401,7 +500,7 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
                            io->seed, io->steps, nullptr, stream));
     hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, (const uint16_t*)d.embed,
                        d.vocab, (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds,
-                       t->resid, io->audio_codes, d.hidden, Q, d.codebook);
+                       t->resid, d.fused_norm ? t->part : nullptr, io->audio_codes, d.hidden, Q, d.codebook);
     OMNI_CHECK_LAUNCH("mtp_finalize");
     return OMNI_OK;
 }
@@ -411,12 +510,17 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
+    if (d.fused_norm)       // slab count: 1 after mtp_finalize, H / 16 after any residual GEMM
+        TRY(xnorm_gemm(t, t->resid, t->part, l == 0 ? 1 : H / 16, w.ln1, nullptr, w.wqkv, t->qkv, B, (hq + 2 * hkv) * D, H,
+                       OMNI_EPI_BF16, nullptr, 0, st));
+    else
     TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, B,
                   (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, 0, st));
     TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, st));
+    if (d.fused_norm) return resid_gemm(t->attn, w.wo, t->resid, t->part, B, H, hq * D, st);
     TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, B, H, hq * D, st));
     return OMNI_OK;
 }
@@ -456,6 +560,13 @@ extern "C" int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, in
 extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
     TRY(check_io(t, io));
     OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_mlp: layer=%d", layer);
+    const omni_talker_desc& d = t->d;
+    if (d.fused_norm) {
+        const omni_layer_weights& w = t->layer[layer];
+        TRY(xnorm_gemm(t, t->resid, t->part, d.hidden / 16, w.ln2, nullptr, w.wgu, t->act, io->B, d.inter, d.hidden,
+                       OMNI_EPI_SILU_MUL, nullptr, 1, stream));
+        return resid_gemm(t->act, w.wdown, t->resid, t->part, io->B, d.hidden, d.inter, stream);
+    }
     return layer_mlp_rows(t, layer, io->B, stream);
 }
 
@@ -479,6 +590,10 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     hipStream_t st = (hipStream_t)stream;
     // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
+    if (d.fused_norm)
+        TRY(xnorm_gemm(t, t->resid, t->part, d.layers > 0 ? d.hidden / 16 : 1, d.final_norm, io->last_hidden, d.lm_head, io->logits,
+                       B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
+    else
     TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
                   io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,

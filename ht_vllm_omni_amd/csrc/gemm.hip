@@ -1,5 +1,4 @@
-// Skinny-M (M <= 64) bf16 GEMM for the decode step: out[M,N] = x[M,K] . W[N,K]^T, with the
-// residual-add + RMSNorm of the producing layer optionally fused into the prologue.
+// Skinny-M (M <= 64) bf16 GEMM for the decode step: out[M,N] = x[M,K] . W[N,K]^T.
 //
 // HBM-bound weight streaming (64 FLOP/B << MFMA ridge): W is read exactly once, straight from
 // HBM into MFMA A-operand registers with non-temporal loads (each W element feeds one wave only,
@@ -9,23 +8,22 @@
 //   B lane(c = l&15, q)        = x[m0 + c][k0 + 8q .. +8)
 //   D[n][m]: lane holds m = l&15, n = 4*(l>>4) + reg.
 // Workgroup = 8 waves = one group of NT 16-row n-tiles x MT 16-row m-tiles; grid = (n groups,
-// m splits) sized to >= 256 workgroups.  The 8 waves split K (k-steps interleaved w, w+8, ...),
-// loads are software-pipelined two groups deep, partial sums combine through LDS.
+// m splits).  The 8 waves split K (k-steps interleaved w, w+8, ...), every wave keeps a deep ring
+// of W loads in flight, partial sums combine through LDS.
 // fp32 accumulate, one rounding to bf16 (oracle: talker_oracle.linear / rms_norm).
 //
-// PRO_RN prologue (K = hidden <= 2048, K % 256 == 0): every workgroup rebuilds the normalised
-// activation rows it needs from the residual stream:
-//   r = bf16(resid + delta);  x = w * bf16(r * rsqrt(mean(r^2) + eps))
-// (64 x K elements, ~2 us of VALU, instead of a separate 5-6 us kernel launch); the workgroups
-// with blockIdx.x == 0 write r to resid_out -- a DIFFERENT buffer than resid: other workgroups are
-// still reading the input -- and x to normed_out when the caller wants the normalised rows.
+// The norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm, see include/omni_talker.h):
+//   EPI_RESID  r = bf16(r + bf16(acc + bias)) in place on the fragment-major stream + this workgroup's
+//              share of sum(r^2) per row (slab [n group][64]);
+//   PRO_XNORM  x = norm_w * bf16(r * rstd) applied to every operand fragment as it is loaded.  The
+//              normalisation is redundant across n groups (every workgroup rebuilds the rows it
+//              multiplies), so PRO_XNORM launches use FEW n groups of wide tiles (NT = 4) and split M
+//              across grid.y instead: VALU per workgroup = rows_of_split x K x ~5 instructions.
 #include "common.cuh"
 #include "kernels.h"
 
 #define GEMM_WAVES 8
 #define GEMM_THREADS (GEMM_WAVES * 64)
-#define GEMM_U 4          // k-steps per pipelined load group
-#define RN_MAX_STEPS 8    // PRO_RN: k-steps per wave (K <= 32 * 8 * 8 = 2048)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,12 +40,26 @@ struct GemmArgs {
     const uint16_t* W; const uint16_t* bias; void* out;
     int M, N, K;
     const uint8_t* mask;
-    // PRO_RN
-    const uint16_t* resid; uint16_t* resid_out; const uint16_t* delta; const uint16_t* norm_w; float eps; uint16_t* normed_out;
+    // EPI_RESID: resid = the stream to add into (NULL: start a new one); PRO_XNORM: norm_w / eps / normed_out (row-major copy)
+    const uint16_t* resid; const uint16_t* norm_w; float eps; uint16_t* normed_out;
     int wshuf, xshuf, oshuf;   // fragment-major layouts (OMNI_LAYOUT_*), see common.cuh frag_off
+    // PRO_XNORM / EPI_RESID: per-row sum-of-squares slabs [np][64 rows] fp32 (deterministic: one slab per producer workgroup)
+    const float* part_in; int np_in; float* part_out;
 };
 
-template <int MT, int NT, int PRO, int EPI, bool NTL, int KS>
+// PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
+// consumed: x = w * bf16(r * rstd), rstd from the producer's per-workgroup partial sums (talker_oracle.rms_norm)
+__device__ __forceinline__ u32x4 xnorm_frag(u32x4 v, u32x4 nw, float rstd) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd);
+        const float hi = bf_hi(nw[e]) * bfround(bf_hi(v[e]) * rstd);
+        v[e] = pack_bf2(lo, hi);
+    }
+    return v;
+}
+
+template <int MT, int NT, int PRO, int EPI, bool NTL>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [WAVES][NT*MT*4][64]
     const int lane = threadIdx.x & 63;
@@ -92,126 +104,57 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntw = (nsteps - wave + GEMM_WAVES - 1) / GEMM_WAVES; // k-steps of this wave (may be 0)
+    // PRO_XNORM, part 1: this thread's share of the sum(r^2) slabs of the workgroup's OWN rows (row = t % rows, every
+    // NCH-th slab; slabs are [n group][64 rows], so a wave-level load is contiguous) -- issued BEFORE the W ring so that
+    // it returns first (loads complete in order) and the reduction overlaps the W latency.  Loads are unconditional
+    // (clamped slab index): a predicated load would force hipcc to drain every outstanding load at each wait.
+    constexpr int XROWS = MT * 16, NCH = GEMM_THREADS / XROWS, PE = 128 / NCH;    // PE slabs per thread cover np <= 128
+    float pv[PE];
+    float psum = 0.f;
+    if (PRO == 2) {
+        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+        const float* pp = a.part_in + m_base + row;
+#pragma unroll
+        for (int e = 0; e < PE; ++e) {
+            const int p = ch + e * NCH;
+            pv[e] = pp[(size_t)min(p, a.np_in - 1) * 64];
+            if (p >= a.np_in) pv[e] = 0.f;
+        }
+        for (int p = ch + PE * NCH; p < a.np_in; p += NCH) psum += pp[(size_t)p * 64];      // hidden > 2048 only
+    }
+    // EPI_RESID: the old residual values this thread will add into (one epilogue item per thread), fetched up front
+    uint2 r_old = make_uint2(0, 0);
+    if (EPI == OMNI_EPI_RESID && a.resid && threadIdx.x < MT * 64) {
+        const int ml = (threadIdx.x >> 6) * 16 + (lane & 15);
+        if (ml < Mloc)
+            r_old = *reinterpret_cast<const uint2*>(a.resid + frag_off(m_base + ml, blockIdx.x * 16 + 4 * (lane >> 4), N));
+    }
 
-    if (PRO == 1) {
-        // ---------------- fused residual-add + RMSNorm prologue -----------------
-        u32x4 wf[RN_MAX_STEPS][NT];
+    float rstd[MT];
+    auto xnorm_rstd = [&]() {
+        // part 2 (after the W ring is in flight): fixed-order reduction -> rstd of this workgroup's rows
+        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+        float s_ = psum;
 #pragma unroll
-        for (int s = 0; s < RN_MAX_STEPS; ++s)
-            if (s < ntw) {
-                const int k0 = (wave + s * GEMM_WAVES) * wstep;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wf[s][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
-            }
-        u32x4 xr[MT][RN_MAX_STEPS];
-        float ss[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int m = i * 16 + r;
-            m = m_base + (m < Mloc ? m : Mloc - 1);
-            const uint16_t* rp = a.resid + (size_t)m * K + 8 * q;
-            const uint16_t* dp = a.delta ? a.delta + (size_t)m * K + 8 * q : nullptr;
-            float s2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < RN_MAX_STEPS; ++s)
-                if (s < ntw) {
-                    const int k0 = (wave + s * GEMM_WAVES) << 5;
-                    u32x4 v = ld16(rp + k0);
-                    if (dp) {
-                        const u32x4 d = ld16(dp + k0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bf_lo(v[e]) + bf_lo(d[e]), bf_hi(v[e]) + bf_hi(d[e]));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bf_lo(v[e]), hi = bf_hi(v[e]);
-                        s2 = fmaf(lo, lo, s2);
-                        s2 = fmaf(hi, hi, s2);
-                    }
-                    xr[i][s] = v;
-                }
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            ss[i] = s2;
-        }
-        // row sums across the 8 waves: lds[wave][MT*16]
-        if (q == 0) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) lds[wave * (MT * 16) + i * 16 + r] = ss[i];
-        }
+        for (int e = 0; e < PE; ++e) s_ += pv[e];
+        lds[ch * XROWS + row] = s_;
         __syncthreads();
-        float rstd[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        if (threadIdx.x < XROWS) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < GEMM_WAVES; ++w) t += lds[w * (MT * 16) + i * 16 + r];
-            rstd[i] = 1.0f / sqrtf(t / (float)K + a.eps);
+            for (int c = 0; c < NCH; ++c) t += lds[c * XROWS + threadIdx.x];
+            lds[GEMM_THREADS + threadIdx.x] = 1.0f / sqrtf(t / (float)K + a.eps);
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rstd[i] = lds[GEMM_THREADS + i * 16 + r];
         __syncthreads();      // lds is reused by the epilogue
-        const bool writer = blockIdx.x == 0;
-#pragma unroll
-        for (int s = 0; s < RN_MAX_STEPS; ++s)
-            if (s < ntw) {
-                const int k0 = (wave + s * GEMM_WAVES) << 5;
-                const u32x4 nw = ld16(a.norm_w + k0 + 8 * q);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int ml = i * 16 + r;
-                    const bool row_ok = ml < Mloc;
-                    const size_t off = (size_t)(m_base + ml) * K + k0 + 8 * q;
-                    u32x4 v = xr[i][s];
-                    if (writer && row_ok && a.resid_out) *reinterpret_cast<u32x4*>(a.resid_out + off) = v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd[i]);
-                        const float hi = bf_hi(nw[e]) * bfround(bf_hi(v[e]) * rstd[i]);
-                        v[e] = pack_bf2(lo, hi);
-                    }
-                    if (writer && row_ok && a.normed_out) *reinterpret_cast<u32x4*>(a.normed_out + off) = v;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[j][i] = mfma16(wf[s][j], v, acc[j][i]);
-                }
-            }
-    } else {
-        // ---------------- plain x operand, K known at compile time (KS = k-steps per wave = K / 256) --------------
-        // Fully static schedule: every W load of the wave goes out first (KS KB in flight), x fragments run XW k-steps
-        // ahead in a register ring; no runtime guard anywhere, so hipcc keeps counted vmcnt waits.
-        if constexpr (KS > 0) {
-            const uint16_t* xr_[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int m = i * 16 + r;
-                m = m_base + (m < Mloc ? m : Mloc - 1);
-                xr_[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8 + wave * xstep
-                                 : a.x + (size_t)m * a.ldx + 8 * q + wave * xstep;
-            }
-            constexpr int XW = (MT == 4) ? 4 : 8;
-            constexpr int XWe = XW < KS ? XW : KS;
-            u32x4 Wr[KS][NT], X[XWe][MT];
-#pragma unroll
-            for (int t = 0; t < KS; ++t)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    Wr[t][j] = NTL ? ld16_nt(wrow[j] + (wave + t * GEMM_WAVES) * wstep) : ld16(wrow[j] + (wave + t * GEMM_WAVES) * wstep);
-#pragma unroll
-            for (int t = 0; t < XWe; ++t)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) X[t][i] = ld16(xr_[i] + t * GEMM_WAVES * xstep);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < KS; ++t) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wr[t][j], X[t % XWe][i], acc[j][i]);
-                if (t + XWe < KS) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) X[t % XWe][i] = ld16(xr_[i] + (t + XWe) * GEMM_WAVES * xstep);
-                }
-            }
-        } else {
+    };
+
+    const int ntw = (nsteps - wave + GEMM_WAVES - 1) / GEMM_WAVES; // k-steps of this wave (may be 0)
+
+    {
+        {
         // ---------------- plain x operand: deep W prefetch ring, x one step ahead -----------------
         // Every wave keeps DEPTH k-steps (DEPTH KB) of W outstanding (Little's law at ~3 us loaded HBM latency);
         // x is L2-resident and fetched one k-step ahead.  (Measured alternatives, scripts/bench_ops.py: issuing a
@@ -233,11 +176,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Wr[d][j] = NTL ? ld16_nt(wrow[j] + k0) : ld16(wrow[j] + k0);
             }
-        u32x4 X[2][MT];
+        u32x4 X[2][MT], NW[2];
         if (ntw > 0) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + wave * xstep);
+            if (PRO == 2) NW[0] = ld16(a.norm_w + wave * 32 + 8 * q);
         }
+        if (PRO == 2) xnorm_rstd();
         for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -247,6 +192,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                         const int k1 = (wave + (t + 1) * GEMM_WAVES) * xstep;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = ld16(xrow[i] + k1);
+                        if (PRO == 2) NW[(d + 1) & 1] = ld16(a.norm_w + (wave + (t + 1) * GEMM_WAVES) * 32 + 8 * q);
+                    }
+                    if (PRO == 2) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) X[d & 1][i] = xnorm_frag(X[d & 1][i], NW[d & 1], rstd[i]);
                     }
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
@@ -260,7 +210,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 }
             }
         }
-        }   // KS == 0
+        }
+    }
+
+    // the normalised rows themselves (h[t+1] of the final norm) leave row-major through one workgroup column: a second
+    // pass over this workgroup's (L2-hot) fragments, kept out of the main loop so that its waits stay counted
+    if (PRO == 2 && blockIdx.x == 0 && a.normed_out != nullptr) {
+        for (int t = 0; t < ntw; ++t) {
+            const int ks = wave + t * GEMM_WAVES;
+            const u32x4 nw = ld16(a.norm_w + ks * 32 + 8 * q);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (i * 16 + r < Mloc) {
+                    const u32x4 v = ld16(a.x + ((size_t)((m_base >> 4) + i) * nsteps + ks) * 512 + lane * 8);
+                    *reinterpret_cast<u32x4*>(a.normed_out + (size_t)(m_base + i * 16 + r) * K + ks * 32 + 8 * q) = xnorm_frag(v, nw, rstd[i]);
+                }
+        }
     }
 
     // ---- combine the 8 K-partials through LDS: lds[wave][e][lane], e = (j*MT+i)*4+reg
@@ -314,7 +279,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
                 for (int g = 0; g < 4; ++g) v[g] += bf2f(a.bias[n + g]);
             }
-            if (EPI == OMNI_EPI_BF16) {
+            if (EPI == OMNI_EPI_RESID) {
+                // r = bf16(r + bf16(acc)) in place on the fragment-major residual stream (every element has exactly one
+                // owner thread), plus this workgroup's 16-column share of sum(r^2) per row for the consumer's RMSNorm
+                static_assert(EPI != OMNI_EPI_RESID || NT == 1, "EPI_RESID: one n-tile per workgroup");
+                uint16_t* rp = reinterpret_cast<uint16_t*>(a.out) + frag_off(m, n, N);
+                float rv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[g] = bfround(v[g]);
+                if (a.resid) {     // item == thread (ITEMS = MT * 64 <= 256): r_old was fetched for exactly this (m, n)
+                    rv[0] = bfround(bf_lo(r_old.x) + rv[0]); rv[1] = bfround(bf_hi(r_old.x) + rv[1]);
+                    rv[2] = bfround(bf_lo(r_old.y) + rv[2]); rv[3] = bfround(bf_hi(r_old.y) + rv[3]);
+                }
+                *reinterpret_cast<uint2*>(rp) = make_uint2(pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3]));
+                float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
+                ss += __shfl_xor(ss, 16, 64);       // the 4 lanes (l & 15) + 16 * {0..3} hold the 16 columns of row m
+                ss += __shfl_xor(ss, 32, 64);
+                if (l < 16) a.part_out[blockIdx.x * 64 + m] = ss;   // slabs [n group][64 rows]
+            } else if (EPI == OMNI_EPI_BF16) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (a.oshuf ? frag_off(m, n, N) : (size_t)m * N + n)) =
                     make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             } else {
@@ -332,56 +314,70 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     }
 }
 
-static int g_gemm_silu_nt4 = 0;   // 32+32-column SiLU tiles: measured slower than 16+16 once the layouts are fragment-major
-static int g_gemm_nt = 1, g_gemm_rn = 0, g_gemm_wgs = 256, g_gemm_static = 0;   // static-K schedule: same time, +20 % fetch (profiles/r01_pmc_gemm_traffic.csv)
-extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_nt = nt & 1; g_gemm_static = (nt >> 1) & 1; g_gemm_silu_nt4 = !((nt >> 2) & 1); g_gemm_rn = rn; g_gemm_wgs = wgs; }
 
-template <int MT, int NT, int PRO, int EPI, int KS>
-static int launch_gemm_ks(const GemmArgs& a, int m_splits, hipStream_t st) {
+static int g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0;
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { (void)rn; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }
+extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt; }   // 0 = policy default
+
+template <int MT, int NT, int PRO, int EPI>
+static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
     const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / (8 * NT) : a.N / (16 * NT);
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
     if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)
         static bool done_t = false, done_f = false;
-        if (!done_t) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
-        if (!done_f) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_f = true; }
+        if (!done_t) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
+        if (!done_f) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_f = true; }
     }
     // non-temporal W loads only when each W byte is read by exactly one workgroup (no m-split)
     if (m_splits == 1 && g_gemm_nt)
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true, KS>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, true>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     else
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, false, KS>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, PRO, EPI, false>), dim3(groups, m_splits), dim3(GEMM_THREADS), lds, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_bf16");
     return OMNI_OK;
 }
 
-template <int MT, int NT, int PRO, int EPI>
-static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
-    if (PRO == 0 && g_gemm_static && a.K % 256 == 0) {
-        switch (a.K / 256) {       // hidden / intermediate sizes of the talker shapes (and their TP shards)
-            case 4: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 4 : 0)>(a, m_splits, st);
-            case 8: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 8 : 0)>(a, m_splits, st);
-            case 12: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? 12 : 0)>(a, m_splits, st);
-            case 24: return launch_gemm_ks<MT, NT, PRO, EPI, (PRO == 0 ? (MT * NT <= 2 ? 24 : 0) : 0)>(a, m_splits, st);
-            default: break;
-        }
-    }
-    return launch_gemm_ks<MT, NT, PRO, EPI, 0>(a, m_splits, st);
-}
-
-template <int NT, int PRO, int EPI>
-static int dispatch_mt(const GemmArgs& a, hipStream_t st) {
-    // m-tiles per workgroup: split M over grid.y until the grid has >= ~256 workgroups
+// Tile policy.  Plain GEMMs: narrow n groups (NT = 1, SiLU 16 + 16 columns), M split over grid.y until the grid has
+// ~256 workgroups.  PRO_XNORM: wide n groups (NT = 4) and as many M splits as that allows -- the normalisation work
+// of a workgroup is proportional to the rows it owns, and is repeated once per n group.
+static void pick_tile(int pro, int epi, const GemmArgs& a, int* nt_out, int* mt_out, int* splits_out) {
     const int mt_total = (a.M + 15) / 16;
-    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / (8 * NT) : a.N / (16 * NT);
-    int splits = (g_gemm_wgs + groups - 1) / groups;
+    const bool silu = epi == OMNI_EPI_SILU_MUL;
+    const int cols = silu ? a.N / 8 : a.N / 16;               // n groups at the narrowest tile
+    int nt = silu ? 2 : 1;
+    if (pro == 2) {
+        // measured at M = 64 (scripts/bench_tiles.py): 64+ groups of NT = 4, else NT = 2
+        nt = (cols % 4 == 0 && cols / 4 >= 64) ? 4 : ((cols % 2 == 0 && cols / 2 >= 32) ? 2 : nt);
+        if (silu && nt < 2) nt = 2;
+    } else if (silu && cols % 4 == 0 && cols / 4 >= 160 && mt_total == 4) {
+        nt = 4;                                               // backbone gate_up at full batch: 32 + 32 columns, no M split
+    }
+    if (g_tile_nt && epi != OMNI_EPI_RESID && (!silu || g_tile_nt >= 2) && cols % g_tile_nt == 0) nt = g_tile_nt;
+    const int groups = silu ? a.N / (8 * nt) : a.N / (16 * nt);
+    int splits = groups >= 160 ? 1 : (g_gemm_wgs + groups - 1) / groups;
     if (splits > mt_total) splits = mt_total;
     if (splits < 1) splits = 1;
     int mt = (mt_total + splits - 1) / splits;       // 1..4
+    if (g_tile_mt) mt = g_tile_mt;
     if (mt == 3) mt = 4;
-    splits = (mt_total + mt - 1) / mt;
-    if (mt == 1) return launch_gemm<1, NT, PRO, EPI>(a, splits, st);
-    if (mt == 2) return launch_gemm<2, NT, PRO, EPI>(a, splits, st);
-    return launch_gemm<4, NT, PRO, EPI>(a, splits, st);
+    if (mt > 4) mt = 4;
+    *nt_out = nt; *mt_out = mt; *splits_out = (mt_total + mt - 1) / mt;
+}
+
+template <int PRO, int EPI>
+static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
+    int nt, mt, splits;
+    pick_tile(PRO, EPI, a, &nt, &mt, &splits);
+#define TILE(N_, M_) if (nt == N_ && mt == M_) return launch_gemm<M_, N_, PRO, EPI>(a, splits, st);
+#define TILE_M(N_) TILE(N_, 1) TILE(N_, 2) TILE(N_, 4)
+    if constexpr (EPI == OMNI_EPI_SILU_MUL) { TILE_M(2) TILE_M(4) }
+    else if constexpr (EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32) { TILE_M(1) }
+    else if constexpr (EPI == OMNI_EPI_F32_BF16RND && PRO == 0) { TILE_M(1) }
+    else { TILE_M(1) TILE_M(2) TILE_M(4) }
+#undef TILE_M
+#undef TILE
+    omni_set_error("omni_gemm_bf16: no kernel for tile NT=%d MT=%d (epilogue %d)", nt, mt, EPI);
+    return OMNI_EINVAL;
 }
 
 static int check_common(const GemmArgs& a) {
@@ -397,20 +393,23 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
     switch (epilogue) {
         case OMNI_EPI_BF16:
             OMNI_CHECK_ARG(a.mask == nullptr, "omni_gemm_bf16: mask needs an fp32 epilogue");
-            return dispatch_mt<1, PRO, OMNI_EPI_BF16>(a, st);
+            return dispatch_tile<PRO, OMNI_EPI_BF16>(a, st);
         case OMNI_EPI_SILU_MUL:
             OMNI_CHECK_ARG(a.bias == nullptr && a.mask == nullptr, "omni_gemm_bf16: silu_mul takes no bias/mask");
-            if (g_gemm_silu_nt4 && a.N % 32 == 0 && a.M > 32 && a.N / 32 >= 160)
-                return dispatch_mt<4, PRO, OMNI_EPI_SILU_MUL>(a, st);
-            return dispatch_mt<2, PRO, OMNI_EPI_SILU_MUL>(a, st);
+            return dispatch_tile<PRO, OMNI_EPI_SILU_MUL>(a, st);
         case OMNI_EPI_F32:
-            return dispatch_mt<1, PRO, OMNI_EPI_F32>(a, st);
+            if constexpr (PRO == 0) return dispatch_tile<0, OMNI_EPI_F32>(a, st);
+            break;
         case OMNI_EPI_F32_BF16RND:
-            return dispatch_mt<1, PRO, OMNI_EPI_F32_BF16RND>(a, st);
+            return dispatch_tile<PRO, OMNI_EPI_F32_BF16RND>(a, st);
+        case OMNI_EPI_RESID:
+            if constexpr (PRO == 0) return dispatch_tile<0, OMNI_EPI_RESID>(a, st);
+            break;
         default:
-            omni_set_error("omni_gemm_bf16: unknown epilogue %d", epilogue);
-            return OMNI_EINVAL;
+            break;
     }
+    omni_set_error("omni_gemm_bf16: unsupported epilogue %d", epilogue);
+    return OMNI_EINVAL;
 }
 
 extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
@@ -419,6 +418,7 @@ extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const vo
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
     a.oshuf = (layout & OMNI_LAYOUT_OUT_FRAG) != 0;
+    OMNI_CHECK_ARG(epilogue != OMNI_EPI_RESID, "omni_gemm_bf16: the residual epilogue is omni_gemm_resid");
     OMNI_CHECK_ARG(!a.oshuf || epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL,
                    "omni_gemm_bf16: fragment-major output needs a bf16 epilogue");
     OMNI_CHECK_ARG(!a.oshuf || N % 32 == 0, "omni_gemm_bf16: fragment-major output needs N %% 32 == 0");
@@ -436,24 +436,45 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
     return omni_gemm_bf16_ex(x, ldx, w, bias, out, M, N, K, epilogue, mask, 0, stream);
 }
 
-// the fused prologue multiplies the activation traffic by the number of workgroups (every workgroup re-reads
-// resid + delta: 2 x 64 x K x 2 B): measured 2-3x SLOWER than a separate norm launch at B = 64 -> off by default
-static bool rn_shape_ok(int K) { return K % 256 == 0 && K <= 32 * GEMM_WAVES * RN_MAX_STEPS; }
-bool k_gemm_rn_supported(int K) { return g_gemm_rn && rn_shape_ok(K); }
-
-extern "C" int omni_gemm_resid_norm(const void* resid, const void* delta, void* resid_out, const void* norm_w, float eps,
-                                    void* normed_out, const void* w, const void* bias, void* out, int M, int N, int K,
-                                    int epilogue, const uint8_t* mask, void* stream) {
+// ---- the norm-free residual stream (fragment-major r + per-row sum-of-squares slabs) ---------------------------------
+// Producer: r = bf16(r + bf16(x . W^T + bias)) in place (accumulate) or r = bf16(x . W^T + bias), and
+// partials[n group][row] = that workgroup's share of sum(r^2); *nparts_out = N / 16.
+extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate,
+                               float* partials, int* nparts_out, int M, int N, int K, int layout, void* stream) {
     GemmArgs a{};
-    a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
-    a.M = M; a.N = N; a.K = K; a.mask = mask;
-    a.resid = (const uint16_t*)resid; a.resid_out = (uint16_t*)resid_out; a.delta = (const uint16_t*)delta; a.norm_w = (const uint16_t*)norm_w; a.eps = eps;
-    a.normed_out = (uint16_t*)normed_out;
+    a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
+    a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
+    a.oshuf = 1;
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = r_io;
+    a.resid = accumulate ? (const uint16_t*)r_io : nullptr;
+    a.part_out = partials;
+    a.M = M; a.N = N; a.K = K;
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
-    OMNI_CHECK_ARG(resid && norm_w, "omni_gemm_resid_norm: null pointer");
-    OMNI_CHECK_ARG(resid_out != resid && (normed_out == nullptr || normed_out != resid),
-                   "omni_gemm_resid_norm: outputs must not alias resid (other workgroups still read it)");
-    OMNI_CHECK_ARG(rn_shape_ok(K), "omni_gemm_resid_norm: K=%d unsupported (multiple of 256, <= 2048)", K);
-    return dispatch_epi<1>(a, epilogue, (hipStream_t)stream);
+    OMNI_CHECK_ARG(x && partials, "omni_gemm_resid: null pointer");
+    OMNI_CHECK_ARG(N % 32 == 0, "omni_gemm_resid: N=%d not a multiple of 32 (fragment-major residual stream)", N);
+    OMNI_CHECK_ARG(a.xshuf || (ldx >= K && ldx % 8 == 0), "omni_gemm_resid: ldx=%d (need >= K, multiple of 8)", ldx);
+    if (nparts_out) *nparts_out = N / 16;
+    return dispatch_epi<0>(a, OMNI_EPI_RESID, (hipStream_t)stream);
+}
+
+// Consumer: out = epilogue( (norm_w * bf16(r * rstd)) . W^T ), rstd = rsqrt(sum_p partials[p][row] / K + eps);
+// normed_out (row-major, optional) receives the normalised rows.  r and W fragment-major.
+extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps,
+                               void* normed_out, const void* w, void* out, int M, int N, int K, int epilogue,
+                               const uint8_t* mask, int out_frag, void* stream) {
+    GemmArgs a{};
+    a.wshuf = 1; a.xshuf = 1; a.oshuf = out_frag != 0;
+    a.x = (const uint16_t*)r; a.ldx = K; a.W = (const uint16_t*)w; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.mask = mask;
+    a.norm_w = (const uint16_t*)norm_w; a.eps = eps; a.normed_out = (uint16_t*)normed_out;
+    a.part_in = partials; a.np_in = nparts;
+    int rc = check_common(a);
+    if (rc != OMNI_OK) return rc;
+    OMNI_CHECK_ARG(r && partials && norm_w && nparts >= 1, "omni_gemm_xnorm: null pointer / nparts=%d", nparts);
+    OMNI_CHECK_ARG(epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL || epilogue == OMNI_EPI_F32_BF16RND,
+                   "omni_gemm_xnorm: epilogue %d unsupported", epilogue);
+    OMNI_CHECK_ARG(!a.oshuf || (epilogue != OMNI_EPI_F32_BF16RND && N % 32 == 0),
+                   "omni_gemm_xnorm: fragment-major output needs a bf16 epilogue and N %% 32 == 0");
+    return dispatch_epi<2>(a, epilogue, (hipStream_t)stream);
 }

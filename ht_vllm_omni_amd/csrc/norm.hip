@@ -119,6 +119,39 @@ __global__ void embed_kernel(const int32_t* __restrict__ ids, int ids_stride, co
     }
 }
 
+// rows -> fragment-major residual stream + slab 0 of the sum-of-squares partials (ids == NULL: row t of `table`)
+__global__ __launch_bounds__(128) void gather_frag_kernel(const int32_t* __restrict__ ids, int ids_stride,
+                                                          const uint16_t* __restrict__ table, uint16_t* __restrict__ r_out,
+                                                          float* __restrict__ part_out, int hidden, int vocab) {
+    const int t = blockIdx.x;
+    const int id = ids ? ids[(size_t)t * ids_stride] : t;
+    const bool ok = !ids || (id >= 0 && id < vocab);
+    float ss = 0.f;
+    for (int v = threadIdx.x; v < hidden / 8; v += 128) {
+        const uint4 a = ok ? *reinterpret_cast<const uint4*>(table + (size_t)id * hidden + v * 8) : make_uint4(0, 0, 0, 0);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += bf_lo(w[j]) * bf_lo(w[j]) + bf_hi(w[j]) * bf_hi(w[j]);
+        *reinterpret_cast<uint4*>(r_out + frag_off(t, v * 8, hidden)) = a;
+    }
+    __shared__ float red[2];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) part_out[t] = red[0] + red[1];
+}
+
+int k_gather_frag(const int32_t* ids, int ids_stride, const void* table, void* r_out, float* part_out, int T, int hidden,
+                  int vocab, void* stream) {
+    OMNI_CHECK_ARG(table && r_out && part_out, "gather_frag: null pointer");
+    OMNI_CHECK_ARG(hidden % 32 == 0, "gather_frag: hidden=%d not a multiple of 32", hidden);
+    if (T <= 0) return OMNI_OK;
+    hipLaunchKernelGGL(gather_frag_kernel, dim3(T), dim3(128), 0, (hipStream_t)stream, ids, ids_stride, (const uint16_t*)table,
+                       (uint16_t*)r_out, part_out, hidden, vocab);
+    OMNI_CHECK_LAUNCH("gather_frag");
+    return OMNI_OK;
+}
+
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
             void* stream) {
     OMNI_CHECK_ARG(ids && table && out, "omni_embed: null pointer");

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              uint8_t* __restrict__ seen, uint32_t seed,
                                                              int32_t* __restrict__ steps, int step_mul, int step_add,
                                                              int inc_steps, int32_t* __restrict__ out_ids, int out_stride,
-                                                             const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim) {
+                                                             const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim,
+                                                             float* __restrict__ gpart) {
     __shared__ float row[SMP_MAXV];
     __shared__ uint32_t hist[256];
     __shared__ float sval[SMP_THREADS / 64];
@@ -120,9 +121,29 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
         pick = block_argmax(bv, bi, sval, sidx);
     }
     if (gtab) {
-        for (int v = threadIdx.x; v < gdim / 8; v += SMP_THREADS)
-            *reinterpret_cast<uint4*>(gout + (size_t)b * gdim + v * 8) =
-                *reinterpret_cast<const uint4*>(gtab + (size_t)pick * gdim + v * 8);
+        float ss = 0.f;
+        for (int v = threadIdx.x; v < gdim / 8; v += SMP_THREADS) {
+            const uint4 a = *reinterpret_cast<const uint4*>(gtab + (size_t)pick * gdim + v * 8);
+            if (gpart) {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss += bf_lo(w[j]) * bf_lo(w[j]) + bf_hi(w[j]) * bf_hi(w[j]);
+                *reinterpret_cast<uint4*>(gout + frag_off(b, v * 8, gdim)) = a;
+            } else {
+                *reinterpret_cast<uint4*>(gout + (size_t)b * gdim + v * 8) = a;
+            }
+        }
+        if (gpart) {        // sval is free again after block_argmax's trailing barrier
+            ss = wave_sum(ss);
+            if ((threadIdx.x & 63) == 0) sval[threadIdx.x >> 6] = ss;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < SMP_THREADS / 64; ++w) t += sval[w];
+                gpart[b] = t;
+            }
+        }
     }
     if (threadIdx.x == 0) {
         out_ids[(size_t)b * out_stride] = pick;
@@ -134,16 +155,17 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
 int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
-                    int gather_dim, void* stream) {
+                    int gather_dim, float* gather_part, void* stream) {
     OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
     OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
     OMNI_CHECK_ARG(rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
     OMNI_CHECK_ARG(!gather_table || (gather_out && gather_dim % 8 == 0), "omni_sample: bad gather arguments");
+    OMNI_CHECK_ARG(!gather_part || (gather_table && gather_dim % 32 == 0), "omni_sample: bad fragment-major gather arguments");
     if (B <= 0) return OMNI_OK;
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,
                        temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids,
-                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim);
+                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part);
     OMNI_CHECK_LAUNCH("omni_sample");
     return OMNI_OK;
 }
@@ -152,7 +174,7 @@ int k_sample(const float* logits, int ld, int B, int V, int greedy, float temper
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
              int out_stride, void* stream) {
     return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add,
-                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, stream);
+                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,

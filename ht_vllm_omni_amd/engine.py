@@ -81,7 +81,8 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
 class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
-                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True):
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
+                 fused_norm: bool | None = None):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -91,6 +92,11 @@ class TalkerEngine:
         assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
         self.kv_dtype = kv_dtype
         self.frag_layout = bool(frag_layout)
+        # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm): single-rank decode only -- the tensor-parallel
+        # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
+        self.fused_norm = (self.frag_layout and not self.tp_path) if fused_norm is None else bool(fused_norm)
+        if self.fused_norm and (self.tp_path or not self.frag_layout):
+            raise ValueError("fused_norm needs frag_layout and a single rank")
         self.kv_code = L.KV_CODES[kv_dtype]
         self.block_size, self.num_blocks, self.max_batch = block_size, num_blocks, max_batch
         self.hq_l = dims.q_heads // tp_size
@@ -177,6 +183,7 @@ class TalkerEngine:
         desc.cp_hidden, desc.cp_layers, desc.cp_q_heads, desc.cp_kv_heads = d.cp_hidden, d.cp_layers, d.cp_q_heads, d.cp_kv_heads
         desc.cp_head_dim, desc.cp_inter, desc.has_cp_projection = d.cp_head_dim, d.cp_inter, int(d.has_cp_projection)
         desc.frag_layout = int(self.frag_layout)
+        desc.fused_norm = int(self.fused_norm)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))

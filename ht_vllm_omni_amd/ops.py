@@ -2,6 +2,7 @@
 arithmetic in libomni_talker.so).  Every wrapper launches on torch's current stream."""
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -46,19 +47,35 @@ def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None, layout=0, M=None):
     return out
 
 
-def gemm_resid_norm(resid, w, norm_w, eps, *, delta=None, bias=None, epilogue=L.EPI_BF16, mask=None, want_normed=False):
-    """out = epilogue(rmsnorm(resid + delta) . w^T). Returns (out, new_resid) or (out, new_resid, normed)."""
-    _chk_dev(resid, w, norm_w, delta, bias, mask)
-    M, K = resid.shape
-    N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
+def gemm_resid(x, w_frag, r_frag, partials, *, bias=None, accumulate=True, x_frag=True, M=None):
+    """In place on the fragment-major residual stream: r = bf16((r if accumulate) + bf16(x . w^T + bias)); fills
+    partials[N/16, 64] (per-row sum(r^2) slabs) and returns the slab count."""
+    _chk_dev(x, w_frag, r_frag, partials, bias)
+    Mx, K = x.shape
+    M = Mx if M is None else M
+    N = w_frag.shape[0]
+    np_out = C.c_int(0)
+    layout = L.LAYOUT_W_FRAG | (L.LAYOUT_X_FRAG if x_frag else 0)
+    L.check(L.load().omni_gemm_resid(L.ptr(x), x.stride(0), L.ptr(w_frag), L.ptr(bias), L.ptr(r_frag), int(accumulate),
+                                     L.ptr(partials), C.addressof(np_out), M, N, K, layout, L.current_stream()),
+            "omni_gemm_resid")
+    return np_out.value
+
+
+def gemm_xnorm(r_frag, partials, nparts, norm_w, w_frag, eps, *, M, epilogue=L.EPI_BF16, mask=None, want_normed=False,
+               out_frag=False):
+    """out = epilogue((norm_w * bf16(r * rstd)) . w^T) on the fragment-major residual stream -> out [, normed rows]."""
+    _chk_dev(r_frag, partials, norm_w, w_frag, mask)
+    K = r_frag.shape[1]
+    N = w_frag.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w_frag.shape[0]
     dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
-    out = torch.empty(M, N, dtype=dt, device=resid.device)
-    normed = torch.empty_like(resid) if want_normed else None
-    new_resid = torch.empty_like(resid)
-    L.check(L.load().omni_gemm_resid_norm(L.ptr(resid), L.ptr(delta), L.ptr(new_resid), L.ptr(norm_w), float(eps),
-                                          L.ptr(normed), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue, L.ptr(mask),
-                                          L.current_stream()), "omni_gemm_resid_norm")
-    return (out, new_resid, normed) if want_normed else (out, new_resid)
+    rows_out = (M + 15) // 16 * 16 if out_frag else M
+    out = torch.zeros(rows_out, N, dtype=dt, device=r_frag.device)
+    normed = torch.empty(M, K, dtype=BF16, device=r_frag.device) if want_normed else None
+    L.check(L.load().omni_gemm_xnorm(L.ptr(r_frag), L.ptr(partials), nparts, L.ptr(norm_w), float(eps), L.ptr(normed),
+                                     L.ptr(w_frag), L.ptr(out), M, N, K, epilogue, L.ptr(mask), int(out_frag),
+                                     L.current_stream()), "omni_gemm_xnorm")
+    return (out, normed) if want_normed else out
 
 
 def attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, k_cache, v_cache, block_table, seq_lens, *, q_heads,

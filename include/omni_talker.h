@@ -44,6 +44,7 @@ extern "C" {
 #define OMNI_EPI_SILU_MUL 1    /* W = [gate rows | up rows] (2N rows); out bf16 [M,N]       */
 #define OMNI_EPI_F32 2         /* out fp32 [M,N]                                            */
 #define OMNI_EPI_F32_BF16RND 3 /* out fp32 [M,N] holding bf16-rounded values (logits)       */
+#define OMNI_EPI_RESID 4       /* omni_gemm_resid only: r += bf16(acc + bias), sum(r^2) slabs */
 
 const char* omni_last_error(void);
 int omni_abi_version(void);
@@ -78,15 +79,22 @@ int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void
 int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K,
                       int epilogue, const uint8_t* mask, int layout, void* stream);
 
-/* The same GEMM with the producing layer's residual-add + RMSNorm fused into the prologue
- * (replaces one fused_add_rms_norm launch + one linear launch of the reference's layer loop):
- *   r = bf16(resid + delta)  (delta may be NULL); r -> resid_out (bf16 [M,K] or NULL; must not alias
- *   resid: every workgroup re-reads resid)
- *   x = norm_w * bf16(r * rsqrt(mean(r^2) + eps));  out = x . W^T (+bias), epilogue as above.
- *   normed_out: bf16 [M,K] or NULL, receives x.  K % 256 == 0 and K <= 2048.                    */
-int omni_gemm_resid_norm(const void* resid, const void* delta, void* resid_out, const void* norm_w, float eps,
-                         void* normed_out, const void* w, const void* bias, void* out, int M, int N, int K,
-                         int epilogue, const uint8_t* mask, void* stream);
+/* The norm-free residual stream of the decode step: the residual r lives fragment-major ([rows16, N], frag_off) next to
+ * per-row sum-of-squares slabs partials[nparts][64] fp32, so that the reference's fused_add_rms_norm launch between
+ * two linears (Qwen3DecoderLayer, V/model_executor/models/qwen3_tts/qwen3_tts_talker.py:297-311 via vLLM Qwen3Model)
+ * disappears: the producing GEMM adds into r and emits its workgroups' shares of sum(r^2), the consuming GEMM applies
+ * x = norm_w * bf16(r * rsqrt(sum / K + eps)) to every operand fragment it loads.  Same arithmetic as omni_rmsnorm
+ * (fp32 statistics, bf16 roundings in the HF order); the slab sum order is fixed, so results are run-to-run
+ * deterministic.
+ *   omni_gemm_resid: r_io = bf16((accumulate ? r_io : 0) + bf16(x . W^T + bias)); partials[N/16][64]; *nparts_out = N/16
+ *                    (x row-major or fragment-major per layout; N % 32 == 0).
+ *   omni_gemm_xnorm: out = epilogue((norm_w * bf16(r * rstd)) . W^T); r and W fragment-major; normed_out (bf16 [M,K]
+ *                    row-major or NULL) receives the normalised rows; out_frag as OMNI_LAYOUT_OUT_FRAG.           */
+int omni_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate, float* partials,
+                    int* nparts_out, int M, int N, int K, int layout, void* stream);
+int omni_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
+                    const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag,
+                    void* stream);
 
 /* Per-head q/k RMSNorm + neox RoPE + KV-cache write with quantisation
  * (vLLM Qwen3Attention q_norm/k_norm + rotary_emb + reshape_and_cache; slot mapping built at
@@ -174,6 +182,9 @@ typedef struct omni_talker_desc {
     int cp_hidden, cp_layers, cp_q_heads, cp_kv_heads, cp_head_dim, cp_inter;
     int has_cp_projection;
     int frag_layout;   /* != 0: every GEMM weight below is fragment-major (OMNI_LAYOUT_W_FRAG); activations follow */
+    int fused_norm;    /* != 0 (needs frag_layout, the folded tables, single rank): the decode step keeps the residual
+                          stream fragment-major and folds every RMSNorm into its neighbouring GEMMs (omni_gemm_resid /
+                          omni_gemm_xnorm); the per-phase attn_out / mlp_out buffers are then NOT produced */
     /* runtime */
     int max_batch, block_size, kv_dtype, max_model_len, bt_stride;
     float k_scale, v_scale;

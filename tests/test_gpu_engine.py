@@ -60,11 +60,11 @@ def test_code_predictor_matches_oracle(B):
 
 
 def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_blocks=64, graph=False, seed=0,
-              mean_tol=4e-3):
+              mean_tol=4e-3, engine_kw=None):
     """Prefill + n_steps decode steps on GPU engine and oracle; returns per-step records."""
     bs = 16
     B = len(prompt_lens)
-    eng = _engine(d, w, kv_dtype=kv, num_blocks=num_blocks, block_size=bs, max_batch=B_pad or B)
+    eng = _engine(d, w, kv_dtype=kv, num_blocks=num_blocks, block_size=bs, max_batch=B_pad or B, **(engine_kw or {}))
     orc = O.TalkerOracle(d, w, kv_dtype=kv, num_blocks=num_blocks, block_size=bs)
     pool = BlockPool(num_blocks, bs)
     g = torch.Generator().manual_seed(seed)
@@ -181,6 +181,24 @@ def test_decode_steps_match_oracle_tiny(kv):
             assert_e2e_close(got, ref, what=f"kv layer {li}")
         else:
             assert (got != ref).float().mean().item() < 0.15, f"kv bytes layer {li}"
+
+
+@pytest.mark.parametrize("engine_kw", [dict(fused_norm=False), dict(frag_layout=False)],
+                         ids=["separate-norms", "row-major"])
+def test_decode_steps_alternate_layout_paths(engine_kw):
+    """The default step keeps the residual stream fragment-major with every RMSNorm folded into its GEMMs; the
+    separate-norm path (what tensor-parallel ranks run) and the row-major path must meet the same oracle bar."""
+    d = get_dims("tiny")
+    w = make_weights(d, seed=5, std=0.06, norm_noise=0.1)
+    rec = _scenario(d, w, "fp8", prompt_lens=[5, 17, 33, 16], n_steps=4, mean_tol=6e-3, engine_kw=engine_kw)
+    assert rec["engine"].fused_norm is False
+    _check(rec, mean_tol=6e-3)
+
+
+def test_default_engine_runs_the_norm_free_stream():
+    d = get_dims("tiny")
+    eng = _engine(d, make_weights(d, seed=5), kv_dtype="fp8", num_blocks=8, block_size=16, max_batch=4)
+    assert eng.frag_layout and eng.fused_norm
 
 
 def test_decode_step_hipgraph_replay_matches_eager():

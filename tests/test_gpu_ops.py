@@ -70,39 +70,6 @@ def test_gemm_silu_mul(ops, M, inter, K):
     assert_bf16_close(out, ref, ulps=2, max_mismatch=0.03, what="gemm silu*mul")
 
 
-@pytest.mark.parametrize("M", [1, 16, 40, 64])
-@pytest.mark.parametrize("N,K,epi", [(4096, 2048, "bf16"), (1024, 256, "bf16"), (6144, 2048, "silu"), (3072, 1024, "logits"),
-                                     (2048, 1024, "silu")])
-def test_gemm_resid_norm_fused(ops, M, N, K, epi):
-    """Residual add + RMSNorm fused into the GEMM prologue == separate rmsnorm then GEMM (oracle)."""
-    from ht_vllm_omni_amd import _lib as L
-    g = torch.Generator().manual_seed(M + N + K)
-    resid, delta = _rand(g, M, K), _rand(g, M, K)
-    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16)
-    rows = 2 * N if epi == "silu" else N
-    w = _rand(g, rows, K, scale=0.03)
-    r_ref = resid + delta
-    x_ref = O.rms_norm(r_ref, nw, 1e-6)
-    code = {"bf16": L.EPI_BF16, "silu": L.EPI_SILU_MUL, "logits": L.EPI_F32_BF16RND}[epi]
-    rd = resid.clone().cuda()
-    out, new_r, normed = ops.gemm_resid_norm(rd, w.cuda(), nw.cuda(), 1e-6, delta=delta.cuda(), epilogue=code, want_normed=True)
-    assert torch.equal(rd.cpu().view(torch.int16), resid.view(torch.int16)), "input residual must stay untouched"
-    assert torch.equal(new_r.cpu().view(torch.int16), r_ref.view(torch.int16)), "residual add must be bit-exact"
-    assert_bf16_close(normed, x_ref, what="fused normed rows")
-    y = O.linear(x_ref, w)
-    if epi == "silu":
-        ref = O.silu_mul(y[:, :N], y[:, N:])
-        assert_bf16_close(out, ref, ulps=2, max_mismatch=0.06, what="fused norm+gemm silu")
-    elif epi == "logits":
-        assert_bf16_close(out, y.float(), ulps=1, max_mismatch=0.06, what="fused norm+gemm logits")
-    else:
-        assert_bf16_close(out, y, ulps=1, max_mismatch=0.06, what="fused norm+gemm")
-    # no delta: residual untouched
-    out2, new_r2 = ops.gemm_resid_norm(resid.cuda(), w.cuda(), nw.cuda(), 1e-6, epilogue=code)
-    assert torch.equal(new_r2.cpu().view(torch.int16), resid.view(torch.int16))
-    assert out2.shape == out.shape
-
-
 @pytest.mark.parametrize("M", [1, 16, 37, 64])
 @pytest.mark.parametrize("N,K,epi", [(4096, 2048, "bf16"), (2048, 6144, "bf16"), (6144, 2048, "silu"), (3072, 1024, "silu"),
                                      (3072, 2048, "logits"), (96, 64, "bf16")])
@@ -129,6 +96,70 @@ def test_gemm_fragment_major_layouts(ops, M, N, K, epi):
         out_f = ops.gemm(xf, wf, epilogue=code, layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG | L.LAYOUT_OUT_FRAG, M=M)
         assert torch.equal(frag_unshuffle(out_f.cpu())[:M], ref.cpu()), "fragment-major output"
     assert torch.equal(frag_unshuffle(frag_shuffle(w)), w)
+
+
+@pytest.mark.parametrize("M", [1, 16, 37, 64])
+@pytest.mark.parametrize("H,K1,N2,epi", [(2048, 2048, 4096, "bf16"), (1024, 3072, 3072, "silu"), (2048, 6144, 3072, "logits"),
+                                         (1024, 2048, 2048, "logits"), (64, 96, 48, "bf16")])
+def test_gemm_norm_free_residual_stream(ops, M, H, K1, N2, epi):
+    """omni_gemm_resid (producer: r += bf16(x.W1^T), per-workgroup sum(r^2) slabs) followed by omni_gemm_xnorm (consumer:
+    RMSNorm applied to the fragments it loads) == residual add, rms_norm, linear of the oracle."""
+    from ht_vllm_omni_amd import _lib as L
+    from ht_vllm_omni_amd.engine import frag_shuffle, frag_unshuffle
+    g = torch.Generator().manual_seed(M + H + K1 + N2)
+    Mp = (M + 15) // 16 * 16
+    r0 = torch.zeros(Mp, H, dtype=BF16)
+    r0[:M] = _rand(g, M, H)
+    x1 = torch.zeros(Mp, K1, dtype=BF16)
+    x1[:M] = _rand(g, M, K1)
+    w1 = _rand(g, H, K1, scale=0.03)
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(BF16)
+    rows2 = 2 * N2 if epi == "silu" else N2
+    w2 = _rand(g, rows2, H, scale=0.03)
+    code = {"bf16": L.EPI_BF16, "silu": L.EPI_SILU_MUL, "logits": L.EPI_F32_BF16RND}[epi]
+
+    # oracle: r = bf16(r0 + linear(x1)); x = rms_norm(r); y = linear(x)
+    r_ref = r0[:M] + O.linear(x1[:M], w1)
+    x_ref = O.rms_norm(r_ref, nw, 1e-6)
+    y = O.linear(x_ref, w2)
+
+    rf = frag_shuffle(r0).cuda()
+    part = torch.full((H // 16, 64), float("nan"), dtype=torch.float32, device="cuda")
+    np_ = ops.gemm_resid(frag_shuffle(x1).cuda(), frag_shuffle(w1).cuda(), rf, part, M=M)
+    assert np_ == H // 16
+    r_got = frag_unshuffle(rf.cpu())[:M]
+    # the add is exact on top of this library's own GEMM output (same kernel, same accumulation order) ...
+    d_dev = ops.gemm(frag_shuffle(x1).cuda(), frag_shuffle(w1).cuda(), layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG, M=M).cpu()
+    assert torch.equal(r_got, r0[:M] + d_dev), "residual stream == bf16(r + bf16(acc)) bit for bit"
+    # ... and that output is the oracle's linear within one rounding (absolute bound: r0 + delta may cancel)
+    assert_bf16_close(d_dev, O.linear(x1[:M], w1), ulps=1, max_mismatch=0.06, what="delta")
+    assert (r_got.float() - r_ref.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, O.linear(x1[:M], w1).float().abs().max().item())
+    ss = part[:, :M].sum(0).cpu()
+    torch.testing.assert_close(ss, r_got.float().pow(2).sum(-1), rtol=1e-5, atol=1e-6)
+
+    out, normed = ops.gemm_xnorm(rf, part, np_, nw.cuda(), frag_shuffle(w2).cuda(), 1e-6, M=M, epilogue=code, want_normed=True)
+    x_same = O.rms_norm(r_got, nw, 1e-6)            # same r as the device: isolates the consumer
+    assert_bf16_close(normed, x_same, what="normalised rows")
+    y_same = O.linear(x_same, w2)
+    if epi == "silu":
+        assert_bf16_close(out, O.silu_mul(y_same[:, :N2], y_same[:, N2:]), ulps=2, max_mismatch=0.06, what="xnorm silu")
+    elif epi == "logits":
+        assert_bf16_close(out, y_same.float(), ulps=1, max_mismatch=0.06, what="xnorm logits")
+    else:
+        assert_bf16_close(out, y_same, ulps=1, max_mismatch=0.06, what="xnorm gemm")
+    # and against the separate-kernel path of this library on the same r: bit-identical GEMM input -> identical output
+    xn = ops.rmsnorm(r_got.cuda(), nw.cuda(), 1e-6)
+    assert torch.equal(xn, normed), "xnorm rows == omni_rmsnorm rows"
+    assert torch.equal(ops.gemm(xn, w2.cuda(), epilogue=code), out), "xnorm GEMM == rmsnorm + GEMM"
+    # fresh stream (no accumulate, bias, row-major x): the projection into the code predictor
+    bias = _rand(g, H)
+    rf2 = torch.zeros_like(rf)
+    ops.gemm_resid(x1[:M].contiguous().cuda(), frag_shuffle(w1).cuda(), rf2, part, bias=bias.cuda(), accumulate=False, x_frag=False)
+    ref2 = ops.gemm(x1[:M].contiguous().cuda(), w1.cuda(), bias=bias.cuda())
+    assert torch.equal(frag_unshuffle(rf2.cpu())[:M], ref2.cpu()), "projection into the stream"
+    if epi != "logits" and N2 % 32 == 0:
+        out_f = ops.gemm_xnorm(rf, part, np_, nw.cuda(), frag_shuffle(w2).cuda(), 1e-6, M=M, epilogue=code, out_frag=True)
+        assert out_f.shape[0] == Mp
 
 
 def test_gemm_rejects_bad_shapes(ops):
