@@ -336,7 +336,8 @@ static int cp_forward_fused(omni_talker* t, int B, int p, int* np, void* st) {
                        OMNI_EPI_BF16, nullptr, 0, st));
         TRY(k_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
                                 t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
-                                t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, 1, st));
+                                t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs, 1,
+                                (p < 16 && t->cp_bs >= 16 && (hq / hkv == 1 || hq / hkv == 2 || hq / hkv == 4)) ? p : -1, st));
         if (p == 0 && l == d.cp_layers - 1) break;
         TRY(resid_gemm(t->cp_attn, w.wo, t->cp_resid, t->cp_part, B, Hc, hq * D, st));
         *np = Hc / 16;
@@ -374,7 +375,7 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
         TRY(k_attn_decode_fused(t->cp_qkv, w.qnorm, w.knorm, t->cp_pos + (size_t)p * Bm, d.cp_cos_sin, d.eps, t->cp_k[l],
                                 t->cp_v[l], nullptr, nullptr, t->cp_bt, 1, t->cp_seq + (size_t)p * Bm, nullptr,
                                 t->cp_attn, nullptr, B, hq, hkv, D, t->cp_bs, OMNI_KV_BF16, 1.f, 1.f, sm, t->cp_bs,
-                                d.frag_layout, st));
+                                d.frag_layout, -1, st));
         // position 0 only feeds later positions through its K/V: nothing after the last layer's KV write is used
         if (p == 0 && l == d.cp_layers - 1) break;
         TRY(act_gemm(t, t->cp_attn, w.wo, nullptr, t->cp_o, B, Hc, hq * D, st));
@@ -519,7 +520,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
     TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
-                            d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, st));
+                            d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st));
     if (d.fused_norm) return resid_gemm(t->attn, w.wo, t->resid, t->part, B, H, hq * D, st);
     TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, B, H, hq * D, st));
     return OMNI_OK;

@@ -25,7 +25,8 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
-                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, void* stream);
+                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag,
+                        int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream);
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,

@@ -33,6 +33,7 @@ struct PAArgs {
     uint16_t* out; float* partial;
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
     int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
+    int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
 };
 
 template <int KV>
@@ -366,7 +367,9 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
 // ---- short-context variant (code predictor: <= 17 keys): ONE wave per (row, kv-head), bf16 KV, fused
 // norm + RoPE + KV write.  The general kernel spends ~12 us of instructions (4 waves x q prologue, batch
 // loop, 32-way combine) on a context that fits one 8-token pass or two; this one is ~4x lighter.
-template <int G>
+// DENSE (the code predictor's private cache): position = a.dense_pos for every row and row b owns block b, so no index
+// is loaded at all and every load of the kernel -- both 8-token history groups included -- goes out in one round trip.
+template <int G, bool DENSE>
 __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, int npairs) {
     constexpr int KV = OMNI_KV_BF16;
     __shared__ float sm[4][G * 128 + 256];
@@ -376,14 +379,21 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     const int kv_heads = a.kv_heads, bs = a.bs;
     const int row = pair / kv_heads, kvh = pair - row * kv_heads;
     const int sub = lane & 7, tg = lane >> 3;
-    const int32_t* bt = a.block_table + (size_t)row * a.bt_stride;
+    const int32_t* bt = DENSE ? nullptr : a.block_table + (size_t)row * a.bt_stride;
     const int max_blk = a.bt_stride - 1;
     const int nslots = a.q_heads + 2 * kv_heads;
     // first 8-token group: issued before the sequence length is known
-    const size_t r0 = ((size_t)bt[min(tg / bs, max_blk)] * bs + tg % bs) * kv_heads + kvh;
+    const size_t r0 = DENSE ? ((size_t)row * bs + tg) * kv_heads + kvh
+                            : ((size_t)bt[min(tg / bs, max_blk)] * bs + tg % bs) * kv_heads + kvh;
     KVRaw<KV> kr = load_row<KV>(a.k_cache, r0, sub), vr = load_row<KV>(a.v_cache, r0, sub);
-    const int cur = a.seq_lens[row] - 1;
-    const int pos = a.positions[row];
+    KVRaw<KV> kr1 = kr, vr1 = vr;
+    if (DENSE) {                                      // tokens 8..15 (block_size >= 16: always a valid address)
+        const size_t r1 = ((size_t)row * bs + 8 + tg) * kv_heads + kvh;
+        kr1 = load_row<KV>(a.k_cache, r1, sub);
+        vr1 = load_row<KV>(a.v_cache, r1, sub);
+    }
+    const int cur = DENSE ? a.dense_pos : a.seq_lens[row] - 1;
+    const int pos = DENSE ? a.dense_pos : a.positions[row];
     const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
     float* wq = sm[wave];
     float* kvs = sm[wave] + G * 128;
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         wq[g * 128 + 64 + lane] = y1;
     }
     {   // new token: K (norm + rope) and V -> cache and LDS
-        const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
+        const int64_t slot = DENSE ? (int64_t)row * bs + pos : (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
         if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
         const size_t crow = (size_t)slot * kv_heads + kvh;
         float kx0, kx1;
@@ -425,10 +435,14 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
     for (int t0 = 0; t0 < cur; t0 += 8) {
         if (t0 > 0) {
-            const int t = t0 + tg;
-            const size_t r_ = ((size_t)bt[min(t / bs, max_blk)] * bs + t % bs) * kv_heads + kvh;
-            kr = load_row<KV>(a.k_cache, r_, sub);
-            vr = load_row<KV>(a.v_cache, r_, sub);
+            if (DENSE) {
+                kr = kr1; vr = vr1;
+            } else {
+                const int t = t0 + tg;
+                const size_t r_ = ((size_t)bt[min(t / bs, max_blk)] * bs + t % bs) * kv_heads + kvh;
+                kr = load_row<KV>(a.k_cache, r_, sub);
+                vr = load_row<KV>(a.v_cache, r_, sub);
+            }
         }
         const bool ok = t0 + tg < cur;
         float kf[16], vf[16];
@@ -608,9 +622,11 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
-                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, void* stream) {
+                        float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, int dense_pos,
+                        void* stream) {
     PAArgs a{};
     a.out_frag = out_frag;
+    a.dense_pos = dense_pos;
     a.qkv = (const uint16_t*)qkv; a.qnorm_w = (const uint16_t*)qnorm_w; a.knorm_w = (const uint16_t*)knorm_w;
     a.positions = positions; a.cos_sin = (const uint16_t*)cos_sin; a.eps = eps; a.slot_out = slot_out;
     a.k_cache = k_cache; a.v_cache = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
@@ -618,21 +634,29 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
     a.partial = (float*)workspace; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
     a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale;
     a.nsplit = (workspace && kv_heads > 0 && B > 0) ? pick_nsplit(B, kv_heads, max_seq_len) : 1;
-    if (kv_dtype == OMNI_KV_BF16 && max_seq_len <= 64 && head_dim == 128 && kv_heads > 0 && q_heads % kv_heads == 0 && B > 0 &&
-        qkv && qnorm_w && knorm_w && positions && cos_sin && k_cache && v_cache && block_table && seq_lens && out &&
-        block_size > 0 && bt_stride > 0) {
+    const bool dense = dense_pos >= 0;
+    OMNI_CHECK_ARG(!dense || (kv_dtype == OMNI_KV_BF16 && block_size >= 16 && dense_pos < 16 && dense_pos < block_size &&
+                              head_dim == 128), "attn_decode_fused: dense mode needs bf16 KV, block_size >= 16, position < 16");
+    if (kv_dtype == OMNI_KV_BF16 && (dense || max_seq_len <= 64) && head_dim == 128 && kv_heads > 0 && q_heads % kv_heads == 0 &&
+        B > 0 && qkv && qnorm_w && knorm_w && cos_sin && k_cache && v_cache && out && block_size > 0 &&
+        (dense || (positions && block_table && seq_lens && bt_stride > 0))) {
         const int G = q_heads / kv_heads, npairs = B * kv_heads;
         dim3 grid((npairs + 3) / 4), block(256);
         hipStream_t st = (hipStream_t)stream;
         a.nsplit = 1;
-        if (G == 1) hipLaunchKernelGGL(attn_small_fused_kernel<1>, grid, block, 0, st, a, npairs);
-        else if (G == 2) hipLaunchKernelGGL(attn_small_fused_kernel<2>, grid, block, 0, st, a, npairs);
-        else if (G == 4) hipLaunchKernelGGL(attn_small_fused_kernel<4>, grid, block, 0, st, a, npairs);
+#define SMALL(G_)                                                                                        \
+        if (G == G_) {                                                                                   \
+            if (dense) hipLaunchKernelGGL((attn_small_fused_kernel<G_, true>), grid, block, 0, st, a, npairs);  \
+            else hipLaunchKernelGGL((attn_small_fused_kernel<G_, false>), grid, block, 0, st, a, npairs);       \
+        }
+        SMALL(1) SMALL(2) SMALL(4)
+#undef SMALL
         if (G == 1 || G == 2 || G == 4) {
             OMNI_CHECK_LAUNCH("omni_attn_decode_fused(small)");
             return OMNI_OK;
         }
     }
+    OMNI_CHECK_ARG(!dense, "attn_decode_fused: dense mode unsupported for q_heads / kv_heads = %d", kv_heads ? q_heads / kv_heads : 0);
     return pa_dispatch(a, B, head_dim, kv_dtype, true, stream);
 }
 
@@ -644,7 +668,7 @@ extern "C" int omni_attn_decode_fused(const void* qkv, const void* qnorm_w, cons
                                       float sm_scale, int max_seq_len, void* stream) {
     return k_attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, eps, k_cache, v_cache, k_scales, v_scales,
                                block_table, bt_stride, seq_lens, slot_out, out, workspace, B, q_heads, kv_heads, head_dim,
-                               block_size, kv_dtype, k_scale, v_scale, sm_scale, max_seq_len, 0, stream);
+                               block_size, kv_dtype, k_scale, v_scale, sm_scale, max_seq_len, 0, -1, stream);
 }
 
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
