@@ -31,3 +31,9 @@ int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,
                          int kv_dtype, float k_scale, float v_scale, float sm_scale, int out_frag, void* stream);
+// causal prefill attention on the matrix cores (prefill_attn.hip); head_dim 128, q_heads / kv_heads in {1, 2, 4}
+bool k_prefill_mfma_supported(int q_heads, int kv_heads, int head_dim);
+int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, const float* k_scales, const float* v_scales,
+                   const int32_t* block_table, int bt_stride, const int32_t* req_of_tok, const int32_t* positions, void* out,
+                   int T, int q_heads, int kv_heads, int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
+                   int out_frag, void* stream);

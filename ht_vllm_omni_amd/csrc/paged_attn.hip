@@ -676,7 +676,10 @@ int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,
                          int kv_dtype, float k_scale, float v_scale, float sm_scale, int out_frag, void* stream) {
     OMNI_CHECK_ARG(req_of_tok && positions, "omni_paged_attn_prefill: null pointer");
-    // every token is a decode row whose context is positions[t] + 1 keys of request req_of_tok[t]
+    if (k_prefill_mfma_supported(q_heads, kv_heads, head_dim))
+        return k_prefill_mfma(q, k_cache, v_cache, k_scales, v_scales, block_table, bt_stride, req_of_tok, positions, out, T,
+                              q_heads, kv_heads, block_size, kv_dtype, k_scale, v_scale, sm_scale, out_frag, stream);
+    // other head ratios: every token is a decode row whose context is positions[t] + 1 keys of request req_of_tok[t]
     PAArgs a{};
     a.out_frag = out_frag;
     a.q = (const uint16_t*)q; a.k_cache = const_cast<void*>(k_cache); a.v_cache = const_cast<void*>(v_cache);

@@ -382,6 +382,45 @@ def test_paged_attn_prefill_causal(ops):
         o += n
 
 
+@pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1), (2, 2)])
+def test_paged_attn_prefill_mfma_ragged(ops, kv, hq, hkv):
+    """Matrix-core prefill attention: ragged prompts (1-token, block-boundary and multi-tile lengths, tiles that
+    straddle up to three requests), scattered blocks, a later chunk of a request (positions start past cached keys),
+    every KV dtype -- against the oracle's fp32 attention through the same cache."""
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, nb = 128, 16, 96
+    g = torch.Generator().manual_seed(3 * hq + hkv + len(kv))
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    pk = _fill_cache(kv, nb, bs, hkv, D, g, k_scale, v_scale)
+    # (first position, number of tokens) per request: the 4th is the second chunk of a 150-token prompt
+    chunks = [(0, 1), (0, 5), (0, 3), (100, 50), (0, 16), (0, 17), (0, 97), (0, 32)]
+    R = len(chunks)
+    perm = torch.randperm(nb - 1, generator=g) + 1
+    bt = torch.zeros(R, 16, dtype=torch.int32)
+    ptr = 0
+    for r, (p0, n) in enumerate(chunks):
+        need = (p0 + n + bs - 1) // bs
+        bt[r, :need] = perm[(ptr + torch.arange(need)) % (nb - 1)]
+        ptr += 11
+    req = torch.cat([torch.full((n,), r) for r, (_, n) in enumerate(chunks)]).to(torch.int32)
+    pos = torch.cat([torch.arange(p0, p0 + n) for p0, n in chunks]).to(torch.int32)
+    T = req.numel()
+    q = _rand(g, T, hq * D)
+    store = pk.data.view(torch.uint8) if kv == "fp8" else pk.data
+    cache = store.cuda()
+    sc = pk.scales.cuda() if kv == "int8" else None
+    out = ops.paged_attn_prefill(q.cuda(), cache[0], cache[1], bt.cuda(), req.cuda(), pos.cuda(), q_heads=hq, kv_heads=hkv,
+                                 head_dim=D, block_size=bs, kv_dtype=L.KV_CODES[kv], k_scale=k_scale, v_scale=v_scale,
+                                 k_scales=None if sc is None else sc[0], v_scales=None if sc is None else sc[1])
+    o = 0
+    for r, (p0, n) in enumerate(chunks):
+        kk, vv = pk.gather(bt[r].tolist(), p0 + n)
+        ref = O.attention_rows(q[o:o + n].view(n, hq, D), kk, vv, torch.arange(p0, p0 + n), D ** -0.5)
+        assert_bf16_close(out[o:o + n].view(n, hq, D), ref, ulps=1, max_mismatch=0.05, what=f"prefill req {r} ({p0}+{n}) {kv}")
+        o += n
+
+
 def test_attention_softmax_property_full_size(ops):
     """BASELINE size (B=64, 16/8 heads, fp8, ctx U{96..608}): V == const -> output == const exactly,
     whatever K, q and the block placement are (softmax weights sum to 1)."""
