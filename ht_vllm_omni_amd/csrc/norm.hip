@@ -167,3 +167,35 @@ extern "C" int omni_embed(const int32_t* ids, const void* table, void* out, int 
                           void* stream) {
     return k_embed(ids, 1, table, out, T, hidden, vocab, stream);
 }
+
+// act[t, i] = bf16(bf16(silu(gate[t, i])) * up[t, i]) for gate_up = [gate | up] rows of 2 * inter (the prefill path's
+// hipBLASLt gate_up GEMM has no fused activation); same roundings as the skinny GEMM's SiLU epilogue
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out, size_t nvec, int inter8) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const size_t t = v / inter8;
+    const int c = (int)(v - t * inter8);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + (t * 2 * inter8 + c) * 8);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + (t * 2 * inter8 + inter8 + c) * 8);
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(&g);
+    const uint32_t* uw = reinterpret_cast<const uint32_t*>(&u);
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float g0 = bf_lo(gw[j]), g1 = bf_hi(gw[j]);
+        const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));
+        o[j] = pack_bf2(s0 * bf_lo(uw[j]), s1 * bf_hi(uw[j]));
+    }
+    *reinterpret_cast<uint4*>(out + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int omni_silu_mul(const void* gate_up, void* out, int T, int inter, void* stream) {
+    OMNI_CHECK_ARG(gate_up && out, "omni_silu_mul: null pointer");
+    OMNI_CHECK_ARG(inter > 0 && inter % 8 == 0, "omni_silu_mul: inter=%d not a multiple of 8", inter);
+    if (T <= 0) return OMNI_OK;
+    const size_t nvec = (size_t)T * (inter / 8);
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)gate_up, (uint16_t*)out, nvec, inter / 8);
+    OMNI_CHECK_LAUNCH("omni_silu_mul");
+    return OMNI_OK;
+}

@@ -1,8 +1,21 @@
 // Per-head q/k RMSNorm + neox RoPE + KV-cache write with bf16 / fp8-e4m3fn / int8 quantisation,
-// and the device-side slot mapping.  One wave per (token, head slot); head_dim = 128 so lane l
-// owns elements l and l+64 -- exactly the rotate_half pair, no cross-lane traffic for RoPE.
+// and the device-side slot mapping.  16 lanes per (token, head slot); head_dim = 128 and a lane owns
+// elements e and e+64 -- exactly the rotate_half pairs, no cross-lane traffic for RoPE.
 // Numerics = oracle (talker_oracle.rms_norm / apply_rope / fp8_quant / int8_quant).
 #include "common.cuh"
+
+// 16 lanes per (token, head slot): lane j owns elements [4j, 4j+4) and [64+4j, 64+4j+4) -- the rotate_half pairs stay
+// in one lane and every access is 8 B (the prefill calls this for thousands of tokens per layer)
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+__device__ __forceinline__ void unpack4(uint2 w, float* f) { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
 
 template <int KV>
 __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
@@ -11,31 +24,42 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
     uint16_t* __restrict__ q_out, void* __restrict__ k_cache, void* __restrict__ v_cache,
     float* __restrict__ k_scales, float* __restrict__ v_scales, int q_heads, int kv_heads, float eps, float inv_k_scale,
     float inv_v_scale, float k_scale, float v_scale) {
-    const int lane = threadIdx.x & 63;
-    const int slot_h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = threadIdx.x & 15;
+    const int slot_h = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int nslots = q_heads + 2 * kv_heads;
-    if (slot_h >= nslots) return;
+    if (slot_h >= nslots) return;                     // whole 16-lane groups leave together (shuffles stay in-group)
     const int t = blockIdx.y;
     const uint16_t* src = qkv + ((size_t)t * nslots + slot_h) * 128;
-    float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
+    float x0[4], x1[4];
+    unpack4(*reinterpret_cast<const uint2*>(src + 4 * j), x0);
+    unpack4(*reinterpret_cast<const uint2*>(src + 64 + 4 * j), x1);
     const bool is_q = slot_h < q_heads;
     const bool is_v = slot_h >= q_heads + kv_heads;
     if (!is_v) {
         const uint16_t* nw = is_q ? qnorm_w : knorm_w;
-        const float ss = wave_sum(x0 * x0 + x1 * x1);
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
-        const float n0 = bfround(bf2f(nw[lane]) * bfround(x0 * rstd));
-        const float n1 = bfround(bf2f(nw[lane + 64]) * bfround(x1 * rstd));
+        float w0[4], w1[4], c[4], sn[4];
+        unpack4(*reinterpret_cast<const uint2*>(nw + 4 * j), w0);
+        unpack4(*reinterpret_cast<const uint2*>(nw + 64 + 4 * j), w1);
         const int pos = positions[t];
-        const float c = bf2f(cos_sin[(size_t)pos * 128 + lane]);
-        const float s = bf2f(cos_sin[(size_t)pos * 128 + 64 + lane]);
-        x0 = bfround(bfround(n0 * c) + bfround(-n1 * s));
-        x1 = bfround(bfround(n1 * c) + bfround(n0 * s));
+        unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 4 * j), c);
+        unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 64 + 4 * j), sn);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
+        ss = sum16(ss);
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float n0 = bfround(w0[e] * bfround(x0[e] * rstd));
+            const float n1 = bfround(w1[e] * bfround(x1[e] * rstd));
+            x0[e] = bfround(bfround(n0 * c[e]) + bfround(-n1 * sn[e]));
+            x1[e] = bfround(bfround(n1 * c[e]) + bfround(n0 * sn[e]));
+        }
     }
     if (is_q) {
         uint16_t* dst = q_out + ((size_t)t * q_heads + slot_h) * 128;
-        dst[lane] = f2bf(x0);
-        dst[lane + 64] = f2bf(x1);
+        *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]));
+        *reinterpret_cast<uint2*>(dst + 64 + 4 * j) = make_uint2(pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]));
         return;
     }
     const int64_t slot = slot_mapping[t];
@@ -45,26 +69,36 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
     void* cache = is_v ? v_cache : k_cache;
     if (KV == OMNI_KV_BF16) {
         uint16_t* dst = reinterpret_cast<uint16_t*>(cache) + row * 128;
-        dst[lane] = f2bf(x0);
-        dst[lane + 64] = f2bf(x1);
+        *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]));
+        *reinterpret_cast<uint2*>(dst + 64 + 4 * j) = make_uint2(pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]));
     } else if (KV == OMNI_KV_FP8) {
         const float inv = is_v ? inv_v_scale : inv_k_scale;
         const float sc = is_v ? v_scale : k_scale;
-        // x / scale (correctly rounded divide unless scale == 1)
-        const float y0 = (inv == 1.0f) ? x0 : x0 / sc;
-        const float y1 = (inv == 1.0f) ? x1 : x1 / sc;
+        if (inv != 1.0f) {            // x / scale: correctly rounded divide
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x0[e] = x0[e] / sc; x1[e] = x1[e] / sc; }
+        }
         uint8_t* dst = reinterpret_cast<uint8_t*>(cache) + row * 128;
-        dst[lane] = (uint8_t)(pack_fp8x4(y0, 0.f, 0.f, 0.f) & 0xFF);
-        dst[lane + 64] = (uint8_t)(pack_fp8x4(y1, 0.f, 0.f, 0.f) & 0xFF);
+        *reinterpret_cast<uint32_t*>(dst + 4 * j) = pack_fp8x4(x0[0], x0[1], x0[2], x0[3]);
+        *reinterpret_cast<uint32_t*>(dst + 64 + 4 * j) = pack_fp8x4(x1[0], x1[1], x1[2], x1[3]);
     } else {
-        const float amax = fmaxf(wave_max(fmaxf(fabsf(x0), fabsf(x1))), 1e-8f);
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(x0[e]), fabsf(x1[e])));
+        const float amax = fmaxf(max16(am), 1e-8f);
         const float sc = amax / 127.0f;
-        const float y0 = fminf(fmaxf(rintf(x0 / sc), -127.f), 127.f);
-        const float y1 = fminf(fmaxf(rintf(x1 / sc), -127.f), 127.f);
+        uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int y0 = (int)fminf(fmaxf(rintf(x0[e] / sc), -127.f), 127.f);
+            const int y1 = (int)fminf(fmaxf(rintf(x1[e] / sc), -127.f), 127.f);
+            p0 |= ((uint32_t)(y0 & 0xFF)) << (8 * e);
+            p1 |= ((uint32_t)(y1 & 0xFF)) << (8 * e);
+        }
         int8_t* dst = reinterpret_cast<int8_t*>(cache) + row * 128;
-        dst[lane] = (int8_t)y0;
-        dst[lane + 64] = (int8_t)y1;
-        if (lane == 0) (is_v ? v_scales : k_scales)[row] = sc;
+        *reinterpret_cast<uint32_t*>(dst + 4 * j) = p0;
+        *reinterpret_cast<uint32_t*>(dst + 64 + 4 * j) = p1;
+        if (j == 0) (is_v ? v_scales : k_scales)[row] = sc;
     }
 }
 
@@ -80,7 +114,7 @@ extern "C" int omni_qknorm_rope_kvwrite(const void* qkv, const void* qnorm_w, co
     OMNI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f, "omni_qknorm_rope_kvwrite: scales must be > 0");
     if (T <= 0) return OMNI_OK;
     const int nslots = q_heads + 2 * kv_heads;
-    dim3 grid((nslots + 3) / 4, T), block(256);
+    dim3 grid((nslots + 15) / 16, T), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(KVT)                                                                                              \
     hipLaunchKernelGGL(qknorm_rope_kvwrite_kernel<KVT>, grid, block, 0, st, (const uint16_t*)qkv,               \

@@ -352,7 +352,7 @@ class TalkerEngine:
                 torch.distributed.all_reduce(o, group=self.tp_group)
             a = ops.rmsnorm(None, w["ln2"], d.eps, delta=o, residual=resid)
             gu = F.linear(a, w["wgu"])
-            act = F.silu(gu[:, : self.inter_l]) * gu[:, self.inter_l:]
+            act = ops.silu_mul(gu)
             delta = F.linear(act, w["wdown"])
             if self.tp_path:
                 torch.distributed.all_reduce(delta, group=self.tp_group)

@@ -47,6 +47,15 @@ def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None, layout=0, M=None):
     return out
 
 
+def silu_mul(gate_up):
+    """[T, 2I] = [gate | up] -> bf16(bf16(silu(gate)) * up) [T, I]."""
+    _chk_dev(gate_up)
+    T, two_i = gate_up.shape
+    out = torch.empty(T, two_i // 2, dtype=BF16, device=gate_up.device)
+    L.check(L.load().omni_silu_mul(L.ptr(gate_up), L.ptr(out), T, two_i // 2, L.current_stream()), "omni_silu_mul")
+    return out
+
+
 def gemm_resid(x, w_frag, r_frag, partials, *, bias=None, accumulate=True, x_frag=True, M=None):
     """In place on the fragment-major residual stream: r = bf16((r if accumulate) + bf16(x . w^T + bias)); fills
     partials[N/16, 64] (per-row sum(r^2) slabs) and returns the slab count."""

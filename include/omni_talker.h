@@ -79,6 +79,11 @@ int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void
 int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K,
                       int epilogue, const uint8_t* mask, int layout, void* stream);
 
+/* act bf16 [T, inter] = bf16(bf16(silu(gate)) * up) for gate_up bf16 [T, 2*inter] = [gate | up]: the SiluAndMul between
+ * gate_up_proj and down_proj of vLLM's Qwen3MLP, for the prefill rows whose gate_up GEMM runs on hipBLASLt (the decode
+ * GEMM fuses it as OMNI_EPI_SILU_MUL).                                                                                */
+int omni_silu_mul(const void* gate_up, void* out, int T, int inter, void* stream);
+
 /* The norm-free residual stream of the decode step: the residual r lives fragment-major ([rows16, N], frag_off) next to
  * per-row sum-of-squares slabs partials[nparts][64] fp32, so that the reference's fused_add_rms_norm launch between
  * two linears (Qwen3DecoderLayer, V/model_executor/models/qwen3_tts/qwen3_tts_talker.py:297-311 via vLLM Qwen3Model)

@@ -162,6 +162,13 @@ def test_gemm_norm_free_residual_stream(ops, M, H, K1, N2, epi):
         assert out_f.shape[0] == Mp
 
 
+def test_silu_mul(ops):
+    g = torch.Generator().manual_seed(4)
+    gu = _rand(g, 37, 2 * 3072, scale=2.0)
+    out = ops.silu_mul(gu.cuda())
+    assert_bf16_close(out, O.silu_mul(gu[:, :3072], gu[:, 3072:]), ulps=1, max_mismatch=0.02, what="silu_mul")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from ht_vllm_omni_amd import _lib as L
     x = torch.zeros(65, 64, dtype=BF16, device="cuda")
