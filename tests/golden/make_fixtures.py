@@ -242,13 +242,93 @@ def mint_kv_extract():
     print("kv extract cases:", len(cases))
 
 
+# --------------------------------------------------------------------------
+def mint_chunk_windows():
+    """Known answers of the reference's streaming window rule (stage_input_processors/qwen3_tts.py:134-270):
+    for a sweep of (codec_chunk_frames, codec_left_context_frames, per-request IC or the dynamic one under a given
+    load, accumulated frames, finished) -> None or (left_context_size, frames in the window, finished), plus the
+    full payload of a few cases with distinct frame contents and reference codes."""
+    install_vllm_stubs()
+    vo = sys.modules["vllm_omni"]
+    vo.__path__ = [V]                         # sub-packages below have empty __init__ files
+    import importlib
+    from collections import defaultdict
+    from types import SimpleNamespace
+    q3 = importlib.import_module("vllm_omni.model_executor.stage_input_processors.qwen3_tts")
+    cu = importlib.import_module("vllm_omni.model_executor.stage_input_processors.chunk_size_utils")
+
+    def tm(chunk, left, max_num_seqs):
+        return SimpleNamespace(code_prompt_token_ids=defaultdict(list), scheduler_max_num_seqs=max_num_seqs,
+                               put_req_chunk=defaultdict(int), request_payload={},
+                               connector=SimpleNamespace(config={"extra": {"codec_chunk_frames": chunk,
+                                                                           "codec_left_context_frames": left}}))
+
+    def req(rid, finished, ic):
+        ai = None
+        if ic is not None:
+            ai = SimpleNamespace(entries={"initial_codec_chunk_frames": SimpleNamespace(list_data=[ic])})
+        return SimpleNamespace(external_req_id=rid, is_finished=lambda: finished, additional_information=ai)
+
+    Q = 4
+    sweep = []
+    for chunk, left in ((25, 25), (25, 10), (25, 0), (16, 25), (8, 3), (2, 1), (1, 0)):
+        for ic in (None, 0, 1, 2, 3, 8, 10, 15, 16, 25, 30):
+            for others in ((0,) if ic is not None else (0, 2, 7)):
+                for n in list(range(0, 64)) + [100, 101]:
+                    for fin in (False, True):
+                        t = tm(chunk, left, 8)
+                        for o in range(others):
+                            t.code_prompt_token_ids[f"other-{o}"] = [[1] * Q]
+                        t.code_prompt_token_ids["r"] = [[f % 7 + 1, 2, 3, 4] for f in range(n)]
+                        pl = q3.talker2code2wav_async_chunk(transfer_manager=t, pooling_output={"audio_codes": torch.zeros((0,))},
+                                                            request=req("r", fin, ic), is_finished=fin)
+                        if pl is None:
+                            res = None
+                        else:
+                            res = [pl.get("left_context_size"), len(pl["code_predictor_codes"]) // Q if pl["code_predictor_codes"] else 0,
+                                   bool(pl["finished"])]
+                        sweep.append([chunk, left, ic, others, n, fin, res])
+    # full payloads: distinct frames, reference codes, speaker / language pass-through
+    full = []
+    for chunk, left, ic, n, fin, with_ref in ((25, 25, 10, 10, False, False), (25, 25, 10, 45, False, True), (25, 5, 8, 33, True, True),
+                                              (16, 25, 8, 24, False, False)):
+        t = tm(chunk, left, 4)
+        frames = [[(7 * f + q) % 2048 for q in range(Q)] for f in range(n)]
+        t.code_prompt_token_ids["r"] = [fr[:] for fr in frames]
+        po = {"audio_codes": torch.zeros((0,))}
+        ref = [[9, 9, 9, 9], [8, 8, 8, 8]]
+        if with_ref:
+            po["ref_code"] = torch.tensor(ref, dtype=torch.long)
+        r = req("r", fin, ic)
+        r.additional_information.entries["speaker"] = SimpleNamespace(list_data=[" Vivian "])
+        r.additional_information.entries["language"] = SimpleNamespace(list_data=["English"])
+        pl = q3.talker2code2wav_async_chunk(transfer_manager=t, pooling_output=po, request=r, is_finished=fin)
+        full.append({"chunk": chunk, "left": left, "ic": ic, "frames": frames, "finished": fin, "ref": ref if with_ref else None,
+                     "payload": {k: (bool(v) if k == "finished" else v) for k, v in pl.items()}})
+    ladder = [[a, m, mi, cu.compute_dynamic_initial_chunk_size(a, m, mi)] for a in range(0, 12) for m in (0, 1, 4, 8) for mi in (1, 2, 4, 16, 32)]
+    maxic = [[c, cu.max_ic_for_chunk_size(c)] for c in range(1, 80)]
+    # the two known answers of the non-streaming processor held by the reference's own test file
+    # (tests/model_executor/stage_input_processors/test_qwen3_tts_async_chunk.py:292-364): data only
+    nonasync = [
+        {"audio_codes": [[0, 0, 0, 0], [1, 2, 3, 4], [5, 6, 7, 8]], "ref_code": [[9, 9, 9, 9], [8, 8, 8, 8]], "n_token_ids": 3,
+         "prompt_token_ids": [9, 8, 1, 5, 9, 8, 2, 6, 9, 8, 3, 7, 9, 8, 4, 8], "additional_information": {"left_context_size": [2]}},
+        {"audio_codes": [[0, 0, 0, 0], [1, 2, 3, 4], [2150, 0, 0, 0], [5, 6, 7, 8]], "ref_code": [[9, 9, 9, 9]], "n_token_ids": 4,
+         "prompt_token_ids_len": 12, "additional_information": {"left_context_size": [1]}},
+    ]
+    json.dump({"Q": Q, "sweep": sweep, "full": full, "ladder": ladder, "max_ic": maxic, "nonasync": nonasync},
+              open(os.path.join(HERE, "chunk_windows.json"), "w"), separators=(",", ":"))
+    print("chunk window cases:", len(sweep), "emits:", sum(1 for c in sweep if c[-1] is not None))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
         mint_backbone()
     if "kv" in which:
         mint_kv_extract()
+    if "cw" in which:
+        mint_chunk_windows()

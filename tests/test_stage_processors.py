@@ -1,0 +1,148 @@
+"""Talker -> Code2Wav hand-off against known answers minted from the reference's
+stage_input_processors/qwen3_tts.py (tests/golden/make_fixtures.py cw) and the cases the reference's own
+test_qwen3_tts_async_chunk.py holds.  Host logic: runs without a GPU."""
+import json
+import os
+from collections import defaultdict
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from ht_vllm_omni_amd import stage_input_processors as SP
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "chunk_windows.json")))
+
+
+def _tm(chunk, left, max_num_seqs=8, store=list):
+    return SimpleNamespace(code_prompt_token_ids=defaultdict(store), scheduler_max_num_seqs=max_num_seqs,
+                           put_req_chunk=defaultdict(int), request_payload={},
+                           connector=SimpleNamespace(config={"extra": {"codec_chunk_frames": chunk,
+                                                                       "codec_left_context_frames": left}}))
+
+
+def _req(rid, finished, ic=None, **extra):
+    ai = None
+    if ic is not None or extra:
+        entries = {k: SimpleNamespace(list_data=[v]) for k, v in extra.items()}
+        if ic is not None:
+            entries["initial_codec_chunk_frames"] = SimpleNamespace(list_data=[ic])
+        ai = SimpleNamespace(entries=entries)
+    return SimpleNamespace(external_req_id=rid, is_finished=lambda: finished, additional_information=ai)
+
+
+@pytest.mark.parametrize("store", ["lists", "frame-buffers"])
+def test_streaming_window_sweep_matches_reference(gold, store):
+    Q = gold["Q"]
+    bad = 0
+    for chunk, left, ic, others, n, fin, res in gold["sweep"]:
+        t = _tm(chunk, left, store=list if store == "lists" else (lambda: SP.FrameBuffer(Q)))
+        for o in range(others):
+            t.code_prompt_token_ids[f"other-{o}"].append([1] * Q)
+        for f in range(n):
+            t.code_prompt_token_ids["r"].append([f % 7 + 1, 2, 3, 4])
+        pl = SP.talker2code2wav_async_chunk(t, {"audio_codes": torch.zeros((0,))}, _req("r", fin, ic), is_finished=fin)
+        got = None if pl is None else [pl.get("left_context_size"), len(pl["code_predictor_codes"]) // Q, bool(pl["finished"])]
+        if got != res:
+            bad += 1
+            assert bad < 3, f"chunk={chunk} left={left} ic={ic} others={others} n={n} finished={fin}: {got} != {res}"
+    assert bad == 0
+
+
+def test_full_payloads_match_reference(gold):
+    for case in gold["full"]:
+        t = _tm(case["chunk"], case["left"], max_num_seqs=4)
+        for fr in case["frames"]:
+            t.code_prompt_token_ids["r"].append(fr)
+        po = {"audio_codes": torch.zeros((0,))}
+        if case["ref"] is not None:
+            po["ref_code"] = torch.tensor(case["ref"], dtype=torch.long)
+        r = _req("r", case["finished"], case["ic"], speaker=" Vivian ", language="English")
+        pl = SP.talker2code2wav_async_chunk(t, po, r, is_finished=case["finished"])
+        assert pl == case["payload"]
+
+
+def test_ic_ladder_and_max_ic(gold):
+    for a, m, mi, want in gold["ladder"]:
+        assert SP.compute_dynamic_initial_chunk_size(a, m, mi) == want
+    for c, want in gold["max_ic"]:
+        assert SP.max_ic_for_chunk_size(c) == want
+
+
+def test_window_plan_is_the_rule_the_processor_applies(gold):
+    for chunk, left, ic, others, n, fin, res in gold["sweep"]:
+        if ic is None or ic < 0:
+            continue
+        plan = SP.window_plan(n, fin, chunk, left, ic)
+        if res is None or n == 0:
+            assert plan is None or n == 0
+        else:
+            end, lc = plan
+            assert [lc, end] == res[:2]
+
+
+def test_eof_marker_hold_and_errors():
+    t = _tm(25, 25)
+    assert SP.talker2code2wav_async_chunk(t, {"audio_codes": torch.zeros((0,))}, _req("r", False)) is None
+    assert SP.talker2code2wav_async_chunk(t, None, _req("r", False)) is None
+    p = SP.talker2code2wav_async_chunk(t, None, _req("r", True), is_finished=True)
+    assert p == {"code_predictor_codes": [], "finished": True}
+    with pytest.raises(ValueError):
+        SP.talker2code2wav_async_chunk(_tm(0, 25), {"audio_codes": torch.tensor([[1, 2, 3, 4]])}, _req("r", False))
+    with pytest.raises(ValueError):
+        SP.talker2code2wav_async_chunk(t, {"audio_codes": torch.zeros(1, 2, 3)}, _req("r", False))
+    # an all-zero frame (padding / EOS step) is not a codec frame
+    SP.talker2code2wav_async_chunk(t, {"audio_codes": torch.zeros(1, 4, dtype=torch.long)}, _req("z", False))
+    assert len(t.code_prompt_token_ids["z"]) == 0
+
+
+def test_non_streaming_processor_known_answers(gold):
+    for case in gold["nonasync"]:
+        out = SimpleNamespace(multimodal_output={"audio_codes": torch.tensor(case["audio_codes"]),
+                                                 "ref_code": torch.tensor(case["ref_code"])},
+                              token_ids=list(range(case["n_token_ids"])))
+        stage = SimpleNamespace(engine_outputs=[SimpleNamespace(outputs=[out], finished=True)])
+        prompts = SP.talker2code2wav(stage_list=[stage], engine_input_source=[0])
+        assert len(prompts) == 1
+        assert prompts[0]["additional_information"] == case["additional_information"]
+        if "prompt_token_ids" in case:
+            assert prompts[0]["prompt_token_ids"] == case["prompt_token_ids"]
+        else:
+            assert len(prompts[0]["prompt_token_ids"]) == case["prompt_token_ids_len"]
+    with pytest.raises(ValueError):
+        SP.talker2code2wav([], [])
+    with pytest.raises(IndexError):
+        SP.talker2code2wav([], [0])
+    with pytest.raises(RuntimeError):
+        SP.talker2code2wav([SimpleNamespace(engine_outputs=None)], [0])
+    unfinished = SimpleNamespace(engine_outputs=[SimpleNamespace(outputs=[], finished=False)])
+    assert SP.talker2code2wav([unfinished], [0]) == []
+
+
+def test_batch_streamer_equals_per_request_calls():
+    """One host copy of the step's [B, Q] codes feeding every request == the reference's per-request calls."""
+    rng = np.random.default_rng(0)
+    B, Q, steps = 5, 16, 70
+    streamer = SP.CodecChunkStreamer(codec_chunk_frames=25, codec_left_context_frames=25, max_num_seqs=8, num_quantizers=Q)
+    ref_tm = _tm(25, 25, max_num_seqs=8)
+    reqs_done_at = [70, 33, 51, 12, 64]
+    got, want = [], []
+    for s in range(steps):
+        codes = rng.integers(1, 2048, size=(B, Q))
+        codes[2] = 0 if s % 9 == 4 else codes[2]                 # an all-zero row now and then: skipped, not appended
+        live = [b for b in range(B) if s < reqs_done_at[b]]
+        reqs = [_req(f"r{b}", s == reqs_done_at[b] - 1) for b in live]
+        fin = [s == reqs_done_at[b] - 1 for b in live]
+        got += streamer.on_step(reqs, codes[live], fin)
+        for b, r, f in zip(live, reqs, fin):
+            pl = SP.talker2code2wav_async_chunk(ref_tm, {"audio_codes": torch.from_numpy(codes[b:b + 1])}, r, is_finished=f)
+            if pl is not None:
+                want.append((f"r{b}", pl))
+    assert got == want and len(got) > 10
+    assert got[-1][1]["finished"] is True
+    streamer.cleanup("r0")
+    assert "r0" not in streamer.code_prompt_token_ids
