@@ -242,10 +242,33 @@ def main():
         dt = float(tmax.item())
     ev_ms = e0.elapsed_time(e1) / args.steps
 
+    # ---- diagnostics (after the timed region): the backbone half of the step alone, as its own graph
+    bb_ms = None
+    if graph is not None and world == 1 and args.sub_batches == 1:
+        try:
+            g2 = torch.cuda.CUDAGraph()
+            eng.backbone_step(B)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g2):
+                eng.backbone_step(B)
+            g2.replay()
+            torch.cuda.synchronize()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
+            for _ in range(32):
+                g2.replay()
+            b1.record()
+            torch.cuda.synchronize()
+            bb_ms = b0.elapsed_time(b1) / 32
+        except Exception as e:   # noqa: BLE001
+            log(f"backbone-only diagnostic failed: {e!r}")
+
     # ---- roofline: algorithmic bytes of one step (each counted once) / measured step time
     mean_ctx = ctx0 + (args.steps - 1) / 2.0
     by = eng.step_bytes(mean_ctx)
     achieved = by["total"] / (ev_ms * 1e-3) / 1e9
+    end_ctx = ctx0 + args.steps
+    by_end = eng.step_bytes(end_ctx) if bb_ms is not None else None
     out = {
         "metric": "speech-tokens/sec", "value": B * args.steps / dt, "unit": "speech-tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -262,6 +285,13 @@ def main():
                      "launch": "one hipGraph replay = one decode step (per TP rank)", "event_ms_per_step": ev_ms,
                      "bytes_per_step": by},
     }
+    if bb_ms is not None:
+        bb_bytes = by_end["weights_backbone"] + by_end["lm_head"] + by_end["kv_read"] + by_end["kv_write"]
+        out["roofline"]["breakdown"] = {
+            "note": "diagnostic, outside the timed region: the backbone half (28 layers + lm_head + sampler) replayed alone "
+                    "at the final context; code predictor + input assembly = step - backbone",
+            "backbone_ms": bb_ms, "code_predictor_ms": ev_ms - bb_ms, "backbone_ctx": float(np.mean(end_ctx)),
+            "backbone_gbs": bb_bytes / (bb_ms * 1e-3) / 1e9, "backbone_frac": bb_bytes / (bb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0:
         # HBM bytes per step from the PMC passes (rocprofv3 cannot ride along with a timed run: separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary committed under profiles/)

@@ -321,6 +321,18 @@ class TalkerEngine:
             dist.all_reduce(self._mlp_out[:B], group=self.tp_group)
         L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
 
+    def backbone_step(self, B: int) -> None:
+        """Diagnostics: the backbone half of a decode step alone (28 layers + lm_head + sampler, no code predictor /
+        input assembly, positions not advanced) on whatever residual stream the last step left -- timing only."""
+        if self.tp_path:
+            raise L.OmniError("backbone_step: single-rank diagnostic")
+        io = self._io(B, False)
+        st = L.current_stream()
+        for l in range(self.d.layers):
+            L.check(self.lib.omni_talker_layer_attn(self.handle, C.byref(io), l, st), "omni_talker_layer_attn")
+            L.check(self.lib.omni_talker_layer_mlp(self.handle, C.byref(io), l, st), "omni_talker_layer_mlp")
+        L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
+
     def prefill_blas(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
                      block_table: torch.Tensor | None = None) -> torch.Tensor:
         """Prefill with the four plain per-layer GEMMs on hipBLASLt (torch.nn.functional.linear; bf16 in, fp32
