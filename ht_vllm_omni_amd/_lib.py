@@ -53,7 +53,7 @@ class StepIO(C.Structure):
         ("seen", vp), ("steps", vp),
         ("greedy", i32), ("temperature", f32), ("top_k", i32), ("rep_penalty", f32), ("seed", u32),
         ("cp_greedy", i32), ("cp_temperature", f32), ("cp_top_k", i32),
-        ("advance", i32),
+        ("advance", i32), ("top_p", f32), ("cp_top_p", f32),
     ]
 
 
@@ -75,7 +75,7 @@ SIGNATURES = {
     "omni_paged_attn_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "omni_paged_attn_prefill": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp]),
     "omni_embed": (i32, [vp, vp, vp, i32, i32, i32, vp]),
-    "omni_sample": (i32, [vp, i32, i32, i32, i32, f32, i32, f32, vp, u32, vp, i32, i32, i32, vp, vp]),
+    "omni_sample": (i32, [vp, i32, i32, i32, i32, f32, i32, f32, f32, vp, u32, vp, i32, i32, i32, vp, vp]),
     "omni_talker_scratch_bytes": (i64, [C.POINTER(TalkerDesc)]),
     "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
     "omni_talker_destroy": (None, [vp]),
@@ -92,7 +92,7 @@ SIGNATURES = {
     "omni_talker_rows_mlp": (i32, [vp, i32, i32, vp]),
     "omni_talker_rows_end": (i32, [vp, vp, i32, vp]),
     "omni_talker_logits": (i32, [vp, vp, vp, i32, i32, vp]),
-    "omni_talker_code_predictor": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, u32, vp, vp]),
+    "omni_talker_code_predictor": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u32, vp, vp]),
 }
 
 _lib = None

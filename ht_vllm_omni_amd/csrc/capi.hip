@@ -400,7 +400,7 @@ static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, vo
 // codes int32 [B,Q] in t->codes (column 0 untouched); cp_logits fp32 [B,Q-1,codebook] optional.
 // layer0_ids != NULL and d.cp_e0_table: position-1 input is gathered from the folded table instead of projected.
 static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed, const void* last_hidden,
-                              int B, int greedy, float temperature, int top_k, uint32_t seed, int32_t* steps,
+                              int B, int greedy, float temperature, int top_k, float top_p, uint32_t seed, int32_t* steps,
                               float* cp_logits_out, void* st) {
     const omni_talker_desc& d = t->d;
     const int Q = d.num_code_groups, Hc = d.cp_hidden;
@@ -429,7 +429,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
             const bool more = g < Q - 1;
             const uint16_t* ptab = (more && d.cp_proj_table)
                                        ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
-            TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q,
+            TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, top_p, 1.0f, nullptr, seed, steps, Q,
                                 g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, ptab ? t->cp_part : nullptr, st));
             if (ptab) np = 1;
             if (more && !ptab) {
@@ -462,7 +462,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         const bool more = g < Q - 1;
         const uint16_t* ptab = (more && d.cp_proj_table)
                                    ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
-        TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, 1.0f, nullptr, seed, steps, Q,
+        TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, top_p, 1.0f, nullptr, seed, steps, Q,
                             g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, nullptr, st));
         if (more && !ptab) {
             const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
@@ -475,7 +475,8 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
 
 extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed,
                                           const void* last_hidden, int64_t* codes, float* cp_logits, int B, int greedy,
-                                          float temperature, int top_k, uint32_t seed, const int32_t* steps, void* stream) {
+                                          float temperature, int top_k, float top_p, uint32_t seed, const int32_t* steps,
+                                          void* stream) {
     OMNI_CHECK_ARG(t && layer0_ids && layer0_embed && last_hidden && codes, "omni_talker_code_predictor: null pointer");
     OMNI_CHECK_ARG(B >= 1 && B <= t->Bm, "omni_talker_code_predictor: B=%d", B);
     const int Q = t->d.num_code_groups;
@@ -483,7 +484,7 @@ extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_
     hipError_t e = hipMemcpy2DAsync(t->codes, (size_t)Q * 4, layer0_ids, 4, 4, B, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { omni_set_error("code_predictor: memcpy2D: %s", hipGetErrorString(e)); return OMNI_EHIP; }
     // explicit layer0_embed given: project it (parity entry point; the folded e0 table is the step path)
-    TRY(run_code_predictor(t, nullptr, layer0_embed, last_hidden, B, greedy, temperature, top_k, seed,
+    TRY(run_code_predictor(t, nullptr, layer0_embed, last_hidden, B, greedy, temperature, top_k, top_p, seed,
                            const_cast<int32_t*>(steps), cp_logits, stream));
     hipLaunchKernelGGL(copy_i32_to_i64_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, st, t->codes, codes, B * Q);
     OMNI_CHECK_LAUNCH("copy_i32_to_i64");
@@ -497,7 +498,7 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
     hipStream_t st = (hipStream_t)stream;
     // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640): gathered only when no folded table
     if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
-    TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k,
+    TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->cp_top_p,
                            io->seed, io->steps, nullptr, stream));
     hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, (const uint16_t*)d.embed,
                        d.vocab, (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds,
@@ -597,7 +598,7 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     else
     TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
                   io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
-    TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->rep_penalty, io->seen, io->seed,
+    TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->top_p, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream));
     if (io->advance) {
         hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, io->positions, io->seq_lens, B);

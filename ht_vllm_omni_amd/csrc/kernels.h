@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
+int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
              int out_stride, void* stream);
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
@@ -11,7 +11,7 @@ int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, in
 int k_gather_frag(const int32_t* ids, int ids_stride, const void* table, void* r_out, float* part_out, int T, int hidden,
                   int vocab, void* stream);
 // sampler with optional fused gather: gather_out[b] = gather_table[picked id] (bf16 rows of gather_dim)
-int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part /* != NULL: gather_out fragment-major + sum-of-squares slab 0 */,

@@ -32,8 +32,10 @@ __device__ __forceinline__ int block_argmax(float v, int idx, float* sval, int* 
     return bi;
 }
 
+#define SMP_PCAP 1024      // top-p candidate capacity (top_k + ties at the threshold)
+
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __restrict__ logits, int ld, int V, int greedy,
-                                                             float temperature, int top_k, float rep_penalty,
+                                                             float temperature, int top_k, float top_p, float rep_penalty,
                                                              uint8_t* __restrict__ seen, uint32_t seed,
                                                              int32_t* __restrict__ steps, int step_mul, int step_add,
                                                              int inc_steps, int32_t* __restrict__ out_ids, int out_stride,
@@ -105,6 +107,45 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
             const uint32_t kb = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
             kth = __uint_as_float(kb);
         }
+        if (top_p > 0.f && top_p < 1.f && top_k > 0 && top_k < V) {
+            // ---- nucleus cut among the top-k candidates {x >= kth}: candidate i stays iff the softmax mass of the
+            // candidates that sort before it (value desc, index asc) is < top_p.  Candidates are compacted in a fixed
+            // order (thread-major) so the sums are run-to-run deterministic; n <= top_k + ties, O(n^2 / 256) per thread.
+            __shared__ float cval[SMP_PCAP];
+            __shared__ int cidx[SMP_PCAP];
+            __shared__ int coff[SMP_THREADS + 1];
+            int cnt = 0;
+            for (int i = threadIdx.x; i < V; i += SMP_THREADS) cnt += (row[i] >= kth && row[i] > -INFINITY) ? 1 : 0;
+            coff[threadIdx.x + 1] = cnt;
+            if (threadIdx.x == 0) coff[0] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int t = 1; t <= SMP_THREADS; ++t) coff[t] += coff[t - 1];
+            __syncthreads();
+            int o = coff[threadIdx.x];
+            const int n = min(coff[SMP_THREADS], SMP_PCAP);
+            for (int i = threadIdx.x; i < V; i += SMP_THREADS)
+                if (row[i] >= kth && row[i] > -INFINITY) {
+                    if (o < SMP_PCAP) { cval[o] = row[i]; cidx[o] = i; }
+                    ++o;
+                }
+            __syncthreads();
+            float mx = -INFINITY;
+            for (int j = 0; j < n; ++j) mx = fmaxf(mx, cval[j]);
+            float z = 0.f;
+            for (int j = 0; j < n; ++j) z += expf(cval[j] - mx);
+            // the kept set is a prefix of the sorted order: find the smallest kept value (and, among equal values, the
+            // largest kept index) = the cut; every thread tests its candidates
+            for (int c = threadIdx.x; c < n; c += SMP_THREADS) {
+                const float v = cval[c];
+                const int vi = cidx[c];
+                float before = 0.f;
+                for (int j = 0; j < n; ++j)
+                    if (cval[j] > v || (cval[j] == v && cidx[j] < vi)) before += expf(cval[j] - mx);
+                if (before / z >= top_p) row[vi] = -INFINITY;        // removed from the row the Gumbel stage reads
+            }
+            __syncthreads();
+        }
         const uint32_t step = (uint32_t)(steps ? steps[b] * step_mul + step_add : step_add);
         float bv = -INFINITY;
         int bi = 0x7FFFFFFF;
@@ -152,7 +193,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     }
 }
 
-int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part, void* stream) {
@@ -160,26 +201,28 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
     OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
     OMNI_CHECK_ARG(rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
+    OMNI_CHECK_ARG(greedy || !(top_p > 0.f && top_p < 1.f) || (top_k > 0 && top_k <= SMP_PCAP),
+                   "omni_sample: top_p needs 0 < top_k <= %d (got top_k=%d)", SMP_PCAP, top_k);
     OMNI_CHECK_ARG(!gather_table || (gather_out && gather_dim % 8 == 0), "omni_sample: bad gather arguments");
     OMNI_CHECK_ARG(!gather_part || (gather_table && gather_dim % 32 == 0), "omni_sample: bad fragment-major gather arguments");
     if (B <= 0) return OMNI_OK;
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,
-                       temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids,
+                       temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids,
                        out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part);
     OMNI_CHECK_LAUNCH("omni_sample");
     return OMNI_OK;
 }
 
-int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float rep_penalty,
+int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
              int out_stride, void* stream) {
-    return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add,
+    return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
                            inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream);
 }
 
-extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                            float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                            int inc_steps, int32_t* out_ids, void* stream) {
-    return k_sample(logits, ld, B, V, greedy, temperature, top_k, rep_penalty, seen, seed, steps, step_mul, step_add,
+    return k_sample(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
                     inc_steps, out_ids, 1, stream);
 }

@@ -249,8 +249,8 @@ class TalkerEngine:
         self.logits = z(Bm, d.vocab, dt=torch.float32)
         self.seen = z(Bm, d.vocab, dt=torch.uint8)
         self.steps = z(Bm, dt=torch.int32)
-        self.sampling = dict(greedy=1, temperature=1.0, top_k=0, rep_penalty=1.0, seed=0, cp_greedy=1,
-                             cp_temperature=0.9, cp_top_k=50)
+        self.sampling = dict(greedy=1, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seed=0, cp_greedy=1,
+                             cp_temperature=0.9, cp_top_k=50, cp_top_p=1.0)
         self._attn_out = self._scratch_view(self.lib.omni_talker_attn_out(self.handle), Bm * H).view(Bm, H)
         self._mlp_out = self._scratch_view(self.lib.omni_talker_mlp_out(self.handle), Bm * H).view(Bm, H)
 
@@ -282,6 +282,7 @@ class TalkerEngine:
         io.rep_penalty, io.seed = float(s["rep_penalty"]), int(s["seed"]) & 0xFFFFFFFF
         io.cp_greedy, io.cp_temperature, io.cp_top_k = int(s["cp_greedy"]), float(s["cp_temperature"]), int(s["cp_top_k"])
         io.advance = int(advance)
+        io.top_p, io.cp_top_p = float(s.get("top_p", 1.0)), float(s.get("cp_top_p", 1.0))
         return io
 
     def decode_step(self, B: int, advance: bool = True) -> None:
@@ -408,13 +409,13 @@ class TalkerEngine:
                                             L.current_stream()), "omni_talker_logits")
         return out
 
-    def sample(self, logits: torch.Tensor, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0,
+    def sample(self, logits: torch.Tensor, *, greedy, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seen=None, seed=0,
                steps=None) -> torch.Tensor:
         """Sampler on arbitrary logits rows (first token after prefill); marks `seen`, increments `steps`."""
-        return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, rep_penalty=rep_penalty, seen=seen,
+        return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, top_p=top_p, rep_penalty=rep_penalty, seen=seen,
                           seed=seed, steps=steps, inc_steps=steps is not None)
 
-    def code_predictor(self, layer0_ids, layer0_embed, last_hidden, *, greedy=True, temperature=0.9, top_k=50, seed=0,
+    def code_predictor(self, layer0_ids, layer0_embed, last_hidden, *, greedy=True, temperature=0.9, top_k=50, top_p=1.0, seed=0,
                        steps=None, return_logits=False):
         B = layer0_ids.shape[0]
         Q = self.d.num_code_groups
@@ -422,7 +423,7 @@ class TalkerEngine:
         lg = torch.empty(B, Q - 1, self.d.codebook, dtype=torch.float32, device=self.device) if return_logits else None
         L.check(self.lib.omni_talker_code_predictor(
             self.handle, L.ptr(layer0_ids), L.ptr(layer0_embed), L.ptr(last_hidden), L.ptr(codes), L.ptr(lg), B,
-            int(greedy), float(temperature), int(top_k), int(seed) & 0xFFFFFFFF, L.ptr(steps), L.current_stream()),
+            int(greedy), float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFF, L.ptr(steps), L.current_stream()),
             "omni_talker_code_predictor")
         return (codes, lg) if return_logits else codes
 

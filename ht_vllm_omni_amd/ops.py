@@ -168,13 +168,13 @@ def embed(ids, table):
     return out
 
 
-def sample(logits, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0, steps=None, step_mul=1,
+def sample(logits, *, greedy, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seen=None, seed=0, steps=None, step_mul=1,
            step_add=0, inc_steps=False):
     _chk_dev(logits, seen, steps)
     B, V = logits.shape
     out = torch.empty(B, dtype=torch.int32, device=logits.device)
     L.check(L.load().omni_sample(L.ptr(logits), logits.stride(0), B, V, int(greedy), float(temperature), int(top_k),
-                                 float(rep_penalty), L.ptr(seen), int(seed) & 0xFFFFFFFF, L.ptr(steps), step_mul,
+                                 float(top_p), float(rep_penalty), L.ptr(seen), int(seed) & 0xFFFFFFFF, L.ptr(steps), step_mul,
                                  step_add, int(inc_steps), L.ptr(out), L.current_stream()), "omni_sample")
     return out
 

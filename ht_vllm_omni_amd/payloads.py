@@ -22,6 +22,7 @@ class SamplingParams:
     """Subset of vLLM SamplingParams the talker stage sets (stage_configs/qwen3_tts.yaml:27-34)."""
     temperature: float = 0.9
     top_k: int = 50
+    top_p: float = 1.0
     repetition_penalty: float = 1.05
     seed: int | None = 42
     max_tokens: int = 4096

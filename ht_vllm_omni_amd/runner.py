@@ -243,7 +243,7 @@ class MI355XARModelRunner:
 
     def _apply_sampling(self, sp: SamplingParams) -> None:
         self.engine.set_sampling(greedy=int(sp.greedy), temperature=sp.temperature or 1.0, top_k=sp.top_k,
-                                 rep_penalty=sp.repetition_penalty, seed=sp.seed or 0)
+                                 top_p=sp.top_p, rep_penalty=sp.repetition_penalty, seed=sp.seed or 0)
 
     def _sample_prefill(self, rows: list[int], logits: torch.Tensor) -> torch.Tensor:
         e = self.engine
@@ -253,7 +253,7 @@ class MI355XARModelRunner:
         seen[:, self.d.codec_pad_id] = 1       # prompt ids are codec_pad placeholders (talker.py:603-605)
         steps = torch.zeros(len(rows), dtype=torch.int32, device=logits.device)
         ids = e.sample(logits, greedy=sp.greedy, temperature=sp.temperature or 1.0, top_k=sp.top_k,
-                       rep_penalty=sp.repetition_penalty, seen=seen, seed=sp.seed or 0, steps=steps)
+                       top_p=sp.top_p, rep_penalty=sp.repetition_penalty, seen=seen, seed=sp.seed or 0, steps=steps)
         e.seen[idx] = seen
         e.steps[idx] = steps
         return ids

@@ -158,10 +158,12 @@ int omni_embed(const int32_t* ids, const void* table, void* out, int T, int hidd
 /* Sampler (vLLM Sampler reached at gpu_ar_model_runner.py:455; params
  * V/model_executor/stage_configs/qwen3_tts.yaml:27-34).  logits fp32 [B, ld]; V columns used.
  *   greedy != 0 : first argmax.  Otherwise: repetition penalty over seen[B,V] (uint8, may be
- *   NULL) -> /temperature -> top-k (ties kept) -> Gumbel-max with the hash RNG of the oracle
- *   keyed by (seed, steps[b], column).  out_ids int32 [B]; if seen != NULL the sampled id is
+ *   NULL) -> /temperature -> top-k (ties kept) -> top-p (0 < top_p < 1: of the candidates sorted by
+ *   (value desc, index asc) keep those whose preceding cumulative softmax mass is < top_p, the rule of
+ *   qwen3_omni_moe_code_predictor_mtp.py:463-469; needs 0 < top_k <= 1024) -> Gumbel-max with the hash
+ *   RNG of the oracle keyed by (seed, steps[b], column).  out_ids int32 [B]; if seen != NULL the sampled id is
  *   marked.  steps int32 [B] (device) is incremented when inc_steps != 0.                     */
-int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k,
+int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                 float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul,
                 int step_add, int inc_steps, int32_t* out_ids, void* stream);
 
@@ -248,6 +250,7 @@ typedef struct omni_step_io {
     int cp_greedy;                /* code predictor sub-steps                               */
     float cp_temperature; int cp_top_k;
     int advance;                  /* !=0: positions/seq_lens += 1 after the step (on device)*/
+    float top_p, cp_top_p;        /* nucleus cut after top-k (>= 1 or <= 0: off)            */
 } omni_step_io;
 
 /* The four phases of one decode step.  With TP > 1 the host
@@ -290,7 +293,7 @@ int omni_talker_logits(omni_talker* t, const void* hidden, float* logits, int R,
  * (qwen3_tts_code_predictor_vllm.py:480-561).  cp_logits fp32 [B,Q-1,codebook] or NULL.     */
 int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed,
                                const void* last_hidden, int64_t* codes, float* cp_logits, int B,
-                               int greedy, float temperature, int top_k, uint32_t seed,
+                               int greedy, float temperature, int top_k, float top_p, uint32_t seed,
                                const int32_t* steps, void* stream);
 
 #ifdef __cplusplus

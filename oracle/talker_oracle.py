@@ -247,9 +247,25 @@ def hash_uniform(seed: int, step: int, idx: np.ndarray) -> np.ndarray:
     return ((x >> M(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
 
 
-def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, top_k: int = 0,
+def top_p_filter(x: torch.Tensor, top_p: float) -> torch.Tensor:
+    """Nucleus cut of qwen3_omni_moe_code_predictor_mtp.py:463-469 on a (top-k-masked) fp32 row: sort by
+    (value desc, index asc), drop every entry whose PRECEDING cumulative softmax mass is >= top_p."""
+    if not (0.0 < top_p < 1.0):
+        return x
+    order = sorted(range(x.numel()), key=lambda i: (-float(x[i]), i))
+    xs = x[order].to(torch.float64)
+    p = torch.softmax(xs, dim=-1)
+    before = torch.cumsum(p, dim=-1) - p
+    out = x.clone()
+    drop = [order[j] for j in range(len(order)) if float(before[j]) >= top_p]
+    if drop:
+        out[torch.as_tensor(drop, dtype=torch.long)] = float("-inf")
+    return out
+
+
+def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
                rep_penalty: float = 1.0, seen_ids=None, seed: int = 0, step: int = 0) -> int:
-    """One row. Order: repetition penalty -> temperature -> top-k -> softmax ->
+    """One row. Order: repetition penalty -> temperature -> top-k -> top-p -> softmax ->
     Gumbel-max, equivalent in distribution to vLLM's argmax(probs / Exp(1)) (SURVEY Appendix A
     'Sampler order'; vLLM's generator stream is not reproducible here).  Greedy = first argmax."""
     x = logits.to(torch.float32).clone()
@@ -263,6 +279,7 @@ def sample_row(logits: torch.Tensor, *, greedy: bool, temperature: float = 1.0, 
     if top_k and top_k < x.numel():
         kth = torch.topk(x, top_k).values[-1]
         x = x.masked_fill(x < kth, float("-inf"))
+    x = top_p_filter(x, top_p)
     # Gumbel-max: argmax(x + g), g = -log(-log u)  ==  argmax(softmax(x) / Exp(1)) in distribution
     xn = x.numpy().astype(np.float32)
     u = hash_uniform(seed, step, np.arange(xn.shape[0]))
@@ -282,6 +299,7 @@ def sample_row_margin(logits: torch.Tensor, **kw) -> float:
     if top_k and top_k < x.numel():
         kth = torch.topk(x, top_k).values[-1]
         x = x.masked_fill(x < kth, float("-inf"))
+    x = top_p_filter(x, kw.get("top_p", 1.0))
     xn = x.numpy().astype(np.float32)
     u = hash_uniform(kw.get("seed", 0), kw.get("step", 0), np.arange(xn.shape[0]))
     score = np.where(np.isfinite(xn), xn - np.log(-np.log(u)).astype(np.float32), -np.inf)
@@ -411,7 +429,7 @@ class TalkerOracle:
         return linear(x, self.w["cp.proj_w"], self.w["cp.proj_b"])
 
     def code_predictor(self, layer0_code: torch.Tensor, layer0_embed: torch.Tensor, last_hidden: torch.Tensor,
-                       *, do_sample: bool = False, temperature: float = 0.9, top_k: int = 50,
+                       *, do_sample: bool = False, temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
                        seed: int = 0, step: int = 0, return_logits: bool = False):
         """layer0_code [B] int64, layer0_embed [B,H] bf16, last_hidden [B,H] bf16 -> all_codes [B,Q].
         Sampling uses this oracle's hash RNG (the reference uses torch.multinomial on the
@@ -431,7 +449,7 @@ class TalkerOracle:
             if do_sample and temperature > 0:
                 st = step if hasattr(step, "__len__") else [step] * B
                 nxt = torch.tensor([sample_row(logits[b], greedy=False, temperature=max(temperature, 1e-6),
-                                               top_k=top_k, seed=seed, step=int(st[b]) * Q + g) for b in range(B)])
+                                               top_k=top_k, top_p=top_p, seed=seed, step=int(st[b]) * Q + g) for b in range(B)])
             else:
                 nxt = logits.argmax(-1)
             codes[:, g] = nxt

@@ -42,7 +42,7 @@ class FakeEngine:
             lg[i, 1 + int(hidden[i, 0].float().abs().item() * 8) % (self.d.codebook - 1)] = 0.0
         return lg
 
-    def sample(self, logits, *, greedy, temperature=1.0, top_k=0, rep_penalty=1.0, seen=None, seed=0, steps=None):
+    def sample(self, logits, *, greedy, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seen=None, seed=0, steps=None):
         ids = logits.argmax(-1).to(torch.int32)
         if seen is not None:
             seen[torch.arange(len(ids)), ids.long()] = 1

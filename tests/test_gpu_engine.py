@@ -92,6 +92,33 @@ def test_code_predictor_16_groups_dense_cache_path():
     assert_e2e_close(lg.cpu()[keep], ref_lg[keep], mean_tol=3e-3, max_ulps=3, what="16-group code predictor logits")
 
 
+def test_code_predictor_omni_style_no_projection_top_p():
+    """The Omni talker's predictor (qwen3_omni_moe_code_predictor_mtp.py:405-482): no small_to_mtp projection
+    (predictor width == talker width, as in the 0.6B TTS config too), growing sequence (== the KV-cached form), T = 1,
+    top-k 50 then top-p 0.8.  Greedy logits against the oracle, sampled codes with the shared hash RNG."""
+    d = get_dims("tts-0.6b").with_(layers=1, cp_layers=2, max_model_len=256)
+    assert not d.has_cp_projection and d.num_code_groups == 16
+    w = make_weights(d, seed=13, std=0.02)
+    B = 12
+    eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=16)
+    orc = O.TalkerOracle(d, w)
+    g = torch.Generator().manual_seed(B)
+    code0 = torch.randint(1, d.codebook, (B,), generator=g)
+    e0 = w["embed"][code0]
+    lh = torch.randn(B, d.hidden, generator=g).to(BF16)
+    codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
+    ref_codes, ref_lg = orc.code_predictor(code0, e0, lh, do_sample=False, return_logits=True)
+    assert_e2e_close(lg.cpu()[:, 0], ref_lg[:, 0], mean_tol=1.5e-3, what="no-projection predictor logits, group 1")
+    assert (codes.cpu()[:, 1] == ref_codes[:, 1]).float().mean().item() >= 0.9
+    steps = torch.full((B,), 3, dtype=torch.int32)
+    kw = dict(temperature=1.0, top_k=50, top_p=0.8, seed=11)
+    got = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=False, steps=steps.cuda(), **kw).cpu()
+    ref = orc.code_predictor(code0, e0, lh, do_sample=True, step=3, **kw)
+    # a flipped pick changes the rest of that row: compare the first sampled group, then whole-row agreement
+    assert (got[:, 1] == ref[:, 1]).float().mean().item() >= 0.9, "first sampled group"
+    assert (got == ref).all(dim=1).float().mean().item() >= 0.5, "whole rows"
+
+
 def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_blocks=64, graph=False, seed=0,
               mean_tol=4e-3, engine_kw=None):
     """Prefill + n_steps decode steps on GPU engine and oracle; returns per-step records."""

@@ -500,3 +500,32 @@ def test_sampler_topk_gumbel(ops, V, top_k):
     if top_k:
         kth = torch.topk(logits, top_k, dim=-1).values[:, -1]
         assert (logits[torch.arange(B), out.long()] >= kth).all(), "sample outside the top-k set"
+
+
+@pytest.mark.parametrize("V,top_k,top_p,scale", [(2048, 50, 0.8, 3.0), (2048, 50, 0.8, 0.3), (3072, 20, 0.5, 2.0), (192, 8, 0.95, 1.0),
+                                                 (2048, 50, 0.05, 3.0)])
+def test_sampler_top_p_after_top_k(ops, V, top_k, top_p, scale):
+    """Nucleus cut of the Omni code predictor (qwen3_omni_moe_code_predictor_mtp.py:463-469): top-k, then keep the
+    candidates whose preceding cumulative softmax mass is < top_p, then sample among them."""
+    g = torch.Generator().manual_seed(V + top_k + int(100 * top_p))
+    B = 64
+    logits = (torch.randn(B, V, generator=g) * scale)
+    logits[3, :40] = 1.5                                  # a block of exact ties inside the candidate set
+    steps = torch.arange(B, dtype=torch.int32)
+    kw = dict(temperature=1.0, top_k=top_k, top_p=top_p, seed=7)
+    out = ops.sample(logits.cuda(), greedy=False, steps=steps.cuda(), step_mul=1, step_add=0, **kw).cpu()
+    n_checked = 0
+    for b in range(B):
+        okw = dict(greedy=False, step=int(steps[b]), **kw)
+        kept = torch.isfinite(O.top_p_filter(logits[b].masked_fill(logits[b] < torch.topk(logits[b], top_k).values[-1], float("-inf")), top_p))
+        assert kept[out[b].item()], f"row {b}: sampled id outside the nucleus"
+        if O.sample_row_margin(logits[b], **okw) < 1e-4:
+            continue
+        assert out[b].item() == O.sample_row(logits[b], **okw), b
+        n_checked += 1
+    assert n_checked >= B - 4
+    # top_p without a usable top-k is refused, not silently ignored
+    from ht_vllm_omni_amd import _lib as L
+    with pytest.raises(L.OmniError):
+        ops.sample(logits.cuda(), greedy=False, temperature=1.0, top_k=0, top_p=0.8)
+
