@@ -373,6 +373,9 @@ class CodecChunkStreamer:
         self.put_req_chunk = defaultdict(int)
         self.scheduler_max_num_seqs = max_num_seqs
         self.connector = connector if connector is not None else _Cfg(codec_chunk_frames, codec_left_context_frames)
+        if connector is not None and not isinstance(getattr(connector, "config", None), dict):
+            connector.config = {"extra": {"codec_chunk_frames": codec_chunk_frames,
+                                          "codec_left_context_frames": codec_left_context_frames}}
 
     def on_step(self, requests: list[Any], audio_codes, finished: list[bool] | None = None, ref_codes: dict | None = None):
         codes = audio_codes.cpu().numpy() if isinstance(audio_codes, torch.Tensor) else np.asarray(audio_codes)
@@ -387,9 +390,28 @@ class CodecChunkStreamer:
                 self.request_payload[rid] = torch.as_tensor(ref_codes[rid]).to(torch.long).cpu().contiguous()
             payload = talker2code2wav_async_chunk(self, {}, req, is_finished=fin)
             if payload is not None:
-                self.put_req_chunk[rid] += 1
                 out.append((rid, payload))
         return out
+
+    def send_step(self, requests: list[Any], audio_codes, finished: list[bool] | None = None, *, stage_id: int = 0,
+                  ref_codes: dict | None = None) -> list[str]:
+        """on_step + the SHM hop: every due payload goes to `connector.put` under the reference's chunk key
+        `{external_req_id}_{stage_id}_{chunk_id}` (chunk_transfer_adapter.py:207-240); the per-request chunk counter
+        advances only on a successful put; a finished request's state is dropped.  Returns the keys that were put."""
+        keys = []
+        fin_of = {}
+        for b, req in enumerate(requests):
+            fin_of[req.external_req_id] = bool(finished[b]) if finished is not None else bool(req.is_finished())
+        for rid, payload in self.on_step(requests, audio_codes, finished, ref_codes):
+            key = f"{rid}_{stage_id}_{self.put_req_chunk[rid]}"
+            ok, _, _ = self.connector.put(from_stage=str(stage_id), to_stage=str(stage_id + 1), put_key=key, data=payload)
+            if ok:
+                self.put_req_chunk[rid] += 1
+                keys.append(key)
+        for rid, fin in fin_of.items():
+            if fin:
+                self.cleanup(rid)
+        return keys
 
     def cleanup(self, request_id) -> None:
         self.code_prompt_token_ids.pop(request_id, None)

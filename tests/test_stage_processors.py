@@ -146,3 +146,33 @@ def test_batch_streamer_equals_per_request_calls():
     assert got[-1][1]["finished"] is True
     streamer.cleanup("r0")
     assert "r0" not in streamer.code_prompt_token_ids
+
+
+@pytest.mark.parametrize("kind", ["inproc", "shm"])
+def test_streamer_sends_chunks_through_the_connector(kind):
+    """Talker side puts `{req}_{stage}_{chunk}` payloads, the Code2Wav side gets them back intact (SHM hop)."""
+    from ht_vllm_omni_amd.connectors import OmniConnectorFactory
+    conn = OmniConnectorFactory.create_connector("InProcConnector" if kind == "inproc" else "SharedMemoryConnector", {})
+    st = SP.CodecChunkStreamer(codec_chunk_frames=25, codec_left_context_frames=25, max_num_seqs=1, num_quantizers=16, connector=conn)
+    rng = np.random.default_rng(1)
+    frames = rng.integers(1, 2048, size=(40, 16))
+    keys, metas = [], {}
+    orig_put = conn.put
+
+    def put(from_stage, to_stage, put_key, data):
+        r = orig_put(from_stage, to_stage, put_key, data)
+        metas[put_key] = r[2]
+        return r
+    conn.put = put
+    for s in range(40):
+        keys += st.send_step([_req("rq", s == 39)], frames[s:s + 1], [s == 39], stage_id=0)
+    # max_num_seqs = 1, one active request -> IC = 16: chunks at 16 frames, then 16 + 25 = 41 > 40 -> flushed at finish
+    assert keys == ["rq_0_0", "rq_0_1"]
+    got0, _ = conn.get("0", "1", "rq_0_0", metadata=metas["rq_0_0"])
+    got1, _ = conn.get("0", "1", "rq_0_1", metadata=metas["rq_0_1"])
+    assert got0["left_context_size"] == 0 and got0["finished"] is False
+    assert got0["code_predictor_codes"] == frames[:16].T.reshape(-1).tolist()
+    assert got1["finished"] is True and got1["left_context_size"] == 16
+    assert got1["code_predictor_codes"] == frames[40 - (16 + 24):40].T.reshape(-1).tolist()
+    assert "rq" not in st.code_prompt_token_ids and "rq" not in st.put_req_chunk
+    conn.close()
