@@ -226,3 +226,25 @@ def test_shard_layer_partitions_weights():
     parts = [shard_layer(d, w, "l0.", r, 4) for r in range(4)]
     D = d.head_dim
     assert torch.equal(parts[0]["wqkv"][D:2 * D], parts[1]["wqkv"][D:2 * D]) and not torch.equal(parts[0]["wqkv"][D:2 * D], parts[2]["wqkv"][D:2 * D])
+
+
+def test_mrope_positions_text_only_and_collapse():
+    """Row a14: text-only M-RoPE ids = three identical aranges, delta 0 (mrope.py:196-203), sliced by context_len / seq_len."""
+    import pytest
+    import torch
+    from ht_vllm_omni_amd import positions as P
+    pos, delta = P.get_input_positions_tensor(list(range(100, 107)))
+    assert delta == 0 and pos.shape == (3, 7) and pos.dtype == torch.int64
+    assert pos.tolist() == [list(range(7))] * 3
+    pos2, _ = P.get_input_positions_tensor([5] * 10, context_len=4, seq_len=9)
+    assert pos2.tolist() == [[4, 5, 6, 7, 8]] * 3
+    assert P.get_input_positions([1, 2, 3])[0] == [[0, 1, 2]] * 3
+    assert P.get_next_input_positions(0, 7, 9) == [[7, 8]] * 3
+    assert P.collapse_mrope_positions(pos).tolist() == list(range(7))
+    assert P.collapse_mrope_positions(torch.arange(4)).dtype == torch.int32
+    bad = pos.clone()
+    bad[1, 3] += 1
+    with pytest.raises(ValueError):
+        P.collapse_mrope_positions(bad)
+    with pytest.raises(ValueError):
+        P.collapse_mrope_positions(torch.zeros(2, 5, dtype=torch.int64))
