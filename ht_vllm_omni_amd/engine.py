@@ -188,7 +188,8 @@ class TalkerEngine:
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
             self._cp_proj_w_f = up(frag_shuffle(self.cp_proj_w)) if self.cp_proj_w is not None else None
-        desc.max_batch, desc.block_size, desc.kv_dtype = max_batch, block_size, self.kv_code
+        # more than 64 rows only as n_sub concurrent row ranges (each <= 64: the skinny GEMM's M limit)
+        desc.max_batch, desc.block_size, desc.kv_dtype = (min(max_batch, 64) if int(n_sub) > 1 else max_batch), block_size, self.kv_code
         desc.max_model_len, desc.bt_stride = d.max_model_len, self.bt_stride
         desc.k_scale, desc.v_scale = k_scale, v_scale
         desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
