@@ -45,6 +45,7 @@ struct GemmArgs {
     int wshuf, xshuf, oshuf;   // fragment-major layouts (OMNI_LAYOUT_*), see common.cuh frag_off
     // PRO_XNORM / EPI_RESID: per-row sum-of-squares slabs [np][64 rows] fp32 (deterministic: one slab per producer workgroup)
     const float* part_in; int np_in; float* part_out;
+    int counted;               // use the counted (unpredicated, P-deep) schedule when K % 1024 == 0
 };
 
 // PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
@@ -167,7 +168,60 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             xrow[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8
                               : a.x + (size_t)m * a.ldx + 8 * q;
         }
-        constexpr int DEPTH = (NT == 1) ? 16 : (NT == 2 ? 8 : 4);
+        // k-steps of W AND x in flight per wave on the counted path: 4 for small tiles; at MT = 4 or NT * MT >= 8 a 4-deep
+        // x ring costs more registers / issue slots than the exposed round trips it removes (x4x4 gate_up 20 -> 41 us,
+        // resid 1x4 6.0 -> 7.1; scripts/bench_tiles.py), so those run 2 deep
+        constexpr int P = ((MT <= 2) && (MT * NT <= 4)) ? 4 : 2;
+        constexpr bool COUNTED = true;
+        if (COUNTED && a.counted && ntw > 0 && nsteps % (GEMM_WAVES * P) == 0) {
+            // ---- counted schedule (K % 1024 == 0: every wave owns a multiple of P k-steps).  No load is predicated, so
+            // hipcc can count: each MFMA group waits for exactly the loads issued P steps earlier (vmcnt((P-1) * loads
+            // per step)) while the younger P-1 steps stay in flight -- with a predicated refill it must wait vmcnt(0)
+            // before every group, i.e. one exposed L2 round trip for x per k-step.
+            u32x4 Wq[P][NT], Xq[P][MT], NWq[P];
+#pragma unroll
+            for (int d = 0; d < P; ++d) {
+                const int ks = wave + d * GEMM_WAVES;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Wq[d][j] = NTL ? ld16_nt(wrow[j] + ks * wstep) : ld16(wrow[j] + ks * wstep);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) Xq[d][i] = ld16(xrow[i] + ks * xstep);
+                if (PRO == 2) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
+            }
+            if (PRO == 2) xnorm_rstd();
+            const int G = ntw / P;
+            for (int g = 0; g + 1 < G; ++g) {
+#pragma unroll
+                for (int d = 0; d < P; ++d) {
+                    if (PRO == 2) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wq[d][j], Xq[d][i], acc[j][i]);
+                    const int ks = wave + ((g + 1) * P + d) * GEMM_WAVES;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) Wq[d][j] = NTL ? ld16_nt(wrow[j] + ks * wstep) : ld16(wrow[j] + ks * wstep);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) Xq[d][i] = ld16(xrow[i] + ks * xstep);
+                    if (PRO == 2) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < P; ++d) {
+                if (PRO == 2) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wq[d][j], Xq[d][i], acc[j][i]);
+            }
+        } else {
+        constexpr int DEPTH = (NT == 1) ? 8 : (NT == 2 ? 4 : 2);   // KB of W in flight per wave; deeper rings (16/8/4) measured 1 % slower in the step
         u32x4 Wr[DEPTH][NT];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
@@ -209,6 +263,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     }
                 }
             }
+        }
         }
         }
     }
@@ -315,8 +370,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 }
 
 
-static int g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0;
-extern "C" void omni_debug_set(int nt, int rn, int wgs) { (void)rn; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }
+static int g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1;
+extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_counted = rn ? 0 : 1; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }   // rn != 0: generic schedule
 extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt; }   // 0 = policy default
 
 template <int MT, int NT, int PRO, int EPI>
@@ -415,6 +470,7 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
 extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
                                  int K, int epilogue, const uint8_t* mask, int layout, void* stream) {
     GemmArgs a{};
+    a.counted = g_gemm_counted;
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
     a.oshuf = (layout & OMNI_LAYOUT_OUT_FRAG) != 0;
@@ -442,6 +498,7 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
 extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate,
                                float* partials, int* nparts_out, int M, int N, int K, int layout, void* stream) {
     GemmArgs a{};
+    a.counted = g_gemm_counted;
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
     a.oshuf = 1;
@@ -464,6 +521,7 @@ extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts,
                                void* normed_out, const void* w, void* out, int M, int N, int K, int epilogue,
                                const uint8_t* mask, int out_frag, void* stream) {
     GemmArgs a{};
+    a.counted = g_gemm_counted;
     a.wshuf = 1; a.xshuf = 1; a.oshuf = out_frag != 0;
     a.x = (const uint16_t*)r; a.ldx = K; a.W = (const uint16_t*)w; a.out = out;
     a.M = M; a.N = N; a.K = K; a.mask = mask;
