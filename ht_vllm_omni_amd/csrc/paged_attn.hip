@@ -369,7 +369,10 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
 // loop, 32-way combine) on a context that fits one 8-token pass or two; this one is ~4x lighter.
 // DENSE (the code predictor's private cache): position = a.dense_pos for every row and row b owns block b, so no index
 // is loaded at all and every load of the kernel -- both 8-token history groups included -- goes out in one round trip.
-template <int G, bool DENSE>
+// SPLITQ: one wave per (row, Q head) instead of per (row, kv head) -- the wave is bound by its own ~1.5 k-instruction
+// dependent chain, not by memory, so the q heads of a group run as separate waves (G = 1; the group's k-norm is
+// recomputed by each, its K / V are stored by the first)
+template <int G, bool DENSE, bool SPLITQ>
 __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, int npairs) {
     constexpr int KV = OMNI_KV_BF16;
     __shared__ float sm[4][G * 128 + 256];
@@ -377,7 +380,13 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     const int pair = blockIdx.x * 4 + wave;
     if (pair >= npairs) return;                       // no workgroup barrier below
     const int kv_heads = a.kv_heads, bs = a.bs;
-    const int row = pair / kv_heads, kvh = pair - row * kv_heads;
+    const int ratio = SPLITQ ? a.q_heads / kv_heads : 1;
+    const int per_row = SPLITQ ? a.q_heads : kv_heads;
+    const int row = pair / per_row;
+    const int hsel = pair - row * per_row;             // SPLITQ: the q head; else the kv head
+    const int kvh = SPLITQ ? hsel / ratio : hsel;
+    const int qh0 = SPLITQ ? hsel : kvh * G;           // first (only) q head of this wave
+    const bool kv_writer = !SPLITQ || hsel % ratio == 0;
     const int sub = lane & 7, tg = lane >> 3;
     const int32_t* bt = DENSE ? nullptr : a.block_table + (size_t)row * a.bt_stride;
     const int max_blk = a.bt_stride - 1;
@@ -402,13 +411,13 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float y0, y1;
-        head_norm_rope(a.qkv + ((size_t)row * nslots + kvh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
+        head_norm_rope(a.qkv + ((size_t)row * nslots + qh0 + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
         wq[g * 128 + lane] = y0;
         wq[g * 128 + 64 + lane] = y1;
     }
     {   // new token: K (norm + rope) and V -> cache and LDS
         const int64_t slot = DENSE ? (int64_t)row * bs + pos : (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
-        if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+        if (hsel == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
         const size_t crow = (size_t)slot * kv_heads + kvh;
         float kx0, kx1;
         head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
@@ -416,8 +425,10 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         const uint16_t v0 = vsrc[lane], v1 = vsrc[lane + 64];
         uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
         uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
-        kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
-        vd[lane] = v0; vd[lane + 64] = v1;
+        if (kv_writer) {
+            kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
+            vd[lane] = v0; vd[lane + 64] = v1;
+        }
         kvs[lane] = kx0; kvs[64 + lane] = kx1;
         kvs[128 + lane] = bf2f(v0); kvs[192 + lane] = bf2f(v1);
     }
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         lw += __shfl_xor(lw, 16, 64);
         lw += __shfl_xor(lw, 32, 64);
         const float inv = 1.0f / lw;                  // >= the new token's weight, never 0
-        const int kq = (kvh * G + g) * 128;
+        const int kq = (qh0 + g) * 128;
         uint16_t* op0 = a.out_frag ? a.out + frag_off(row, kq + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + sub * 8;
         uint16_t* op1 = a.out_frag ? a.out + frag_off(row, kq + 64 + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + 64 + sub * 8;
         uint32_t packed[8];
@@ -618,6 +629,9 @@ extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const 
     return pa_dispatch(a, B, head_dim, kv_dtype, false, stream);
 }
 
+static int g_small_splitq = 1;
+extern "C" void omni_debug_small_splitq(int on) { g_small_splitq = on; }
+
 int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
                         const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
@@ -640,14 +654,23 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
     if (kv_dtype == OMNI_KV_BF16 && (dense || max_seq_len <= 64) && head_dim == 128 && kv_heads > 0 && q_heads % kv_heads == 0 &&
         B > 0 && qkv && qnorm_w && knorm_w && cos_sin && k_cache && v_cache && out && block_size > 0 &&
         (dense || (positions && block_table && seq_lens && bt_stride > 0))) {
-        const int G = q_heads / kv_heads, npairs = B * kv_heads;
-        dim3 grid((npairs + 3) / 4), block(256);
+        const int G = q_heads / kv_heads;
         hipStream_t st = (hipStream_t)stream;
         a.nsplit = 1;
+        if (g_small_splitq && G > 1) {
+            const int npairs = B * q_heads;
+            dim3 grid((npairs + 3) / 4), block(256);
+            if (dense) hipLaunchKernelGGL((attn_small_fused_kernel<1, true, true>), grid, block, 0, st, a, npairs);
+            else hipLaunchKernelGGL((attn_small_fused_kernel<1, false, true>), grid, block, 0, st, a, npairs);
+            OMNI_CHECK_LAUNCH("omni_attn_decode_fused(small, per q head)");
+            return OMNI_OK;
+        }
+        const int npairs = B * kv_heads;
+        dim3 grid((npairs + 3) / 4), block(256);
 #define SMALL(G_)                                                                                        \
         if (G == G_) {                                                                                   \
-            if (dense) hipLaunchKernelGGL((attn_small_fused_kernel<G_, true>), grid, block, 0, st, a, npairs);  \
-            else hipLaunchKernelGGL((attn_small_fused_kernel<G_, false>), grid, block, 0, st, a, npairs);       \
+            if (dense) hipLaunchKernelGGL((attn_small_fused_kernel<G_, true, false>), grid, block, 0, st, a, npairs);  \
+            else hipLaunchKernelGGL((attn_small_fused_kernel<G_, false, false>), grid, block, 0, st, a, npairs);       \
         }
         SMALL(1) SMALL(2) SMALL(4)
 #undef SMALL
