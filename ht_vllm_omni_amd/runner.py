@@ -165,6 +165,11 @@ class MI355XARModelRunner:
             block_size=e.block_size, cache_dtype=str(e.kv_dtype)) or None
         self._update_states(scheduler_output)
         if not scheduler_output.total_num_scheduled_tokens:
+            if self.kv_extracted_req_ids:
+                # nothing to run but a KV extraction happened: ack it now (the reference returns the bare empty output,
+                # gpu_ar_model_runner.py:152-166, and the ack is overwritten by the next step -- the held blocks leak)
+                ack, self.kv_extracted_req_ids = self.kv_extracted_req_ids, None
+                return OmniModelRunnerOutput(req_ids=[], req_id_to_index={}, sampled_token_ids=[], kv_extracted_req_ids=ack)
             return EMPTY_MODEL_RUNNER_OUTPUT
 
         sched = scheduler_output.num_scheduled_tokens

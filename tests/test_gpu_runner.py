@@ -129,3 +129,73 @@ def test_worker_runner_matches_oracle(graphs):
     if graphs:
         assert out.cudagraph_stats["replays"] >= 5 and out.cudagraph_stats["eager_steps"] == 0
     wk.shutdown()
+
+
+def test_engine_core_loop_scheduler_worker_oracle():
+    """Row a12 end to end on the GPU: MI355XARScheduler (admission under a token budget, chunked prefill, block
+    allocation, stop at max_tokens, KV hand-off + ack) drives MI355XARWorker through TalkerStageEngine; the token
+    streams and the per-step audio codes must be the oracle's, driven by the same schedule."""
+    from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+    d = get_dims("tiny")
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 64
+    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0, max_tokens=5, stop_token_ids=())
+    cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w,
+                      enforce_eager=False, default_sampling_params=sp)
+    wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    conn = InProcConnector()
+    wk.model_runner.kv_transfer_manager = OmniKVTransferManager(conn)
+    wk.engine.set_sampling(cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    run, eng = wk.model_runner, wk.engine
+    sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=4, max_num_batched_tokens=48, max_model_len=d.max_model_len,
+                              need_send_cache=True)
+    core = TalkerStageEngine(wk, sched)
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    g = torch.Generator().manual_seed(4)
+    spec = {"a": 7, "b": 60, "c": 20}                     # b needs two prefill chunks under the 48-token budget
+    prompts = {k: torch.randn(n, d.hidden, generator=g).to(BF16) for k, n in spec.items()}
+    pads = {k: torch.randn(d.hidden, generator=g).to(BF16) for k in spec}
+    ostate = {k: O.OracleState(tail_text=[], tts_pad=pads[k]) for k in spec}
+    reqs = {}
+    for k, n in spec.items():
+        info = {"talker_prompt_embeds": encode_tensor(prompts[k]), "tts_pad_embed": encode_tensor(pads[k])}
+        reqs[k] = Request(request_id=k, num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp,
+                          additional_information=info)
+        core.add_request(reqs[k])
+    prefilled, streams, finished = set(), {k: [] for k in spec}, {}
+    for step in range(40):
+        outs = core.step()
+        decoding = [o.request_id for o in outs if o.request_id in prefilled and o.new_token_ids]
+        if decoding:                                    # the oracle takes the same decode step for the same requests
+            ol, oi, oh, oc, _ = orc.decode_step([ostate[k] for k in decoding], [sched.pool.block_ids(k) for k in decoding])
+        for o in outs:
+            k = o.request_id
+            if o.finished:
+                finished[k] = o
+            if not o.new_token_ids:
+                continue
+            if k not in prefilled:                      # the step that completed the prompt: oracle prefill of the whole prompt
+                _, ids, h = orc.prefill([ostate[k]], [prompts[k]], [sched.pool.block_ids(k)])
+                tok, hid = int(ids[0]), h[0]
+                prefilled.add(k)
+            else:
+                j = decoding.index(k)
+                tok, hid = int(oi[j]), oh[j]
+                assert torch.equal(o.pooling_output["audio_codes"], oc[j:j + 1]), f"{k}: audio codes at step {step}"
+            got = o.new_token_ids[0]
+            streams[k].append(got)
+            assert got == tok, f"{k}: token {got} != oracle {tok} at step {step}"
+            if k in run.requests:                       # keep the device on the oracle's hidden state (1-ulp drift must not fork)
+                r = run.rows.index(k)
+                eng.last_hidden[r] = hid.cuda()
+        if not sched.has_unfinished_requests() and not sched.waiting_for_transfer_free and not sched.requests_needing_kv_transfer:
+            break
+    assert all(len(v) == 5 for v in streams.values()), streams
+    assert set(finished) == set(spec) and all(o.finish_reason == "length" for o in finished.values())
+    assert not sched.requests and sched.pool.num_free == nb - 1 and run.rows == []
+    for k, n in spec.items():                           # every finished request shipped ceil(seq / 16) blocks of KV
+        kv, _ = conn.get("0", "1", f"omni_0_to_1_kv_cache_{k}")
+        assert kv["metadata"]["seq_len"] == n + 4
+    wk.shutdown()

@@ -1,0 +1,156 @@
+"""Row a12: the AR-stage scheduler (vLLM V1 admission / block allocation / stop check as stated in SURVEY Appendix A,
+plus the Omni KV hand-off protocol of V/core/sched/omni_ar_scheduler.py) driving the runner -- host logic, no GPU."""
+import pytest
+import torch
+
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.connectors import InProcConnector, OmniKVTransferManager
+from ht_vllm_omni_amd.payloads import SamplingParams, encode_tensor
+from ht_vllm_omni_amd.runner import MI355XARModelRunner
+from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, RequestStatus, TalkerStageEngine
+from ht_vllm_omni_amd.stage_input_processors import CodecChunkStreamer
+from tests.fakes import FakeEngine
+
+BF16 = torch.bfloat16
+
+
+def _request(d, rid, n_prompt, *, max_tokens=8, stop=(), tail=1, seed=0):
+    g = torch.Generator().manual_seed(seed + n_prompt)
+    info = {"talker_prompt_embeds": encode_tensor(torch.randn(n_prompt, d.hidden, generator=g).to(BF16)),
+            "tailing_text_hidden": encode_tensor(torch.randn(tail, d.hidden, generator=g).to(BF16)),
+            "tts_pad_embed": encode_tensor(torch.zeros(d.hidden).to(BF16))}
+    sp = SamplingParams(temperature=0.0, max_tokens=max_tokens, stop_token_ids=tuple(stop))
+    return Request(request_id=rid, num_prompt_tokens=n_prompt, prompt_token_ids=[d.codec_pad_id] * n_prompt,
+                   sampling_params=sp, additional_information=info)
+
+
+class _Worker:
+    def __init__(self, runner):
+        self.model_runner = runner
+
+    def execute_model(self, so):
+        return self.model_runner.execute_model(so)
+
+    def sample_tokens(self, g):
+        return self.model_runner.sample_tokens(g)
+
+
+def test_admission_budget_chunked_prefill_and_block_order():
+    d = get_dims("tiny")
+    s = MI355XARScheduler(num_blocks=32, block_size=16, max_num_seqs=2, max_num_batched_tokens=24, max_model_len=512)
+    for rid, n in (("a", 5), ("b", 40), ("c", 3)):
+        s.add_request(_request(d, rid, n))
+    so = s.schedule()
+    # FCFS under a 24-token budget: a whole (5), b chunked to the remaining 19; c waits (max_num_seqs = 2)
+    assert so.num_scheduled_tokens == {"a": 5, "b": 19} and so.total_num_scheduled_tokens == 24
+    assert [r.req_id for r in so.scheduled_new_reqs] == ["a", "b"]
+    # block 0 is the null block; ids in queue order; b holds ceil(19 / 16) = 2 blocks so far
+    assert so.scheduled_new_reqs[0].block_ids == ([1],) and so.scheduled_new_reqs[1].block_ids == ([2, 3],)
+    assert s.requests["b"].num_computed_tokens == 19 and len(s.waiting) == 1
+    with pytest.raises(ValueError):
+        s.add_request(_request(d, "a", 4))
+    with pytest.raises(ValueError):
+        s.add_request(Request("z", num_prompt_tokens=0))
+
+
+def test_preemption_when_the_pool_runs_dry():
+    d = get_dims("tiny")
+    s = MI355XARScheduler(num_blocks=4, block_size=16, max_num_seqs=4, max_num_batched_tokens=64, max_model_len=512)   # 3 usable blocks
+    s.add_request(_request(d, "a", 16, max_tokens=40))
+    s.add_request(_request(d, "b", 30, max_tokens=40))
+    so = s.schedule()
+    assert so.num_scheduled_tokens == {"a": 16, "b": 30}
+    for r in ("a", "b"):
+        s.requests[r].output_token_ids.append(7)       # both sampled their first token
+    so = s.schedule()                                   # a needs a 2nd block for token 17: none free -> b (newest) is preempted
+    assert so.preempted_req_ids == {"b"} and so.num_scheduled_tokens == {"a": 1}
+    assert s.requests["b"].status == RequestStatus.PREEMPTED and s.requests["b"].num_computed_tokens == 0
+    assert s.waiting[0].request_id == "b" and not so.scheduled_new_reqs     # no admission in a preempting step
+    assert s.pool.block_ids("a") == [1, 3]        # b's blocks went back in reverse order: 3 is at the head
+
+
+def test_engine_loop_stop_conditions_kv_handoff_and_chunk_stream():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    conn = InProcConnector()
+    runner = MI355XARModelRunner(eng, kv_transfer=OmniKVTransferManager(conn), use_graphs=False)
+    chunk_conn = InProcConnector()
+    streamer = CodecChunkStreamer(codec_chunk_frames=4, codec_left_context_frames=2, max_num_seqs=4,
+                                  num_quantizers=d.num_code_groups, connector=chunk_conn)
+    sched = MI355XARScheduler(num_blocks=32, block_size=16, max_num_seqs=4, max_num_batched_tokens=64, max_model_len=512,
+                              need_send_cache=True, chunk_streamer=streamer)
+    core = TalkerStageEngine(_Worker(runner), sched)
+    core.add_request(_request(d, "a", 5, max_tokens=6))
+    core.add_request(_request(d, "b", 20, max_tokens=3))
+    outs = core.step()                                   # prefill of both, first tokens sampled
+    assert {o.request_id: len(o.new_token_ids) for o in outs} == {"a": 1, "b": 1}
+    tokens = {o.request_id: list(o.new_token_ids) for o in outs}
+    finished = {}
+    for _ in range(20):
+        for o in core.step():
+            tokens[o.request_id] += o.new_token_ids
+            if o.finished:
+                finished[o.request_id] = o
+        if not sched.has_unfinished_requests() and not sched.waiting_for_transfer_free and not sched.requests_needing_kv_transfer:
+            break
+    assert len(tokens["a"]) == 6 and len(tokens["b"]) == 3
+    assert finished["a"].finish_reason == "length" and finished["b"].finish_reason == "length"
+    # finished requests shipped their KV (block list truncated to the sequence), were acked, and gave their blocks back
+    assert finished["b"].kv_transfer_params["kv_metadata"]["seq_len"] == 20 + 2     # the last sampled token was never computed
+    kv_b, _ = conn.get("0", "1", "omni_0_to_1_kv_cache_b")
+    assert kv_b["metadata"]["seq_len"] == finished["b"].kv_transfer_params["kv_metadata"]["seq_len"]
+    assert len(finished["b"].kv_transfer_params["past_key_values"]) == (kv_b["metadata"]["seq_len"] + 15) // 16
+    assert not sched.requests and sched.pool.num_free == 31 and not sched.active_kv_transfers
+    assert runner.rows == []
+    # the codec frames of every decode step went through the chunk connector under {req}_{stage}_{chunk}
+    assert "a_0_0" in chunk_conn.store and "a" not in streamer.code_prompt_token_ids
+    first, _ = chunk_conn.get("0", "1", "a_0_0")
+    assert len(first["code_predictor_codes"]) % d.num_code_groups == 0 and first["left_context_size"] == 0
+
+
+def test_stop_token_and_eos_and_abort():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    runner = MI355XARModelRunner(eng, use_graphs=False)
+    sched = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512)
+    core = TalkerStageEngine(_Worker(runner), sched)
+    probe = _request(d, "p", 6, max_tokens=5)
+    core.add_request(probe)
+    toks = core.run()["p"]                                # deterministic fake engine: learn its token stream
+    assert len(toks) == 5 and probe.status == RequestStatus.FINISHED_LENGTH_CAPPED
+    r2 = _request(d, "q", 6, max_tokens=50, stop=(toks[2],))
+    core.add_request(r2)
+    toks2 = core.run()["q"]
+    assert toks2 == toks[:3] and r2.status == RequestStatus.FINISHED_STOPPED and r2.stop_reason == toks[2]
+    r3 = _request(d, "e", 6, max_tokens=50)
+    r3.eos_token_id = toks[1]
+    core.add_request(r3)
+    assert core.run()["e"] == toks[:2] and r3.get_finished_reason() == "stop" and r3.stop_reason is None
+    r4 = _request(d, "x", 6, max_tokens=50)
+    core.add_request(r4)
+    core.step()
+    sched.abort_request("x")
+    assert r4.get_finished_reason() == "abort" and not sched.has_unfinished_requests()
+    core.step()                                           # the runner drops the row on the next step
+    assert runner.rows == [] and sched.pool.num_free == 15
+
+
+def test_kv_transfer_criteria_trigger_once_without_stopping():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    conn = InProcConnector()
+    runner = MI355XARModelRunner(eng, kv_transfer=OmniKVTransferManager(conn), use_graphs=False)
+    sched = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512,
+                              kv_transfer_criteria={"type": "prefill_finished"})
+    core = TalkerStageEngine(_Worker(runner), sched)
+    req = _request(d, "a", 18, max_tokens=4)
+    core.add_request(req)
+    core.step()                                           # prefill done -> transfer marked, request keeps running
+    assert "a" in sched.transfer_triggered_requests and sched.requests_needing_kv_transfer["a"] == {"seq_len": 18, "block_ids": [1, 2]}
+    core.step()                                           # delivered to the runner exactly once, acked in the same step
+    assert not sched.requests_needing_kv_transfer and not sched.active_kv_transfers
+    kv, _ = conn.get("0", "1", "omni_0_to_1_kv_cache_a")
+    assert kv["metadata"]["seq_len"] == 18
+    toks = core.run()
+    assert req.is_finished() and not sched.requests and sched.pool.num_free == 15     # finished later: no second transfer
+    assert conn.get("0", "1", "omni_0_to_1_kv_cache_a") is None
