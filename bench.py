@@ -43,7 +43,7 @@ def build_engine(args, rank, world):
     log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
                        device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False,
-                       n_sub=args.sub_batches)
+                       n_sub=args.sub_batches, tp_force=args.tp_force)
     return d, w, eng
 
 
@@ -149,6 +149,11 @@ def copy_probe_gbs():
 
 
 def main():
+    # the ONE JSON line owns stdout: native libraries (the RCCL version banner, hipBLASLt notices) write to fd 1 too, so
+    # fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
@@ -165,6 +170,8 @@ def main():
     ap.add_argument("--device-weights", action="store_true", help="profiler runs only: draw weights on the GPU (no H2D copy)")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--tp-force", action="store_true", help="diagnostics: run the tensor-parallel code path (process group, "
+                    "separate norms, all-reduces inside the graph) on a 1-rank group")
     ap.add_argument("--ctx-extra", type=int, default=0, help="long-context points: start decoding this many positions later")
     args = ap.parse_args()
 
@@ -175,7 +182,7 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.tp_force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -248,7 +255,7 @@ def main():
 
     # ---- diagnostics (after the timed region): the backbone half of the step alone, as its own graph
     bb_ms = None
-    if graph is not None and world == 1 and args.sub_batches == 1:
+    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force:
         try:
             g2 = torch.cuda.CUDAGraph()
             eng.backbone_step(B)
@@ -290,6 +297,8 @@ def main():
                      "launch": "one hipGraph replay = one decode step (per TP rank)", "event_ms_per_step": ev_ms,
                      "bytes_per_step": by},
     }
+    if args.tp_force:
+        out["config"]["parallelism"] += " (tensor-parallel code path forced on one rank)"
     if bb_ms is not None:
         bb_bytes = by_end["weights_backbone"] + by_end["lm_head"] + by_end["kv_read"] + by_end["kv_write"]
         out["roofline"]["breakdown"] = {
@@ -320,7 +329,8 @@ def main():
             except Exception as e:   # noqa: BLE001
                 log(f"cpu baseline failed: {e!r}")
                 out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
