@@ -11,6 +11,7 @@ input/output tensors are saved.
   qwen3_backbone_tiny.npz   HF transformers Qwen3Model (bf16, CPU): prefill + decode hidden states
   kv_extract.npz            reference OmniKVTransferManager._extract_kv_cache in/out
   chunk_windows.json        reference talker2code2wav_async_chunk windowing known answers
+  omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
 """
 from __future__ import annotations
 
@@ -320,10 +321,94 @@ def mint_chunk_windows():
     print("chunk window cases:", len(sweep), "emits:", sum(1 for c in sweep if c[-1] is not None))
 
 
+# --------------------------------------------------------------------------
+def mint_omni_stage_processors():
+    """Known answers of the Qwen3-Omni stage hand-offs (stage_input_processors/qwen3_omni.py): seeded inputs run through
+    the reference functions; inputs and outputs saved with torch.save (tensors + plain containers only)."""
+    install_vllm_stubs()
+    vo = sys.modules["vllm_omni"]
+    vo.__path__ = [V]
+    _stub("vllm.inputs", TextPrompt=dict)
+    _stub("vllm.platforms", current_platform=types.SimpleNamespace(device_type="cpu"))
+    _stub("vllm_omni.engine", OmniEngineCoreRequest=object)
+
+    class _Prompt(dict):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+    _stub("vllm_omni.inputs")
+    _stub("vllm_omni.inputs.data", OmniTokensPrompt=_Prompt)
+    import importlib
+    from collections import defaultdict
+    from types import SimpleNamespace
+    qo = importlib.import_module("vllm_omni.model_executor.stage_input_processors.qwen3_omni")
+    g = torch.Generator().manual_seed(17)
+    IM, SYS, USR, AST = 151644, 8948, 872, 77091
+
+    def turn(role, n):
+        return [IM, role] + torch.randint(1000, 2000, (n,), generator=g).tolist()
+
+    cases = {"length": [], "t2t_chunks": [], "t2t": [], "c2w_chunks": [], "c2w": []}
+    for turns in ([(SYS, 5), (USR, 7), (AST, 0)], [(USR, 3), (AST, 2), (USR, 9), (AST, 0)], [(SYS, 2), (AST, 0)], [(USR, 4)]):
+        ids = sum((turn(r, n) for r, n in turns), [])
+        seq = ids + torch.randint(1000, 2000, (6,), generator=g).tolist()
+        info = {"thinker_sequences": seq, "thinker_input_ids": ids}
+        cases["length"].append({"info": info, "out": qo._compute_talker_prompt_ids_length(info, device="cpu")})
+
+    H = 8
+    def pool(n):
+        return {"0": torch.randn(n, H, generator=g), "24": torch.randn(n, H, generator=g), "tts_bos_embed": torch.randn(1, H, generator=g),
+                "tts_eos_embed": torch.randn(1, H, generator=g), "tts_pad_embed": torch.randn(1, H, generator=g)}
+
+    def mkreq(prompt_ids, out_ids, speaker=None):
+        ai = None
+        if speaker:
+            ai = SimpleNamespace(entries={"speaker": SimpleNamespace(list_data=[speaker]), "language": SimpleNamespace(list_data=["English"])})
+        return SimpleNamespace(external_req_id="rq", all_token_ids=prompt_ids + out_ids, prompt_token_ids=prompt_ids,
+                               output_token_ids=out_ids, additional_information=ai)
+
+    # streaming thinker -> talker: chunked prefill (2 pieces), then decode steps, then finish
+    tm = SimpleNamespace(put_req_chunk=defaultdict(int), request_payload={})
+    script = [(pool(5), [1, 2, 3, 4, 5], [], False), (pool(3), [1, 2, 3, 4, 5, 6, 7, 8], [], False), (pool(1), [1, 2, 3, 4, 5, 6, 7, 8], [9], False),
+              (pool(1), [1, 2, 3, 4, 5, 6, 7, 8], [9, 10], True)]
+    for po, pids, oids, fin in script:
+        req = mkreq(pids, oids, speaker=" Ethan ")
+        out = qo.thinker2talker_async_chunk(tm, po, req, is_finished=fin)
+        cases["t2t_chunks"].append({"pooling_output": po, "prompt_ids": pids, "output_ids": oids, "finished": fin, "out": out})
+        if out is not None:
+            tm.put_req_chunk["rq"] += 1
+    # non-streaming thinker -> talker
+    for turns in ([(SYS, 4), (USR, 6), (AST, 0)], [(USR, 5), (AST, 0)]):
+        pids = sum((turn(r, n) for r, n in turns), [])
+        oids = torch.randint(1000, 2000, (4,), generator=g).tolist()
+        mm = pool(len(pids) + len(oids))
+        stage = SimpleNamespace(engine_outputs=[SimpleNamespace(prompt_token_ids=pids, outputs=[SimpleNamespace(multimodal_output=mm, token_ids=oids)])])
+        prm = [{"additional_information": {"speaker": ["ethan"], "language": ["English"]}}]
+        out = qo.thinker2talker([stage], [0], prompt=prm)
+        cases["t2t"].append({"prompt_ids": pids, "output_ids": oids, "mm": mm, "prompt": prm, "out": [dict(o) for o in out]})
+    # streaming talker -> code2wav (Omni cadence)
+    for chunk, left, n, fin_at in ((4, 2, 11, 10), (25, 25, 30, 29), (3, 5, 7, None)):
+        tm2 = SimpleNamespace(code_prompt_token_ids=defaultdict(list),
+                              connector=SimpleNamespace(config={"extra": {"codec_chunk_frames": chunk, "codec_left_context_frames": left}}))
+        steps = []
+        for t in range(n):
+            codes = torch.randint(0, 2048, (16, 1), generator=g)
+            if t == 2:
+                codes = torch.zeros(16, 1, dtype=torch.long)       # an all-zero frame is skipped
+            fin = fin_at is not None and t == fin_at
+            out = qo.talker2code2wav_async_chunk(tm2, {"code_predictor_codes": codes}, SimpleNamespace(external_req_id="r"), is_finished=fin)
+            steps.append({"codes": codes, "finished": fin, "out": out})
+        cases["c2w_chunks"].append({"chunk": chunk, "left": left, "steps": steps})
+    codes = torch.randint(0, 2048, (9, 16), generator=g)
+    stage = SimpleNamespace(engine_outputs=[SimpleNamespace(outputs=[SimpleNamespace(multimodal_output={"code_predictor_codes": codes}, token_ids=list(range(6)))])])
+    cases["c2w"].append({"codes": codes, "n_token_ids": 6, "out": [dict(o) for o in qo.talker2code2wav([stage], [0])]})
+    torch.save(cases, os.path.join(HERE, "omni_stage_processors.pt"))
+    print("omni stage processor cases:", {k: len(v) for k, v in cases.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -332,3 +417,5 @@ if __name__ == "__main__":
         mint_kv_extract()
     if "cw" in which:
         mint_chunk_windows()
+    if "os" in which:
+        mint_omni_stage_processors()

@@ -176,3 +176,82 @@ def test_streamer_sends_chunks_through_the_connector(kind):
     assert got1["code_predictor_codes"] == frames[40 - (16 + 24):40].T.reshape(-1).tolist()
     assert "rq" not in st.code_prompt_token_ids and "rq" not in st.put_req_chunk
     conn.close()
+
+
+# ------------------------------------------------------------------ Qwen3-Omni hand-offs
+def _same(a, b, path=""):
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        assert isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor), path
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), path
+    elif isinstance(a, dict):
+        assert isinstance(b, dict) and set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _same(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]")
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.fixture(scope="module")
+def omni_gold(golden_dir):
+    return torch.load(os.path.join(golden_dir, "omni_stage_processors.pt"), weights_only=True)
+
+
+def test_omni_talker_prompt_length(omni_gold):
+    from ht_vllm_omni_amd import stage_input_processors_omni as SO
+    for case in omni_gold["length"]:
+        assert SO._compute_talker_prompt_ids_length(case["info"]) == case["out"]
+
+
+def test_omni_thinker2talker_streaming_chunks(omni_gold):
+    """Chunked thinker prefill parks the first piece and concatenates; decode chunks carry override keys."""
+    from ht_vllm_omni_amd import stage_input_processors_omni as SO
+    tm = SimpleNamespace(put_req_chunk=defaultdict(int), request_payload={})
+    for step in omni_gold["t2t_chunks"]:
+        ai = SimpleNamespace(entries={"speaker": SimpleNamespace(list_data=[" Ethan "]), "language": SimpleNamespace(list_data=["English"])})
+        req = SimpleNamespace(external_req_id="rq", all_token_ids=step["prompt_ids"] + step["output_ids"],
+                              prompt_token_ids=step["prompt_ids"], output_token_ids=step["output_ids"], additional_information=ai)
+        out = SO.thinker2talker_async_chunk(tm, step["pooling_output"], req, is_finished=step["finished"])
+        if step["out"] is None:
+            assert out is None
+        else:
+            _same(out, step["out"], "t2t_chunk")
+            tm.put_req_chunk["rq"] += 1
+
+
+def test_omni_thinker2talker_and_talker2code2wav(omni_gold):
+    from ht_vllm_omni_amd import stage_input_processors_omni as SO
+    for case in omni_gold["t2t"]:
+        stage = SimpleNamespace(engine_outputs=[SimpleNamespace(prompt_token_ids=case["prompt_ids"], outputs=[
+            SimpleNamespace(multimodal_output=case["mm"], token_ids=case["output_ids"])])])
+        out = SO.thinker2talker([stage], [0], prompt=case["prompt"], device="cpu")
+        want = case["out"]
+        assert len(out) == len(want)
+        for o, w in zip(out, want):
+            assert o["prompt_token_ids"] == w["prompt_token_ids"] and o["multi_modal_data"] is None
+            _same(o["additional_information"], w["additional_information"], "t2t.info")
+    for case in omni_gold["c2w"]:
+        stage = SimpleNamespace(engine_outputs=[SimpleNamespace(outputs=[SimpleNamespace(
+            multimodal_output={"code_predictor_codes": case["codes"]}, token_ids=list(range(case["n_token_ids"])))])])
+        out = SO.talker2code2wav([stage], [0])
+        assert [o["prompt_token_ids"] for o in out] == [w["prompt_token_ids"] for w in case["out"]]
+
+
+@pytest.mark.parametrize("store", ["lists", "frame-buffers"])
+def test_omni_talker2code2wav_streaming(omni_gold, store):
+    from ht_vllm_omni_amd import stage_input_processors_omni as SO
+    for case in omni_gold["c2w_chunks"]:
+        tm = SimpleNamespace(code_prompt_token_ids=defaultdict(list if store == "lists" else (lambda: SP.FrameBuffer(16))),
+                             connector=SimpleNamespace(config={"extra": {"codec_chunk_frames": case["chunk"],
+                                                                         "codec_left_context_frames": case["left"]}}))
+        for step in case["steps"]:
+            out = SO.talker2code2wav_async_chunk(tm, {"code_predictor_codes": step["codes"]}, SimpleNamespace(external_req_id="r"),
+                                                 is_finished=step["finished"])
+            if step["out"] is None:
+                assert out is None
+            else:
+                _same(out, step["out"], "c2w_chunk")
+    assert SO.talker2code2wav_async_chunk(SimpleNamespace(), {}, SimpleNamespace(external_req_id="r")) is None
