@@ -168,10 +168,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             xrow[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8
                               : a.x + (size_t)m * a.ldx + 8 * q;
         }
-        // k-steps of W AND x in flight per wave on the counted path: 4 for small tiles; at MT = 4 or NT * MT >= 8 a 4-deep
-        // x ring costs more registers / issue slots than the exposed round trips it removes (x4x4 gate_up 20 -> 41 us,
-        // resid 1x4 6.0 -> 7.1; scripts/bench_tiles.py), so those run 2 deep
-        constexpr int P = ((MT <= 2) && (MT * NT <= 4)) ? 4 : 2;
+        // k-steps of W AND x in flight per wave on the counted path.  Same-box A/B of the whole step (scripts/ab.sh):
+        // 1 step 4.42 ms, 2 steps 4.20, 4 steps (small tiles) 4.22, 8 / 12 steps (o / down) 4.28 -- two is enough to cover
+        // the round trip; every further load issued up front only delays the first MFMA group
+        constexpr int P = 2;
         constexpr bool COUNTED = true;
         if (COUNTED && a.counted && ntw > 0 && nsteps % (GEMM_WAVES * P) == 0) {
             // ---- counted schedule (K % 1024 == 0: every wave owns a multiple of P k-steps).  No load is predicated, so
