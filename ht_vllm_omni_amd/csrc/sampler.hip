@@ -111,29 +111,53 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
             // ---- nucleus cut among the top-k candidates {x >= kth}: candidate i stays iff the softmax mass of the
             // candidates that sort before it (value desc, index asc) is < top_p.  Candidates are compacted in a fixed
             // order (thread-major) so the sums are run-to-run deterministic; n <= top_k + ties, O(n^2 / 256) per thread.
-            __shared__ float cval[SMP_PCAP];
+            __shared__ float cval[SMP_PCAP], cexp[SMP_PCAP];
             __shared__ int cidx[SMP_PCAP];
-            __shared__ int coff[SMP_THREADS + 1];
+            __shared__ int coff[SMP_THREADS / 64];
             int cnt = 0;
             for (int i = threadIdx.x; i < V; i += SMP_THREADS) cnt += (row[i] >= kth && row[i] > -INFINITY) ? 1 : 0;
-            coff[threadIdx.x + 1] = cnt;
-            if (threadIdx.x == 0) coff[0] = 0;
+            // exclusive prefix of the per-thread counts: shuffle scan inside each wave + the 4 wave totals through LDS
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(inc, d, 64);
+                if ((int)(threadIdx.x & 63) >= d) inc += up;
+            }
+            if ((threadIdx.x & 63) == 63) coff[threadIdx.x >> 6] = inc;
             __syncthreads();
-            if (threadIdx.x == 0)
-                for (int t = 1; t <= SMP_THREADS; ++t) coff[t] += coff[t - 1];
-            __syncthreads();
-            int o = coff[threadIdx.x];
-            const int n = min(coff[SMP_THREADS], SMP_PCAP);
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < SMP_THREADS / 64; ++w) {
+                if (w < (int)(threadIdx.x >> 6)) base += coff[w];
+                total += coff[w];
+            }
+            int o = base + inc - cnt;
+            const int n = min(total, SMP_PCAP);
             for (int i = threadIdx.x; i < V; i += SMP_THREADS)
                 if (row[i] >= kth && row[i] > -INFINITY) {
                     if (o < SMP_PCAP) { cval[o] = row[i]; cidx[o] = i; }
                     ++o;
                 }
             __syncthreads();
+            // max and partition sum over the candidates by block reductions (a serial loop over n LDS reads per thread
+            // cost ~2 us each)
             float mx = -INFINITY;
-            for (int j = 0; j < n; ++j) mx = fmaxf(mx, cval[j]);
+            for (int c = threadIdx.x; c < n; c += SMP_THREADS) mx = fmaxf(mx, cval[c]);
+            mx = wave_max(mx);
+            if ((threadIdx.x & 63) == 0) sval[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(sval[0], sval[1]), fmaxf(sval[2], sval[3]));
+            __syncthreads();
             float z = 0.f;
-            for (int j = 0; j < n; ++j) z += expf(cval[j] - mx);
+            for (int c = threadIdx.x; c < n; c += SMP_THREADS) {
+                const float e = expf(cval[c] - mx);
+                cexp[c] = e;
+                z += e;
+            }
+            z = wave_sum(z);
+            if ((threadIdx.x & 63) == 0) sval[threadIdx.x >> 6] = z;
+            __syncthreads();
+            z = (sval[0] + sval[1]) + (sval[2] + sval[3]);
             // the kept set is a prefix of the sorted order: find the smallest kept value (and, among equal values, the
             // largest kept index) = the cut; every thread tests its candidates
             for (int c = threadIdx.x; c < n; c += SMP_THREADS) {
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                 const int vi = cidx[c];
                 float before = 0.f;
                 for (int j = 0; j < n; ++j)
-                    if (cval[j] > v || (cval[j] == v && cidx[j] < vi)) before += expf(cval[j] - mx);
+                    if (cval[j] > v || (cval[j] == v && cidx[j] < vi)) before += cexp[j];
                 if (before / z >= top_p) row[vi] = -INFINITY;        // removed from the row the Gumbel stage reads
             }
             __syncthreads();
