@@ -42,11 +42,11 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim,
                                                              float* __restrict__ gpart) {
     __shared__ float row[SMP_MAXV];
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[4][256];              // one histogram per radix pass, cleared once
     __shared__ float sval[SMP_THREADS / 64];
     __shared__ int sidx[SMP_THREADS / 64];
-    __shared__ uint32_t sel_prefix, sel_k;
-    __shared__ uint32_t wtot[SMP_THREADS / 64];
+    __shared__ uint32_t sel_prefix[4], sel_k[4];   // per pass: no barrier needed before the next pass overwrites
+    __shared__ uint32_t wtot[4][SMP_THREADS / 64];
     const int b = blockIdx.x;
     const float* src = logits + (size_t)b * ld;
     uint8_t* sn = seen ? seen + (size_t)b * V : nullptr;
@@ -56,6 +56,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
         if (!greedy) x = x / temperature;
         row[i] = x;
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hist[p][threadIdx.x] = 0;
     __syncthreads();
     int pick;
     if (greedy) {
@@ -74,35 +76,32 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
             uint32_t prefix = 0, mask = 0, krem = (uint32_t)top_k;
             for (int pass = 0; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
-                for (int i = threadIdx.x; i < 256; i += SMP_THREADS) hist[i] = 0;
-                __syncthreads();
                 for (int i = threadIdx.x; i < V; i += SMP_THREADS) {
                     const uint32_t k = ord_key(row[i]);
-                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1u);
+                    if ((k & mask) == prefix) atomicAdd(&hist[pass][(k >> shift) & 0xFF], 1u);
                 }
                 __syncthreads();
                 {
                     // thread t owns bin t: inclusive suffix sum S[t] = sum_{b >= t} hist[b]
-                    const uint32_t cnt = hist[threadIdx.x];
+                    const uint32_t cnt = hist[pass][threadIdx.x];
                     uint32_t sfx = cnt;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) {
                         const uint32_t up = __shfl_down(sfx, o, 64);
                         if ((int)(threadIdx.x & 63) + o < 64) sfx += up;
                     }
-                    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = sfx;
+                    if ((threadIdx.x & 63) == 0) wtot[pass][threadIdx.x >> 6] = sfx;
                     __syncthreads();
-                    for (int w = (threadIdx.x >> 6) + 1; w < SMP_THREADS / 64; ++w) sfx += wtot[w];
+                    for (int w = (threadIdx.x >> 6) + 1; w < SMP_THREADS / 64; ++w) sfx += wtot[pass][w];
                     if (sfx >= krem && sfx - cnt < krem) {          // exactly one bin satisfies this
-                        sel_prefix = prefix | ((uint32_t)threadIdx.x << shift);
-                        sel_k = krem - (sfx - cnt);
+                        sel_prefix[pass] = prefix | ((uint32_t)threadIdx.x << shift);
+                        sel_k[pass] = krem - (sfx - cnt);
                     }
                 }
                 __syncthreads();
-                prefix = sel_prefix;
-                krem = sel_k;
+                prefix = sel_prefix[pass];
+                krem = sel_k[pass];
                 mask |= 0xFFu << shift;
-                __syncthreads();
             }
             const uint32_t kb = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
             kth = __uint_as_float(kb);
