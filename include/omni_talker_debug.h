@@ -1,0 +1,20 @@
+/* Diagnostic hooks exported by libomni_talker.so next to the ABI of omni_talker.h.  NOT part of the drop-in boundary:
+ * they exist so that scripts/ (tile sweeps, same-box A/B runs, launch-cost probes) can flip a policy at run time.
+ * Process-global, not thread-safe, defaults = the shipped policy. */
+#pragma once
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+void omni_debug_set(int nt, int generic_schedule, int wgs); /* nt & 1: non-temporal W loads; != 0: predicated (pre-v8) GEMM
+                                                               schedule; target workgroups per GEMM launch (256) */
+void omni_debug_tile(int nt, int mt);                       /* force the GEMM tile (0 = policy)                       */
+void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
+void omni_debug_prefill_mfma(int on);                       /* prefill attention on MFMA (off: per-token VALU path)   */
+void omni_debug_extra_trivial(int n);                       /* append n no-op launches per layer phase                */
+int omni_debug_launch(int mode, int blocks, int threads, void* p0, void* p1, int arg, int reps, void* stream);
+int omni_debug_mix(int pattern, float* small, const void* big, size_t big_bytes, int reps, void* stream);
+int omni_debug_cfgmix(int mode, float* p, int reps, void* stream);
+#ifdef __cplusplus
+}
+#endif

@@ -71,3 +71,14 @@ def test_engine_refuses_without_gpu():
     from ht_vllm_omni_amd import ops
     with pytest.raises(_lib.OmniError):
         ops.rmsnorm(torch.zeros(1, 8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16), 1e-6)
+
+
+def test_debug_header_symbols_exported():
+    """include/omni_talker_debug.h (diagnostic hooks, outside the boundary) matches what the library exports."""
+    from ht_vllm_omni_amd import _lib
+    lib = _lib.load()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "omni_talker_debug.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(omni_debug_[a-z0-9_]+)\s*\(", txt)))
+    assert len(names) >= 6
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in omni_talker_debug.h but not exported"
