@@ -42,7 +42,8 @@ def build_engine(args, rank, world):
     w = make_weights(d, seed=1234, std=0.02, device="cuda" if args.device_weights else "cpu")
     log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
-                       device=f"cuda:{torch.cuda.current_device()}", tp_rank=rank, tp_size=world, allow_eos=False,
+                       device=f"cuda:{torch.cuda.current_device()}", tp_rank=0 if args.parallel == "dp" else rank,
+                       tp_size=1 if args.parallel == "dp" else world, allow_eos=False,
                        n_sub=args.sub_batches, tp_force=args.tp_force)
     return d, w, eng
 
@@ -170,6 +171,9 @@ def main():
     ap.add_argument("--device-weights", action="store_true", help="profiler runs only: draw weights on the GPU (no H2D copy)")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--parallel", choices=("tp", "dp"), default="tp",
+                    help="N > 1: tp = one batch of 64 sharded tensor-parallel over the ranks (BASELINE config, strong scaling); "
+                         "dp = independent replicas, 64 requests per GPU, no data-path collective (weak scaling)")
     ap.add_argument("--tp-force", action="store_true", help="diagnostics: run the tensor-parallel code path (process group, "
                     "separate norms, all-reduces inside the graph) on a 1-rank group")
     ap.add_argument("--ctx-extra", type=int, default=0, help="long-context points: start decoding this many positions later")
@@ -281,14 +285,15 @@ def main():
     end_ctx = ctx0 + args.steps
     by_end = eng.step_bytes(end_ctx) if bb_ms is not None else None
     out = {
-        "metric": "speech-tokens/sec", "value": B * args.steps / dt, "unit": "speech-tokens/s", "n_gpus": world,
+        "metric": "speech-tokens/sec", "value": B * args.steps / dt * (world if args.parallel == "dp" else 1),
+        "unit": "speech-tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak" if args.parallel == "dp" else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"W3: Qwen3-TTS-1.7B-shaped talker decode, random bf16 weights, {args.kv} KV, B={B}, "
                                f"prompts U{{32..160}} seed 7, KV block 16, T=0.9/top-k 50/rep 1.05 sampling"
                                if args.model == "tts-1.7b" else f"{args.model} {args.kv} B={B}",
                    "model": args.model, "kv_cache": args.kv, "batch": B, "mean_ctx": float(np.mean(mean_ctx)),
-                   "parallelism": f"tp{world}", "hipgraph": graph is not None, "sub_batches": args.sub_batches,
+                   "parallelism": f"{args.parallel}{world}", "hipgraph": graph is not None, "sub_batches": args.sub_batches,
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
                    **({"ctx_extra": args.ctx_extra} if args.ctx_extra else {})},
         "p50_ttfa_ms": ttfa_ms, "ttfa": {"prefill_ms": prefill_ms, "ic_steps": args.ttfa_steps, "ic_ms": ic_ms},
