@@ -199,3 +199,53 @@ extern "C" int omni_silu_mul(const void* gate_up, void* out, int T, int inter, v
     OMNI_CHECK_LAUNCH("omni_silu_mul");
     return OMNI_OK;
 }
+
+// SnakeBeta activation of the Code2Wav decoder: out = x + inv_beta[c] * sin^2(x * exp_alpha[c]) over
+// [B, C, T] rows of length T, one (b, c) row per blockIdx.y; exp_alpha = exp(alpha), inv_beta = 1 / (exp(beta) + 1e-9) are
+// precomputed per channel as the reference's precompute_exp_cache does.  Replaces the reference's Triton kernel
+// (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:632-655, same fused form).  fp32 math; T-contiguous 16-B accesses.
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void snake_beta_kernel(const void* __restrict__ x, const float* __restrict__ exp_alpha,
+                                                         const float* __restrict__ inv_beta, void* __restrict__ out, int C, int T) {
+    const size_t rowi = blockIdx.x;          // grid.x = B * C rows (up to 2^31 - 1), grid.y = chunks of T
+    const int c = (int)(rowi % C);
+    const float ea = exp_alpha[c], ib = inv_beta[c];
+    constexpr int VEC = IS_BF16 ? 8 : 4;
+    const int t0 = (blockIdx.y * 256 + threadIdx.x) * VEC;
+    if (t0 >= T) return;
+    if constexpr (VEC == 4) {        // fp32
+        const float* xr = reinterpret_cast<const float*>(x) + rowi * T;
+        float* orow = reinterpret_cast<float*>(out) + rowi * T;
+        if (t0 + 4 <= T && ((reinterpret_cast<uintptr_t>(xr + t0) | reinterpret_cast<uintptr_t>(orow + t0)) & 15) == 0) {
+            float4 v = *reinterpret_cast<const float4*>(xr + t0);
+            float s;
+            s = sinf(v.x * ea); v.x += ib * s * s;
+            s = sinf(v.y * ea); v.y += ib * s * s;
+            s = sinf(v.z * ea); v.z += ib * s * s;
+            s = sinf(v.w * ea); v.w += ib * s * s;
+            *reinterpret_cast<float4*>(orow + t0) = v;
+        } else {
+            for (int t = t0; t < min(t0 + 4, T); ++t) { const float v = xr[t], s = sinf(v * ea); orow[t] = v + ib * s * s; }
+        }
+    } else {                         // bf16 storage, fp32 math, one rounding
+        const uint16_t* xr = reinterpret_cast<const uint16_t*>(x) + rowi * T;
+        uint16_t* orow = reinterpret_cast<uint16_t*>(out) + rowi * T;
+        for (int t = t0; t < min(t0 + 8, T); ++t) { const float v = bf2f(xr[t]), s = sinf(v * ea); orow[t] = f2bf(v + ib * s * s); }
+    }
+}
+
+extern "C" int omni_snake_beta(const void* x, const float* exp_alpha, const float* inv_beta, void* out, int B, int C, int T,
+                               int is_bf16, void* stream) {
+    OMNI_CHECK_ARG(x && exp_alpha && inv_beta && out, "omni_snake_beta: null pointer");
+    OMNI_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "omni_snake_beta: bad shape");
+    if (B == 0 || T == 0) return OMNI_OK;
+    const int vec = is_bf16 ? 8 : 4;
+    const long long chunks = ((long long)T + 256 * vec - 1) / (256 * vec);
+    OMNI_CHECK_ARG((long long)B * C <= 2147483647LL && chunks <= 65535, "omni_snake_beta: B * C = %lld rows, %lld chunks of T: too large",
+                   (long long)B * C, chunks);
+    dim3 grid((unsigned)(B * C), (unsigned)chunks);
+    if (is_bf16) hipLaunchKernelGGL(snake_beta_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, exp_alpha, inv_beta, out, C, T);
+    else hipLaunchKernelGGL(snake_beta_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, exp_alpha, inv_beta, out, C, T);
+    OMNI_CHECK_LAUNCH("omni_snake_beta");
+    return OMNI_OK;
+}

@@ -56,6 +56,18 @@ def silu_mul(gate_up):
     return out
 
 
+def snake_beta(x, exp_alpha, inv_beta):
+    """SnakeBeta of the Code2Wav decoder: x [B, C, T] fp32 or bf16 -> x + inv_beta[c] * sin(x * exp_alpha[c])^2."""
+    _chk_dev(x, exp_alpha, inv_beta)
+    if x.ndim != 3 or x.dtype not in (torch.float32, BF16) or exp_alpha.dtype != torch.float32 or inv_beta.dtype != torch.float32:
+        raise L.OmniError("snake_beta: x [B, C, T] fp32 / bf16, per-channel fp32 parameters")
+    B, Cc, T = x.shape
+    out = torch.empty_like(x)
+    L.check(L.load().omni_snake_beta(L.ptr(x), L.ptr(exp_alpha), L.ptr(inv_beta), L.ptr(out), B, Cc, T, int(x.dtype == BF16),
+                                     L.current_stream()), "omni_snake_beta")
+    return out
+
+
 def gemm_resid(x, w_frag, r_frag, partials, *, bias=None, accumulate=True, x_frag=True, M=None):
     """In place on the fragment-major residual stream: r = bf16((r if accumulate) + bf16(x . w^T + bias)); fills
     partials[N/16, 64] (per-row sum(r^2) slabs) and returns the slab count."""

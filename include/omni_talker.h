@@ -84,6 +84,13 @@ int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, v
  * GEMM fuses it as OMNI_EPI_SILU_MUL).                                                                                */
 int omni_silu_mul(const void* gate_up, void* out, int T, int inter, void* stream);
 
+/* SnakeBeta activation of the Code2Wav decoder (next stage after the talker):
+ *   out[b, c, t] = x + inv_beta[c] * sin^2(x * exp_alpha[c]),  x / out [B, C, T] contiguous fp32 (is_bf16 = 0) or bf16,
+ *   exp_alpha = exp(alpha), inv_beta = 1 / (exp(beta) + 1e-9) fp32 [C].
+ * Replaces the Triton kernel of tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:617-700 (SnakeBeta._triton_forward). */
+int omni_snake_beta(const void* x, const float* exp_alpha, const float* inv_beta, void* out, int B, int C, int T, int is_bf16,
+                    void* stream);
+
 /* The norm-free residual stream of the decode step: the residual r lives fragment-major ([rows16, N], frag_off) next to
  * per-row sum-of-squares slabs partials[nparts][64] fp32, so that the reference's fused_add_rms_norm launch between
  * two linears (Qwen3DecoderLayer, V/model_executor/models/qwen3_tts/qwen3_tts_talker.py:297-311 via vLLM Qwen3Model)

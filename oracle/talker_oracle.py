@@ -536,6 +536,17 @@ class TalkerOracle:
 
 
 # --------------------------------------------------------------------------
+# SnakeBeta activation of the Code2Wav decoder (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:602-700)
+# --------------------------------------------------------------------------
+def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """x [B, C, T]: x + 1 / (exp(beta) + 1e-9) * sin(x * exp(alpha))^2, per channel, fp32."""
+    ea = torch.exp(alpha.to(torch.float32))[None, :, None]
+    ib = (1.0 / (torch.exp(beta.to(torch.float32)) + 1e-9))[None, :, None]
+    xf = x.to(torch.float32)
+    return (xf + ib * torch.sin(xf * ea) ** 2).to(x.dtype)
+
+
+# --------------------------------------------------------------------------
 # KV extraction (kv_transfer_manager.py:224-301, kv_utils.py:13-85)
 # --------------------------------------------------------------------------
 def extract_kv(layer_kv: torch.Tensor, block_ids: list[int], seq_len: int) -> tuple[torch.Tensor, torch.Tensor]:

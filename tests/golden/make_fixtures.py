@@ -11,6 +11,7 @@ input/output tensors are saved.
   qwen3_backbone_tiny.npz   HF transformers Qwen3Model (bf16, CPU): prefill + decode hidden states
   kv_extract.npz            reference OmniKVTransferManager._extract_kv_cache in/out
   chunk_windows.json        reference talker2code2wav_async_chunk windowing known answers
+  snake_beta.npz            reference SnakeBeta module (12 Hz tokenizer decoder) in/out
   omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
 """
 from __future__ import annotations
@@ -405,10 +406,37 @@ def mint_omni_stage_processors():
     print("omni stage processor cases:", {k: len(v) for k, v in cases.items()})
 
 
+# --------------------------------------------------------------------------
+def mint_snake_beta():
+    """The reference's own SnakeBeta module (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:602-700, eager CPU form)
+    on seeded inputs: x, alpha, beta and the output, fp32."""
+    install_vllm_stubs()
+    pkg = "reftok12"
+    pk = types.ModuleType(pkg)
+    pk.__path__ = [os.path.join(V, "model_executor/models/qwen3_tts/tokenizer_12hz")]
+    sys.modules[pkg] = pk
+    load_by_path(pkg + ".configuration_qwen3_tts_tokenizer_v2", os.path.join(pk.__path__[0], "configuration_qwen3_tts_tokenizer_v2.py"), pkg)
+    mod = load_by_path(pkg + ".modeling_qwen3_tts_tokenizer_v2", os.path.join(pk.__path__[0], "modeling_qwen3_tts_tokenizer_v2.py"), pkg)
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    for i, (B, C, T) in enumerate(((1, 8, 37), (2, 48, 257), (1, 1536, 5), (3, 5, 1027))):
+        m = mod.SnakeBeta(C)
+        with torch.no_grad():
+            m.alpha.copy_(torch.randn(C, generator=g) * 0.5)
+            m.beta.copy_(torch.randn(C, generator=g) * 0.5)
+        x = torch.randn(B, C, T, generator=g) * 2
+        with torch.no_grad():
+            y = m._eager_forward(x)
+        out[f"x{i}"], out[f"alpha{i}"], out[f"beta{i}"], out[f"y{i}"] = x.numpy(), m.alpha.detach().numpy(), m.beta.detach().numpy(), y.numpy()
+    out["n"] = np.int64(4)
+    np.savez_compressed(os.path.join(HERE, "snake_beta.npz"), **out)
+    print("snake beta cases: 4")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -419,3 +447,5 @@ if __name__ == "__main__":
         mint_chunk_windows()
     if "os" in which:
         mint_omni_stage_processors()
+    if "sb" in which:
+        mint_snake_beta()

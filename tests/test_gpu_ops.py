@@ -2,6 +2,7 @@
 seeded inputs.  Bar: integer/index outputs bit-exact; bf16 outputs within 1 bf16 ulp (same rounding
 points, different fp32 summation order) and fp32 outputs within 1e-3 (north_star tolerance)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -529,3 +530,28 @@ def test_sampler_top_p_after_top_k(ops, V, top_k, top_p, scale):
     with pytest.raises(L.OmniError):
         ops.sample(logits.cuda(), greedy=False, temperature=1.0, top_k=0, top_p=0.8)
 
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_snake_beta(ops, golden_dir, dtype):
+    """SnakeBeta of the Code2Wav decoder (the reference's Triton kernel -> HIP): golden vectors minted from the
+    reference module, plus a decoder-sized seeded case against the oracle; odd T exercises the unaligned tail."""
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "snake_beta.npz"))
+    cases = [tuple(torch.from_numpy(z[f"{k}{i}"]) for k in ("x", "alpha", "beta", "y")) for i in range(int(z["n"]))]
+    g = torch.Generator().manual_seed(31)
+    xa = torch.randn(2, 192, 4801, generator=g) * 3
+    aa, ba = torch.randn(192, generator=g) * 0.3, torch.randn(192, generator=g) * 0.3
+    cases.append((xa, aa, ba, O.snake_beta(xa, aa, ba)))
+    for x, a, b, y in cases:
+        ea, ib = torch.exp(a).cuda(), (1.0 / (torch.exp(b) + 1e-9)).cuda()
+        if dtype == "fp32":
+            got = ops.snake_beta(x.cuda(), ea, ib).cpu()
+            torch.testing.assert_close(got, y, rtol=2e-6, atol=2e-6)
+        else:
+            xb = x.to(BF16)
+            got = ops.snake_beta(xb.cuda(), ea, ib)
+            assert_bf16_close(got, O.snake_beta(xb, a, b), ulps=1, max_mismatch=0.01, what="snake beta bf16")
+    from ht_vllm_omni_amd import _lib as L
+    with pytest.raises(L.OmniError):
+        ops.snake_beta(torch.zeros(4, 4, device="cuda"), torch.ones(4, device="cuda"), torch.ones(4, device="cuda"))

@@ -67,3 +67,12 @@ def test_kv_extract_matches_reference(golden_dir):
             assert torch.equal(v, torch.from_numpy(z[f"v{i}_{layout}"]))
         i += 1
     assert i == 4
+
+
+def test_snake_beta_matches_reference_module(golden_dir):
+    """Oracle restatement of the Code2Wav decoder's SnakeBeta against outputs of the reference's own module."""
+    z = np.load(os.path.join(golden_dir, "snake_beta.npz"))
+    for i in range(int(z["n"])):
+        x, a, b, y = (torch.from_numpy(z[f"{k}{i}"]) for k in ("x", "alpha", "beta", "y"))
+        got = O.snake_beta(x, a, b)
+        torch.testing.assert_close(got, y, rtol=1e-6, atol=1e-6)
