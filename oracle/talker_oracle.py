@@ -536,6 +536,47 @@ class TalkerOracle:
 
 
 # --------------------------------------------------------------------------
+# Sparse MoE block of the Qwen3-Omni talker backbone.  The reference runs it on vLLM's FusedMoE
+# (third party, absent: qwen3_omni_moe_talker.py via vllm Qwen3MoeSparseMoeBlock); the published algorithm restated
+# here is HF transformers 5.15 Qwen3OmniMoeTalkerTextSparseMoeBlock (modeling_qwen3_omni_moe.py:2651-2733), bf16
+# tensors with its rounding points: bf16 router logits -> fp32 softmax -> top-k (weights cast to bf16, optionally
+# renormalised) -> per expert IN INDEX ORDER: gate_up, silu * up, down, * weight, bf16 index_add -> + sigmoid-gated
+# shared expert.
+# --------------------------------------------------------------------------
+def moe_route(x: torch.Tensor, w_router: torch.Tensor, top_k: int, norm_topk_prob: bool = False):
+    logits = linear(x, w_router)                                             # bf16 [T, E]
+    probs = torch.softmax(logits.to(torch.float32), dim=-1)
+    val, idx = torch.topk(probs, top_k, dim=-1)
+    if norm_topk_prob:
+        val = val / val.sum(dim=-1, keepdim=True)
+    return logits, val.to(BF16), idx
+
+
+def moe_block(x: torch.Tensor, w: dict, top_k: int, norm_topk_prob: bool = False) -> torch.Tensor:
+    """x bf16 [T, H]; w: router [E, H], gate_up [E, 2I, H], down [E, H, I], shared_gate_up [2Is, H], shared_down [H, Is],
+    shared_gate [1, H] -> bf16 [T, H]."""
+    T, H = x.shape
+    E, two_i = w["gate_up"].shape[0], w["gate_up"].shape[1]
+    I = two_i // 2
+    _, weights, idx = moe_route(x, w["router"], top_k, norm_topk_prob)
+    out = torch.zeros_like(x)
+    for e in range(E):
+        kpos, tok = torch.where(idx.t() == e)                                # [k, T] mask like HF's expert_mask[e]
+        if tok.numel() == 0:
+            continue
+        gu = linear(x[tok], w["gate_up"][e])
+        act = silu_mul(gu[:, :I], gu[:, I:])
+        y = linear(act, w["down"][e])
+        y = y * weights[tok, kpos, None]
+        out.index_add_(0, tok, y)                                            # bf16 accumulate, expert index order
+    sgu = linear(x, w["shared_gate_up"])
+    Is = w["shared_gate_up"].shape[0] // 2
+    shared = linear(silu_mul(sgu[:, :Is], sgu[:, Is:]), w["shared_down"])
+    shared = torch.sigmoid(linear(x, w["shared_gate"])) * shared
+    return out + shared
+
+
+# --------------------------------------------------------------------------
 # SnakeBeta activation of the Code2Wav decoder (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:602-700)
 # --------------------------------------------------------------------------
 def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:

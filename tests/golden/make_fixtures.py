@@ -11,6 +11,7 @@ input/output tensors are saved.
   qwen3_backbone_tiny.npz   HF transformers Qwen3Model (bf16, CPU): prefill + decode hidden states
   kv_extract.npz            reference OmniKVTransferManager._extract_kv_cache in/out
   chunk_windows.json        reference talker2code2wav_async_chunk windowing known answers
+  moe_block.npz             HF Qwen3OmniMoeTalkerTextSparseMoeBlock (bf16) in/out + weights + routing
   snake_beta.npz            reference SnakeBeta module (12 Hz tokenizer decoder) in/out
   omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
 """
@@ -433,10 +434,41 @@ def mint_snake_beta():
     print("snake beta cases: 4")
 
 
+# --------------------------------------------------------------------------
+def mint_moe_block():
+    """HF transformers Qwen3OmniMoeTalkerTextSparseMoeBlock (bf16, CPU) on seeded inputs: the published algorithm of the
+    Omni talker's MoE MLP (the reference itself runs vLLM's FusedMoE, absent here)."""
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import Qwen3OmniMoeTalkerTextConfig
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import Qwen3OmniMoeTalkerTextSparseMoeBlock
+    from tests.util import make_moe_weights
+    out = {}
+    for ci, (H, E, K, I, Is, T, norm) in enumerate(((64, 16, 4, 32, 48, 9, False), (128, 128, 8, 96, 64, 37, False), (64, 8, 2, 32, 32, 5, True))):
+        cfg = Qwen3OmniMoeTalkerTextConfig(hidden_size=H, num_experts=E, num_experts_per_tok=K, moe_intermediate_size=I,
+                                           shared_expert_intermediate_size=Is, norm_topk_prob=norm, num_hidden_layers=1,
+                                           num_attention_heads=2, num_key_value_heads=1)
+        m = Qwen3OmniMoeTalkerTextSparseMoeBlock(cfg).to(torch.bfloat16).eval()
+        w = make_moe_weights(H, E, I, Is, seed=40 + ci)
+        sd = {"gate.weight": w["router"], "experts.gate_up_proj": w["gate_up"], "experts.down_proj": w["down"],
+              "shared_expert.gate_proj.weight": w["shared_gate_up"][:Is], "shared_expert.up_proj.weight": w["shared_gate_up"][Is:],
+              "shared_expert.down_proj.weight": w["shared_down"], "shared_expert_gate.weight": w["shared_gate"]}
+        missing, unexpected = m.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(140 + ci)
+        x = torch.randn(1, T, H, generator=g).to(torch.bfloat16)
+        with torch.no_grad():
+            y = m(x)
+            _, rw, ri = m.gate(x.reshape(-1, H))
+        out[f"c{ci}_meta"] = np.array([H, E, K, I, Is, T, int(norm), 40 + ci])
+        out[f"c{ci}_x"], out[f"c{ci}_y"] = np16(x[0]), np16(y.reshape(T, H))
+        out[f"c{ci}_topk_idx"], out[f"c{ci}_topk_w"] = ri.numpy(), np16(rw)
+    out["n"] = np.int64(3)
+    np.savez_compressed(os.path.join(HERE, "moe_block.npz"), **out)
+    print("moe block cases: 3")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -449,3 +481,5 @@ if __name__ == "__main__":
         mint_omni_stage_processors()
     if "sb" in which:
         mint_snake_beta()
+    if "moe" in which:
+        mint_moe_block()

@@ -76,3 +76,22 @@ def test_snake_beta_matches_reference_module(golden_dir):
         x, a, b, y = (torch.from_numpy(z[f"{k}{i}"]) for k in ("x", "alpha", "beta", "y"))
         got = O.snake_beta(x, a, b)
         torch.testing.assert_close(got, y, rtol=1e-6, atol=1e-6)
+
+
+def test_moe_block_matches_hf_module(golden_dir):
+    """Oracle restatement of the Omni talker's sparse-MoE MLP against HF's Qwen3OmniMoeTalkerTextSparseMoeBlock (bf16):
+    routing indices and weights bit-exact, block output bit-exact (same rounding points, same accumulation order)."""
+    from tests.util import bf16_from_u16, make_moe_weights
+    z = np.load(os.path.join(golden_dir, "moe_block.npz"))
+    for ci in range(int(z["n"])):
+        H, E, K, I, Is, T, norm, seed = (int(v) for v in z[f"c{ci}_meta"])
+        w = make_moe_weights(H, E, I, Is, seed)
+        x = bf16_from_u16(z[f"c{ci}_x"]).reshape(T, H)
+        _, rw, ri = O.moe_route(x, w["router"], K, bool(norm))
+        assert torch.equal(ri, torch.from_numpy(z[f"c{ci}_topk_idx"]))
+        assert torch.equal(rw.view(torch.int16), bf16_from_u16(z[f"c{ci}_topk_w"]).reshape(T, K).view(torch.int16))
+        y = O.moe_block(x, w, K, bool(norm))
+        ref = bf16_from_u16(z[f"c{ci}_y"]).reshape(T, H)
+        diff = (y.float() - ref.float()).abs()
+        assert (y.view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 0.02, f"case {ci}: max diff {diff.max().item()}"
+        assert diff.max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item())

@@ -51,3 +51,15 @@ def assert_e2e_close(got: torch.Tensor, ref: torch.Tensor, *, mean_tol: float = 
     assert d.max().item() <= (max_ulps + 0.02) * ulp, \
         f"{what}: max diff {d.max().item():.4g} > {max_ulps} ulp ({max_ulps * ulp:.4g}) at scale {amax:.3g}"
     assert d.mean().item() <= mean_tol, f"{what}: mean diff {d.mean().item():.4g} > {mean_tol}"
+
+
+def make_moe_weights(H: int, E: int, I: int, Is: int, seed: int) -> dict:
+    """Seeded bf16 weights of one sparse-MoE block (oracle.moe_block layout); the golden fixture stores only the seed,
+    tests and tests/golden/make_fixtures.py both regenerate the tensors from it (CPU generator: reproducible)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*shape, scale):
+        return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+    return {"router": rnd(E, H, scale=0.5), "gate_up": rnd(E, 2 * I, H, scale=0.08), "down": rnd(E, H, I, scale=0.08),
+            "shared_gate_up": rnd(2 * Is, H, scale=0.08), "shared_down": rnd(H, Is, scale=0.08), "shared_gate": rnd(1, H, scale=0.3)}
