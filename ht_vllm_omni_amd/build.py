@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libomni_talker.so")
-SOURCES = ["capi.hip", "gemm.hip", "norm.hip", "rope_kv.hip", "paged_attn.hip", "prefill_attn.hip", "sampler.hip", "debug.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "norm.hip", "rope_kv.hip", "paged_attn.hip", "prefill_attn.hip", "moe.hip", "sampler.hip", "debug.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]

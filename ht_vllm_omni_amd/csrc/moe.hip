@@ -1,0 +1,272 @@
+// Sparse-MoE MLP of the Qwen3-Omni talker backbone at decode batch sizes (T <= 64 tokens).
+// Arithmetic = oracle/talker_oracle.py moe_route / moe_block (HF Qwen3OmniMoeTalkerTextSparseMoeBlock, bf16 rounding
+// points): bf16 router logits -> fp32 softmax -> top-k (weights to bf16) -> per expert gate_up, SiLU * up, down,
+// * weight (each rounded to bf16) -> per token bf16 accumulation IN EXPERT-INDEX ORDER -> + sigmoid-gated shared expert.
+//
+// HBM-bound like the dense MLP, but the bytes are the experts that were hit: with T * k = 512 assignments over 128
+// experts nearly every expert streams its 2.4 MB once per layer.  One workgroup = (expert, n group); it finds the
+// expert's tokens itself (T * k <= 512 routing entries, one per thread, ballot compaction in token order), exits when
+// the expert was not hit, and otherwise runs the skinny-GEMM scheme of gemm.hip: expert weights fragment-major straight
+// into MFMA A operands, the (gathered) activation rows as B operand, 8 waves splitting K, LDS combine.
+#include "common.cuh"
+#include "kernels.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MOE_WAVES 8
+#define MOE_THREADS (MOE_WAVES * 64)
+#define MOE_MAXT 64            // tokens per call (decode batch)
+#define MOE_MAXK 8
+#define MOE_MAXE 256
+
+__device__ __forceinline__ f32x4 moe_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- routing: one wave per token
+__global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restrict__ logits, int T, int E, int top_k, int norm,
+                                                        int32_t* __restrict__ topk_idx, uint16_t* __restrict__ topk_w) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    constexpr int PER = MOE_MAXE / 64;
+    float p[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int e = lane + 64 * j;
+        p[j] = e < E ? bf2f(logits[(size_t)t * E + e]) : -INFINITY;
+        mx = fmaxf(mx, p[j]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        p[j] = (lane + 64 * j < E) ? expf(p[j] - mx) : 0.f;
+        sum += p[j];
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) p[j] = (lane + 64 * j < E) ? p[j] / sum : -1.f;      // -1: never selected
+    float vals[MOE_MAXK];
+    float vsum = 0.f;
+    for (int k = 0; k < top_k; ++k) {
+        float bv = -2.f;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = lane + 64 * j;
+            if (p[j] > bv || (p[j] == bv && e < bi)) { bv = p[j]; bi = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (lane + 64 * j == bi) p[j] = -1.f;
+        vals[k] = bv;
+        vsum += bv;
+        if (lane == 0) topk_idx[(size_t)t * top_k + k] = bi;
+    }
+    if (lane == 0)
+        for (int k = 0; k < top_k; ++k) topk_w[(size_t)t * top_k + k] = f2bf(norm ? vals[k] / vsum : vals[k]);
+}
+
+// ---------------------------------------------------------------- expert GEMMs
+struct MoeArgs {
+    const uint16_t* x;          // phase 1: bf16 [T, K] tokens; phase 2: bf16 [T * k, K] activation slots
+    const uint16_t* W;          // [E, N_rows, K] fragment-major per expert (phase 1: N_rows = 2 * I gate | up; phase 2: H)
+    const int32_t* topk_idx; const uint16_t* topk_w;
+    uint16_t* out;              // phase 1: act [T * k, I]; phase 2: y [T * k, H] (already * routing weight)
+    int T, top_k, K, N;         // N = output columns (I or H)
+};
+
+// PHASE 1: NT = 2 tiles (16 gate + 16 up columns) -> SiLU * up; PHASE 2: NT tiles of 16 output columns, * weight
+template <int PHASE, int NT>
+__global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [WAVES][NT*4][64] partial sums
+    __shared__ int s_tok[MOE_MAXT], s_slot[MOE_MAXT];
+    __shared__ int s_cnt[MOE_WAVES + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int e = blockIdx.y;
+    const int K = a.K, nsteps = K >> 5;
+
+    // ---- this expert's (token, slot) list, in token order: entry i = token i / k, position i % k
+    const int entries = a.T * a.top_k;
+    const bool mine = (int)threadIdx.x < entries && a.topk_idx[threadIdx.x] == e;
+    const uint64_t bal = __ballot(mine);
+    if (lane == 0) s_cnt[wave + 1] = __builtin_popcountll(bal);
+    if (threadIdx.x == 0) s_cnt[0] = 0;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < MOE_WAVES; ++w) {
+        const int c = s_cnt[w + 1];
+        if (w < wave) base += c;
+        total += c;
+    }
+    if (total == 0) return;                               // expert not hit: nothing to stream
+    if (mine) {
+        const int o = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (o < MOE_MAXT) { s_tok[o] = threadIdx.x / a.top_k; s_slot[o] = threadIdx.x; }
+    }
+    __syncthreads();
+    const int n_e = min(total, MOE_MAXT);                 // a token selects an expert at most once: total <= T <= 64
+
+    // ---- W rows of this workgroup (fragment-major per expert: tile (row tile, k step) = 512 contiguous elements)
+    const size_t rows_e = PHASE == 1 ? 2 * (size_t)a.N : (size_t)a.N;
+    const uint16_t* We = a.W + (size_t)e * rows_e * K;
+    const uint16_t* wrow[NT];
+    if (PHASE == 1) {
+        wrow[0] = We + ((size_t)blockIdx.x * nsteps) * 512 + lane * 8;                                   // gate tile
+        wrow[NT - 1] = We + ((size_t)(a.N / 16 + blockIdx.x) * nsteps) * 512 + lane * 8;                 // matching up tile
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wrow[j] = We + ((size_t)(blockIdx.x * NT + j) * nsteps) * 512 + lane * 8;
+    }
+
+    for (int m0 = 0; m0 < n_e; m0 += 16) {
+        const int mrow = min(m0 + r, n_e - 1);            // rows past the end: valid address, result discarded
+        const uint16_t* xrow = a.x + (size_t)(PHASE == 1 ? s_tok[mrow] : s_slot[mrow]) * K + 8 * q;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = wave; ks < nsteps; ks += MOE_WAVES) {
+            const u32x4 X = *reinterpret_cast<const u32x4*>(xrow + ks * 32);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const u32x4 Wf = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[j] + (size_t)ks * 512));
+                acc[j] = moe_mfma(Wf, X, acc[j]);
+            }
+        }
+        __syncthreads();                                   // previous m tile's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lds[(wave * NT * 4 + j * 4 + g) * 64 + lane] = acc[j][g];
+        __syncthreads();
+        // item = lane l of output tile j: row m = l & 15, 4 consecutive columns n = 4 * (l >> 4) + g
+        constexpr int NTO = PHASE == 1 ? 1 : NT;
+        for (int it = threadIdx.x; it < NTO * 64; it += MOE_THREADS) {
+            const int l = it & 63, j = it >> 6;
+            const int m = m0 + (l & 15);
+            if (m >= n_e) continue;
+            float v[4], v2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < MOE_WAVES; ++w) {
+                    s1 += lds[(w * NT * 4 + j * 4 + g) * 64 + l];
+                    if (PHASE == 1) s2 += lds[(w * NT * 4 + (NT - 1) * 4 + g) * 64 + l];
+                }
+                v[g] = s1;
+                v2[g] = s2;
+            }
+            const int slot = s_slot[m];
+            float o[4];
+            if (PHASE == 1) {
+                const int n = blockIdx.x * 16 + 4 * (l >> 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float gt = bfround(v[g]), up = bfround(v2[g]);
+                    o[g] = bfround(gt / (1.0f + expf(-gt))) * up;
+                }
+                *reinterpret_cast<uint2*>(a.out + (size_t)slot * a.N + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            } else {
+                const int n = (blockIdx.x * NT + j) * 16 + 4 * (l >> 4);
+                const float wgt = bf2f(a.topk_w[slot]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) o[g] = bfround(v[g]) * wgt;
+                *reinterpret_cast<uint2*>(a.out + (size_t)slot * a.N + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- combine: one workgroup per token
+// out = bf16( sum over the token's experts in ascending expert index of y[slot] (bf16 accumulate)
+//             + bf16(sigmoid(bf16(x . w_shared_gate)) * shared) )
+__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ y, const int32_t* __restrict__ topk_idx,
+                                                          const uint16_t* __restrict__ x, const uint16_t* __restrict__ w_sg,
+                                                          const uint16_t* __restrict__ shared, uint16_t* __restrict__ out,
+                                                          int top_k, int H) {
+    const int t = blockIdx.x;
+    __shared__ int order[MOE_MAXK];
+    __shared__ float red[4];
+    __shared__ float s_gate;
+    if (threadIdx.x == 0) {
+        int idx[MOE_MAXK], pos[MOE_MAXK];
+        for (int k = 0; k < top_k; ++k) { idx[k] = topk_idx[(size_t)t * top_k + k]; pos[k] = k; }
+        for (int i = 1; i < top_k; ++i)                       // insertion sort by expert index (k <= 8)
+            for (int j = i; j > 0 && idx[j] < idx[j - 1]; --j) {
+                const int a_ = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = a_;
+                const int b_ = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = b_;
+            }
+        for (int k = 0; k < top_k; ++k) order[k] = pos[k];
+    }
+    float gate = 0.f;
+    if (shared) {
+        float d = 0.f;
+        for (int h = threadIdx.x; h < H; h += 256) d = fmaf(bf2f(x[(size_t)t * H + h]), bf2f(w_sg[h]), d);
+        d = wave_sum(d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    }
+    __syncthreads();
+    if (shared) {
+        if (threadIdx.x == 0) {
+            const float lg = bfround((red[0] + red[1]) + (red[2] + red[3]));
+            s_gate = bfround(1.0f / (1.0f + expf(-lg)));
+        }
+        __syncthreads();
+        gate = s_gate;
+    }
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < top_k; ++k) acc = bfround(acc + bf2f(y[((size_t)t * top_k + order[k]) * H + h]));
+        if (shared) acc = bfround(acc + bfround(gate * bf2f(shared[(size_t)t * H + h])));
+        out[(size_t)t * H + h] = f2bf(acc);
+    }
+}
+
+// ---------------------------------------------------------------- C entry points
+extern "C" int omni_moe_route(const void* logits, int T, int E, int top_k, int norm_topk_prob, int32_t* topk_idx, void* topk_w,
+                              void* stream) {
+    OMNI_CHECK_ARG(logits && topk_idx && topk_w, "omni_moe_route: null pointer");
+    OMNI_CHECK_ARG(T >= 0 && E >= 1 && E <= MOE_MAXE && top_k >= 1 && top_k <= MOE_MAXK && top_k <= E,
+                   "omni_moe_route: T=%d E=%d top_k=%d (E <= %d, top_k <= %d)", T, E, top_k, MOE_MAXE, MOE_MAXK);
+    if (T == 0) return OMNI_OK;
+    hipLaunchKernelGGL(moe_route_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits, T, E,
+                       top_k, norm_topk_prob, topk_idx, (uint16_t*)topk_w);
+    OMNI_CHECK_LAUNCH("omni_moe_route");
+    return OMNI_OK;
+}
+
+extern "C" int omni_moe_experts(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,
+                                const void* w_down, const void* shared, const void* w_shared_gate, void* act_ws, void* y_ws,
+                                void* out, int T, int H, int I, int E, int top_k, void* stream) {
+    OMNI_CHECK_ARG(x && topk_idx && topk_w && w_gate_up && w_down && act_ws && y_ws && out, "omni_moe_experts: null pointer");
+    OMNI_CHECK_ARG(T >= 1 && T <= MOE_MAXT && top_k >= 1 && top_k <= MOE_MAXK && T * top_k <= MOE_THREADS,
+                   "omni_moe_experts: T=%d top_k=%d (T <= %d, T * top_k <= %d)", T, top_k, MOE_MAXT, MOE_THREADS);
+    OMNI_CHECK_ARG(H % 64 == 0 && I % 32 == 0 && E >= 1 && E <= 65535, "omni_moe_experts: H=%d I=%d E=%d (H %% 64, I %% 32)", H, I, E);
+    OMNI_CHECK_ARG(!shared || w_shared_gate, "omni_moe_experts: shared expert output without its gate weight");
+    hipStream_t st = (hipStream_t)stream;
+    MoeArgs a{};
+    a.topk_idx = topk_idx; a.topk_w = (const uint16_t*)topk_w; a.T = T; a.top_k = top_k;
+    // phase 1: act[slot] = silu(x . Wg^T) * (x . Wu^T)
+    a.x = (const uint16_t*)x; a.W = (const uint16_t*)w_gate_up; a.out = (uint16_t*)act_ws; a.K = H; a.N = I;
+    hipLaunchKernelGGL((moe_expert_kernel<1, 2>), dim3(I / 16, E), dim3(MOE_THREADS), MOE_WAVES * 2 * 4 * 64 * sizeof(float), st, a);
+    OMNI_CHECK_LAUNCH("omni_moe_experts(gate_up)");
+    // phase 2: y[slot] = bf16(act . Wd^T) * weight
+    a.x = (const uint16_t*)act_ws; a.W = (const uint16_t*)w_down; a.out = (uint16_t*)y_ws; a.K = I; a.N = H;
+    hipLaunchKernelGGL((moe_expert_kernel<2, 4>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
+    OMNI_CHECK_LAUNCH("omni_moe_experts(down)");
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(T), dim3(256), 0, st, (const uint16_t*)y_ws, topk_idx, (const uint16_t*)x,
+                       (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, top_k, H);
+    OMNI_CHECK_LAUNCH("omni_moe_experts(combine)");
+    return OMNI_OK;
+}

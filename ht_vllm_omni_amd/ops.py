@@ -56,6 +56,38 @@ def silu_mul(gate_up):
     return out
 
 
+def moe_route(logits, top_k, norm_topk_prob=False):
+    """bf16 router logits [T, E] -> (topk_idx int32 [T, k], topk_w bf16 [T, k])."""
+    _chk_dev(logits)
+    T, E = logits.shape
+    idx = torch.empty(T, top_k, dtype=torch.int32, device=logits.device)
+    wts = torch.empty(T, top_k, dtype=BF16, device=logits.device)
+    L.check(L.load().omni_moe_route(L.ptr(logits), T, E, top_k, int(norm_topk_prob), L.ptr(idx), L.ptr(wts), L.current_stream()),
+            "omni_moe_route")
+    return idx, wts
+
+
+def moe_block(x, w, top_k, norm_topk_prob=False):
+    """Sparse-MoE MLP of the Omni talker on device tensors.  w: router [E, H] (row-major), gate_up_f [E, 2I, H] and down_f
+    [E, H, I] fragment-major per expert (engine.frag_shuffle), shared_gate_up [2Is, H], shared_down [H, Is], shared_gate
+    [1, H] (row-major).  Returns bf16 [T, H]."""
+    T, H = x.shape
+    E, two_i = w["gate_up_f"].shape[0], w["gate_up_f"].shape[1]
+    I = two_i // 2
+    logits = gemm(x, w["router"])
+    idx, wts = moe_route(logits, top_k, norm_topk_prob)
+    shared = None
+    if w.get("shared_gate_up") is not None:
+        shared = gemm(gemm(x, w["shared_gate_up"], epilogue=L.EPI_SILU_MUL), w["shared_down"])
+    act = torch.empty(T * top_k, I, dtype=BF16, device=x.device)
+    y = torch.empty(T * top_k, H, dtype=BF16, device=x.device)
+    out = torch.empty(T, H, dtype=BF16, device=x.device)
+    L.check(L.load().omni_moe_experts(L.ptr(x), L.ptr(idx), L.ptr(wts), L.ptr(w["gate_up_f"]), L.ptr(w["down_f"]), L.ptr(shared),
+                                      L.ptr(w.get("shared_gate")), L.ptr(act), L.ptr(y), L.ptr(out), T, H, I, E, top_k,
+                                      L.current_stream()), "omni_moe_experts")
+    return out, idx, wts
+
+
 def snake_beta(x, exp_alpha, inv_beta):
     """SnakeBeta of the Code2Wav decoder: x [B, C, T] fp32 or bf16 -> x + inv_beta[c] * sin(x * exp_alpha[c])^2."""
     _chk_dev(x, exp_alpha, inv_beta)

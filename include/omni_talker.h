@@ -84,6 +84,21 @@ int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, v
  * GEMM fuses it as OMNI_EPI_SILU_MUL).                                                                                */
 int omni_silu_mul(const void* gate_up, void* out, int T, int inter, void* stream);
 
+/* Sparse-MoE MLP of the Qwen3-Omni talker backbone (the reference runs vLLM's FusedMoE through
+ * V/model_executor/models/qwen3_omni/qwen3_omni_moe_talker.py; arithmetic here = HF Qwen3OmniMoeTalkerTextSparseMoeBlock,
+ * the algorithm the oracle restates), decode batch sizes: T <= 64 tokens, top_k <= 8, E <= 256 experts.
+ *   omni_moe_route:   logits bf16 [T, E] (= x . W_router^T, e.g. omni_gemm_bf16) -> fp32 softmax -> top_k experts per token
+ *                     (ties: lower index), topk_idx int32 [T, k], topk_w bf16 [T, k] (renormalised when norm_topk_prob).
+ *   omni_moe_experts: per hit expert e: act = silu(x_e . Wg_e^T) * (x_e . Wu_e^T); y = bf16(act . Wd_e^T) * weight; then per
+ *                     token out = sum of its y in ascending expert order (bf16 accumulate) + bf16(sigmoid(bf16(x . w_shared_gate))
+ *                     * shared) when shared != NULL (shared bf16 [T, H] = the shared expert's MLP output).
+ *                     w_gate_up bf16 [E, 2I, H] = [gate rows | up rows] and w_down bf16 [E, H, I], each expert matrix
+ *                     fragment-major (OMNI_LAYOUT_W_FRAG); workspaces act_ws bf16 [T * k, I], y_ws bf16 [T * k, H].     */
+int omni_moe_route(const void* logits, int T, int E, int top_k, int norm_topk_prob, int32_t* topk_idx, void* topk_w, void* stream);
+int omni_moe_experts(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const void* w_down,
+                     const void* shared, const void* w_shared_gate, void* act_ws, void* y_ws, void* out, int T, int H, int I,
+                     int E, int top_k, void* stream);
+
 /* SnakeBeta activation of the Code2Wav decoder (next stage after the talker):
  *   out[b, c, t] = x + inv_beta[c] * sin^2(x * exp_alpha[c]),  x / out [B, C, T] contiguous fp32 (is_bf16 = 0) or bf16,
  *   exp_alpha = exp(alpha), inv_beta = 1 / (exp(beta) + 1e-9) fp32 [C].

@@ -555,3 +555,57 @@ def test_snake_beta(ops, golden_dir, dtype):
     from ht_vllm_omni_amd import _lib as L
     with pytest.raises(L.OmniError):
         ops.snake_beta(torch.zeros(4, 4, device="cuda"), torch.ones(4, device="cuda"), torch.ones(4, device="cuda"))
+
+
+def _moe_dev(w):
+    from ht_vllm_omni_amd.engine import frag_shuffle
+    d = {k: v.cuda() for k, v in w.items() if k not in ("gate_up", "down")}
+    d["gate_up_f"], d["down_f"] = frag_shuffle(w["gate_up"]).cuda(), frag_shuffle(w["down"]).cuda()
+    return d
+
+
+@pytest.mark.parametrize("H,E,K,I,Is,T,norm", [(64, 16, 4, 32, 64, 9, False), (128, 128, 8, 96, 64, 37, False), (64, 16, 2, 32, 32, 5, True),
+                                               (1024, 128, 8, 384, 768, 64, False), (1024, 128, 8, 384, 768, 1, False)])
+def test_moe_block(ops, H, E, K, I, Is, T, norm):
+    """Sparse-MoE MLP of the Omni talker (row a11): routing (indices exact up to exact ties, weights within one bf16 ulp),
+    then the expert path + bf16 accumulation in expert order + gated shared expert against the oracle (which is pinned to
+    HF's module by tests/test_oracle_golden.py); the last two shapes are the real talker's (H 1024, 128 experts, top-8)."""
+    from tests.util import make_moe_weights
+    w = make_moe_weights(H, E, I, Is, seed=7 * E + K)
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, H, generator=g).to(BF16)
+    out, idx, wts = ops.moe_block(x.cuda(), _moe_dev(w), K, norm)
+    logits, rw, ri = O.moe_route(x, w["router"], K, norm)
+    # routing: the device picks the same expert set unless two probabilities tie within fp32 rounding
+    same_rows = (idx.cpu().sort(-1).values == ri.to(torch.int32).sort(-1).values).all(-1)
+    probs = torch.softmax(logits.float(), -1).sort(-1, descending=True).values
+    tie = (probs[:, K - 1] - probs[:, K]).abs() <= 1e-6 * probs[:, K - 1]      # bf16 logits: the k-th and (k+1)-th can be EQUAL
+    assert bool((same_rows | tie).all()), "routing sets differ without a tie at the cut"
+    assert (idx.cpu()[same_rows] == ri.to(torch.int32)[same_rows]).float().mean().item() >= 0.9, "routing order (ties inside the set may swap)"
+    assert_bf16_close(wts.cpu()[same_rows], rw[same_rows], ulps=1, max_mismatch=0.05, what="routing weights")
+    ref = O.moe_block(x, w, K, norm)
+    ok = same_rows.nonzero().flatten()
+    # eight bf16 contributions per element may cancel, and a 1-ulp routing weight moves one of them: bound at tensor scale
+    from tests.util import assert_e2e_close
+    assert_e2e_close(out.cpu()[ok], ref[ok], mean_tol=2e-3 * max(1.0, ref.float().abs().max().item()), max_ulps=2, what="moe block output")
+    # exactness of the expert path given the device's own routing: oracle block with the routing forced
+    ref2 = _moe_oracle_with_routing(x, w, idx.cpu().long(), wts.cpu())
+    scale = max(1.0, ref2.float().abs().max().item())
+    assert_e2e_close(out.cpu(), ref2, mean_tol=5e-4 * scale, max_ulps=2, what="moe experts given routing")
+    assert (out.cpu().view(torch.int16) != ref2.view(torch.int16)).float().mean().item() < 0.1, "bit-identical for > 90 % of the outputs"
+
+
+def _moe_oracle_with_routing(x, w, idx, wts):
+    I = w["gate_up"].shape[1] // 2
+    out = torch.zeros_like(x)
+    for e in range(w["gate_up"].shape[0]):
+        kpos, tok = torch.where(idx.t() == e)
+        if tok.numel() == 0:
+            continue
+        gu = O.linear(x[tok], w["gate_up"][e])
+        y = O.linear(O.silu_mul(gu[:, :I], gu[:, I:]), w["down"][e]) * wts[tok, kpos, None]
+        out.index_add_(0, tok, y)
+    Is = w["shared_gate_up"].shape[0] // 2
+    sgu = O.linear(x, w["shared_gate_up"])
+    shared = torch.sigmoid(O.linear(x, w["shared_gate"])) * O.linear(O.silu_mul(sgu[:, :Is], sgu[:, Is:]), w["shared_down"])
+    return out + shared
