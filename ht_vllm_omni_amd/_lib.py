@@ -27,7 +27,8 @@ class OmniError(RuntimeError):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [(n, vp) for n in ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")]
+    _fields_ = [(n, vp) for n in ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown", "moe_router", "moe_gate_up",
+                                  "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate")]
 
 
 class TalkerDesc(C.Structure):
@@ -35,7 +36,9 @@ class TalkerDesc(C.Structure):
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
         ("vocab", i32), ("codebook", i32), ("num_code_groups", i32), ("eps", f32),
         ("cp_hidden", i32), ("cp_layers", i32), ("cp_q_heads", i32), ("cp_kv_heads", i32), ("cp_head_dim", i32),
-        ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32), ("fused_norm", i32),
+        ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32),
+        ("moe_experts", i32), ("moe_top_k", i32), ("moe_inter", i32), ("moe_shared_inter", i32), ("moe_norm_topk", i32),
+        ("fused_norm", i32),
         ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
         ("k_scale", f32), ("v_scale", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),

@@ -36,6 +36,12 @@ class TalkerDims:
     cp_inter: int
     cp_rope_theta: float
     max_model_len: int = 4096  # qwen3_tts.yaml:22
+    # sparse-MoE backbone MLP (Qwen3-Omni talker: HF Qwen3OmniMoeTalkerTextConfig); 0 experts = dense MLP
+    moe_experts: int = 0
+    moe_top_k: int = 0
+    moe_inter: int = 0
+    moe_shared_inter: int = 0
+    moe_norm_topk: bool = False
 
     @property
     def qkv_out(self) -> int:
@@ -72,6 +78,15 @@ PRESETS: dict[str, TalkerDims] = {
         rope_theta=1_000_000.0, eps=1e-6,
         cp_hidden=128, cp_layers=2, cp_q_heads=2, cp_kv_heads=1, cp_head_dim=128, cp_inter=256,
         cp_rope_theta=10_000.0, max_model_len=512,
+    ),
+    # MoE talker in miniature (Omni: no code-predictor projection, top-k experts + gated shared expert)
+    "omni-moe-tiny": TalkerDims(
+        name="omni-moe-tiny", hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=128,
+        vocab=192, codebook=128, eos_id=150, codec_pad_id=148, num_code_groups=4,
+        rope_theta=1_000_000.0, eps=1e-6,
+        cp_hidden=256, cp_layers=2, cp_q_heads=2, cp_kv_heads=1, cp_head_dim=128, cp_inter=256,
+        cp_rope_theta=10_000.0, max_model_len=512,
+        moe_experts=16, moe_top_k=4, moe_inter=64, moe_shared_inter=64,
     ),
     "tts-0.6b": _tts("tts-0.6b", 1024, 3072),   # BASELINE config #2
     "tts-1.7b": _tts("tts-1.7b", 2048, 6144),   # BASELINE config #3 (headline)

@@ -110,6 +110,8 @@ struct omni_talker {
     int Bm, cp_bs;
     // scratch carve
     uint16_t *resid, *resid_b, *normed, *qkv, *q, *attn, *attn_out, *act, *mlp_out, *hidden, *e0;
+    uint16_t *normed_rm, *moe_logits, *moe_w, *moe_act, *moe_y, *moe_shared;   // sparse-MoE MLP scratch
+    int32_t* moe_idx;
     float *attn_ws, *part, *cp_part;   // sum-of-squares slabs of the fused-norm residual streams
     uint16_t *cp_resid, *cp_resid_b, *cp_normed, *cp_qkv, *cp_q, *cp_attn, *cp_o, *cp_act, *cp_mlp, *cp_hidden, *cp_in, *cp_row;
     float* cp_logits;
@@ -172,6 +174,17 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->cp_seq = c.take<int32_t>((Q + 1) * B);
     t->cp_slots = c.take<int64_t>((Q + 1) * B);
     t->pf_seq = c.take<int32_t>(8);
+    if (d.moe_experts > 0) {
+        const size_t k = d.moe_top_k, Im = d.moe_inter, Is = d.moe_shared_inter;
+        t->normed_rm = c.take<uint16_t>(B * H);
+        t->moe_logits = c.take<uint16_t>(B * d.moe_experts);
+        t->moe_idx = c.take<int32_t>(B * k);
+        t->moe_w = c.take<uint16_t>(B * k);
+        t->moe_act = c.take<uint16_t>(B * k * Im);
+        t->moe_y = c.take<uint16_t>(B * k * H);
+        t->moe_shared = c.take<uint16_t>(B * H);
+        if (Is > d.inter) c.take<uint16_t>(B16 * (Is - d.inter));      // t->act doubles as the shared expert's activation
+    }
     t->cp_k.resize(d.cp_layers);
     t->cp_v.resize(d.cp_layers);
     const size_t cpkv = B * t->cp_bs * d.cp_kv_heads * d.cp_head_dim;
@@ -222,6 +235,13 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
     }
     if (desc->fused_norm && !desc->frag_layout) {
         omni_set_error("omni_talker_create: fused_norm needs frag_layout");
+        return nullptr;
+    }
+    if (desc->moe_experts > 0 && (desc->fused_norm || !desc->frag_layout || desc->moe_top_k < 1 || desc->moe_top_k > 8 ||
+                                  desc->moe_experts % 16 || desc->moe_experts > 256 || desc->moe_inter % 32 ||
+                                  desc->moe_shared_inter % 32 || desc->hidden % 64 || desc->moe_shared_inter > desc->inter)) {
+        omni_set_error("omni_talker_create: MoE backbone needs frag_layout, fused_norm = 0, top_k <= 8, experts %% 16 == 0 (<= 256), "
+                       "moe / shared intermediate %% 32 == 0, hidden %% 64 == 0, shared intermediate <= inter (scratch)");
         return nullptr;
     }
     omni_talker* t = new omni_talker();
@@ -547,6 +567,23 @@ static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* po
 static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
+    if (d.moe_experts > 0) {
+        // sparse-MoE MLP (Omni talker): norm -> router -> shared expert -> routed experts + combine -> mlp_out
+        const int H = d.hidden, E = d.moe_experts, Is = d.moe_shared_inter;
+        const int lay = OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG;
+        TRY(k_rmsnorm(nullptr, t->attn_out, t->resid_b, t->resid, w.ln2, t->normed_rm, t->normed, rows, H, d.eps, st));
+        TRY(omni_gemm_bf16_ex(t->normed, H, w.moe_router, nullptr, t->moe_logits, rows, E, H, OMNI_EPI_BF16, nullptr, OMNI_LAYOUT_X_FRAG, st));
+        TRY(omni_moe_route(t->moe_logits, rows, E, d.moe_top_k, d.moe_norm_topk, t->moe_idx, t->moe_w, st));
+        const void* shared = nullptr;
+        if (Is > 0) {
+            TRY(omni_gemm_bf16_ex(t->normed, H, w.moe_shared_gate_up, nullptr, t->act, rows, Is, H, OMNI_EPI_SILU_MUL, nullptr,
+                                  lay | OMNI_LAYOUT_OUT_FRAG, st));
+            TRY(omni_gemm_bf16_ex(t->act, Is, w.moe_shared_down, nullptr, t->moe_shared, rows, H, Is, OMNI_EPI_BF16, nullptr, lay, st));
+            shared = t->moe_shared;
+        }
+        return omni_moe_experts(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, w.moe_down, shared, w.moe_shared_gate, t->moe_act,
+                                t->moe_y, t->mlp_out, rows, H, d.moe_inter, E, d.moe_top_k, st);
+    }
     TRY(norm_gemm(t, t->resid_b, t->attn_out, t->resid, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
                   OMNI_EPI_SILU_MUL, nullptr, d.frag_layout, st));
     TRY(act_gemm(t, t->act, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, st));

@@ -52,6 +52,9 @@ def frag_unshuffle(w: torch.Tensor) -> torch.Tensor:
     return v.contiguous().reshape(*lead, N, K)
 
 
+MOE_NAMES = ("moe_router", "moe_gate_up", "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate")
+
+
 def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict:
     """Per-rank slices of one backbone layer."""
     D = d.head_dim
@@ -67,6 +70,12 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
     q = wqkv[qo + rank * hq_l * D: qo + (rank + 1) * hq_l * D]
     k = wqkv[ko + kv0 * D: ko + (kv0 + hkv_l) * D]
     v = wqkv[vo + kv0 * D: vo + (kv0 + hkv_l) * D]
+    if d.moe_experts > 0:
+        if tp != 1:
+            raise ValueError("the sparse-MoE backbone is single-rank (no expert / tensor parallel sharding yet)")
+        return {"ln1": w[prefix + "ln1"], "ln2": w[prefix + "ln2"], "qnorm": w[prefix + "qnorm"], "knorm": w[prefix + "knorm"],
+                "wqkv": w[prefix + "wqkv"].contiguous(), "wo": w[prefix + "wo"].contiguous(),
+                **{n: w[prefix + n] for n in MOE_NAMES}}
     i_l = d.inter // tp
     wgu = w[prefix + "wgu"]
     return {
@@ -94,7 +103,9 @@ class TalkerEngine:
         self.frag_layout = bool(frag_layout)
         # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm): single-rank decode only -- the tensor-parallel
         # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
-        self.fused_norm = (self.frag_layout and not self.tp_path) if fused_norm is None else bool(fused_norm)
+        self.fused_norm = (self.frag_layout and not self.tp_path and dims.moe_experts == 0) if fused_norm is None else bool(fused_norm)
+        if dims.moe_experts > 0 and (self.fused_norm or not self.frag_layout or tp_size > 1):
+            raise ValueError("the sparse-MoE backbone runs the separate-norm, fragment-major, single-rank path")
         if self.fused_norm and (self.tp_path or not self.frag_layout):
             raise ValueError("fused_norm needs frag_layout and a single rank")
         self.kv_code = L.KV_CODES[kv_dtype]
@@ -139,16 +150,18 @@ class TalkerEngine:
         else:
             self.cp_proj_table, self.cp_e0_table = self.cp_embed, self.embed
         names = ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")
+        bb_names = names[:6] + MOE_NAMES if d.moe_experts > 0 else names
+        frag_names = ("wqkv", "wo", "wgu", "wdown", "moe_gate_up", "moe_down", "moe_shared_gate_up", "moe_shared_down")
         self._layers = (L.LayerWeights * d.layers)()
         self.layer_w: list[dict] = []
         for i in range(d.layers):
             sh = shard_layer(d, weights, f"l{i}.", tp_rank, tp_size)
-            lw = {n: up(sh[n]) for n in names}
+            lw = {n: up(sh[n]) for n in bb_names}
             self.layer_w.append(lw)                 # row-major: hipBLASLt prefill path
-            for n in names:
+            for n in bb_names:
                 t_ = lw[n]
-                if self.frag_layout and n in ("wqkv", "wo", "wgu", "wdown"):
-                    t_ = up(frag_shuffle(lw[n]))    # fragment-major copy for the native decode GEMMs
+                if self.frag_layout and n in frag_names:
+                    t_ = up(frag_shuffle(lw[n]))    # fragment-major copy for the native decode GEMMs (per expert for MoE)
                 setattr(self._layers[i], n, t_.data_ptr())
         self._cp_layers = (L.LayerWeights * d.cp_layers)()
         self.cp_layer_w: list[dict] = []
@@ -184,6 +197,8 @@ class TalkerEngine:
         desc.cp_head_dim, desc.cp_inter, desc.has_cp_projection = d.cp_head_dim, d.cp_inter, int(d.has_cp_projection)
         desc.frag_layout = int(self.frag_layout)
         desc.fused_norm = int(self.fused_norm)
+        desc.moe_experts, desc.moe_top_k, desc.moe_inter = d.moe_experts, d.moe_top_k, d.moe_inter
+        desc.moe_shared_inter, desc.moe_norm_topk = d.moe_shared_inter, int(d.moe_norm_topk)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
@@ -343,6 +358,8 @@ class TalkerEngine:
         instead of max_batch-row chunks that each re-stream the weights."""
         import torch.nn.functional as F
         d = self.d
+        if d.moe_experts > 0:
+            raise L.OmniError("prefill_blas: dense MLP only (the sparse-MoE backbone prefills through the native chunk path)")
         bt = self.block_table if block_table is None else block_table
         D, hq, hkv = d.head_dim, self.hq_l, self.hkv_l
         resid = x.clone()
@@ -378,7 +395,7 @@ class TalkerEngine:
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
         if use_blas is None:
-            use_blas = T > self.max_batch
+            use_blas = T > self.max_batch and self.d.moe_experts == 0     # MoE layers: native chunks of <= max_batch rows
         if use_blas:
             return self.prefill_blas(x, positions, req_of_tok, slot_mapping, bt)
         out = torch.empty_like(x)

@@ -8,6 +8,8 @@ prefix mapping (qwen3_tts_talker.py:297-311,1569-1590): per layer a fused
 Keys (all bf16, CPU):
   embed [V,H]  l{i}.ln1 [H]  l{i}.wqkv [(Hq+2Hkv)D,H]  l{i}.qnorm [D]  l{i}.knorm [D]
   l{i}.wo [H,Hq*D]  l{i}.ln2 [H]  l{i}.wgu [2I,H]  l{i}.wdown [H,I]  norm [H]  lm_head [V,H]
+  MoE backbone (moe_experts > 0) instead of wgu / wdown: l{i}.moe_router [E,H]  moe_gate_up [E,2Im,H]  moe_down [E,H,Im]
+  moe_shared_gate_up [2Is,H]  moe_shared_down [H,Is]  moe_shared_gate [1,H]
   cp.proj_w [Hc,H] cp.proj_b [Hc] (only when Hc != H)   cp.l{i}.* (same names, Hc dims)
   cp.norm [Hc]  cp.lm_head [Q-1,Vc,Hc]  cp.embed [Q-1,Vc,H]
 """
@@ -43,8 +45,16 @@ def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise:
         w[p + "knorm"] = nrm(d.head_dim)
         w[p + "wo"] = rnd(d.hidden, d.q_heads * d.head_dim)
         w[p + "ln2"] = nrm(d.hidden)
-        w[p + "wgu"] = rnd(2 * d.inter, d.hidden)
-        w[p + "wdown"] = rnd(d.hidden, d.inter)
+        if d.moe_experts > 0:
+            w[p + "moe_router"] = (rnd(d.moe_experts, d.hidden).float() * 8).to(torch.bfloat16)     # spread the routing logits
+            w[p + "moe_gate_up"] = rnd(d.moe_experts, 2 * d.moe_inter, d.hidden)
+            w[p + "moe_down"] = rnd(d.moe_experts, d.hidden, d.moe_inter)
+            w[p + "moe_shared_gate_up"] = rnd(2 * d.moe_shared_inter, d.hidden)
+            w[p + "moe_shared_down"] = rnd(d.hidden, d.moe_shared_inter)
+            w[p + "moe_shared_gate"] = rnd(1, d.hidden)
+        else:
+            w[p + "wgu"] = rnd(2 * d.inter, d.hidden)
+            w[p + "wdown"] = rnd(d.hidden, d.inter)
     w["norm"] = nrm(d.hidden)
     w["lm_head"] = rnd(d.vocab, d.hidden)
     if d.has_cp_projection:

@@ -200,6 +200,13 @@ typedef struct omni_layer_weights {
     const void* ln2;    /* bf16 [H]               */
     const void* wgu;    /* bf16 [2I, H]           */
     const void* wdown;  /* bf16 [H, I]            */
+    /* sparse-MoE MLP instead of wgu / wdown when desc.moe_experts > 0 (backbone layers of the Omni talker) */
+    const void* moe_router;          /* bf16 [E, H]                                   */
+    const void* moe_gate_up;         /* bf16 [E, 2*Im, H], each expert fragment-major  */
+    const void* moe_down;            /* bf16 [E, H, Im],   each expert fragment-major  */
+    const void* moe_shared_gate_up;  /* bf16 [2*Is, H]  (layout as wgu)                */
+    const void* moe_shared_down;     /* bf16 [H, Is]    (layout as wdown)              */
+    const void* moe_shared_gate;     /* bf16 [H]                                       */
 } omni_layer_weights;
 
 typedef struct omni_talker_desc {
@@ -211,6 +218,8 @@ typedef struct omni_talker_desc {
     int cp_hidden, cp_layers, cp_q_heads, cp_kv_heads, cp_head_dim, cp_inter;
     int has_cp_projection;
     int frag_layout;   /* != 0: every GEMM weight below is fragment-major (OMNI_LAYOUT_W_FRAG); activations follow */
+    /* backbone MLP = sparse MoE when moe_experts > 0 (omni_moe_route / omni_moe_experts; needs fused_norm == 0) */
+    int moe_experts, moe_top_k, moe_inter, moe_shared_inter, moe_norm_topk;
     int fused_norm;    /* != 0 (needs frag_layout, the folded tables, single rank): the decode step keeps the residual
                           stream fragment-major and folds every RMSNorm into its neighbouring GEMMs (omni_gemm_resid /
                           omni_gemm_xnorm); the per-phase attn_out / mlp_out buffers are then NOT produced */

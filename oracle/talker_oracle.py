@@ -377,6 +377,12 @@ class TalkerOracle:
             h = resid + linear(o.reshape(T, hq * D), w[p + "wo"])
             resid = h
             a = rms_norm(h, w[p + "ln2"], d.eps)
+            if getattr(d, "moe_experts", 0) > 0:       # Omni talker: sparse-MoE MLP
+                mw = {"router": w[p + "moe_router"], "gate_up": w[p + "moe_gate_up"], "down": w[p + "moe_down"],
+                      "shared_gate_up": w[p + "moe_shared_gate_up"], "shared_down": w[p + "moe_shared_down"],
+                      "shared_gate": w[p + "moe_shared_gate"]}
+                h = resid + moe_block(a, mw, d.moe_top_k, d.moe_norm_topk)
+                continue
             gu = linear(a, w[p + "wgu"])
             act = silu_mul(gu[:, : d.inter], gu[:, d.inter:])
             h = resid + linear(act, w[p + "wdown"])
