@@ -88,6 +88,17 @@ PRESETS: dict[str, TalkerDims] = {
         cp_rope_theta=10_000.0, max_model_len=512,
         moe_experts=16, moe_top_k=4, moe_inter=64, moe_shared_inter=64,
     ),
+    # Qwen3-Omni talker (BASELINE configs #4 / #5): HF Qwen3OmniMoeTalkerTextConfig defaults (hidden 1024, 20 layers, 16 q /
+    # 2 kv heads, 128 experts top-8 of width 384) + shared expert 768 and head_dim 128 as in the released checkpoint
+    # (not stated in R/: parameters); code predictor as the TTS one but without projection (width == talker width)
+    "omni-talker": TalkerDims(
+        name="omni-talker", hidden=1024, layers=20, q_heads=16, kv_heads=2, head_dim=128, inter=768,
+        vocab=3072, codebook=2048, eos_id=2150, codec_pad_id=2148, num_code_groups=16,
+        rope_theta=1_000_000.0, eps=1e-6,
+        cp_hidden=1024, cp_layers=5, cp_q_heads=16, cp_kv_heads=8, cp_head_dim=128, cp_inter=3072,
+        cp_rope_theta=10_000.0,
+        moe_experts=128, moe_top_k=8, moe_inter=384, moe_shared_inter=768,
+    ),
     "tts-0.6b": _tts("tts-0.6b", 1024, 3072),   # BASELINE config #2
     "tts-1.7b": _tts("tts-1.7b", 2048, 6144),   # BASELINE config #3 (headline)
 }

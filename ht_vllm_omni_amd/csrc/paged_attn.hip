@@ -33,6 +33,8 @@ struct PAArgs {
     uint16_t* out; float* partial;
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
     int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
+    int kv_rep;                    // decode kernel: grid.x = kv_heads * kv_rep "virtual" kv heads of q_heads / (kv_heads * kv_rep)
+                                   // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
     int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
 };
 
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [PA_WAVES][G][PA_REC] | q scratch | kv scratch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 7, tg = lane >> 3;
-    const int kvh = blockIdx.x, row = blockIdx.y, sp = blockIdx.z;
+    const int vh = blockIdx.x, row = blockIdx.y, sp = blockIdx.z;     // vh: virtual kv head = group of G q heads
+    const int kvh = vh / a.kv_rep;
     const int req = a.req_of_row ? a.req_of_row[row] : row;
     const int kv_heads = a.kv_heads, bs = a.bs;
     const int32_t* bt = a.block_table + (size_t)req * a.bt_stride;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float y0, y1;
-            head_norm_rope(a.qkv + ((size_t)row * nslots + kvh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
+            head_norm_rope(a.qkv + ((size_t)row * nslots + vh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
             wq[g * 128 + lane] = y0;
             wq[g * 128 + 64 + lane] = y1;
         }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const uint16_t* qp = a.q + ((size_t)row * a.q_heads + kvh * G + g) * 128;
+            const uint16_t* qp = a.q + ((size_t)row * a.q_heads + vh * G + g) * 128;
 #pragma unroll
             for (int e = 0; e < 16; ++e) qf[g][e] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
         }
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             const int pos = a.positions[row];
             const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
             const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
-            if (kvh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+            if (vh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
             const size_t crow = (size_t)slot * kv_heads + kvh;
+            const bool kv_writer = vh % a.kv_rep == 0;      // the other groups of this kv head fold the same values
             float* kvs = lds + PA_WAVES * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
             float kx0, kx1;
             head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
@@ -241,16 +245,20 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             if (KV == OMNI_KV_BF16) {
                 uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
                 uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
-                kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
-                vd[lane] = f2bf(vx0); vd[lane + 64] = f2bf(vx1);
+                if (kv_writer) {
+                    kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
+                    vd[lane] = f2bf(vx0); vd[lane + 64] = f2bf(vx1);
+                }
             } else if (KV == OMNI_KV_FP8) {
                 const float ik = a.k_scale, iv = a.v_scale;
                 const uint32_t pk = pack_fp8x4(ik == 1.f ? kx0 : kx0 / ik, ik == 1.f ? kx1 : kx1 / ik, 0.f, 0.f);
                 const uint32_t pv = pack_fp8x4(iv == 1.f ? vx0 : vx0 / iv, iv == 1.f ? vx1 : vx1 / iv, 0.f, 0.f);
                 uint8_t* kd = reinterpret_cast<uint8_t*>(a.k_cache) + crow * 128;
                 uint8_t* vd = reinterpret_cast<uint8_t*>(a.v_cache) + crow * 128;
-                kd[lane] = (uint8_t)(pk & 0xFF); kd[lane + 64] = (uint8_t)((pk >> 8) & 0xFF);
-                vd[lane] = (uint8_t)(pv & 0xFF); vd[lane + 64] = (uint8_t)((pv >> 8) & 0xFF);
+                if (kv_writer) {
+                    kd[lane] = (uint8_t)(pk & 0xFF); kd[lane + 64] = (uint8_t)((pk >> 8) & 0xFF);
+                    vd[lane] = (uint8_t)(pv & 0xFF); vd[lane + 64] = (uint8_t)((pv >> 8) & 0xFF);
+                }
                 float t4[4];
                 unpack_fp8x4(pk, t4); kx0 = t4[0]; kx1 = t4[1];       // what the cache now holds (unscaled)
                 unpack_fp8x4(pv, t4); vx0 = t4[0]; vx1 = t4[1];
@@ -262,9 +270,11 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
                 vx0 = fminf(fmaxf(rintf(vx0 / vsc_new), -127.f), 127.f); vx1 = fminf(fmaxf(rintf(vx1 / vsc_new), -127.f), 127.f);
                 int8_t* kd = reinterpret_cast<int8_t*>(a.k_cache) + crow * 128;
                 int8_t* vd = reinterpret_cast<int8_t*>(a.v_cache) + crow * 128;
-                kd[lane] = (int8_t)kx0; kd[lane + 64] = (int8_t)kx1;
-                vd[lane] = (int8_t)vx0; vd[lane + 64] = (int8_t)vx1;
-                if (lane == 0) { a.k_scales[crow] = ksc_new; a.v_scales[crow] = vsc_new; }
+                if (kv_writer) {
+                    kd[lane] = (int8_t)kx0; kd[lane + 64] = (int8_t)kx1;
+                    vd[lane] = (int8_t)vx0; vd[lane + 64] = (int8_t)vx1;
+                    if (lane == 0) { a.k_scales[crow] = ksc_new; a.v_scales[crow] = vsc_new; }
+                }
             }
             kvs[lane] = kx0; kvs[64 + lane] = kx1;
             kvs[128 + lane] = vx0; kvs[192 + lane] = vx1;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             L = fmaf(rec[1], w, L);
             A = fmaf(rec[2 + d], w, A);
         }
-        const int qh = kvh * G + g;
+        const int qh = vh * G + g;
         if (a.nsplit == 1) {
             const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
             const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
@@ -571,16 +581,19 @@ extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_
 }
 
 template <int KV, bool FUSED>
-static int launch_pa(const PAArgs& a, int rows, hipStream_t st) {
-    const int G = a.q_heads / a.kv_heads;
-    dim3 grid(a.kv_heads, rows, a.nsplit), block(PA_THREADS);
+static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
+    PAArgs a = a_in;
+    int G = a.q_heads / a.kv_heads;
+    a.kv_rep = 1;
+    while (G > 4 && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }      // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head
+    dim3 grid(a.kv_heads * a.kv_rep, rows, a.nsplit), block(PA_THREADS);
     const size_t lds = ((size_t)PA_WAVES * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
 #define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
     switch (G) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
         case 4: LAUNCH(4); break;
-        default: omni_set_error("omni_paged_attn: Hq/Hkv=%d unsupported (1,2,4)", G); return OMNI_EINVAL;
+        default: omni_set_error("omni_paged_attn: Hq/Hkv=%d unsupported (1, 2, 4 and their multiples by powers of two)", a.q_heads / a.kv_heads); return OMNI_EINVAL;
     }
 #undef LAUNCH
     OMNI_CHECK_LAUNCH("omni_paged_attn_decode");

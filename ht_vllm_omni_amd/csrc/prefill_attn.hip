@@ -215,7 +215,8 @@ static int pf_launch_g(const PFArgs& a, int G, hipStream_t st) {
     dim3 grid((a.T + 15) / 16, a.kv_heads);
     if (G == 1) hipLaunchKernelGGL((paged_attn_prefill_mfma_kernel<KV, 1>), grid, dim3(64), 0, st, a);
     else if (G == 2) hipLaunchKernelGGL((paged_attn_prefill_mfma_kernel<KV, 2>), grid, dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((paged_attn_prefill_mfma_kernel<KV, 4>), grid, dim3(256), 0, st, a);
+    else if (G == 4) hipLaunchKernelGGL((paged_attn_prefill_mfma_kernel<KV, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((paged_attn_prefill_mfma_kernel<KV, 8>), grid, dim3(512), 0, st, a);
     OMNI_CHECK_LAUNCH("omni_paged_attn_prefill(mfma)");
     return OMNI_OK;
 }
@@ -226,7 +227,7 @@ extern "C" void omni_debug_prefill_mfma(int on) { g_prefill_mfma = on; }   // A/
 bool k_prefill_mfma_supported(int q_heads, int kv_heads, int head_dim) {
     if (!g_prefill_mfma || head_dim != 128 || kv_heads <= 0 || q_heads % kv_heads) return false;
     const int G = q_heads / kv_heads;
-    return G == 1 || G == 2 || G == 4;
+    return G == 1 || G == 2 || G == 4 || G == 8;
 }
 
 int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, const float* k_scales, const float* v_scales,

@@ -406,3 +406,22 @@ def test_moe_backbone_decode_steps_match_oracle():
         assert_e2e_close(g[same], o[same], mean_tol=8e-3, max_ulps=3, what=f"MoE step {i} logits")
     # a routing near-tie (bf16 router logits) may send a token to a different 4th expert than the oracle's torch.topk
     assert bad_rows <= 2, f"{bad_rows} rows diverged"
+
+
+def test_omni_talker_real_dims_one_layer():
+    """The Omni talker's real layer shapes (H 1024, 16 q / 2 kv heads = four virtual groups of 4 per kv head, 128 experts
+    top-8 of width 384 + shared 768) with one backbone / one predictor layer, B = 64, int8 KV (BASELINE config #4)."""
+    d = get_dims("omni-talker").with_(layers=1, cp_layers=1, num_code_groups=3, max_model_len=256)
+    w = make_weights(d, seed=21, std=0.02)
+    g = torch.Generator().manual_seed(1)
+    lens = torch.randint(4, 40, (64,), generator=g).tolist()
+    rec = _scenario(d, w, "int8", prompt_lens=lens, n_steps=2, num_blocks=300, mean_tol=2e-3)
+    lg, ol = rec["prefill_logits"]
+    assert_e2e_close(lg, ol, mean_tol=2e-3, max_ulps=3, what="omni talker prefill logits")
+    diverged = 0
+    for i, st in enumerate(rec["steps"]):
+        assert torch.equal(st["slots"][0], st["slots"][1]), f"step {i}: slot mapping must be bit-exact"
+        same = (st["codes"][0] == st["codes"][1]).all(-1)
+        diverged += int((~same).sum())
+        assert_e2e_close(st["logits"][0][same], st["logits"][1][same], mean_tol=2e-3, max_ulps=3, what=f"omni talker step {i} logits")
+    assert diverged <= 6, f"{diverged} of 128 rows took a different expert / code at a near-tie"

@@ -250,7 +250,7 @@ def _fill_cache(kv, nb, bs, hkv, D, gen, k_scale, v_scale):
 
 
 @pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
-@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1)])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1), (16, 2)])
 @pytest.mark.parametrize("split", [False, True])
 def test_paged_attn_decode(ops, kv, hq, hkv, split):
     from ht_vllm_omni_amd import _lib as L
@@ -282,7 +282,7 @@ def test_paged_attn_decode(ops, kv, hq, hkv, split):
 
 
 @pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
-@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8)])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (16, 2)])
 @pytest.mark.parametrize("split", [False, True])
 def test_attn_decode_fused(ops, kv, hq, hkv, split):
     """Fused q/k-norm + RoPE + KV write + attention == the two separate ops (oracle), incl. slot indices."""
@@ -336,7 +336,7 @@ def test_attn_decode_fused(ops, kv, hq, hkv, split):
         torch.testing.assert_close(sc.cpu(), pk.scales, rtol=1e-2, atol=0)
 
 
-@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (2, 2)])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (2, 2), (16, 2)])
 def test_attn_decode_fused_short_context(ops, hq, hkv):
     """Code-predictor geometry: block = one request's 17 positions, contexts 1..17 (one-wave kernel)."""
     from ht_vllm_omni_amd import _lib as L
@@ -391,7 +391,7 @@ def test_paged_attn_prefill_causal(ops):
 
 
 @pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
-@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1), (2, 2)])
+@pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (4, 1), (2, 2), (16, 2)])
 def test_paged_attn_prefill_mfma_ragged(ops, kv, hq, hkv):
     """Matrix-core prefill attention: ragged prompts (1-token, block-boundary and multi-tile lengths, tiles that
     straddle up to three requests), scattered blocks, a later chunk of a request (positions start past cached keys),
