@@ -307,7 +307,7 @@ def main():
     if bb_ms is not None:
         bb_bytes = by_end["weights_backbone"] + by_end["lm_head"] + by_end["kv_read"] + by_end["kv_write"]
         out["roofline"]["breakdown"] = {
-            "note": "diagnostic, outside the timed region: the backbone half (28 layers + lm_head + sampler) replayed alone "
+            "note": f"diagnostic, outside the timed region: the backbone half ({d.layers} layers + lm_head + sampler) replayed alone "
                     "at the final context; code predictor + input assembly = step - backbone",
             "backbone_ms": bb_ms, "code_predictor_ms": ev_ms - bb_ms, "backbone_ctx": float(np.mean(end_ctx)),
             "backbone_gbs": bb_bytes / (bb_ms * 1e-3) / 1e9, "backbone_frac": bb_bytes / (bb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

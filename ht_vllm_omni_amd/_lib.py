@@ -38,7 +38,7 @@ class TalkerDesc(C.Structure):
         ("cp_hidden", i32), ("cp_layers", i32), ("cp_q_heads", i32), ("cp_kv_heads", i32), ("cp_head_dim", i32),
         ("cp_inter", i32), ("has_cp_projection", i32), ("frag_layout", i32),
         ("moe_experts", i32), ("moe_top_k", i32), ("moe_inter", i32), ("moe_shared_inter", i32), ("moe_norm_topk", i32),
-        ("fused_norm", i32),
+        ("fused_norm", i32), ("cp_fused_norm", i32),
         ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
         ("k_scale", f32), ("v_scale", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),

@@ -233,8 +233,8 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
         omni_set_error("omni_talker_create: cp_hidden != hidden needs the projection");
         return nullptr;
     }
-    if (desc->fused_norm && !desc->frag_layout) {
-        omni_set_error("omni_talker_create: fused_norm needs frag_layout");
+    if ((desc->fused_norm || desc->cp_fused_norm) && !desc->frag_layout) {
+        omni_set_error("omni_talker_create: fused_norm / cp_fused_norm need frag_layout");
         return nullptr;
     }
     if (desc->moe_experts > 0 && (desc->fused_norm || !desc->frag_layout || desc->moe_top_k < 1 || desc->moe_top_k > 8 ||
@@ -425,7 +425,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
     const omni_talker_desc& d = t->d;
     const int Q = d.num_code_groups, Hc = d.cp_hidden;
     if (Q <= 1) return OMNI_OK;
-    if (d.fused_norm) {
+    if (d.cp_fused_norm) {
         int np = 1;
         TRY(cp_project_fused(t, last_hidden, B, &np, st));
         TRY(cp_forward_fused(t, B, 0, &np, st));

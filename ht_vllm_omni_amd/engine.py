@@ -197,6 +197,9 @@ class TalkerEngine:
         desc.cp_head_dim, desc.cp_inter, desc.has_cp_projection = d.cp_head_dim, d.cp_inter, int(d.has_cp_projection)
         desc.frag_layout = int(self.frag_layout)
         desc.fused_norm = int(self.fused_norm)
+        # the code predictor is replicated on every rank and has no collective inside: norm-free whenever layouts allow
+        self.cp_fused_norm = self.frag_layout if fused_norm is None else bool(fused_norm)
+        desc.cp_fused_norm = int(self.cp_fused_norm)
         desc.moe_experts, desc.moe_top_k, desc.moe_inter = d.moe_experts, d.moe_top_k, d.moe_inter
         desc.moe_shared_inter, desc.moe_norm_topk = d.moe_shared_inter, int(d.moe_norm_topk)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies

@@ -78,7 +78,11 @@ def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise:
 
 def weight_bytes(d: TalkerDims) -> dict[str, int]:
     """Algorithmic weight bytes read once per talker step."""
-    bb = d.layers * (d.hidden * d.qkv_out + d.q_heads * d.head_dim * d.hidden + 3 * d.hidden * d.inter) * 2
+    if d.moe_experts > 0:      # every expert counted once (T * k = 512 assignments over 128 experts hit ~98 % of them) + shared + router
+        mlp = d.moe_experts * 3 * d.hidden * d.moe_inter + 3 * d.hidden * d.moe_shared_inter + d.moe_experts * d.hidden + d.hidden
+    else:
+        mlp = 3 * d.hidden * d.inter
+    bb = d.layers * (d.hidden * d.qkv_out + d.q_heads * d.head_dim * d.hidden + mlp) * 2
     head = d.vocab * d.hidden * 2
     cp = d.cp_layers * (d.cp_hidden * d.cp_qkv_out + d.cp_q_heads * d.cp_head_dim * d.cp_hidden
                         + 3 * d.cp_hidden * d.cp_inter) * 2

@@ -223,6 +223,8 @@ typedef struct omni_talker_desc {
     int fused_norm;    /* != 0 (needs frag_layout, the folded tables, single rank): the decode step keeps the residual
                           stream fragment-major and folds every RMSNorm into its neighbouring GEMMs (omni_gemm_resid /
                           omni_gemm_xnorm); the per-phase attn_out / mlp_out buffers are then NOT produced */
+    int cp_fused_norm; /* the same for the code predictor alone: it is replicated and has no all-reduce inside, so tensor-
+                          parallel ranks and MoE backbones (fused_norm == 0) still run it on the norm-free stream */
     /* runtime */
     int max_batch, block_size, kv_dtype, max_model_len, bt_stride;
     float k_scale, v_scale;
