@@ -425,3 +425,83 @@ def test_omni_talker_real_dims_one_layer():
         diverged += int((~same).sum())
         assert_e2e_close(st["logits"][0][same], st["logits"][1][same], mean_tol=2e-3, max_ulps=3, what=f"omni talker step {i} logits")
     assert diverged <= 6, f"{diverged} of 128 rows took a different expert / code at a near-tie"
+
+
+@pytest.mark.parametrize("model,tp", [("tiny", 2), ("tts-1.7b-1layer", 8), ("tts-1.7b-1layer", 4)])
+def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
+    """Tensor parallel on ONE GPU: all rank engines of a TP group (sharded qkv / o / gate_up / down, one
+    KV head each, replicated code predictor) are driven phase by phase, the two all-reduces of every layer replaced by
+    adding the two partial buffers -- the sharded kernels, the phase API and the KV-head split of the cache against the
+    unsharded oracle.  (The RCCL all-reduce itself: test_tp_collective_path_captured_in_hipgraph, 1-rank group.)"""
+    import ctypes as C
+    from ht_vllm_omni_amd import _lib as L
+    if model == "tiny":
+        d = get_dims("tiny")
+        w = make_weights(d, seed=17, std=0.06, norm_noise=0.1)
+    else:                                             # real layer shapes: TP = 8 -> 2 q heads / 1 kv head / 768 columns per rank
+        d = get_dims("tts-1.7b").with_(layers=1, cp_layers=1, num_code_groups=3, max_model_len=256)
+        w = make_weights(d, seed=17, std=0.02)
+    bs, nb, n_steps = 16, 32, 3
+    prompt_lens = [5, 17, 33]
+    B = len(prompt_lens)
+    orc = O.TalkerOracle(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs)
+    pool = BlockPool(nb, bs)
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in prompt_lens]
+    pads = [torch.randn(d.hidden, generator=g).to(BF16) for _ in range(B)]
+    for r, n in enumerate(prompt_lens):
+        pool.allocate(f"r{r}", n + n_steps + 1)
+    bts = [pool.block_ids(f"r{r}") for r in range(B)]
+    states = [O.OracleState(tail_text=[], tts_pad=pads[r]) for r in range(B)]
+    _, o_ids, o_h = orc.prefill(states, prompts, bts, greedy=True, sampling={})
+    engs = [_engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=B, tp_rank=r, tp_size=tp) for r in range(tp)]
+    lib = engs[0].lib
+    for r, e in enumerate(engs):
+        assert e.tp_path and e.hq_l == d.q_heads // tp and e.hkv_l == d.kv_heads // tp and not e.fused_norm and e.cp_fused_norm
+        for li in range(d.layers):                       # this rank's KV head of the prefilled cache
+            e.kv_caches[li].copy_(orc.kv[li].data[:, :, :, r * e.hkv_l:(r + 1) * e.hkv_l].cuda())
+        bt = torch.zeros(e.max_batch, e.bt_stride, dtype=torch.int32)
+        for q in range(B):
+            bt[q, :len(bts[q])] = torch.tensor(bts[q])
+        e.block_table.copy_(bt)
+        e.input_ids[:B] = o_ids.to(torch.int32).cuda()
+        e.last_hidden[:B] = o_h.cuda()
+        e.positions[:B] = torch.tensor(prompt_lens, dtype=torch.int32).cuda()
+        e.seq_lens[:B] = (torch.tensor(prompt_lens, dtype=torch.int32) + 1).cuda()
+        e.steps[:B] = 1
+        e.text_step[:B] = torch.stack(pads).cuda()
+    st = L.current_stream()
+
+    def all_reduce(name):
+        tot = sum(getattr(e, name)[:B].float() for e in engs)       # fp32 sum of the bf16 partials, one rounding
+        for e in engs:
+            getattr(e, name)[:B] = tot.to(BF16)
+
+    for s in range(n_steps):
+        ios = [e._io(B, True) for e in engs]
+        for e, io in zip(engs, ios):
+            L.check(lib.omni_talker_mtp(e.handle, C.byref(io), st), "mtp")
+        for li in range(d.layers):
+            for e, io in zip(engs, ios):
+                L.check(lib.omni_talker_layer_attn(e.handle, C.byref(io), li, st), "layer_attn")
+            all_reduce("_attn_out")
+            for e, io in zip(engs, ios):
+                L.check(lib.omni_talker_layer_mlp(e.handle, C.byref(io), li, st), "layer_mlp")
+            all_reduce("_mlp_out")
+        for e, io in zip(engs, ios):
+            L.check(lib.omni_talker_finish(e.handle, C.byref(io), st), "finish")
+        torch.cuda.synchronize()
+        ol, oi, oh, oc, osl = orc.decode_step(states, bts, greedy=True, sampling={}, cp_kw=dict(do_sample=False))
+        for r, e in enumerate(engs):
+            assert torch.equal(e.slot_mapping[:B].cpu(), osl), f"step {s} rank {r}: slots"
+            assert torch.equal(e.audio_codes[:B].cpu(), oc), f"step {s} rank {r}: codes"
+            assert_e2e_close(e.logits[:B].cpu(), ol, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} logits")
+            assert_e2e_close(e.last_hidden[:B].cpu(), oh, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} hidden")
+        assert torch.equal(engs[0].logits[:B], engs[1].logits[:B]), "ranks must agree bit for bit (replicated tail)"
+        for e in engs:                                   # stay on the oracle's trajectory
+            e.input_ids[:B] = oi.to(torch.int32).cuda()
+            e.last_hidden[:B] = oh.cuda()
+    # each rank's cache holds its own KV head of the new tokens
+    for li in range(d.layers):
+        for r, e in enumerate(engs):
+            assert_e2e_close(e.kv_caches[li].cpu(), orc.kv[li].data[:, :, :, r * e.hkv_l:(r + 1) * e.hkv_l], what=f"kv layer {li} rank {r}")
