@@ -48,31 +48,43 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
     sum = wave_sum(sum);
 #pragma unroll
     for (int j = 0; j < PER; ++j) p[j] = (lane + 64 * j < E) ? p[j] / sum : -1.f;      // -1: never selected
+    // top_k rounds of a wave-wide argmax (value desc, index asc); fully unrolled so vals[] stays in registers
     float vals[MOE_MAXK];
+    int sel[MOE_MAXK];
     float vsum = 0.f;
-    for (int k = 0; k < top_k; ++k) {
-        float bv = -2.f;
-        int bi = 0x7FFFFFFF;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = lane + 64 * j;
-            if (p[j] > bv || (p[j] == bv && e < bi)) { bv = p[j]; bi = e; }
+    for (int k = 0; k < MOE_MAXK; ++k) {
+        vals[k] = 0.f;
+        sel[k] = 0;
+        if (k < top_k) {
+            float bv = -2.f;
+            int bi = 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int e = lane + 64 * j;
+                if (p[j] > bv || (p[j] == bv && e < bi)) { bv = p[j]; bi = e; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (lane + 64 * j == bi) p[j] = -1.f;
+            vals[k] = bv;
+            sel[k] = bi;
+            vsum += bv;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (lane + 64 * j == bi) p[j] = -1.f;
-        vals[k] = bv;
-        vsum += bv;
-        if (lane == 0) topk_idx[(size_t)t * top_k + k] = bi;
     }
-    if (lane == 0)
-        for (int k = 0; k < top_k; ++k) topk_w[(size_t)t * top_k + k] = f2bf(norm ? vals[k] / vsum : vals[k]);
+    // lane k writes entry k
+#pragma unroll
+    for (int k = 0; k < MOE_MAXK; ++k)
+        if (lane == k && k < top_k) {
+            topk_idx[(size_t)t * top_k + k] = sel[k];
+            topk_w[(size_t)t * top_k + k] = f2bf(norm ? vals[k] / vsum : vals[k]);
+        }
 }
 
 // ---------------------------------------------------------------- expert GEMMs
@@ -199,15 +211,11 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
     __shared__ int order[MOE_MAXK];
     __shared__ float red[4];
     __shared__ float s_gate;
-    if (threadIdx.x == 0) {
-        int idx[MOE_MAXK], pos[MOE_MAXK];
-        for (int k = 0; k < top_k; ++k) { idx[k] = topk_idx[(size_t)t * top_k + k]; pos[k] = k; }
-        for (int i = 1; i < top_k; ++i)                       // insertion sort by expert index (k <= 8)
-            for (int j = i; j > 0 && idx[j] < idx[j - 1]; --j) {
-                const int a_ = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = a_;
-                const int b_ = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = b_;
-            }
-        for (int k = 0; k < top_k; ++k) order[k] = pos[k];
+    if (threadIdx.x < (unsigned)top_k) {                  // thread k: rank of expert k among the token's experts
+        const int mine = topk_idx[(size_t)t * top_k + threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < top_k; ++j) rank += topk_idx[(size_t)t * top_k + j] < mine ? 1 : 0;
+        order[rank] = threadIdx.x;                        // experts of a token are distinct: ranks are a permutation
     }
     float gate = 0.f;
     if (shared) {
@@ -225,11 +233,24 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
         __syncthreads();
         gate = s_gate;
     }
-    for (int h = threadIdx.x; h < H; h += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < top_k; ++k) acc = bfround(acc + bf2f(y[((size_t)t * top_k + order[k]) * H + h]));
-        if (shared) acc = bfround(acc + bfround(gate * bf2f(shared[(size_t)t * H + h])));
-        out[(size_t)t * H + h] = f2bf(acc);
+    int ord[MOE_MAXK];
+#pragma unroll
+    for (int k = 0; k < MOE_MAXK; ++k) ord[k] = k < top_k ? order[k] : 0;
+    for (int h = threadIdx.x * 2; h < H; h += 512) {       // two columns per thread: 4-B accesses
+        uint32_t yv[MOE_MAXK];
+#pragma unroll
+        for (int k = 0; k < MOE_MAXK; ++k)
+            yv[k] = k < top_k ? *reinterpret_cast<const uint32_t*>(y + ((size_t)t * top_k + ord[k]) * H + h) : 0u;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MOE_MAXK; ++k)
+            if (k < top_k) { a0 = bfround(a0 + bf_lo(yv[k])); a1 = bfround(a1 + bf_hi(yv[k])); }
+        if (shared) {
+            const uint32_t sv = *reinterpret_cast<const uint32_t*>(shared + (size_t)t * H + h);
+            a0 = bfround(a0 + bfround(gate * bf_lo(sv)));
+            a1 = bfround(a1 + bfround(gate * bf_hi(sv)));
+        }
+        *reinterpret_cast<uint32_t*>(out + (size_t)t * H + h) = pack_bf2(a0, a1);
     }
 }
 

@@ -585,7 +585,11 @@ static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     PAArgs a = a_in;
     int G = a.q_heads / a.kv_heads;
     a.kv_rep = 1;
-    while (G > 4 && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }      // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head
+    // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head; int8 KV keeps its per-token scales live and spills at G = 4
+    // (512 VGPRs + 144 spilled, 65 us per layer), so it runs groups of 2
+    const int max_g = (KV == OMNI_KV_INT8) ? 2 : 4;
+    while (G > max_g && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }
+    if (rows * a.kv_heads * a.kv_rep >= 512) a.nsplit = 1;      // the virtual heads already fill the chip: no KV split
     dim3 grid(a.kv_heads * a.kv_rep, rows, a.nsplit), block(PA_THREADS);
     const size_t lds = ((size_t)PA_WAVES * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
 #define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
