@@ -8,8 +8,10 @@
 //   B lane(c = l&15, q)        = x[m0 + c][k0 + 8q .. +8)
 //   D[n][m]: lane holds m = l&15, n = 4*(l>>4) + reg.
 // Workgroup = 8 waves = one group of NT 16-row n-tiles x MT 16-row m-tiles; grid = (n groups,
-// m splits).  The 8 waves split K (k-steps interleaved w, w+8, ...), every wave keeps a deep ring
-// of W loads in flight, partial sums combine through LDS.
+// m splits).  The 8 waves split K (k-steps interleaved w, w+8, ...); when K % 512 == 0 (every talker
+// shape) a wave runs the COUNTED schedule: two k-steps of W and x in flight, no predicated load, so each
+// MFMA group waits only for its own operands (vmcnt(N), not vmcnt(0)); other K take the generic ring
+// loop.  Partial sums combine through LDS.
 // fp32 accumulate, one rounding to bf16 (oracle: talker_oracle.linear / rms_norm).
 //
 // The norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm, see include/omni_talker.h):
@@ -45,7 +47,7 @@ struct GemmArgs {
     int wshuf, xshuf, oshuf;   // fragment-major layouts (OMNI_LAYOUT_*), see common.cuh frag_off
     // PRO_XNORM / EPI_RESID: per-row sum-of-squares slabs [np][64 rows] fp32 (deterministic: one slab per producer workgroup)
     const float* part_in; int np_in; float* part_out;
-    int counted;               // use the counted (unpredicated, P-deep) schedule when K % 1024 == 0
+    int counted;               // use the counted (unpredicated, 2-deep) schedule when K % 512 == 0
 };
 
 // PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         constexpr int P = 2;
         constexpr bool COUNTED = true;
         if (COUNTED && a.counted && ntw > 0 && nsteps % (GEMM_WAVES * P) == 0) {
-            // ---- counted schedule (K % 1024 == 0: every wave owns a multiple of P k-steps).  No load is predicated, so
+            // ---- counted schedule (K % (256 P) == 0: every wave owns a multiple of P k-steps).  No load is predicated, so
             // hipcc can count: each MFMA group waits for exactly the loads issued P steps earlier (vmcnt((P-1) * loads
             // per step)) while the younger P-1 steps stay in flight -- with a predicated refill it must wait vmcnt(0)
             // before every group, i.e. one exposed L2 round trip for x per k-step.
