@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(HERE, "libomni_talker.so")
 KV_BF16, KV_FP8, KV_INT8 = 0, 1, 2
 KV_CODES = {"bf16": KV_BF16, "auto": KV_BF16, "fp8": KV_FP8, "fp8_e4m3": KV_FP8, "int8": KV_INT8}
 EPI_BF16, EPI_SILU_MUL, EPI_F32, EPI_F32_BF16RND = 0, 1, 2, 3
+EPI_RESID, EPI_SILU_MUL_GU8 = 4, 5
+SILU_EPIS = (EPI_SILU_MUL, EPI_SILU_MUL_GU8)
 LAYOUT_W_FRAG, LAYOUT_X_FRAG, LAYOUT_OUT_FRAG = 1, 2, 4
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32

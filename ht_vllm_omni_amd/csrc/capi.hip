@@ -307,6 +307,9 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
     return OMNI_OK;
 }
 
+// dense gate_up weights (layer.wgu): fragment-major engines hold them gate / up interleaved by 8 rows (OMNI_EPI_SILU_MUL_GU8)
+static inline int silu_epi(const omni_talker* t) { return t->d.frag_layout ? OMNI_EPI_SILU_MUL_GU8 : OMNI_EPI_SILU_MUL; }
+
 // ---- fused-or-fallback building blocks --------------------------------------------------------
 // separate-norm path (tensor-parallel ranks, prefill rows): out = epilogue( rmsnorm(resid_in (+delta)) . W^T );
 // r = resid_in + delta -> resid_out
@@ -361,7 +364,7 @@ static int cp_forward_fused(omni_talker* t, int B, int p, int* np, void* st) {
         if (p == 0 && l == d.cp_layers - 1) break;
         TRY(resid_gemm(t->cp_attn, w.wo, t->cp_resid, t->cp_part, B, Hc, hq * D, st));
         *np = Hc / 16;
-        TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, *np, w.ln2, nullptr, w.wgu, t->cp_act, B, d.cp_inter, Hc, OMNI_EPI_SILU_MUL,
+        TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, *np, w.ln2, nullptr, w.wgu, t->cp_act, B, d.cp_inter, Hc, silu_epi(t),
                        nullptr, 1, st));
         TRY(resid_gemm(t->cp_act, w.wdown, t->cp_resid, t->cp_part, B, Hc, d.cp_inter, st));
     }
@@ -400,7 +403,7 @@ static int cp_forward(omni_talker* t, int B, int p, void* st) {
         if (p == 0 && l == d.cp_layers - 1) break;
         TRY(act_gemm(t, t->cp_attn, w.wo, nullptr, t->cp_o, B, Hc, hq * D, st));
         TRY(norm_gemm(t, t->cp_resid_b, t->cp_o, t->cp_resid, w.ln2, t->cp_normed, nullptr, w.wgu, t->cp_act, B, d.cp_inter,
-                      Hc, OMNI_EPI_SILU_MUL, nullptr, d.frag_layout, st));
+                      Hc, silu_epi(t), nullptr, d.frag_layout, st));
         TRY(act_gemm(t, t->cp_act, w.wdown, nullptr, t->cp_mlp, B, Hc, d.cp_inter, st));
     }
     return OMNI_OK;
@@ -585,7 +588,7 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
                                 t->moe_y, t->mlp_out, rows, H, d.moe_inter, E, d.moe_top_k, st);
     }
     TRY(norm_gemm(t, t->resid_b, t->attn_out, t->resid, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
-                  OMNI_EPI_SILU_MUL, nullptr, d.frag_layout, st));
+                  silu_epi(t), nullptr, d.frag_layout, st));
     TRY(act_gemm(t, t->act, w.wdown, nullptr, t->mlp_out, rows, d.hidden, d.inter, st));
     return OMNI_OK;
 }
@@ -603,7 +606,7 @@ extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int
     if (d.fused_norm) {
         const omni_layer_weights& w = t->layer[layer];
         TRY(xnorm_gemm(t, t->resid, t->part, d.hidden / 16, w.ln2, nullptr, w.wgu, t->act, io->B, d.inter, d.hidden,
-                       OMNI_EPI_SILU_MUL, nullptr, 1, stream));
+                       silu_epi(t), nullptr, 1, stream));
         return resid_gemm(t->act, w.wdown, t->resid, t->part, io->B, d.hidden, d.inter, stream);
     }
     return layer_mlp_rows(t, layer, io->B, stream);

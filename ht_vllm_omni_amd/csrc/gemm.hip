@@ -82,6 +82,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     const uint16_t* wrow[NT];
     {
         int row0[NT];
+        static_assert(NT != 3 || EPI == OMNI_EPI_SILU_MUL_GU8, "NT = 3 only for the interleaved gate_up layout");
         if (EPI == OMNI_EPI_SILU_MUL) {
             // tiles [0, NT/2) = gate rows, tiles [NT/2, NT) = the matching up rows (W = [gate | up], N = inter)
             const int n0 = blockIdx.x * 16 * (NT / 2);
@@ -135,23 +136,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 
     float rstd[MT];
     auto xnorm_rstd = [&]() {
-        // part 2 (after the W ring is in flight): fixed-order reduction -> rstd of this workgroup's rows
-        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+        // part 2 (after the W ring is in flight): fixed-order reduction -> rstd of this workgroup's rows.  row = lane % XROWS:
+        // fold the channels that share a wave by shuffles, the 8 waves through a private LDS area past the epilogue's
+        // (ONE barrier; every wave then holds all row sums and picks its MFMA rows by shuffle)
         float s_ = psum;
 #pragma unroll
         for (int e = 0; e < PE; ++e) s_ += pv[e];
-        lds[ch * XROWS + row] = s_;
+        if (XROWS <= 32) s_ += __shfl_xor(s_, 32, 64);
+        if (XROWS <= 16) s_ += __shfl_xor(s_, 16, 64);
+        float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;
+        red[wave * 64 + lane] = s_;
         __syncthreads();
-        if (threadIdx.x < XROWS) {
-            float t = 0.f;
+        float t = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) t += lds[c * XROWS + threadIdx.x];
-            lds[GEMM_THREADS + threadIdx.x] = 1.0f / sqrtf(t / (float)K + a.eps);
-        }
-        __syncthreads();
+        for (int w = 0; w < GEMM_WAVES; ++w) t += red[w * 64 + lane];
+        const float rl = 1.0f / sqrtf(t / (float)K + a.eps);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) rstd[i] = lds[GEMM_THREADS + i * 16 + r];
-        __syncthreads();      // lds is reused by the epilogue
+        for (int i = 0; i < MT; ++i) rstd[i] = __shfl(rl, i * 16 + r, 64);
     };
 
     const int ntw = (nsteps - wave + GEMM_WAVES - 1) / GEMM_WAVES; // k-steps of this wave (may be 0)
@@ -296,11 +297,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     __syncthreads();
 
     // item = (m-tile i, [n-tile j], lane l): 4 consecutive n (reg 0..3) of one row m
+    // OMNI_EPI_SILU_MUL_GU8: every 16-row W tile = 8 gate rows (D lanes 0..31) + the 8 matching up rows (lanes 32..63)
+    constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
+    constexpr bool SILU = EPI == OMNI_EPI_SILU_MUL || GU8;
     constexpr int NTO = (EPI == OMNI_EPI_SILU_MUL) ? NT / 2 : NT;
-    constexpr int ITEMS = NTO * MT * 64;
+    constexpr int LN = GU8 ? 32 : 64;
+    constexpr int ITEMS = NTO * MT * LN;
     for (int it = threadIdx.x; it < ITEMS; it += GEMM_THREADS) {
-        const int l = it & 63;
-        const int t = it >> 6;
+        const int l = it % LN;
+        const int t = it / LN;
         const int i = t % MT, j = t / MT;
         const int ml = i * 16 + (l & 15);
         if (ml >= Mloc) continue;
@@ -313,12 +318,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             for (int w = 0; w < GEMM_WAVES; ++w) {
                 sum += lds[(w * E + (j * MT + i) * 4 + g) * 64 + l];
                 if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds[(w * E + ((NT / 2 + j) * MT + i) * 4 + g) * 64 + l];
+                if (GU8) sum2 += lds[(w * E + (j * MT + i) * 4 + g) * 64 + l + 32];
             }
             v[g] = sum;
             v2[g] = sum2;
         }
-        if (EPI == OMNI_EPI_SILU_MUL) {
-            const int n = blockIdx.x * 16 * (NT / 2) + j * 16 + 4 * (l >> 4);
+        if (SILU) {
+            const int n = GU8 ? (blockIdx.x * NT + j) * 8 + 4 * (l >> 4) : blockIdx.x * 16 * (NT / 2) + j * 16 + 4 * (l >> 4);
             float o[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -378,8 +384,8 @@ extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt
 
 template <int MT, int NT, int PRO, int EPI>
 static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
-    const int groups = (EPI == OMNI_EPI_SILU_MUL) ? a.N / (8 * NT) : a.N / (16 * NT);
-    size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float);
+    const int groups = (EPI == OMNI_EPI_SILU_MUL || EPI == OMNI_EPI_SILU_MUL_GU8) ? a.N / (8 * NT) : a.N / (16 * NT);
+    size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float) + (PRO == 2 ? GEMM_WAVES * 64 * sizeof(float) : 0);
     if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)
         static bool done_t = false, done_f = false;
         if (!done_t) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
@@ -399,17 +405,20 @@ static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
 // of a workgroup is proportional to the rows it owns, and is repeated once per n group.
 static void pick_tile(int pro, int epi, const GemmArgs& a, int* nt_out, int* mt_out, int* splits_out) {
     const int mt_total = (a.M + 15) / 16;
-    const bool silu = epi == OMNI_EPI_SILU_MUL;
+    const bool gu8 = epi == OMNI_EPI_SILU_MUL_GU8;
+    const bool silu = epi == OMNI_EPI_SILU_MUL || gu8;
     const int cols = silu ? a.N / 8 : a.N / 16;               // n groups at the narrowest tile
     int nt = silu ? 2 : 1;
     if (pro == 2) {
         // measured at M = 64 (scripts/bench_tiles.py): 64+ groups of NT = 4, else NT = 2
         nt = (cols % 4 == 0 && cols / 4 >= 64) ? 4 : ((cols % 2 == 0 && cols / 2 >= 32) ? 2 : nt);
         if (silu && nt < 2) nt = 2;
+        if (gu8 && cols % 3 == 0 && cols / 3 >= 128) nt = 3;  // 256 workgroups (backbone), 128 x 2 m-splits (code predictor)
     } else if (silu && cols % 4 == 0 && cols / 4 >= 160 && mt_total == 4) {
         nt = 4;                                               // backbone gate_up at full batch: 32 + 32 columns, no M split
+        if (gu8 && cols % 3 == 0 && cols / 3 >= 256) nt = 3;  // 24 columns x 256 workgroups: 14.8 vs 16.1 us
     }
-    if (g_tile_nt && epi != OMNI_EPI_RESID && (!silu || g_tile_nt >= 2) && cols % g_tile_nt == 0) nt = g_tile_nt;
+    if (g_tile_nt && epi != OMNI_EPI_RESID && (!silu || g_tile_nt >= 2) && (g_tile_nt != 3 || gu8) && cols % g_tile_nt == 0) nt = g_tile_nt;
     const int groups = silu ? a.N / (8 * nt) : a.N / (16 * nt);
     int splits = groups >= 160 ? 1 : (g_gemm_wgs + groups - 1) / groups;
     if (splits > mt_total) splits = mt_total;
@@ -428,6 +437,7 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
 #define TILE(N_, M_) if (nt == N_ && mt == M_) return launch_gemm<M_, N_, PRO, EPI>(a, splits, st);
 #define TILE_M(N_) TILE(N_, 1) TILE(N_, 2) TILE(N_, 4)
     if constexpr (EPI == OMNI_EPI_SILU_MUL) { TILE_M(2) TILE_M(4) }
+    else if constexpr (EPI == OMNI_EPI_SILU_MUL_GU8) { TILE_M(2) TILE_M(3) TILE_M(4) }
     else if constexpr (EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32) { TILE_M(1) }
     else if constexpr (EPI == OMNI_EPI_F32_BF16RND && PRO == 0) { TILE_M(1) }
     else { TILE_M(1) TILE_M(2) TILE_M(4) }
@@ -454,6 +464,9 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
         case OMNI_EPI_SILU_MUL:
             OMNI_CHECK_ARG(a.bias == nullptr && a.mask == nullptr, "omni_gemm_bf16: silu_mul takes no bias/mask");
             return dispatch_tile<PRO, OMNI_EPI_SILU_MUL>(a, st);
+        case OMNI_EPI_SILU_MUL_GU8:
+            OMNI_CHECK_ARG(a.bias == nullptr && a.mask == nullptr && a.wshuf, "omni_gemm_bf16: silu_mul_gu8 takes no bias/mask and a fragment-major W");
+            return dispatch_tile<PRO, OMNI_EPI_SILU_MUL_GU8>(a, st);
         case OMNI_EPI_F32:
             if constexpr (PRO == 0) return dispatch_tile<0, OMNI_EPI_F32>(a, st);
             break;
@@ -477,7 +490,7 @@ extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const vo
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
     a.oshuf = (layout & OMNI_LAYOUT_OUT_FRAG) != 0;
     OMNI_CHECK_ARG(epilogue != OMNI_EPI_RESID, "omni_gemm_bf16: the residual epilogue is omni_gemm_resid");
-    OMNI_CHECK_ARG(!a.oshuf || epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL,
+    OMNI_CHECK_ARG(!a.oshuf || epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL || epilogue == OMNI_EPI_SILU_MUL_GU8,
                    "omni_gemm_bf16: fragment-major output needs a bf16 epilogue");
     OMNI_CHECK_ARG(!a.oshuf || N % 32 == 0, "omni_gemm_bf16: fragment-major output needs N %% 32 == 0");
     a.x = (const uint16_t*)x; a.ldx = ldx; a.W = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.out = out;
@@ -532,8 +545,8 @@ extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts,
     int rc = check_common(a);
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_ARG(r && partials && norm_w && nparts >= 1, "omni_gemm_xnorm: null pointer / nparts=%d", nparts);
-    OMNI_CHECK_ARG(epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL || epilogue == OMNI_EPI_F32_BF16RND,
-                   "omni_gemm_xnorm: epilogue %d unsupported", epilogue);
+    OMNI_CHECK_ARG(epilogue == OMNI_EPI_BF16 || epilogue == OMNI_EPI_SILU_MUL || epilogue == OMNI_EPI_SILU_MUL_GU8 ||
+                   epilogue == OMNI_EPI_F32_BF16RND, "omni_gemm_xnorm: epilogue %d unsupported", epilogue);
     OMNI_CHECK_ARG(!a.oshuf || (epilogue != OMNI_EPI_F32_BF16RND && N % 32 == 0),
                    "omni_gemm_xnorm: fragment-major output needs a bf16 epilogue and N %% 32 == 0");
     return dispatch_epi<2>(a, epilogue, (hipStream_t)stream);

@@ -43,6 +43,17 @@ def frag_shuffle(w: torch.Tensor) -> torch.Tensor:
     return v.contiguous().reshape(*lead, N, K)
 
 
+def gu8_shuffle(w: torch.Tensor) -> torch.Tensor:
+    """[2I, K] = [gate rows | up rows] -> fragment-major with gate / up interleaved in groups of 8 rows
+    (include/omni_talker.h OMNI_EPI_SILU_MUL_GU8): tile t = gate[8t..8t+7] then up[8t..8t+7]."""
+    two_i, K = w.shape[-2], w.shape[-1]
+    I = two_i // 2
+    assert I % 8 == 0, I
+    lead = w.shape[:-2]
+    v = w.reshape(*lead, 2, I // 8, 8, K).transpose(-4, -3)        # [..., I/8, 2, 8, K]
+    return frag_shuffle(v.reshape(*lead, two_i, K))
+
+
 def frag_unshuffle(w: torch.Tensor) -> torch.Tensor:
     N, K = w.shape[-2], w.shape[-1]
     lead = w.shape[:-2]
@@ -161,7 +172,8 @@ class TalkerEngine:
             for n in bb_names:
                 t_ = lw[n]
                 if self.frag_layout and n in frag_names:
-                    t_ = up(frag_shuffle(lw[n]))    # fragment-major copy for the native decode GEMMs (per expert for MoE)
+                    # fragment-major copy for the native decode GEMMs (per expert for MoE; dense gate_up interleaved by 8)
+                    t_ = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
                 setattr(self._layers[i], n, t_.data_ptr())
         self._cp_layers = (L.LayerWeights * d.cp_layers)()
         self.cp_layer_w: list[dict] = []
@@ -169,7 +181,7 @@ class TalkerEngine:
             lw = {n: up(weights[f"cp.l{i}.{n}"]) for n in names}
             if self.frag_layout:
                 for n in ("wqkv", "wo", "wgu", "wdown"):
-                    lw[n] = up(frag_shuffle(lw[n]))
+                    lw[n] = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
             self.cp_layer_w.append(lw)
             for n in names:
                 setattr(self._cp_layers[i], n, lw[n].data_ptr())

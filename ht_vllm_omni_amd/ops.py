@@ -38,8 +38,8 @@ def gemm(x, w, *, bias=None, epilogue=L.EPI_BF16, mask=None, layout=0, M=None):
     _chk_dev(x, w, bias, mask)
     Mx, K = x.shape
     M = Mx if M is None else M
-    N = w.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w.shape[0]
-    dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
+    N = w.shape[0] // 2 if epilogue in L.SILU_EPIS else w.shape[0]
+    dt = BF16 if epilogue in (L.EPI_BF16,) + L.SILU_EPIS else torch.float32
     rows_out = (M + 15) // 16 * 16 if layout & L.LAYOUT_OUT_FRAG else M
     out = torch.zeros(rows_out, N, dtype=dt, device=x.device)
     L.check(L.load().omni_gemm_bf16_ex(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), M, N, K, epilogue,
@@ -120,8 +120,8 @@ def gemm_xnorm(r_frag, partials, nparts, norm_w, w_frag, eps, *, M, epilogue=L.E
     """out = epilogue((norm_w * bf16(r * rstd)) . w^T) on the fragment-major residual stream -> out [, normed rows]."""
     _chk_dev(r_frag, partials, norm_w, w_frag, mask)
     K = r_frag.shape[1]
-    N = w_frag.shape[0] // 2 if epilogue == L.EPI_SILU_MUL else w_frag.shape[0]
-    dt = BF16 if epilogue in (L.EPI_BF16, L.EPI_SILU_MUL) else torch.float32
+    N = w_frag.shape[0] // 2 if epilogue in L.SILU_EPIS else w_frag.shape[0]
+    dt = BF16 if epilogue in (L.EPI_BF16,) + L.SILU_EPIS else torch.float32
     rows_out = (M + 15) // 16 * 16 if out_frag else M
     out = torch.zeros(rows_out, N, dtype=dt, device=r_frag.device)
     normed = torch.empty(M, K, dtype=BF16, device=r_frag.device) if want_normed else None

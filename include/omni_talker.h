@@ -45,6 +45,9 @@ extern "C" {
 #define OMNI_EPI_F32 2         /* out fp32 [M,N]                                            */
 #define OMNI_EPI_F32_BF16RND 3 /* out fp32 [M,N] holding bf16-rounded values (logits)       */
 #define OMNI_EPI_RESID 4       /* omni_gemm_resid only: r += bf16(acc + bias), sum(r^2) slabs */
+#define OMNI_EPI_SILU_MUL_GU8 5 /* as SILU_MUL for a fragment-major W whose rows were interleaved first: rows 16t..16t+7 =
+                                 * gate[8t..8t+7], rows 16t+8..16t+15 = up[8t..8t+7] -- one 16-row MFMA tile then yields 8
+                                 * finished act columns, so any number of tiles per workgroup divides the chip evenly */
 
 const char* omni_last_error(void);
 int omni_abi_version(void);
@@ -198,13 +201,13 @@ typedef struct omni_layer_weights {
     const void* knorm;  /* bf16 [D]               */
     const void* wo;     /* bf16 [H, Hq*D]         */
     const void* ln2;    /* bf16 [H]               */
-    const void* wgu;    /* bf16 [2I, H]           */
+    const void* wgu;    /* bf16 [2I, H] = [gate | up]; under desc.frag_layout: OMNI_EPI_SILU_MUL_GU8 row order */
     const void* wdown;  /* bf16 [H, I]            */
     /* sparse-MoE MLP instead of wgu / wdown when desc.moe_experts > 0 (backbone layers of the Omni talker) */
     const void* moe_router;          /* bf16 [E, H]                                   */
     const void* moe_gate_up;         /* bf16 [E, 2*Im, H], each expert fragment-major  */
     const void* moe_down;            /* bf16 [E, H, Im],   each expert fragment-major  */
-    const void* moe_shared_gate_up;  /* bf16 [2*Is, H]  (layout as wgu)                */
+    const void* moe_shared_gate_up;  /* bf16 [2*Is, H]  ([gate | up] rows)             */
     const void* moe_shared_down;     /* bf16 [H, Is]    (layout as wdown)              */
     const void* moe_shared_gate;     /* bf16 [H]                                       */
 } omni_layer_weights;

@@ -21,7 +21,7 @@ def graph_time(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e3
 
 def sweep(name, N, K, epi, M=64, modes=("plain", "xnorm")):
-    rows = 2 * N if epi == L.EPI_SILU_MUL else N
+    rows = 2 * N if epi in L.SILU_EPIS else N
     wbytes = rows * K * 2
     R = max(2, min(48, int(1.0e9 // wbytes)))
     Ws = [frag_shuffle(torch.randn(rows, K, device=dev, dtype=BF16) * 0.02) for _ in range(R)]
@@ -32,8 +32,9 @@ def sweep(name, N, K, epi, M=64, modes=("plain", "xnorm")):
     lay = L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG
     out = []
     for mode in modes:
-        for nt in (1, 2, 4):
-            if epi == L.EPI_SILU_MUL and nt == 1: continue
+        for nt in (1, 2, 3, 4):
+            if epi in L.SILU_EPIS and nt == 1: continue
+            if nt == 3 and epi != L.EPI_SILU_MUL_GU8: continue
             for mt in (1, 2, 4):
                 lib.omni_debug_tile(nt, mt)
                 try:
@@ -72,9 +73,11 @@ def sweep_resid(name, N, K, M=64):
 if __name__ == "__main__":
     sweep("cp qkv", 4096, 1024, L.EPI_BF16)
     sweep("cp gate_up", 3072, 1024, L.EPI_SILU_MUL)
+    sweep("cp gate_up gu8", 3072, 1024, L.EPI_SILU_MUL_GU8)
     sweep("cp head", 2048, 1024, L.EPI_F32_BF16RND, modes=("xnorm",))
     sweep("bb qkv", 4096, 2048, L.EPI_BF16)
     sweep("bb gate_up", 6144, 2048, L.EPI_SILU_MUL)
+    sweep("bb gate_up gu8", 6144, 2048, L.EPI_SILU_MUL_GU8)
     sweep("lm_head", 3072, 2048, L.EPI_F32_BF16RND, modes=("xnorm",))
     sweep_resid("cp o", 1024, 2048)
     sweep_resid("cp down", 1024, 3072)
