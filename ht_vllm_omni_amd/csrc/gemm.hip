@@ -174,7 +174,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         // k-steps of W AND x in flight per wave on the counted path.  Same-box A/B of the whole step (scripts/ab.sh):
         // 1 step 4.42 ms, 2 steps 4.20, 4 steps (small tiles) 4.22, 8 / 12 steps (o / down) 4.28 -- two is enough to cover
         // the round trip; every further load issued up front only delays the first MFMA group
-        constexpr int P = 2;
+        // -- except the residual-epilogue GEMMs (one 16 x 16 tile, long K, all weights cold): 4 steps, 4.135 -> 4.085 ms
+        constexpr int P = (EPI == OMNI_EPI_RESID) ? 4 : 2;
         constexpr bool COUNTED = true;
         if (COUNTED && a.counted && ntw > 0 && nsteps % (GEMM_WAVES * P) == 0) {
             // ---- counted schedule (K % (256 P) == 0: every wave owns a multiple of P k-steps).  No load is predicated, so

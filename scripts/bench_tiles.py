@@ -24,7 +24,9 @@ def sweep(name, N, K, epi, M=64, modes=("plain", "xnorm")):
     rows = 2 * N if epi in L.SILU_EPIS else N
     wbytes = rows * K * 2
     R = max(2, min(48, int(1.0e9 // wbytes)))
-    Ws = [frag_shuffle(torch.randn(rows, K, device=dev, dtype=BF16) * 0.02) for _ in range(R)]
+    D = int(os.environ.get('BT_D', 0)) or R      # distinct weight copies (1 = L2-hot)
+    Ws = [frag_shuffle(torch.randn(rows, K, device=dev, dtype=BF16) * 0.02) for _ in range(D)]
+    Ws = [Ws[i % D] for i in range(R)]
     Mp = (M + 15) // 16 * 16
     x = frag_shuffle(torch.randn(Mp, K, device=dev, dtype=BF16))
     nw = torch.ones(K, device=dev, dtype=BF16)
@@ -35,8 +37,14 @@ def sweep(name, N, K, epi, M=64, modes=("plain", "xnorm")):
         for nt in (1, 2, 3, 4):
             if epi in L.SILU_EPIS and nt == 1: continue
             if nt == 3 and epi != L.EPI_SILU_MUL_GU8: continue
+            if os.environ.get('BT_POLICY') and nt != 1 and not (nt == 2 and epi in L.SILU_EPIS): continue
             for mt in (1, 2, 4):
-                lib.omni_debug_tile(nt, mt)
+                if os.environ.get('BT_POLICY'):
+                    if mt != 1: continue
+                    nt_, mt_ = 0, 0
+                else:
+                    nt_, mt_ = nt, mt
+                lib.omni_debug_tile(nt_, mt_)
                 try:
                     if mode == "plain":
                         def fn():
@@ -54,13 +62,19 @@ def sweep(name, N, K, epi, M=64, modes=("plain", "xnorm")):
 def sweep_resid(name, N, K, M=64):
     wbytes = N * K * 2
     R = max(2, min(48, int(1.0e9 // wbytes)))
-    Ws = [frag_shuffle(torch.randn(N, K, device=dev, dtype=BF16) * 0.02) for _ in range(R)]
+    D = int(os.environ.get('BT_D', 0)) or R
+    Ws = [frag_shuffle(torch.randn(N, K, device=dev, dtype=BF16) * 0.02) for _ in range(D)]
+    Ws = [Ws[i % D] for i in range(R)]
     x = frag_shuffle(torch.randn(64, K, device=dev, dtype=BF16))
     r = frag_shuffle(torch.randn(64, N, device=dev, dtype=BF16))
     part = torch.zeros(N // 16, 64, device=dev)
     out = []
     for mt in (1, 2, 4):
-        lib.omni_debug_tile(1, mt)
+        if os.environ.get('BT_POLICY'):
+            if mt != 1: continue
+            lib.omni_debug_tile(0, 0)
+        else:
+            lib.omni_debug_tile(1, mt)
         def fn():
             for i in range(R): ops.gemm_resid(x, Ws[i], r, part, M=M)
         out.append(f"resid 1x{mt}:{graph_time(fn)/R:5.1f}")
@@ -71,6 +85,10 @@ def sweep_resid(name, N, K, M=64):
     print(f"{name:14s} N={N:5d} K={K:5d} {wbytes/1e6:5.1f}MB | " + " ".join(out), flush=True)
 
 if __name__ == "__main__":
+    if os.environ.get("BT_ONLY") == "resid":
+        sweep_resid("cp o", 1024, 2048); sweep_resid("cp down", 1024, 3072)
+        sweep_resid("bb o", 2048, 2048); sweep_resid("bb down", 2048, 6144)
+        sys.exit(0)
     sweep("cp qkv", 4096, 1024, L.EPI_BF16)
     sweep("cp gate_up", 3072, 1024, L.EPI_SILU_MUL)
     sweep("cp gate_up gu8", 3072, 1024, L.EPI_SILU_MUL_GU8)
