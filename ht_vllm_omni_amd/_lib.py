@@ -70,6 +70,8 @@ SIGNATURES = {
     "omni_gemm_bf16": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "omni_gemm_bf16_ex": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_silu_mul": (i32, [vp, vp, i32, i32, vp]),
+    "omni_silu": (i32, [vp, vp, C.c_longlong, vp]),
+    "omni_resize_mlp": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "omni_moe_route": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "omni_moe_experts": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omni_snake_beta": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -593,6 +593,23 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
     return OMNI_OK;
 }
 
+// thinker -> talker projection MLP (HF Qwen3OmniMoeTalkerResizeMLP: linear_fc2(silu(linear_fc1(x))), both with bias) over T
+// rows, 64 at a time through the skinny GEMM (a row's result does not depend on its launch mates); act_ws bf16 [min(T,64), I]
+extern "C" int omni_resize_mlp(const void* x, const void* fc1_w, const void* fc1_b, const void* fc2_w, const void* fc2_b,
+                               void* act_ws, void* out, int T, int H_in, int I, int H_out, void* stream) {
+    OMNI_CHECK_ARG(x && fc1_w && fc2_w && act_ws && out, "omni_resize_mlp: null pointer");
+    OMNI_CHECK_ARG(T >= 0 && H_in % 32 == 0 && I % 32 == 0 && H_out % 16 == 0, "omni_resize_mlp: T=%d H_in=%d I=%d H_out=%d", T, H_in, I, H_out);
+    for (int r0 = 0; r0 < T; r0 += 64) {
+        const int rows = T - r0 < 64 ? T - r0 : 64;
+        const uint16_t* xr = reinterpret_cast<const uint16_t*>(x) + (size_t)r0 * H_in;
+        TRY(omni_gemm_bf16(xr, H_in, fc1_w, fc1_b, act_ws, rows, I, H_in, OMNI_EPI_BF16, nullptr, stream));
+        TRY(omni_silu(act_ws, act_ws, (long long)rows * I, stream));
+        TRY(omni_gemm_bf16(act_ws, I, fc2_w, fc2_b, reinterpret_cast<uint16_t*>(out) + (size_t)r0 * H_out, rows, H_out, I, OMNI_EPI_BF16,
+                           nullptr, stream));
+    }
+    return OMNI_OK;
+}
+
 extern "C" int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, int layer, void* stream) {
     TRY(check_io(t, io));
     OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_attn: layer=%d", layer);

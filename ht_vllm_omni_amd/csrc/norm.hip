@@ -200,6 +200,37 @@ extern "C" int omni_silu_mul(const void* gate_up, void* out, int T, int inter, v
     return OMNI_OK;
 }
 
+// y = bf16(silu(x)) elementwise (fp32 math, one rounding): the activation between linear_fc1 and linear_fc2 of the Omni talker's
+// thinker -> talker projections (HF Qwen3OmniMoeTalkerResizeMLP; reference use sites qwen3_omni.py:671,987-997)
+__global__ __launch_bounds__(256) void silu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, size_t n) {
+    const size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (v >= n) return;
+    if (v + 8 <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(x + v);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&a);
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = bf_lo(w[j]), g1 = bf_hi(w[j]);
+            o[j] = pack_bf2(g0 / (1.0f + expf(-g0)), g1 / (1.0f + expf(-g1)));
+        }
+        *reinterpret_cast<uint4*>(out + v) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (size_t i = v; i < n; ++i) { const float g = bf2f(x[i]); out[i] = f2bf(g / (1.0f + expf(-g))); }
+    }
+}
+
+extern "C" int omni_silu(const void* x, void* out, long long n, void* stream) {
+    OMNI_CHECK_ARG(x && out, "omni_silu: null pointer");
+    OMNI_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "omni_silu: buffers must be 16-byte aligned");
+    if (n <= 0) return OMNI_OK;
+    const size_t nv = ((size_t)n + 7) / 8;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)out, (size_t)n);
+    OMNI_CHECK_LAUNCH("omni_silu");
+    return OMNI_OK;
+}
+
 // SnakeBeta activation of the Code2Wav decoder: out = x + inv_beta[c] * sin^2(x * exp_alpha[c]) over
 // [B, C, T] rows of length T, one (b, c) row per blockIdx.y; exp_alpha = exp(alpha), inv_beta = 1 / (exp(beta) + 1e-9) are
 // precomputed per channel as the reference's precompute_exp_cache does.  Replaces the reference's Triton kernel

@@ -56,6 +56,27 @@ def silu_mul(gate_up):
     return out
 
 
+def silu(x):
+    """bf16(silu(x)) elementwise."""
+    _chk_dev(x)
+    out = torch.empty_like(x)
+    L.check(L.load().omni_silu(L.ptr(x), L.ptr(out), x.numel(), L.current_stream()), "omni_silu")
+    return out
+
+
+def resize_mlp(x, w):
+    """HF Qwen3OmniMoeTalkerResizeMLP: linear_fc2(silu(linear_fc1(x))) over x bf16 [T, H_in]; w = {fc1_w [I, H_in], fc1_b [I],
+    fc2_w [H_out, I], fc2_b [H_out]} (biases optional)."""
+    _chk_dev(x, w["fc1_w"], w.get("fc1_b"), w["fc2_w"], w.get("fc2_b"))
+    T, h_in = x.shape
+    inter, h_out = w["fc1_w"].shape[0], w["fc2_w"].shape[0]
+    out = torch.empty(T, h_out, dtype=BF16, device=x.device)
+    ws = torch.empty(max(1, min(T, 64)), inter, dtype=BF16, device=x.device)
+    L.check(L.load().omni_resize_mlp(L.ptr(x), L.ptr(w["fc1_w"]), L.ptr(w.get("fc1_b")), L.ptr(w["fc2_w"]), L.ptr(w.get("fc2_b")),
+                                     L.ptr(ws), L.ptr(out), T, h_in, inter, h_out, L.current_stream()), "omni_resize_mlp")
+    return out
+
+
 def moe_route(logits, top_k, norm_topk_prob=False):
     """bf16 router logits [T, E] -> (topk_idx int32 [T, k], topk_w bf16 [T, k])."""
     _chk_dev(logits)

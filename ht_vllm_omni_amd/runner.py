@@ -67,8 +67,12 @@ _ROW_BUFFERS = ("input_ids", "positions", "seq_lens", "block_table", "last_hidde
 
 class MI355XARModelRunner:
     def __init__(self, engine, *, kv_transfer: OmniKVTransferManager | None = None, use_graphs: bool = True,
-                 engine_output_type: str = "latent"):
+                 engine_output_type: str = "latent", prompt_builder=None):
         self.engine = engine
+        # Qwen3-Omni requests arrive with the thinker's outputs instead of ready talker_prompt_embeds: the builder
+        # (prompt_builder_omni.OmniTalkerPromptBuilder = the reference's talker_preprocess_prefill) turns them into the
+        # prompt embeddings + the queue of text steps on the device
+        self.prompt_builder = prompt_builder
         self.d = engine.d
         self.max_num_seqs = engine.max_batch
         self.kv_caches = engine.kv_caches               # runner-owned list, one [2,nb,bs,h,d] tensor per layer
@@ -124,11 +128,17 @@ class MI355XARModelRunner:
                 raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
             info = decode_additional_information(nr.additional_information)
             pe = nr.prompt_embeds if nr.prompt_embeds is not None else info.get("talker_prompt_embeds")
+            tail = info.get("tailing_text_hidden")
+            pad = info.get("tts_pad_embed")
+            if pe is None and info.get("thinker_prefill_embeddings") is not None:
+                if self.prompt_builder is None:
+                    raise ValueError(f"request {nr.req_id}: thinker outputs given but the runner has no prompt_builder")
+                prompt, upd = self.prompt_builder.from_info(info)     # qwen3_omni.py:678-809
+                pe, tail, pad = prompt.embeds, upd.get("trailing_text_hidden"), prompt.tts_pad
+                info.update(upd)
             if pe is None or pe.ndim != 2 or pe.shape[1] != self.d.hidden:
                 raise ValueError(f"request {nr.req_id}: missing talker_prompt_embeds [T,{self.d.hidden}]")
             dev = e.input_ids.device
-            tail = info.get("tailing_text_hidden")
-            pad = info.get("tts_pad_embed")
             if pad is None:
                 raise ValueError(f"request {nr.req_id}: missing tts_pad_embed (prefill must initialise it)")
             st = RequestState(req_id=nr.req_id, prompt_embeds=pe.to(BF16).cpu().contiguous(),

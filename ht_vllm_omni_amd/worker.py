@@ -27,11 +27,13 @@ logger = logging.getLogger("ht_vllm_omni_amd.worker")
 def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "fp8", block_size: int = 16,
                 max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
                 num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
-                connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None) -> SimpleNamespace:
+                connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None,
+                prompt_builder: dict | None = None) -> SimpleNamespace:
     return SimpleNamespace(model=model, kv_cache_dtype=kv_cache_dtype, block_size=block_size, max_num_seqs=max_num_seqs,
                            tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
                            num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
-                           enforce_eager=enforce_eager, default_sampling_params=default_sampling_params)
+                           enforce_eager=enforce_eager, default_sampling_params=default_sampling_params,
+                           prompt_builder=prompt_builder)
 
 
 class MI355XARWorker:
@@ -92,10 +94,19 @@ class MI355XARWorker:
         self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(nb),
                                    block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
                                    tp_rank=self.rank, tp_size=self.tp_size)
+        embed_table = self._weights["embed"]
         self._weights = None
         conn = OmniConnectorFactory.create_connector(cfg.connector) if getattr(cfg, "connector", None) else None
+        # Qwen3-Omni talker: config.prompt_builder = {"weights": {text, hidden, codec_embed}, "ids": OmniPromptIds | dict}
+        pb_cfg, builder = getattr(cfg, "prompt_builder", None), None
+        if pb_cfg:
+            from .prompt_builder_omni import OmniPromptIds, OmniTalkerPromptBuilder
+            ids = pb_cfg["ids"] if isinstance(pb_cfg["ids"], OmniPromptIds) else OmniPromptIds.from_dict(pb_cfg["ids"])
+            pw = dict(pb_cfg["weights"])
+            pw.setdefault("codec_embed", embed_table)        # talker.embed_input_ids = the talker's own codec table
+            builder = OmniTalkerPromptBuilder(pw, ids, self.device)
         self.model_runner = MI355XARModelRunner(self.engine, kv_transfer=OmniKVTransferManager(conn),
-                                                use_graphs=not getattr(cfg, "enforce_eager", False))
+                                                use_graphs=not getattr(cfg, "enforce_eager", False), prompt_builder=builder)
 
     def compile_or_warm_up_model(self) -> None:
         # the stage's default_sampling_params (stage_configs/qwen3_tts.yaml:27-34) are baked into the captured step;

@@ -87,6 +87,15 @@ int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, v
  * GEMM fuses it as OMNI_EPI_SILU_MUL).                                                                                */
 int omni_silu_mul(const void* gate_up, void* out, int T, int inter, void* stream);
 
+/* Thinker -> talker projections of the Qwen3-Omni talker's prompt builder (reference: qwen3_omni.py:650-676 _get_tts_embed,
+ * 975-992 _get_talker_user_parts, 994-1060 _get_talker_assistant_parts; module = HF Qwen3OmniMoeTalkerResizeMLP):
+ * out bf16 [T, H_out] = linear_fc2(silu(linear_fc1(x))), x bf16 [T, H_in] row-major, weights bf16 row-major [I, H_in] /
+ * [H_out, I] with bf16 biases (may be NULL); each op rounds to bf16 as the bf16 torch modules do.  act_ws: bf16
+ * [min(T, 64), I] scratch.  omni_silu: out = bf16(silu(x)) over n bf16 elements (16-byte aligned, in place allowed).       */
+int omni_silu(const void* x, void* out, long long n, void* stream);
+int omni_resize_mlp(const void* x, const void* fc1_w, const void* fc1_b, const void* fc2_w, const void* fc2_b, void* act_ws,
+                    void* out, int T, int H_in, int I, int H_out, void* stream);
+
 /* Sparse-MoE MLP of the Qwen3-Omni talker backbone (the reference runs vLLM's FusedMoE through
  * V/model_executor/models/qwen3_omni/qwen3_omni_moe_talker.py; arithmetic here = HF Qwen3OmniMoeTalkerTextSparseMoeBlock,
  * the algorithm the oracle restates), decode batch sizes: T <= 64 tokens, top_k <= 8, E <= 256 experts.

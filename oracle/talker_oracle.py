@@ -607,3 +607,105 @@ def extract_kv(layer_kv: torch.Tensor, block_ids: list[int], seq_len: int) -> tu
     if seq_len < fk.shape[0]:
         fk, fv = fk[:seq_len], fv[:seq_len]
     return fk.contiguous(), fv.contiguous()
+
+
+# --------------------------------------------------------------------------
+# Qwen3-Omni talker prompt builder (row a11: qwen3_omni.py:586-606 talker_preprocess, 650-676 _get_tts_embed,
+# 678-809 talker_preprocess_prefill, 834-905 _thinker_to_talker_prefill, 975-992 _get_talker_user_parts,
+# 994-1060 _get_talker_assistant_parts, 907-973 decode-side text steps)
+# --------------------------------------------------------------------------
+def resize_mlp(x: torch.Tensor, w: dict) -> torch.Tensor:
+    """HF Qwen3OmniMoeTalkerResizeMLP in bf16: linear_fc2(silu(linear_fc1(x))), every module output rounded to bf16."""
+    h = linear(x, w["fc1_w"], w.get("fc1_b"))
+    hf = h.to(torch.float32)
+    h = (hf / (1.0 + torch.exp(-hf))).to(BF16)
+    return linear(h, w["fc2_w"], w.get("fc2_b"))
+
+
+def _last_row(x, width: int) -> torch.Tensor:
+    """_get_tts_embed._ensure_1x1 (qwen3_omni.py:654-660) + the zero fallback (662-670) -> [1, width] bf16."""
+    if not isinstance(x, torch.Tensor) or x.numel() == 0:
+        return torch.zeros(1, width, dtype=BF16)
+    if x.ndim == 3:
+        return x[0, -1:, :].to(BF16)
+    if x.ndim == 2:
+        return x[-1:].to(BF16)
+    return x.reshape(1, -1).to(BF16)
+
+
+def omni_talker_prompt(thinker_embed: torch.Tensor, thinker_hidden: torch.Tensor, input_ids, result_ids, speaker_id: int,
+                       tts_bos, tts_eos, tts_pad, w: dict, ids: dict):
+    """_thinker_to_talker_prefill: (talker_input_ids int64 [P], talker_input_embeds bf16 [P, H], trailing_text_hidden bf16
+    [n, H]).  thinker_embed / thinker_hidden bf16 [T, Ht]; input_ids = the thinker's chatml prompt ids, result_ids = prompt +
+    generated ids [T]; w = {"text": resize-mlp weights, "hidden": resize-mlp weights, "codec_embed": [V, H]};
+    ids = token ids (im_start, system, user, assistant, tts_pad_token, audio, image, video, codec_nothink, codec_think_bos,
+    codec_think_eos, codec_pad, codec_bos)."""
+    input_ids = torch.as_tensor(input_ids, dtype=torch.long).reshape(-1)
+    result_ids = torch.as_tensor(result_ids, dtype=torch.long).reshape(-1)
+    thinker_embed, thinker_hidden = thinker_embed.to(BF16), thinker_hidden.to(BF16)
+    Ht = thinker_embed.shape[-1]
+    H = w["codec_embed"].shape[1]
+    starts = torch.nonzero(input_ids == ids["im_start"]).reshape(-1).tolist()
+    if len(starts) < 2:   # the reference's torch.cat over a 0-d / empty index tensor raises here (qwen3_omni.py:851-857,903)
+        raise ValueError("omni_talker_prompt: need at least two <|im_start|> segments")
+    bounds = starts + [int(result_ids.shape[0])]
+    mm = (result_ids == ids["audio"]) | (result_ids == ids["image"]) | (result_ids == ids["video"])
+    bos, eos, pad = (resize_mlp(_last_row(t, Ht), w["text"]) for t in (tts_bos, tts_eos, tts_pad))
+    emb, tid, trailing = [], [], None
+    for i in range(len(bounds) - 1):
+        s, e = bounds[i], bounds[i + 1]
+        role = int(input_ids[s + 1])
+        if role == ids["system"]:
+            continue
+        if role == ids["user"]:
+            part = torch.zeros(e - s, H, dtype=BF16)
+            m = mm[s:e]
+            if bool(m.any()):
+                part[m] = resize_mlp(thinker_hidden[s:e][m], w["hidden"])
+            part[~m] = resize_mlp(thinker_embed[s:e][~m], w["text"])
+            emb.append(part)
+            tid.append(result_ids[s:e])
+        elif role == ids["assistant"] and i == len(bounds) - 2:
+            ah = resize_mlp(thinker_embed[s:e], w["text"])
+            first = ah[3:4] if ah.shape[0] > 3 else torch.zeros(1, H, dtype=BF16)
+            text = torch.cat([ah[:3], pad.expand(4, -1), bos, first], 0)
+            codec_ids = torch.tensor([ids["codec_nothink"], ids["codec_think_bos"], ids["codec_think_eos"], int(speaker_id),
+                                      ids["codec_pad"], ids["codec_bos"]], dtype=torch.long)
+            codec = torch.cat([torch.zeros(3, H, dtype=BF16), w["codec_embed"][codec_ids].to(BF16)], 0)
+            emb.append(text + codec)
+            tid.append(torch.full((text.shape[0],), ids["tts_pad_token"], dtype=torch.long))
+            trailing = torch.cat([ah[4:], eos], 0) if ah.shape[0] > 4 else eos
+        elif role == ids["assistant"]:
+            continue
+        else:
+            raise AssertionError("Expect role id after <|im_start|> (assistant, user, system)")
+    if not emb:
+        raise ValueError("omni_talker_prompt: no user / assistant segment")
+    return torch.cat(tid, 0), torch.cat(emb, 0), trailing
+
+
+def omni_text_step_pop(tail, tts_pad_proj: torch.Tensor):
+    """talker_preprocess_decode, non-streaming branch (qwen3_omni.py:948-960): (text_step [1, H], new tail)."""
+    if isinstance(tail, torch.Tensor) and tail.numel() > 0:
+        return tail[0:1], (tail[1:] if tail.shape[0] > 1 else tts_pad_proj.reshape(1, -1))
+    return tts_pad_proj.reshape(1, -1), tail
+
+
+def omni_text_step_streaming(state: dict, n_thinker_output_ids: int, tts_eos_proj, tts_pad_proj, w_text: dict):
+    """_thinker_decode_to_talker_decode (qwen3_omni.py:907-937), streaming (async_chunk) branch.  state: num_processed_tokens,
+    finished_flag, cached [n, Ht] or None, fresh [m, Ht] or None; mutated like the reference's update_dict."""
+    start = state.get("num_processed_tokens", 0)
+    if start >= n_thinker_output_ids - 1:
+        if state.get("finished_flag"):
+            return tts_pad_proj
+        state["finished_flag"] = True
+        return tts_eos_proj
+    cached, fresh = state.get("cached"), state.get("fresh")
+    if cached is not None and start < cached.shape[0]:
+        x = cached[start]
+        if fresh is not None:
+            state["cached"] = torch.cat([cached, fresh], 0)
+    else:
+        x = fresh
+    state["fresh"] = None
+    return resize_mlp(x.to(BF16), w_text)

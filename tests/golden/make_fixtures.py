@@ -14,6 +14,8 @@ input/output tensors are saved.
   moe_block.npz             HF Qwen3OmniMoeTalkerTextSparseMoeBlock (bf16) in/out + weights + routing
   snake_beta.npz            reference SnakeBeta module (12 Hz tokenizer decoder) in/out
   omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
+  omni_prompt_builder.pt    reference Qwen3OmniMoeForConditionalGeneration prompt-embedding methods (models/qwen3_omni/
+                            qwen3_omni.py) called on a stand-in `self` holding HF's ResizeMLP modules: in/out
 """
 from __future__ import annotations
 
@@ -465,10 +467,176 @@ def mint_moe_block():
     print("moe block cases: 3")
 
 
+def install_auto_stubs():
+    """qwen3_omni.py imports ~20 vllm / vllm_omni symbols at module level (registries, interfaces, thinker classes) that its
+    prompt-embedding methods never touch: every such name resolves to an empty placeholder class so that the module
+    imports; the methods under test run on torch tensors and HF modules only."""
+    import importlib.abc
+    import importlib.machinery
+
+    class _Meta(type):
+        def __getattr__(cls, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return lambda *a, **k: (lambda x: x)
+
+    class _AutoMod(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            c = _Meta(name, (), {})
+            setattr(self, name, c)
+            return c
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, fullname, path, target=None):
+            if fullname.split(".")[0] in ("vllm", "vllm_omni", "flash_attn") and fullname not in sys.modules:
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            m = _AutoMod(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, module):
+            pass
+
+    install_vllm_stubs()
+    sys.meta_path.insert(0, _Finder())
+    for n in list(sys.modules):
+        if n.split(".")[0] in ("vllm", "vllm_omni") and not isinstance(sys.modules[n], _AutoMod):
+            old, m = sys.modules[n], _AutoMod(n)
+            m.__path__ = []
+            m.__dict__.update({k: v for k, v in old.__dict__.items() if not k.startswith("__")})
+            sys.modules[n] = m
+
+
+def mint_omni_prompt_builder():
+    """Known answers of the Omni talker's prompt-embedding builder: the reference's own methods
+    (_thinker_to_talker_prefill, _get_talker_user_parts, _get_talker_assistant_parts, _get_tts_embed,
+    talker_preprocess_decode, _thinker_decode_to_talker_decode; qwen3_omni.py:650-1060) bound to a stand-in `self` whose
+    projections are HF Qwen3OmniMoeTalkerResizeMLP modules (bf16, CPU) with seeded weights."""
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import Qwen3OmniMoeTalkerResizeMLP
+    install_auto_stubs()
+    mod = load_by_path("ref_qwen3_omni_model", os.path.join(V, "model_executor/models/qwen3_omni/qwen3_omni.py"))
+    Cls = mod.Qwen3OmniMoeForConditionalGeneration
+    NS = types.SimpleNamespace
+    Ht, I, H, Vc = 64, 96, 32, 64
+    ids = dict(im_start=5, system=6, user=7, assistant=8, audio=9, image=10, video=11, tts_pad_token=12,
+               codec_nothink=40, codec_think_bos=41, codec_think_eos=42, codec_pad=43, codec_bos=44)
+    g = torch.Generator().manual_seed(2026)
+    mcfg = NS(thinker_hidden_size=Ht, text_config=NS(intermediate_size=I, hidden_size=H, hidden_act="silu"))
+
+    def mlp():
+        m = Qwen3OmniMoeTalkerResizeMLP(mcfg)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.2 if p_.ndim == 2 else 0.1))
+        return m.to(torch.bfloat16).eval()
+
+    text_p, hid_p = mlp(), mlp()
+    table = (torch.randn(Vc, H, generator=g) * 0.5).to(torch.bfloat16)
+    tcfg = NS(codec_nothink_id=ids["codec_nothink"], codec_think_bos_id=ids["codec_think_bos"],
+              codec_think_eos_id=ids["codec_think_eos"], codec_pad_id=ids["codec_pad"], codec_bos_id=ids["codec_bos"],
+              text_config=NS(hidden_size=H))
+    cfg = NS(im_start_token_id=ids["im_start"], system_token_id=ids["system"], user_token_id=ids["user"],
+             assistant_token_id=ids["assistant"], tts_pad_token_id=ids["tts_pad_token"], talker_config=tcfg)
+    fake = NS(config=cfg, talker_config=tcfg,
+              thinker_config=NS(audio_token_id=ids["audio"], image_token_id=ids["image"], video_token_id=ids["video"]),
+              talker=NS(text_projection=text_p, hidden_projection=hid_p, embed_input_ids=lambda t: table[t]),
+              _module_device=lambda m: torch.device("cpu"),
+              vllm_config=NS(model_config=NS(async_chunk=False)))
+    for name in ("_thinker_to_talker_prefill", "_get_talker_user_parts", "_get_talker_assistant_parts", "_get_tts_embed",
+                 "talker_preprocess_decode", "_thinker_decode_to_talker_decode"):
+        setattr(fake, name, types.MethodType(getattr(Cls, name), fake))
+
+    def w_of(m):
+        return {"fc1_w": m.linear_fc1.weight.detach().clone(), "fc1_b": m.linear_fc1.bias.detach().clone(),
+                "fc2_w": m.linear_fc2.weight.detach().clone(), "fc2_b": m.linear_fc2.bias.detach().clone()}
+
+    def seg(role, n_text, n_mm=0, mm_tok=None):
+        body = [20 + int(x) for x in torch.randint(0, 10, (n_text,), generator=g)]
+        if n_mm:
+            body = body[: n_text // 2] + [mm_tok] * n_mm + body[n_text // 2:]
+        return [ids["im_start"], role] + body
+
+    layouts = {
+        "system_user_assistant": [seg(ids["system"], 4), seg(ids["user"], 6), seg(ids["assistant"], 9)],
+        "user_audio_assistant_short": [seg(ids["user"], 4, 5, ids["audio"]), seg(ids["assistant"], 1)],      # 3 rows: no first text
+        "history": [seg(ids["system"], 2), seg(ids["user"], 3, 2, ids["image"]), seg(ids["assistant"], 5),
+                    seg(ids["user"], 4, 3, ids["video"]), seg(ids["assistant"], 2)],                          # exactly 4 rows
+        "user_only_mm_assistant_5": [seg(ids["user"], 0, 7, ids["audio"]), seg(ids["assistant"], 3)],          # 5 rows: 1 trailing
+        "long": [seg(ids["system"], 8), seg(ids["user"], 70, 90, ids["image"]), seg(ids["assistant"], 40)],
+    }
+    cases = []
+    with torch.no_grad():
+        for name, segs in layouts.items():
+            result_ids = torch.tensor([t for s_ in segs for t in s_], dtype=torch.long)
+            T = int(result_ids.shape[0])
+            n_gen = len(segs[-1]) - 3          # the thinker's generated ids: everything after "<|im_start|>assistant\n"
+            prompt_ids = result_ids[: T - max(n_gen, 0)]
+            emb = (torch.randn(T, Ht, generator=g)).to(torch.bfloat16)
+            hid = (torch.randn(T, Ht, generator=g)).to(torch.bfloat16)
+            bos, eos, pad = ((torch.randn(1, 1, Ht, generator=g)).to(torch.bfloat16) for _ in range(3))   # [1, 1, Ht] as shipped
+            if name == "history":
+                pad = None                                           # the zero fallback of _get_tts_embed
+            spk = 50 + len(cases)
+            o_ids, o_emb, o_tail = fake._thinker_to_talker_prefill(
+                thinker_embed=emb, thinker_hidden=hid, multimodal_mask=None, input_ids=prompt_ids.unsqueeze(0),
+                thinker_result_ids=result_ids, speaker_id=spk, tts_bos_thinker=bos, tts_eos_thinker=eos, tts_pad_thinker=pad)
+            c = {"name": name, "thinker_embed": emb, "thinker_hidden": hid, "input_ids": prompt_ids, "result_ids": result_ids,
+                 "speaker_id": spk, "tts_bos": bos, "tts_eos": eos, "tts_pad": pad,
+                 "out_ids": o_ids.clone(), "out_embeds": o_emb.clone(), "out_trailing": o_tail.clone(),
+                 "tts_pad_proj": fake.tts_pad_embed.clone(), "tts_eos_proj": fake.tts_eos_embed.clone()}
+            # decode side, non-streaming: pop the queue past its end (talker_preprocess_decode)
+            tail, steps = o_tail, []
+            dummy = torch.zeros(1, H, dtype=torch.bfloat16)
+            for _ in range(int(o_tail.shape[0]) + 3):
+                upd = {}
+                _, text_step, upd = fake.talker_preprocess_decode(torch.zeros(1, dtype=torch.long), dummy, upd,
+                                                                  trailing_text_hidden=tail, last_talker_hidden=None)
+                steps.append(text_step.clone())
+                tail = upd.get("trailing_text_hidden", tail)
+            c["decode_text_steps"] = torch.cat(steps, 0)
+            cases.append(c)
+        # decode side, streaming: _thinker_decode_to_talker_decode over a scripted arrival of thinker decode embeddings
+        # (the prefill seeds the cache with the embeddings that arrived so far: _talker_cache_thinker_decode_embeds)
+        script, n_out = [], 7
+        cached, finished = (torch.randn(3, Ht, generator=g)).to(torch.bfloat16), False
+        arrivals = {1: 2, 3: 1}
+        for stepno in list(range(1, 9)) + ["beyond_cache"]:
+            if stepno == "beyond_cache":     # index past the cache: the reference projects the fresh rows as they are
+                start, cached_in, fin_in = 2, (torch.randn(2, Ht, generator=g)).to(torch.bfloat16), False
+                fresh = (torch.randn(1, Ht, generator=g)).to(torch.bfloat16)
+            else:
+                start, cached_in, fin_in = stepno, cached, finished
+                n_new = arrivals.get(stepno, 0)
+                fresh = (torch.randn(n_new, Ht, generator=g)).to(torch.bfloat16) if n_new else None
+            info_d = {"num_processed_tokens": start, "thinker_output_token_ids": list(range(n_out)),
+                      "cached_thinker_decode_embeddings": cached_in, "thinker_decode_embeddings": fresh, "finished_flag": fin_in}
+            upd = {}
+            out = fake._thinker_decode_to_talker_decode(info_d, torch.device("cpu"), upd).clone()
+            script.append({"num_processed_tokens": start, "cached": cached_in.clone(), "fresh": fresh, "finished_flag": fin_in,
+                           "out": out, "cached_after": upd.get("cached_thinker_decode_embeddings"),
+                           "finished_after": upd.get("finished_flag")})
+            if stepno != "beyond_cache":
+                if upd.get("cached_thinker_decode_embeddings") is not None:
+                    cached = upd["cached_thinker_decode_embeddings"]
+                finished = upd.get("finished_flag", finished)
+    out = {"ids": ids, "dims": {"thinker_hidden": Ht, "inter": I, "hidden": H, "codec_vocab": Vc},
+           "weights": {"text": w_of(text_p), "hidden": w_of(hid_p), "codec_embed": table}, "cases": cases,
+           "streaming": {"n_thinker_output_ids": n_out, "script": script}}
+    path = os.path.join(HERE, "omni_prompt_builder.pt")
+    torch.save(out, path)
+    print("omni_prompt_builder.pt", os.path.getsize(path), "bytes;", [(c["name"], tuple(c["out_embeds"].shape), tuple(c["out_trailing"].shape)) for c in cases])
+    print("streaming:", [(s_["num_processed_tokens"], s_["out"] if isinstance(s_["out"], str) else tuple(s_["out"].shape)) for s_ in script])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "op"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -483,3 +651,5 @@ if __name__ == "__main__":
         mint_snake_beta()
     if "moe" in which:
         mint_moe_block()
+    if "op" in which:
+        mint_omni_prompt_builder()

@@ -199,3 +199,64 @@ def test_engine_core_loop_scheduler_worker_oracle():
         kv, _ = conn.get("0", "1", f"omni_0_to_1_kv_cache_{k}")
         assert kv["metadata"]["seq_len"] == n + 4
     wk.shutdown()
+
+
+def test_omni_request_prompt_built_on_device_then_decodes_with_queued_text_steps():
+    """A Qwen3-Omni style request carries the thinker's outputs, not ready talker embeddings: the runner's prompt builder
+    (prompt_builder_omni = the reference's talker_preprocess_prefill) makes the prompt and the text-step queue on the
+    device; prefill + decode then follow the oracle fed with the same prompt rows and queue (builder parity itself:
+    tests/test_gpu_prompt_builder.py)."""
+    from ht_vllm_omni_amd.prompt_builder_omni import OmniPromptIds
+    d = get_dims("tiny")
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb, Ht, I = 16, 64, 64, 96
+    g = torch.Generator().manual_seed(12)
+    rnd = lambda *s, sc=0.15: (torch.randn(*s, generator=g) * sc).to(BF16)
+    mlp = lambda: {"fc1_w": rnd(I, Ht), "fc1_b": rnd(I), "fc2_w": rnd(d.hidden, I), "fc2_b": rnd(d.hidden)}
+    ids = OmniPromptIds(im_start=5, system=6, user=7, assistant=8, tts_pad_token=12, audio=9, image=10, video=11,
+                        codec_nothink=140, codec_think_bos=141, codec_think_eos=142, codec_pad=d.codec_pad_id, codec_bos=149,
+                        speaker_ids={"ethan": 160}, default_speaker="ethan")
+    pbw = {"text": mlp(), "hidden": mlp()}
+    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
+    cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w,
+                      enforce_eager=True, default_sampling_params=sp, prompt_builder={"weights": pbw, "ids": ids})
+    wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    wk.engine.set_sampling(cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    run, eng = wk.model_runner, wk.engine
+    assert run.prompt_builder is not None and torch.equal(run.prompt_builder.codec_embed.cpu(), w["embed"])
+    # thinker side: system + user (3 audio tokens) + assistant (7 generated tokens)
+    chat = [5, 6, 30, 31] + [5, 7, 32, 9, 9, 9, 33] + [5, 8, 34]
+    seq = chat + [35, 36, 37, 38, 39, 40, 41]
+    T = len(seq)
+    info = {"thinker_prefill_embeddings": encode_tensor(torch.randn(T, Ht, generator=g)),
+            "thinker_hidden_states": encode_tensor(torch.randn(T, Ht, generator=g)),
+            "thinker_sequences": seq, "thinker_input_ids": chat, "speaker": "Ethan",
+            "tts_bos_embed": encode_tensor(torch.randn(1, 1, Ht, generator=g)), "tts_eos_embed": encode_tensor(torch.randn(1, 1, Ht, generator=g)),
+            "tts_pad_embed": encode_tensor(torch.randn(1, 1, Ht, generator=g))}
+    P = 7 + 9                                   # user segment rows + the 9-row assistant block (system is skipped)
+    pool = BlockPool(nb, bs)
+    pool.allocate("o", P + 1)
+    nr = OmniNewRequestData(req_id="o", prompt_token_ids=[0] * P, block_ids=(pool.block_ids("o"),), sampling_params=sp,
+                            additional_information=info)
+    so = OmniSchedulerOutput(scheduled_new_reqs=[nr], num_scheduled_tokens={"o": P}, total_num_scheduled_tokens=P)
+    assert wk.execute_model(so) is None
+    out = wk.sample_tokens(None)
+    st = run.requests["o"]
+    assert st.prompt_embeds.shape == (P, d.hidden) and st.tail.shape == (7 - 1 + 1, d.hidden)      # generated[1:] + tts_eos
+    assert st.info["prefill_consumed_text_tokens"] == 1
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    ost = O.OracleState(tail_text=list(st.tail.cpu()), tts_pad=st.tts_pad.cpu())
+    _, oids, oh = orc.prefill([ost], [st.prompt_embeds.clone()], [pool.block_ids("o")])
+    assert out.sampled_token_ids[0] == [int(oids[0])]
+    eng.input_ids[0] = int(oids[0]); eng.last_hidden[0] = oh[0].cuda()
+    for stepno in range(9):                     # 7 queued text steps, then tts_pad
+        nb_new = pool.allocate("o", st.num_computed + 2)
+        so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["o"], new_block_ids=[(nb_new,) if nb_new else None]),
+                                 num_scheduled_tokens={"o": 1}, total_num_scheduled_tokens=1)
+        wk.execute_model(so); out = wk.sample_tokens(None)
+        ol, oi, oh, oc, _ = orc.decode_step([ost], [pool.block_ids("o")])
+        assert torch.equal(out.pooler_output[0]["audio_codes"], oc[0:1]), f"audio codes at decode step {stepno}"
+        eng.input_ids[0] = int(oi[0]); eng.last_hidden[0] = oh[0].cuda()
+    wk.shutdown()

@@ -3,11 +3,13 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from ht_vllm_omni_amd.config import get_dims
 from ht_vllm_omni_amd.weights import make_weights
 from oracle import talker_oracle as O
+from tests.util import assert_bf16_close
 
 
 def _bf16(a: np.ndarray) -> torch.Tensor:
@@ -95,3 +97,45 @@ def test_moe_block_matches_hf_module(golden_dir):
         diff = (y.float() - ref.float()).abs()
         assert (y.view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 0.02, f"case {ci}: max diff {diff.max().item()}"
         assert diff.max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def omni_prompt_gold(golden_dir):
+    return torch.load(os.path.join(golden_dir, "omni_prompt_builder.pt"), weights_only=True)
+
+
+def test_omni_prompt_builder_matches_reference_methods(omni_prompt_gold):
+    """oracle.omni_talker_prompt == the reference's _thinker_to_talker_prefill (+ user / assistant parts, _get_tts_embed) run
+    on HF ResizeMLP modules: ids exact, embeddings / trailing text rows within one bf16 rounding of the module's GEMMs."""
+    g = omni_prompt_gold
+    w, ids = g["weights"], g["ids"]
+    for c in g["cases"]:
+        o_ids, o_emb, o_tail = O.omni_talker_prompt(c["thinker_embed"], c["thinker_hidden"], c["input_ids"], c["result_ids"],
+                                                    c["speaker_id"], c["tts_bos"], c["tts_eos"], c["tts_pad"], w, ids)
+        assert torch.equal(o_ids, c["out_ids"]), c["name"]
+        assert o_emb.shape == c["out_embeds"].shape and o_tail.shape == c["out_trailing"].shape, c["name"]
+        assert_bf16_close(o_emb, c["out_embeds"], ulps=1, max_mismatch=0.02, what=c["name"] + " embeds")
+        assert_bf16_close(o_tail, c["out_trailing"], ulps=1, max_mismatch=0.02, what=c["name"] + " trailing")
+        # decode side: the queue pops, then tts_pad for ever (talker_preprocess_decode)
+        tail, steps = c["out_trailing"], []
+        for _ in range(c["decode_text_steps"].shape[0]):
+            step, tail = O.omni_text_step_pop(tail, c["tts_pad_proj"])
+            steps.append(step)
+        assert torch.equal(torch.cat(steps, 0), c["decode_text_steps"]), c["name"]
+    with pytest.raises(ValueError):
+        c = g["cases"][0]
+        O.omni_talker_prompt(c["thinker_embed"], c["thinker_hidden"], c["input_ids"][:1], c["result_ids"], 1, None, None, None, w, ids)
+
+
+def test_omni_streaming_text_steps_match_reference(omni_prompt_gold):
+    g = omni_prompt_gold
+    pad, eos = g["cases"][-1]["tts_pad_proj"], g["cases"][-1]["tts_eos_proj"]
+    for s in g["streaming"]["script"]:
+        st = {"num_processed_tokens": s["num_processed_tokens"], "finished_flag": s["finished_flag"], "cached": s["cached"],
+              "fresh": s["fresh"]}
+        out = O.omni_text_step_streaming(st, g["streaming"]["n_thinker_output_ids"], eos, pad, g["weights"]["text"])
+        assert out.shape == s["out"].shape, s["num_processed_tokens"]
+        assert_bf16_close(out, s["out"], ulps=1, max_mismatch=0.02, what="streaming text step")
+        if s["cached_after"] is not None:
+            assert torch.equal(st["cached"], s["cached_after"])
+        assert bool(st.get("finished_flag")) == bool(s["finished_after"] or s["finished_flag"])
