@@ -194,7 +194,9 @@ int omni_embed(const int32_t* ids, const void* table, void* out, int T, int hidd
  *   greedy != 0 : first argmax.  Otherwise: repetition penalty over seen[B,V] (uint8, may be
  *   NULL) -> /temperature -> top-k (ties kept) -> top-p (0 < top_p < 1: of the candidates sorted by
  *   (value desc, index asc) keep those whose preceding cumulative softmax mass is < top_p, the rule of
- *   qwen3_omni_moe_code_predictor_mtp.py:463-469; needs 0 < top_k <= 1024) -> Gumbel-max with the hash
+ *   qwen3_omni_moe_code_predictor_mtp.py:463-469; needs 0 < top_k <= 1024, and the cut sees at most 1024
+ *   candidates: a row with more than 1024 - top_k exact ties AT the k-th value is cut among its first 1024
+ *   candidates in index order) -> Gumbel-max with the hash
  *   RNG of the oracle keyed by (seed, steps[b], column).  out_ids int32 [B]; if seen != NULL the sampled id is
  *   marked.  steps int32 [B] (device) is incremented when inc_steps != 0.                     */
 int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,

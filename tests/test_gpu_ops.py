@@ -576,6 +576,45 @@ def test_sampler_top_p_after_top_k(ops, V, top_k, top_p, scale):
 
 
 
+@pytest.mark.parametrize("V,top_k,top_p", [(2048, 50, 1.0), (3072, 256, 1.0), (3072, 257, 1.0), (8192, 50, 0.9), (8192, 300, 0.9),
+                                           (4096, 64, 1.0), (300, 299, 1.0)])
+def test_sampler_candidate_filter_edges(ops, V, top_k, top_p):
+    """The candidate-filter path of the sampler and its fallbacks: constant rows (every element is a candidate -> radix
+    fallback), rows with fewer finite values than top_k, heavy ties at the threshold, masked (-inf) tails, top_k at / above
+    the 256 limit of the fast path, the 12- and 32-elements-per-thread instantiations -- always the oracle's pick."""
+    g = torch.Generator().manual_seed(V * 7 + top_k)
+    B = 12
+    logits = torch.randn(B, V, generator=g) * 2
+    logits[0] = 0.25                                              # constant row
+    logits[1] = float("-inf"); logits[1, 5:5 + min(top_k, 30) // 2] = torch.randn(min(top_k, 30) // 2, generator=g)   # < top_k finite
+    logits[2, : V // 2] = 1.0                                     # half the row tied: threshold inside the tie block or above it
+    logits[3, V // 3:] = float("-inf")                            # masked tail (allowed-codec mask)
+    logits[4] = (logits[4] * 8).round() / 8                       # coarse grid: many duplicates everywhere
+    logits[5] = torch.arange(V, dtype=torch.float32) * 1e-3       # strictly increasing: the top-k are the last indices
+    logits[6, 7] = float("inf")                                   # +inf wins whatever the noise
+    steps = torch.arange(B, dtype=torch.int32)
+    kw = dict(temperature=0.7, top_k=top_k, top_p=top_p, seed=99)
+    out = ops.sample(logits.cuda(), greedy=False, steps=steps.cuda(), step_mul=1, step_add=5, **kw).cpu()
+    for b in range(B):
+        okw = dict(greedy=False, step=int(steps[b]) + 5, **kw)
+        x = logits[b] / 0.7
+        kth = torch.topk(x, top_k).values[-1]
+        kept = torch.isfinite(O.top_p_filter(x.masked_fill(x < kth, float("-inf")), top_p))
+        if b == 6:
+            assert out[b].item() == 7
+            continue
+        if b == 0 and top_p < 1.0 and V > 1024:
+            continue        # documented limit (omni_talker.h, omni_sample): the nucleus cut sees at most 1024 candidates
+        assert kept[out[b].item()], f"row {b}: sampled id outside the kept set"
+        if O.sample_row_margin(logits[b], **okw) >= 1e-4:
+            assert out[b].item() == O.sample_row(logits[b], **okw), b
+    # greedy on the same rows (first index among ties; the all--inf row falls back to index 0 like torch.argmax)
+    outg = ops.sample(logits.cuda(), greedy=True).cpu()
+    for b in range(B):
+        if b != 6:
+            assert outg[b].item() == int(torch.argmax(logits[b])), b
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_snake_beta(ops, golden_dir, dtype):
     """SnakeBeta of the Code2Wav decoder (the reference's Triton kernel -> HIP): golden vectors minted from the
