@@ -14,6 +14,7 @@ input/output tensors are saved.
   moe_block.npz             HF Qwen3OmniMoeTalkerTextSparseMoeBlock (bf16) in/out + weights + routing
   snake_beta.npz            reference SnakeBeta module (12 Hz tokenizer decoder) in/out
   omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
+  graph_decoder.json        reference CUDAGraphDecoderWrapper host logic: capture-size tables, bucket lookup, chunk windows
   omni_prompt_builder.pt    reference Qwen3OmniMoeForConditionalGeneration prompt-embedding methods (models/qwen3_omni/
                             qwen3_omni.py) called on a stand-in `self` holding HF's ResizeMLP modules: in/out
 """
@@ -467,6 +468,47 @@ def mint_moe_block():
     print("moe block cases: 3")
 
 
+def mint_graph_decoder():
+    """Known answers of the reference's CUDAGraphDecoderWrapper host logic (cuda_graph_decoder_wrapper.py): capture-size
+    tables for a sweep of chunking configs, bucket lookup, and the chunk / left-context boundaries of the chunked decode
+    (recorded by running the reference wrapper, disabled = eager, on a decoder that returns its input length)."""
+    install_vllm_stubs()
+    mod = load_by_path("ref_cuda_graph_decoder_wrapper", os.path.join(V, "model_executor/models/qwen3_tts/cuda_graph_decoder_wrapper.py"))
+    W = mod.CUDAGraphDecoderWrapper
+    sizes = []
+    for ccf in (0, 1, 12, 25, 33, 50, 300, 400):
+        for lcf in (0, 25, 72):
+            for dcs, dlc in ((300, 25), (100, 10), (16, 0), (1000, 50)):
+                kw = dict(codec_chunk_frames=ccf, codec_left_context_frames=lcf, decode_chunk_size=dcs, decode_left_context=dlc)
+                sizes.append({"kw": kw, "out": W.compute_capture_sizes(**kw)})
+    w = W(decoder=None, capture_sizes=[100, 25, 50])
+    lookup = [{"n": n, "out": w._get_padded_size(n)} for n in (0, 1, 24, 25, 26, 50, 51, 100, 101, 5000)]
+
+    class Probe(torch.nn.Module):
+        total_upsample = 3
+
+        def __init__(self):
+            super().__init__()
+            self.calls = []
+
+        def forward(self, codes):
+            self.calls.append((int(codes[0, 0, 0]), int(codes.shape[-1])))       # first frame index, window length
+            return codes[:, :1, :].float().repeat_interleave(3, dim=-1)
+
+    chunked = []
+    for total, cs, lc in ((1, 300, 25), (24, 300, 25), (300, 300, 25), (301, 300, 25), (650, 300, 25), (100, 30, 10), (100, 30, 0),
+                          (61, 30, 30), (90, 30, 45)):
+        pr = Probe()
+        wr = W(decoder=pr, capture_sizes=[8], enabled=False)
+        codes = torch.arange(total).reshape(1, 1, total).expand(1, 2, total)
+        out = wr.chunked_decode_with_cudagraph(codes, chunk_size=cs, left_context_size=lc)
+        chunked.append({"total": total, "chunk_size": cs, "left_context_size": lc, "windows": pr.calls, "out": out[0, 0].long().tolist()})
+    path = os.path.join(HERE, "graph_decoder.json")
+    with open(path, "w") as f:
+        json.dump({"capture_sizes": sizes, "lookup": lookup, "chunked": chunked}, f, separators=(",", ":"))
+    print("graph_decoder.json", os.path.getsize(path), "bytes;", len(sizes), "size tables,", len(chunked), "chunked decodes")
+
+
 def install_auto_stubs():
     """qwen3_omni.py imports ~20 vllm / vllm_omni symbols at module level (registries, interfaces, thinker classes) that its
     prompt-embedding methods never touch: every such name resolves to an empty placeholder class so that the module
@@ -636,7 +678,7 @@ def mint_omni_prompt_builder():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "op"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -651,5 +693,7 @@ if __name__ == "__main__":
         mint_snake_beta()
     if "moe" in which:
         mint_moe_block()
+    if "gd" in which:
+        mint_graph_decoder()
     if "op" in which:
         mint_omni_prompt_builder()
