@@ -38,15 +38,46 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint3
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 
-// ---- wave64 reductions (butterfly over all 64 lanes)
+// ---- lane exchanges inside a 16-lane row as DPP modifiers (~1 VALU op; hipcc lowers __shfl_xor to ds_bpermute_b32, an
+// LDS-pipe round trip of ~120 cycles that a one-wave-per-SIMD kernel cannot hide).  Full waves only (a disabled source
+// lane reads as 0).  For REDUCTIONS any pairing that merges disjoint groups works, so the 8- and 16-lane steps use the
+// mirror controls: after xor1 + xor2 every lane holds its quad's total, half_mirror (i <-> 7 - i) brings in the other quad
+// of the 8-lane group, mirror (i <-> 15 - i) the other half of the row.
+#define OMNI_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define OMNI_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define OMNI_DPP_HALF_MIRROR 0x141  // row_half_mirror
+#define OMNI_DPP_MIRROR 0x140       // row_mirror
+#define OMNI_DPP_ROR8 0x128         // row_ror:8  == lane ^ 8 inside the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum / max over the 8-lane group (lane >> 3) and over the 16-lane row, result in every lane of the group
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f<OMNI_DPP_XOR1>(v);
+    v += dpp_f<OMNI_DPP_XOR2>(v);
+    v += dpp_f<OMNI_DPP_HALF_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) { v = group8_sum(v); return v + dpp_f<OMNI_DPP_MIRROR>(v); }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<OMNI_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<OMNI_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<OMNI_DPP_HALF_MIRROR>(v));
+    return fmaxf(v, dpp_f<OMNI_DPP_MIRROR>(v));
+}
+
+// ---- wave64 reductions (all 64 lanes hold the result): 4 DPP steps inside the rows + 2 cross-row exchanges
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

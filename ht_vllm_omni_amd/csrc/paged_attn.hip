@@ -474,9 +474,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
+            d = group8_sum(d);
             d = ok ? d : -INFINITY;
             const float mn = fmaxf(m[g], d);
             const float corr = (mn == -INFINITY) ? 1.0f : exp2f(m[g] - mn);
@@ -499,9 +497,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
+            d = group8_sum(d);
             if (tg == 0) {
                 const float mn = fmaxf(m[g], d);
                 const float corr = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mn);
@@ -516,30 +512,44 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float mw = m[g];
-        mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+        mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));       // the 8 token groups = lane bits 3..5: one in-row step, two cross-row
         mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
         mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
         const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
         float lw = l[g] * sc;
-        lw += __shfl_xor(lw, 8, 64);
+        lw += dpp_f<OMNI_DPP_ROR8>(lw);
         lw += __shfl_xor(lw, 16, 64);
         lw += __shfl_xor(lw, 32, 64);
         const float inv = 1.0f / lw;                  // >= the new token's weight, never 0
-        const int kq = (qh0 + g) * 128;
-        uint16_t* op0 = a.out_frag ? a.out + frag_off(row, kq + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + sub * 8;
-        uint16_t* op1 = a.out_frag ? a.out + frag_off(row, kq + 64 + sub * 8, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq + 64 + sub * 8;
-        uint32_t packed[8];
+        // 16 partial outputs per lane, to be summed over the 8 token groups: lane ^ 8 as a DPP step on all 16, then two
+        // HALVING exchanges (each lane passes on the half its partner keeps): 8 + 4 ds_bpermute instead of 48, and every
+        // lane ends with 4 finished, adjacent outputs
+        float a16[16];
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            float v0 = acc[g][e] * sc, v1 = acc[g][e + 1] * sc;
-            v0 += __shfl_xor(v0, 8, 64); v1 += __shfl_xor(v1, 8, 64);
-            v0 += __shfl_xor(v0, 16, 64); v1 += __shfl_xor(v1, 16, 64);
-            v0 += __shfl_xor(v0, 32, 64); v1 += __shfl_xor(v1, 32, 64);
-            packed[e >> 1] = pack_bf2(v0 * inv, v1 * inv);
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[g][e] * sc;
+            a16[e] = v + dpp_f<OMNI_DPP_ROR8>(v);
         }
-        if (tg == 0) {   // bf16 layout: elements [8 sub, +8) and [64 + 8 sub, +8): two 16-B stores
-            *reinterpret_cast<uint4*>(op0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-            *reinterpret_cast<uint4*>(op1) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+        const bool b1 = (lane & 16) != 0, b2 = (lane & 32) != 0;
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float keep = b1 ? a16[8 + e] : a16[e];
+            const float send = b1 ? a16[e] : a16[8 + e];
+            a8[e] = keep + __shfl_xor(send, 16, 64);
+        }
+        float a4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float keep = b2 ? a8[4 + e] : a8[e];
+            const float send = b2 ? a8[e] : a8[4 + e];
+            a4[e] = keep + __shfl_xor(send, 32, 64);
+        }
+        // the lane holds elements e0 .. e0 + 3 of its sub slice, e0 = 8 b1 + 4 b2 (elem_of<bf16>: e >= 8 -> dims 64 + ...)
+        const int kq = (qh0 + g) * 128 + (b1 ? 64 : 0) + sub * 8 + (b2 ? 4 : 0);
+        if ((lane & 8) == 0) {          // lanes ^ 8 hold the same four values
+            uint16_t* op = a.out_frag ? a.out + frag_off(row, kq, a.q_heads * 128) : a.out + (size_t)row * a.q_heads * 128 + kq;
+            *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf2(a4[0] * inv, a4[1] * inv), pack_bf2(a4[2] * inv, a4[3] * inv));
         }
     }
 }
