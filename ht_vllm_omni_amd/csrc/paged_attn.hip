@@ -185,9 +185,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
                 float d_ = 0.f;                                                                      \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
-                d_ += __shfl_xor(d_, 1, 64);                                                         \
-                d_ += __shfl_xor(d_, 2, 64);                                                         \
-                d_ += __shfl_xor(d_, 4, 64);                                                         \
+                d_ = group8_sum(d_);       /* 3 DPP steps over the token's 8 lanes */                 \
                 if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
                 d_ = ok_[u] ? d_ : -INFINITY;                                                        \
                 s_[u][g] = d_;                                                                       \
@@ -290,9 +288,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
+                d = group8_sum(d);
                 if (KV == OMNI_KV_INT8) d *= ksc_new;
                 if (tg == 0) {
                     const float mn = fmaxf(m[g], d);
@@ -313,35 +309,42 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float mw = m[g];
-        mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+        mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));
         mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
         mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
         const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
         float lw = l[g] * sc;
-        lw += __shfl_xor(lw, 8, 64);
+        lw += dpp_f<OMNI_DPP_ROR8>(lw);
         lw += __shfl_xor(lw, 16, 64);
         lw += __shfl_xor(lw, 32, 64);
-        m[g] = mw;
-        l[g] = lw;
+        // the 16 partial outputs: lane ^ 8 as a DPP step, then two halving exchanges (each lane passes on the half its
+        // partner keeps) -- 12 ds_bpermute instead of 48; the lane ends with elements e0 .. e0 + 3, e0 = 8 b1 + 4 b2
+        float a16[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float v = acc[g][e] * sc;
-            v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            acc[g][e] = v;
+            const float v = acc[g][e] * sc;
+            a16[e] = v + dpp_f<OMNI_DPP_ROR8>(v);
         }
-    }
-    if (tg == 0) {
+        const bool b1 = (lane & 16) != 0, b2 = (lane & 32) != 0;
+        float a8[8];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float* rec = lds + ((size_t)wave * G + g) * PA_REC;
-            if (sub == 0) {
-                rec[0] = m[g];
-                rec[1] = l[g];
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float keep = b1 ? a16[8 + e] : a16[e];
+            const float send = b1 ? a16[e] : a16[8 + e];
+            a8[e] = keep + __shfl_xor(send, 16, 64);
+        }
+        float* rec = lds + ((size_t)wave * G + g) * PA_REC;
+        const int e0 = (b1 ? 8 : 0) + (b2 ? 4 : 0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) rec[2 + elem_of<KV>(sub, e)] = acc[g][e];
+        for (int e = 0; e < 4; ++e) {
+            const float keep = b2 ? a8[4 + e] : a8[e];
+            const float send = b2 ? a8[e] : a8[4 + e];
+            const float v = keep + __shfl_xor(send, 32, 64);
+            if ((lane & 8) == 0) rec[2 + elem_of<KV>(sub, e0 + e)] = v;      // lanes ^ 8 hold the same values
+        }
+        if (lane == 0) {
+            rec[0] = mw;
+            rec[1] = lw;
         }
     }
     __syncthreads();

@@ -6,15 +6,9 @@
 
 // 16 lanes per (token, head slot): lane j owns elements [4j, 4j+4) and [64+4j, 64+4j+4) -- the rotate_half pairs stay
 // in one lane and every access is 8 B (the prefill calls this for thousands of tokens per layer)
-__device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
-}
-__device__ __forceinline__ float max16(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
-    return v;
-}
+// (a group is one 16-lane DPP row and leaves the kernel as a whole, so the row-local DPP reductions see no disabled lane)
+__device__ __forceinline__ float sum16(float v) { return row16_sum(v); }
+__device__ __forceinline__ float max16(float v) { return row16_max(v); }
 __device__ __forceinline__ void unpack4(uint2 w, float* f) { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
 
 template <int KV>
