@@ -67,19 +67,38 @@ __device__ __forceinline__ float row16_max(float v) {
     return fmaxf(v, dpp_f<OMNI_DPP_MIRROR>(v));
 }
 
-// ---- wave64 reductions (all 64 lanes hold the result): 4 DPP steps inside the rows + 2 cross-row exchanges
-__device__ __forceinline__ float wave_sum(float v) {
-    v = row16_sum(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+// ---- exchanges ACROSS rows: gfx950's v_permlane16_swap / v_permlane32_swap (VALU, no LDS pipe).  With both operands = v,
+// permlane16_swap leaves {rows 0,0,2,2 of v} in the first result and {rows 1,1,3,3} in the second; permlane32_swap
+// {lanes 0-31 twice} and {lanes 32-63 twice}: their sum / max is the lane ^ 16 / lane ^ 32 butterfly step, and picking the
+// first result on the odd rows (upper half) and the second on the even rows (lower half) is the plain exchange.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float wave_max(float v) {
-    v = row16_max(v);
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xchg16(float v, bool odd_row) {      // value of lane ^ 16; odd_row = (lane & 16) != 0
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(odd_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xchg32(float v, bool upper) {        // value of lane ^ 32; upper = (lane & 32) != 0
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(upper ? r[0] : r[1]);
+}
+
+// ---- wave64 reductions (all 64 lanes hold the result): 4 DPP steps inside the rows + 2 permlane swaps, no LDS traffic
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // ---- OCP e4m3fn <-> f32 (saturating, round-nearest-even: clamp then hardware cvt)
 #define OMNI_FP8_MAX 448.0f

@@ -142,8 +142,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         float s_ = psum;
 #pragma unroll
         for (int e = 0; e < PE; ++e) s_ += pv[e];
-        if (XROWS <= 32) s_ += __shfl_xor(s_, 32, 64);
-        if (XROWS <= 16) s_ += __shfl_xor(s_, 16, 64);
+        if (XROWS <= 32) s_ = xor32_sum(s_);
+        if (XROWS <= 16) s_ = xor16_sum(s_);
         float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;
         red[wave * 64 + lane] = s_;
         __syncthreads();
@@ -357,8 +357,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 }
                 *reinterpret_cast<uint2*>(rp) = make_uint2(pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3]));
                 float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
-                ss += __shfl_xor(ss, 16, 64);       // the 4 lanes (l & 15) + 16 * {0..3} hold the 16 columns of row m
-                ss += __shfl_xor(ss, 32, 64);
+                ss = xor32_sum(xor16_sum(ss));       // the 4 lanes (l & 15) + 16 * {0..3} hold the 16 columns of row m
                 if (l < 16) a.part_out[blockIdx.x * 64 + m] = ss;   // slabs [n group][64 rows]
             } else if (EPI == OMNI_EPI_BF16) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (a.oshuf ? frag_off(m, n, N) : (size_t)m * N + n)) =

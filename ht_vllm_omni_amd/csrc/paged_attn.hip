@@ -310,13 +310,11 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     for (int g = 0; g < G; ++g) {
         float mw = m[g];
         mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));
-        mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
-        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        mw = xor32_max(xor16_max(mw));
         const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
         float lw = l[g] * sc;
         lw += dpp_f<OMNI_DPP_ROR8>(lw);
-        lw += __shfl_xor(lw, 16, 64);
-        lw += __shfl_xor(lw, 32, 64);
+        lw = xor32_sum(xor16_sum(lw));
         // the 16 partial outputs: lane ^ 8 as a DPP step, then two halving exchanges (each lane passes on the half its
         // partner keeps) -- 12 ds_bpermute instead of 48; the lane ends with elements e0 .. e0 + 3, e0 = 8 b1 + 4 b2
         float a16[16];
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         for (int e = 0; e < 8; ++e) {
             const float keep = b1 ? a16[8 + e] : a16[e];
             const float send = b1 ? a16[e] : a16[8 + e];
-            a8[e] = keep + __shfl_xor(send, 16, 64);
+            a8[e] = keep + xchg16(send, b1);
         }
         float* rec = lds + ((size_t)wave * G + g) * PA_REC;
         const int e0 = (b1 ? 8 : 0) + (b2 ? 4 : 0);
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         for (int e = 0; e < 4; ++e) {
             const float keep = b2 ? a8[4 + e] : a8[e];
             const float send = b2 ? a8[e] : a8[4 + e];
-            const float v = keep + __shfl_xor(send, 32, 64);
+            const float v = keep + xchg32(send, b2);
             if ((lane & 8) == 0) rec[2 + elem_of<KV>(sub, e0 + e)] = v;      // lanes ^ 8 hold the same values
         }
         if (lane == 0) {
@@ -516,13 +514,11 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     for (int g = 0; g < G; ++g) {
         float mw = m[g];
         mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));       // the 8 token groups = lane bits 3..5: one in-row step, two cross-row
-        mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
-        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        mw = xor32_max(xor16_max(mw));
         const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
         float lw = l[g] * sc;
         lw += dpp_f<OMNI_DPP_ROR8>(lw);
-        lw += __shfl_xor(lw, 16, 64);
-        lw += __shfl_xor(lw, 32, 64);
+        lw = xor32_sum(xor16_sum(lw));
         const float inv = 1.0f / lw;                  // >= the new token's weight, never 0
         // 16 partial outputs per lane, to be summed over the 8 token groups: lane ^ 8 as a DPP step on all 16, then two
         // HALVING exchanges (each lane passes on the half its partner keeps): 8 + 4 ds_bpermute instead of 48, and every
@@ -539,14 +535,14 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         for (int e = 0; e < 8; ++e) {
             const float keep = b1 ? a16[8 + e] : a16[e];
             const float send = b1 ? a16[e] : a16[8 + e];
-            a8[e] = keep + __shfl_xor(send, 16, 64);
+            a8[e] = keep + xchg16(send, b1);
         }
         float a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float keep = b2 ? a8[4 + e] : a8[e];
             const float send = b2 ? a8[e] : a8[4 + e];
-            a4[e] = keep + __shfl_xor(send, 32, 64);
+            a4[e] = keep + xchg32(send, b2);
         }
         // the lane holds elements e0 .. e0 + 3 of its sub slice, e0 = 8 b1 + 4 b2 (elem_of<bf16>: e >= 8 -> dims 64 + ...)
         const int kq = (qh0 + g) * 128 + (b1 ? 64 : 0) + sub * 8 + (b2 ? 4 : 0);
