@@ -197,6 +197,10 @@ def main():
         import ctypes
         eng.lib.omni_debug_extra_trivial.argtypes = [ctypes.c_int]
         eng.lib.omni_debug_extra_trivial(int(os.environ["OMNI_EXTRA_TRIVIAL"]))
+    if os.environ.get("OMNI_INT8_MAX_G"):           # diagnostics: q heads per workgroup of the int8-KV decode attention
+        import ctypes
+        eng.lib.omni_debug_int8_max_g.argtypes = [ctypes.c_int]
+        eng.lib.omni_debug_int8_max_g(int(os.environ["OMNI_INT8_MAX_G"]))
     B = args.batch
     if args.greedy:
         eng.set_sampling(greedy=1, cp_greedy=1)

@@ -79,11 +79,11 @@ __device__ __forceinline__ void to_f32(const KVRaw<KV>& r, float* f) {
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t w = r.a[j];
-            f[4 * j + 0] = (float)(int8_t)(w & 0xFF);
-            f[4 * j + 1] = (float)(int8_t)((w >> 8) & 0xFF);
-            f[4 * j + 2] = (float)(int8_t)((w >> 16) & 0xFF);
-            f[4 * j + 3] = (float)(int8_t)(w >> 24);
+            const uint32_t w = r.a[j] ^ 0x80808080u;       // signed byte + 128 as an unsigned byte: v_cvt_f32_ubyteN, then - 128
+            f[4 * j + 0] = (float)(w & 0xFF) - 128.0f;
+            f[4 * j + 1] = (float)((w >> 8) & 0xFF) - 128.0f;
+            f[4 * j + 2] = (float)((w >> 16) & 0xFF) - 128.0f;
+            f[4 * j + 3] = (float)(w >> 24) - 128.0f;
         }
     }
 }
@@ -589,14 +589,15 @@ extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_
     return (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
 }
 
+static int g_pa_int8_max_g = 2;
+extern "C" void omni_debug_int8_max_g(int g) { g_pa_int8_max_g = g; }
 template <int KV, bool FUSED>
 static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     PAArgs a = a_in;
     int G = a.q_heads / a.kv_heads;
     a.kv_rep = 1;
-    // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head; int8 KV keeps its per-token scales live and spills at G = 4
-    // (512 VGPRs + 144 spilled, 65 us per layer), so it runs groups of 2
-    const int max_g = (KV == OMNI_KV_INT8) ? 2 : 4;
+    // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head (int8: see g_pa_int8_max_g)
+    const int max_g = (KV == OMNI_KV_INT8) ? g_pa_int8_max_g : 4;
     while (G > max_g && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }
     if (rows * a.kv_heads * a.kv_rep >= 512) a.nsplit = 1;      // the virtual heads already fill the chip: no KV split
     dim3 grid(a.kv_heads * a.kv_rep, rows, a.nsplit), block(PA_THREADS);
