@@ -144,7 +144,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->resid = c.take<uint16_t>(B16 * H);          // fragment-major in the fused-norm step
     t->resid_b = c.take<uint16_t>(B * H);
     t->part = c.take<float>(H / 16 * 64);
-    t->cp_part = c.take<float>(Hc / 16 * 64);
+    t->cp_part = c.take<float>(Hc / 16 * 128);       // two-position pass: 128 rows per slab
     t->normed = c.take<uint16_t>(B16 * H);
     t->qkv = c.take<uint16_t>(B * qkv_out);
     t->q = c.take<uint16_t>(B * d.q_heads * d.head_dim);
@@ -155,14 +155,14 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->hidden = c.take<uint16_t>(B * H);
     t->e0 = c.take<uint16_t>(B * H);
     t->attn_ws = c.take<float>((size_t)omni_paged_attn_workspace_bytes(d.max_batch, d.q_heads, d.head_dim, d.max_model_len) / 4);
-    t->cp_resid = c.take<uint16_t>(B16 * Hc);
+    t->cp_resid = c.take<uint16_t>(2 * B16 * Hc);     // rows [0, B) position 0 and [B16, B16 + B) position 1 in the pair pass
     t->cp_resid_b = c.take<uint16_t>(B * Hc);
     t->cp_normed = c.take<uint16_t>(B16 * Hc);
-    t->cp_qkv = c.take<uint16_t>(B * cp_qkv_out);
+    t->cp_qkv = c.take<uint16_t>(2 * B16 * cp_qkv_out);
     t->cp_q = c.take<uint16_t>(B * d.cp_q_heads * d.cp_head_dim);
-    t->cp_attn = c.take<uint16_t>(B16 * d.cp_q_heads * d.cp_head_dim);
+    t->cp_attn = c.take<uint16_t>(2 * B16 * d.cp_q_heads * d.cp_head_dim);
     t->cp_o = c.take<uint16_t>(B * Hc);
-    t->cp_act = c.take<uint16_t>(B16 * d.cp_inter);
+    t->cp_act = c.take<uint16_t>(2 * B16 * d.cp_inter);
     t->cp_mlp = c.take<uint16_t>(B * Hc);
     t->cp_hidden = c.take<uint16_t>(B * Hc);
     t->cp_in = c.take<uint16_t>(B * Hc);
@@ -371,6 +371,37 @@ static int cp_forward_fused(omni_talker* t, int B, int p, int* np, void* st) {
     return OMNI_OK;
 }
 
+// positions 0 and 1 of the code predictor as ONE pass over a two-block stream: rows [0, B) = position 0 (the talker's last
+// hidden state), rows [Bp, Bp + B) = position 1 (the layer-0 code embedding), Bp = B rounded up to 16; slabs 128 rows wide.
+// Both inputs exist when the predictor starts, and a row's GEMM result does not depend on the rows beside it: 25 launches
+// instead of 22 + 25.  Position 0 only feeds its K / V (written by the pair attention); its rows ride along.
+static int g_cp_pair01 = 1;
+extern "C" void omni_debug_cp_pair01(int on) { g_cp_pair01 = on; }
+static bool cp_pair01_ok(const omni_talker* t, int B) {
+    const omni_talker_desc& d = t->d;
+    const int Bp = (B + 15) & ~15;
+    return g_cp_pair01 && d.cp_fused_norm && d.num_code_groups >= 2 && Bp + B <= 128 && d.cp_head_dim == 128 && t->cp_bs >= 2;
+}
+static int cp_forward_pair01(omni_talker* t, int B, int* np, void* st) {
+    const omni_talker_desc& d = t->d;
+    const int Hc = d.cp_hidden, hq = d.cp_q_heads, hkv = d.cp_kv_heads, D = d.cp_head_dim;
+    const int Bp = (B + 15) & ~15, M2 = Bp + B;
+    const int lay = OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG;
+    for (int l = 0; l < d.cp_layers; ++l) {
+        const omni_layer_weights& w = t->cp_layer[l];
+        TRY(k_gemm_xnorm(t->cp_resid, t->cp_part, *np, w.ln1, d.eps, nullptr, w.wqkv, t->cp_qkv, M2, (hq + 2 * hkv) * D, Hc,
+                         OMNI_EPI_BF16, nullptr, 0, 128, st));
+        TRY(k_attn_pair01(t->cp_qkv, Bp, w.qnorm, w.knorm, d.cp_cos_sin, d.eps, t->cp_k[l], t->cp_v[l], t->cp_attn, B, hq, hkv,
+                          t->cp_bs, 1.0f / sqrtf((float)D), st));
+        TRY(k_gemm_resid(t->cp_attn, hq * D, w.wo, nullptr, t->cp_resid, 1, t->cp_part, nullptr, M2, Hc, hq * D, lay, 128, st));
+        *np = Hc / 16;
+        TRY(k_gemm_xnorm(t->cp_resid, t->cp_part, *np, w.ln2, d.eps, nullptr, w.wgu, t->cp_act, M2, d.cp_inter, Hc, silu_epi(t),
+                         nullptr, 1, 128, st));
+        TRY(k_gemm_resid(t->cp_act, d.cp_inter, w.wdown, nullptr, t->cp_resid, 1, t->cp_part, nullptr, M2, Hc, d.cp_inter, lay, 128, st));
+    }
+    return OMNI_OK;
+}
+
 // small_to_mtp_projection of row-major rows into the fused stream
 static int cp_project_fused(omni_talker* t, const void* rows, int B, int* np, void* st) {
     const omni_talker_desc& d = t->d;
@@ -430,19 +461,47 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
     if (Q <= 1) return OMNI_OK;
     if (d.cp_fused_norm) {
         int np = 1;
-        TRY(cp_project_fused(t, last_hidden, B, &np, st));
-        TRY(cp_forward_fused(t, B, 0, &np, st));
-        if (layer0_ids && d.cp_e0_table) {
-            TRY(k_gather_frag(layer0_ids, 1, d.cp_e0_table, t->cp_resid, t->cp_part, B, Hc, d.vocab, st));
-            np = 1;
+        const bool pair = cp_pair01_ok(t, B);
+        const int Bp = (B + 15) & ~15;
+        // rows of the stream / slabs that position 1 (and the head GEMM after it) uses: behind the position-0 block in the pair pass
+        uint16_t* r1 = pair ? t->cp_resid + (size_t)Bp * Hc : t->cp_resid;
+        float* part1 = pair ? t->cp_part + Bp : t->cp_part;
+        const int ps = pair ? 128 : 64;
+        if (pair) {
+            if (d.has_cp_projection) {
+                np = Hc / 16;
+                TRY(k_gemm_resid(last_hidden, d.hidden, d.cp_proj_w, d.cp_proj_b, t->cp_resid, 0, t->cp_part, nullptr, B, Hc, d.hidden,
+                                 OMNI_LAYOUT_W_FRAG, 128, st));
+                if (layer0_ids && d.cp_e0_table)
+                    TRY(k_gather_frag(layer0_ids, 1, d.cp_e0_table, r1, part1, B, Hc, d.vocab, st, np, 128));
+                else
+                    TRY(k_gemm_resid(layer0_embed, d.hidden, d.cp_proj_w, d.cp_proj_b, r1, 0, part1, nullptr, B, Hc, d.hidden,
+                                     OMNI_LAYOUT_W_FRAG, 128, st));
+            } else {
+                np = 1;
+                TRY(k_gather_frag(nullptr, 0, last_hidden, t->cp_resid, t->cp_part, B, d.hidden, 0, st, 1, 128));
+                if (layer0_ids && d.cp_e0_table)
+                    TRY(k_gather_frag(layer0_ids, 1, d.cp_e0_table, r1, part1, B, Hc, d.vocab, st, 1, 128));
+                else
+                    TRY(k_gather_frag(nullptr, 0, layer0_embed, r1, part1, B, d.hidden, 0, st, 1, 128));
+            }
+            TRY(cp_forward_pair01(t, B, &np, st));
         } else {
-            TRY(cp_project_fused(t, layer0_embed, B, &np, st));
+            TRY(cp_project_fused(t, last_hidden, B, &np, st));
+            TRY(cp_forward_fused(t, B, 0, &np, st));
+            if (layer0_ids && d.cp_e0_table) {
+                TRY(k_gather_frag(layer0_ids, 1, d.cp_e0_table, t->cp_resid, t->cp_part, B, Hc, d.vocab, st));
+                np = 1;
+            } else {
+                TRY(cp_project_fused(t, layer0_embed, B, &np, st));
+            }
         }
         for (int g = 1; g < Q; ++g) {
-            TRY(cp_forward_fused(t, B, g, &np, st));
+            const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
+            if (!in_pair) TRY(cp_forward_fused(t, B, g, &np, st));
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
-            TRY(xnorm_gemm(t, t->cp_resid, t->cp_part, np, d.cp_norm, nullptr, head, t->cp_logits, B, d.codebook, Hc,
-                           OMNI_EPI_F32_BF16RND, nullptr, 0, st));
+            TRY(k_gemm_xnorm(in_pair ? r1 : t->cp_resid, in_pair ? part1 : t->cp_part, np, d.cp_norm, d.eps, nullptr, head, t->cp_logits,
+                             B, d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, 0, in_pair ? ps : 64, st));
             if (cp_logits_out) {
                 hipError_t e = hipMemcpy2DAsync(cp_logits_out + (size_t)(g - 1) * d.codebook, (size_t)(Q - 1) * d.codebook * 4,
                                                 t->cp_logits, (size_t)d.codebook * 4, (size_t)d.codebook * 4, B,

@@ -47,6 +47,7 @@ struct GemmArgs {
     int wshuf, xshuf, oshuf;   // fragment-major layouts (OMNI_LAYOUT_*), see common.cuh frag_off
     // PRO_XNORM / EPI_RESID: per-row sum-of-squares slabs [np][64 rows] fp32 (deterministic: one slab per producer workgroup)
     const float* part_in; int np_in; float* part_out;
+    int pstride;               // rows per slab (64; 128 for the code predictor's two-position pass)
     int counted;               // use the counted (unpredicated, 2-deep) schedule when K % 512 == 0
 };
 
@@ -121,10 +122,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
             const int p = ch + e * NCH;
-            pv[e] = pp[(size_t)min(p, a.np_in - 1) * 64];
+            pv[e] = pp[(size_t)min(p, a.np_in - 1) * a.pstride];
             if (p >= a.np_in) pv[e] = 0.f;
         }
-        for (int p = ch + PE * NCH; p < a.np_in; p += NCH) psum += pp[(size_t)p * 64];      // hidden > 2048 only
+        for (int p = ch + PE * NCH; p < a.np_in; p += NCH) psum += pp[(size_t)p * a.pstride];      // hidden > 2048 only
     }
     // EPI_RESID: the old residual values this thread will add into (one epilogue item per thread), fetched up front
     uint2 r_old = make_uint2(0, 0);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 *reinterpret_cast<uint2*>(rp) = make_uint2(pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3]));
                 float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
                 ss = xor32_sum(xor16_sum(ss));       // the 4 lanes (l & 15) + 16 * {0..3} hold the 16 columns of row m
-                if (l < 16) a.part_out[blockIdx.x * 64 + m] = ss;   // slabs [n group][64 rows]
+                if (l < 16) a.part_out[blockIdx.x * a.pstride + m] = ss;   // slabs [n group][pstride rows]
             } else if (EPI == OMNI_EPI_BF16) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + (a.oshuf ? frag_off(m, n, N) : (size_t)m * N + n)) =
                     make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
@@ -449,7 +450,7 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
 
 static int check_common(const GemmArgs& a) {
     OMNI_CHECK_ARG(a.W && a.out, "omni_gemm_bf16: null pointer");
-    OMNI_CHECK_ARG(a.M >= 1 && a.M <= 64, "omni_gemm_bf16: M=%d outside 1..64", a.M);
+    OMNI_CHECK_ARG(a.M >= 1 && a.M <= a.pstride, "omni_gemm_bf16: M=%d outside 1..%d", a.M, a.pstride);
     OMNI_CHECK_ARG(a.N > 0 && a.N % 16 == 0, "omni_gemm_bf16: N=%d not a multiple of 16", a.N);
     OMNI_CHECK_ARG(a.K > 0 && a.K % 32 == 0, "omni_gemm_bf16: K=%d not a multiple of 32", a.K);
     return OMNI_OK;
@@ -485,6 +486,7 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
 extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
                                  int K, int epilogue, const uint8_t* mask, int layout, void* stream) {
     GemmArgs a{};
+    a.pstride = 64;
     a.counted = g_gemm_counted;
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
@@ -510,9 +512,11 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
 // ---- the norm-free residual stream (fragment-major r + per-row sum-of-squares slabs) ---------------------------------
 // Producer: r = bf16(r + bf16(x . W^T + bias)) in place (accumulate) or r = bf16(x . W^T + bias), and
 // partials[n group][row] = that workgroup's share of sum(r^2); *nparts_out = N / 16.
-extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate,
-                               float* partials, int* nparts_out, int M, int N, int K, int layout, void* stream) {
+int k_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate, float* partials,
+                 int* nparts_out, int M, int N, int K, int layout, int pstride, void* stream) {
     GemmArgs a{};
+    OMNI_CHECK_ARG(pstride == 64 || pstride == 128, "omni_gemm_resid: slab stride %d", pstride);
+    a.pstride = pstride;
     a.counted = g_gemm_counted;
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
     a.xshuf = (layout & OMNI_LAYOUT_X_FRAG) != 0;
@@ -529,13 +533,19 @@ extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void
     if (nparts_out) *nparts_out = N / 16;
     return dispatch_epi<0>(a, OMNI_EPI_RESID, (hipStream_t)stream);
 }
+extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate,
+                               float* partials, int* nparts_out, int M, int N, int K, int layout, void* stream) {
+    return k_gemm_resid(x, ldx, w, bias, r_io, accumulate, partials, nparts_out, M, N, K, layout, 64, stream);
+}
 
 // Consumer: out = epilogue( (norm_w * bf16(r * rstd)) . W^T ), rstd = rsqrt(sum_p partials[p][row] / K + eps);
 // normed_out (row-major, optional) receives the normalised rows.  r and W fragment-major.
-extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps,
-                               void* normed_out, const void* w, void* out, int M, int N, int K, int epilogue,
-                               const uint8_t* mask, int out_frag, void* stream) {
+int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
+                 const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
+                 void* stream) {
     GemmArgs a{};
+    OMNI_CHECK_ARG(pstride == 64 || pstride == 128, "omni_gemm_xnorm: slab stride %d", pstride);
+    a.pstride = pstride;
     a.counted = g_gemm_counted;
     a.wshuf = 1; a.xshuf = 1; a.oshuf = out_frag != 0;
     a.x = (const uint16_t*)r; a.ldx = K; a.W = (const uint16_t*)w; a.out = out;
@@ -550,4 +560,9 @@ extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts,
     OMNI_CHECK_ARG(!a.oshuf || (epilogue != OMNI_EPI_F32_BF16RND && N % 32 == 0),
                    "omni_gemm_xnorm: fragment-major output needs a bf16 epilogue and N %% 32 == 0");
     return dispatch_epi<2>(a, epilogue, (hipStream_t)stream);
+}
+extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps,
+                               void* normed_out, const void* w, void* out, int M, int N, int K, int epilogue,
+                               const uint8_t* mask, int out_frag, void* stream) {
+    return k_gemm_xnorm(r, partials, nparts, norm_w, eps, normed_out, w, out, M, N, K, epilogue, mask, out_frag, 64, stream);
 }

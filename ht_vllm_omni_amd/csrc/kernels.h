@@ -7,9 +7,22 @@ int k_sample(const float* logits, int ld, int B, int V, int greedy, float temper
              int out_stride, void* stream);
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
             void* stream);
-// rows of `table` (ids == NULL: rows 0..T-1) -> fragment-major residual stream + slab 0 of the sum(r^2) partials
+// rows of `table` (ids == NULL: rows 0..T-1) -> fragment-major residual stream + slab 0 of the sum(r^2) partials;
+// zero_slabs > 1: slabs 1 .. zero_slabs - 1 of these rows are cleared (rows that join a stream with that many slabs);
+// pstride = rows per slab
 int k_gather_frag(const int32_t* ids, int ids_stride, const void* table, void* r_out, float* part_out, int T, int hidden,
-                  int vocab, void* stream);
+                  int vocab, void* stream, int zero_slabs = 1, int pstride = 64);
+// the residual-stream GEMMs with an explicit slab stride (64 | 128 rows per slab; M <= pstride)
+int k_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate, float* partials,
+                 int* nparts_out, int M, int N, int K, int layout, int pstride, void* stream);
+int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
+                 const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
+                 void* stream);
+// code predictor, positions 0 and 1 of every row in one launch (dense private cache: row b owns block b): qkv rows b
+// (position 0) and row1_off + b (position 1), fragment-major output rows likewise
+int k_attn_pair01(const void* qkv, int row1_off, const void* qnorm_w, const void* knorm_w, const void* cos_sin, float eps,
+                  void* k_cache, void* v_cache, void* out, int B, int q_heads, int kv_heads, int block_size, float sm_scale,
+                  void* stream);
 // sampler with optional fused gather: gather_out[b] = gather_table[picked id] (bf16 rows of gather_dim)
 int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,

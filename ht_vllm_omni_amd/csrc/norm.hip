@@ -122,7 +122,8 @@ __global__ void embed_kernel(const int32_t* __restrict__ ids, int ids_stride, co
 // rows -> fragment-major residual stream + slab 0 of the sum-of-squares partials (ids == NULL: row t of `table`)
 __global__ __launch_bounds__(128) void gather_frag_kernel(const int32_t* __restrict__ ids, int ids_stride,
                                                           const uint16_t* __restrict__ table, uint16_t* __restrict__ r_out,
-                                                          float* __restrict__ part_out, int hidden, int vocab) {
+                                                          float* __restrict__ part_out, int hidden, int vocab,
+                                                          int zero_slabs, int pstride) {
     const int t = blockIdx.x;
     const int id = ids ? ids[(size_t)t * ids_stride] : t;
     const bool ok = !ids || (id >= 0 && id < vocab);
@@ -139,15 +140,16 @@ __global__ __launch_bounds__(128) void gather_frag_kernel(const int32_t* __restr
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     if (threadIdx.x == 0) part_out[t] = red[0] + red[1];
+    for (int p = 1 + threadIdx.x; p < zero_slabs; p += 128) part_out[(size_t)p * pstride + t] = 0.f;
 }
 
 int k_gather_frag(const int32_t* ids, int ids_stride, const void* table, void* r_out, float* part_out, int T, int hidden,
-                  int vocab, void* stream) {
+                  int vocab, void* stream, int zero_slabs, int pstride) {
     OMNI_CHECK_ARG(table && r_out && part_out, "gather_frag: null pointer");
     OMNI_CHECK_ARG(hidden % 32 == 0, "gather_frag: hidden=%d not a multiple of 32", hidden);
     if (T <= 0) return OMNI_OK;
     hipLaunchKernelGGL(gather_frag_kernel, dim3(T), dim3(128), 0, (hipStream_t)stream, ids, ids_stride, (const uint16_t*)table,
-                       (uint16_t*)r_out, part_out, hidden, vocab);
+                       (uint16_t*)r_out, part_out, hidden, vocab, zero_slabs, pstride);
     OMNI_CHECK_LAUNCH("gather_frag");
     return OMNI_OK;
 }

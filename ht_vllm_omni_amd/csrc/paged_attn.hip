@@ -553,6 +553,65 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
 }
 
+// ---- code predictor, positions 0 and 1 of every row in ONE launch (both inputs are known when the pass starts: the
+// talker's last hidden state and the layer-0 code embedding).  One wave per (row, q head): position 0 attends to itself
+// only (output = its V row, exactly), position 1 to both; the position-0 K is rebuilt from the qkv rows by every wave
+// that needs it instead of being read back from the cache.  Dense private cache: row b owns block b.
+__global__ __launch_bounds__(256) void attn_pair01_kernel(const uint16_t* __restrict__ qkv, int row1_off,
+                                                          const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
+                                                          const uint16_t* __restrict__ cos_sin, float eps,
+                                                          uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                          uint16_t* __restrict__ out, int npairs, int q_heads, int kv_heads, int bs,
+                                                          float sm_scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= npairs) return;                       // whole waves leave: the reductions below see full waves
+    const int row = pair / q_heads, h = pair - row * q_heads;
+    const int ratio = q_heads / kv_heads, kvh = h / ratio;
+    const int nslots = q_heads + 2 * kv_heads;
+    const uint16_t* r0 = qkv + (size_t)row * nslots * 128;
+    const uint16_t* r1 = qkv + (size_t)(row1_off + row) * nslots * 128;
+    const uint16_t* v0p = r0 + (size_t)(q_heads + kv_heads + kvh) * 128;
+    const uint16_t* v1p = r1 + (size_t)(q_heads + kv_heads + kvh) * 128;
+    const uint16_t v0a = v0p[lane], v0b = v0p[lane + 64], v1a = v1p[lane], v1b = v1p[lane + 64];
+    float k00, k01, k10, k11, q0, q1;
+    head_norm_rope(r0 + (size_t)(q_heads + kvh) * 128, knorm_w, cos_sin, eps, lane, k00, k01);
+    head_norm_rope(r1 + (size_t)(q_heads + kvh) * 128, knorm_w, cos_sin + 128, eps, lane, k10, k11);
+    head_norm_rope(r1 + (size_t)h * 128, qnorm_w, cos_sin + 128, eps, lane, q0, q1);
+    if (h % ratio == 0) {                             // one writer per kv head
+        const size_t c0 = ((size_t)row * bs * kv_heads + kvh) * 128, c1 = (((size_t)row * bs + 1) * kv_heads + kvh) * 128;
+        k_cache[c0 + lane] = f2bf(k00); k_cache[c0 + 64 + lane] = f2bf(k01);
+        v_cache[c0 + lane] = v0a;       v_cache[c0 + 64 + lane] = v0b;
+        k_cache[c1 + lane] = f2bf(k10); k_cache[c1 + 64 + lane] = f2bf(k11);
+        v_cache[c1 + lane] = v1a;       v_cache[c1 + 64 + lane] = v1b;
+    }
+    const float qs = sm_scale * LOG2E;
+    const float s0 = wave_sum(fmaf(q0 * qs, k00, (q1 * qs) * k01));
+    const float s1 = wave_sum(fmaf(q0 * qs, k10, (q1 * qs) * k11));
+    const float m = fmaxf(s0, s1);
+    const float p0 = exp2f(s0 - m), p1 = exp2f(s1 - m);
+    const float inv = 1.0f / (p0 + p1);
+    const int width = q_heads * 128, col = h * 128 + lane;
+    out[frag_off(row, col, width)] = v0a;
+    out[frag_off(row, col + 64, width)] = v0b;
+    out[frag_off(row1_off + row, col, width)] = f2bf(fmaf(p1, bf2f(v1a), p0 * bf2f(v0a)) * inv);
+    out[frag_off(row1_off + row, col + 64, width)] = f2bf(fmaf(p1, bf2f(v1b), p0 * bf2f(v0b)) * inv);
+}
+
+int k_attn_pair01(const void* qkv, int row1_off, const void* qnorm_w, const void* knorm_w, const void* cos_sin, float eps,
+                  void* k_cache, void* v_cache, void* out, int B, int q_heads, int kv_heads, int block_size, float sm_scale,
+                  void* stream) {
+    OMNI_CHECK_ARG(qkv && qnorm_w && knorm_w && cos_sin && k_cache && v_cache && out, "attn_pair01: null pointer");
+    OMNI_CHECK_ARG(B >= 1 && kv_heads >= 1 && q_heads % kv_heads == 0 && block_size >= 2 && row1_off % 16 == 0 && row1_off >= B,
+                   "attn_pair01: B=%d heads %d/%d block %d row1_off %d", B, q_heads, kv_heads, block_size, row1_off);
+    const int npairs = B * q_heads;
+    hipLaunchKernelGGL(attn_pair01_kernel, dim3((npairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, row1_off,
+                       (const uint16_t*)qnorm_w, (const uint16_t*)knorm_w, (const uint16_t*)cos_sin, eps, (uint16_t*)k_cache,
+                       (uint16_t*)v_cache, (uint16_t*)out, npairs, q_heads, kv_heads, block_size, sm_scale);
+    OMNI_CHECK_LAUNCH("attn_pair01");
+    return OMNI_OK;
+}
+
 // merge KV splits: one 128-thread block per (row, q-head)
 __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ partial,
                                                                uint16_t* __restrict__ out, int nsplit, float v_mul,

@@ -10,6 +10,7 @@ void omni_debug_set(int nt, int generic_schedule, int wgs); /* nt & 1: non-tempo
                                                                schedule; target workgroups per GEMM launch (256) */
 void omni_debug_tile(int nt, int mt);                       /* force the GEMM tile (0 = policy)                       */
 void omni_debug_int8_max_g(int g);                         /* int8-KV decode attention: q heads per workgroup (2 | 4) */
+void omni_debug_cp_pair01(int on);                         /* code predictor: positions 0 and 1 as one two-block pass */
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
 void omni_debug_prefill_mfma(int on);                       /* prefill attention on MFMA (off: per-token VALU path)   */
 void omni_debug_extra_trivial(int n);                       /* append n no-op launches per layer phase                */
