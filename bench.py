@@ -176,6 +176,8 @@ def main():
                          "dp = independent replicas, 64 requests per GPU, no data-path collective (weak scaling)")
     ap.add_argument("--tp-force", action="store_true", help="diagnostics: run the tensor-parallel code path (process group, "
                     "separate norms, all-reduces inside the graph) on a 1-rank group")
+    ap.add_argument("--no-replica-leg", action="store_true", help="N > 1 with --parallel tp: skip the second, untimed-for-`value` "
+                    "leg that runs the same step as independent replicas (reported under \"replicas\")")
     ap.add_argument("--ctx-extra", type=int, default=0, help="long-context points: start decoding this many positions later")
     args = ap.parse_args()
 
@@ -315,6 +317,48 @@ def main():
                     "at the final context; code predictor + input assembly = step - backbone",
             "backbone_ms": bb_ms, "code_predictor_ms": ev_ms - bb_ms, "backbone_ctx": float(np.mean(end_ctx)),
             "backbone_gbs": bb_bytes / (bb_ms * 1e-3) / 1e9, "backbone_frac": bb_bytes / (bb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # ---- second leg (N > 1, tensor-parallel runs only; never part of `value`): the same step as independent replicas --
+    # one full engine per GPU, 64 requests each, no data-path collective -- so the line carries both axes of SURVEY 8e.
+    # Every rank makes the same collective calls whether or not its local part succeeded.
+    if dist is not None and args.parallel == "tp" and not args.no_replica_leg:
+        ok, dt_r, run2 = 1, 0.0, None
+        try:
+            graph = None
+            del eng
+            torch.cuda.empty_cache()
+            from ht_vllm_omni_amd.engine import TalkerEngine
+            eng2 = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
+                                device=f"cuda:{torch.cuda.current_device()}", tp_rank=0, tp_size=1, allow_eos=False)
+            eng2.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+            setup_requests(d, eng2, args)
+            eng2.decode_step(B)
+            torch.cuda.synchronize()
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3):
+                eng2.decode_step(B)
+            for _ in range(args.warmup + args.ttfa_steps):      # same context as the tensor-parallel leg's timed region
+                g3.replay()
+            torch.cuda.synchronize()
+            run2 = g3.replay
+        except Exception as e:   # noqa: BLE001
+            log(f"[rank {rank}] replica leg set-up failed: {e!r}")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run2()
+            sync()
+            tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            dt_r = float(tr.item())
+            out["replicas"] = {"value": world * B * args.steps / dt_r, "unit": "speech-tokens/s", "ms_per_step": dt_r / args.steps * 1e3,
+                               "scaling": "weak", "parallelism": f"dp{world}",
+                               "note": "same step, one full engine and 64 requests per GPU, no data-path collective; "
+                                       "second leg of this run, not part of `value`"}
+        eng = None
     if rank == 0:
         # HBM bytes per step from the PMC passes (rocprofv3 cannot ride along with a timed run: separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary committed under profiles/)
@@ -332,7 +376,7 @@ def main():
             log(f"copy probe failed: {e!r}")
         if world == 1 and not args.no_cpu_baseline:
             try:
-                del eng
+                eng = None
                 torch.cuda.empty_cache()
                 out["cpu_baseline"] = cpu_baseline(d, w, args, lens)
             except Exception as e:   # noqa: BLE001
