@@ -96,6 +96,37 @@ __device__ __forceinline__ float xchg32(float v, bool upper) {        // value o
     return __uint_as_float(upper ? r[0] : r[1]);
 }
 
+// ---- wave-wide argmax of (value, index) pairs, larger value first, smaller index on ties; every lane gets the winner
+__device__ __forceinline__ void argmax_merge(float& v, int& idx, float ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(float& v, int& idx) {
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xF, 0xF, true);
+    argmax_merge(v, idx, ov, oi);
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+    argmax_dpp<OMNI_DPP_XOR1>(v, idx);
+    argmax_dpp<OMNI_DPP_XOR2>(v, idx);
+    argmax_dpp<OMNI_DPP_HALF_MIRROR>(v, idx);
+    argmax_dpp<OMNI_DPP_MIRROR>(v, idx);
+    {
+        const auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
+        float a = __uint_as_float(rv[0]); int ai = (int)ri[0];
+        argmax_merge(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
+        v = a; idx = ai;
+    }
+    {
+        const auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
+        float a = __uint_as_float(rv[0]); int ai = (int)ri[0];
+        argmax_merge(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
+        v = a; idx = ai;
+    }
+}
+
 // ---- wave64 reductions (all 64 lanes hold the result): 4 DPP steps inside the rows + 2 permlane swaps, no LDS traffic
 __device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }

@@ -64,12 +64,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
                 const int e = lane + 64 * j;
                 if (p[j] > bv || (p[j] == bv && e < bi)) { bv = p[j]; bi = e; }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            wave_argmax(bv, bi);      // DPP / permlane exchanges: 8 rounds of ds_bpermute butterflies were most of this kernel
 #pragma unroll
             for (int j = 0; j < PER; ++j)
                 if (lane + 64 * j == bi) p[j] = -1.f;

@@ -19,34 +19,8 @@ __device__ __forceinline__ float key_val(uint32_t k) {   // inverse of ord_key
 // block-wide argmax with smallest-index tie-break; result broadcast to all threads.  (value, index) pairs merge through
 // DPP row steps and permlane swaps (any pairing that merges disjoint lane groups: the merge is associative and
 // commutative), not ds_bpermute
-__device__ __forceinline__ void argmax_merge(float& v, int& idx, float ov, int oi) {
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-}
-template <int CTRL>
-__device__ __forceinline__ void argmax_dpp(float& v, int& idx) {
-    const float ov = dpp_f<CTRL>(v);
-    const int oi = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xF, 0xF, true);
-    argmax_merge(v, idx, ov, oi);
-}
 __device__ __forceinline__ int block_argmax(float v, int idx, float* sval, int* sidx) {
-    argmax_dpp<OMNI_DPP_XOR1>(v, idx);
-    argmax_dpp<OMNI_DPP_XOR2>(v, idx);
-    argmax_dpp<OMNI_DPP_HALF_MIRROR>(v, idx);
-    argmax_dpp<OMNI_DPP_MIRROR>(v, idx);
-    {
-        const auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
-        float a = __uint_as_float(rv[0]); int ai = (int)ri[0];
-        argmax_merge(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
-        v = a; idx = ai;
-    }
-    {
-        const auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
-        float a = __uint_as_float(rv[0]); int ai = (int)ri[0];
-        argmax_merge(a, ai, __uint_as_float(rv[1]), (int)ri[1]);
-        v = a; idx = ai;
-    }
+    wave_argmax(v, idx);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sval[wave] = v; sidx[wave] = idx; }
     __syncthreads();
