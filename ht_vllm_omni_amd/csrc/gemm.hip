@@ -273,11 +273,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         }
     }
 
-    // the normalised rows themselves (h[t+1] of the final norm) leave row-major through one workgroup column: a second
-    // pass over this workgroup's (L2-hot) fragments, kept out of the main loop so that its waits stay counted
-    if (PRO == 2 && blockIdx.x == 0 && a.normed_out != nullptr) {
-        for (int t = 0; t < ntw; ++t) {
-            const int ks = wave + t * GEMM_WAVES;
+    // the normalised rows themselves (h[t+1] of the final norm) leave row-major, spread over the n groups: workgroup column x
+    // re-reads the (L2-hot) fragments of k-steps x, x + gridDim.x, ... of its rows -- a second pass kept out of the main loop so
+    // that its waits stay counted, and short (one k-step per wave at most) so that no workgroup column carries a tail
+    if (PRO == 2 && a.normed_out != nullptr) {
+        for (int ks = blockIdx.x + wave * gridDim.x; ks < nsteps; ks += GEMM_WAVES * gridDim.x) {
             const u32x4 nw = ld16(a.norm_w + ks * 32 + 8 * q);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
