@@ -175,6 +175,12 @@ class TalkerEngine:
                     # fragment-major copy for the native decode GEMMs (per expert for MoE; dense gate_up interleaved by 8)
                     t_ = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
                 setattr(self._layers[i], n, t_.data_ptr())
+            if d.moe_experts > 0:
+                # the batched hipBLASLt prefill wants [E, K, N] operands stored that way: torch.bmm on the transposed VIEW of
+                # [E, N, K] faults on this ROCm build at the talker's shapes (scripts/diag_bmm.py); they replace the row-major
+                # expert copies, which nothing else reads
+                for n in ("moe_gate_up", "moe_down"):
+                    lw[n + "_t"] = lw.pop(n).transpose(1, 2).contiguous()
         self._cp_layers = (L.LayerWeights * d.cp_layers)()
         self.cp_layer_w: list[dict] = []
         for i in range(d.cp_layers):
@@ -373,8 +379,6 @@ class TalkerEngine:
         instead of max_batch-row chunks that each re-stream the weights."""
         import torch.nn.functional as F
         d = self.d
-        if d.moe_experts > 0:
-            raise L.OmniError("prefill_blas: dense MLP only (the sparse-MoE backbone prefills through the native chunk path)")
         bt = self.block_table if block_table is None else block_table
         D, hq, hkv = d.head_dim, self.hq_l, self.hkv_l
         resid = x.clone()
@@ -397,12 +401,52 @@ class TalkerEngine:
             if self.tp_path:
                 torch.distributed.all_reduce(o, group=self.tp_group)
             a = ops.rmsnorm(None, w["ln2"], d.eps, delta=o, residual=resid)
-            gu = F.linear(a, w["wgu"])
-            act = ops.silu_mul(gu)
-            delta = F.linear(act, w["wdown"])
+            if d.moe_experts > 0:
+                delta = self._moe_mlp_blas(a, w)
+            else:
+                gu = F.linear(a, w["wgu"])
+                act = ops.silu_mul(gu)
+                delta = F.linear(act, w["wdown"])
             if self.tp_path:
                 torch.distributed.all_reduce(delta, group=self.tp_group)
         return ops.rmsnorm(None, self.final_norm, d.eps, delta=delta, residual=resid)
+
+    def _moe_mlp_blas(self, a: torch.Tensor, w: dict) -> torch.Tensor:
+        """Sparse-MoE MLP over T prompt rows (a = normalised rows, bf16 [T, H]) with the expert GEMMs as TWO batched hipBLASLt
+        calls: the (token, expert) slots are grouped by expert into a padded [E, cap, H] batch (cap = the busiest expert's
+        token count, one host read per layer), gate_up -> SiLU*up (omni_silu_mul) -> down run for all experts at once, and
+        the weighted results are added back per token in ascending expert order in bf16 -- the accumulation order and the
+        rounding points of HF's expert loop (oracle.moe_block); routing on the HIP kernel.  The native per-expert kernels
+        stay the decode path (<= 64 rows); re-running them per 64-row prompt chunk streamed every hit expert 100 times."""
+        import torch.nn.functional as F
+        d = self.d
+        T, H = a.shape
+        E, k, I = d.moe_experts, d.moe_top_k, d.moe_inter
+        idx, wts = ops.moe_route(F.linear(a, w["moe_router"]), k, d.moe_norm_topk)       # int32 [T, k], bf16 [T, k]
+        idx_s, perm = torch.sort(idx.long(), dim=1)                     # per token: its experts in ascending order
+        wts_s = torch.gather(wts, 1, perm)
+        flat_e = idx_s.reshape(-1)                                      # expert of slot (t, j), slot = t * k + j
+        order = torch.argsort(flat_e, stable=True)                      # slots grouped by expert
+        counts = torch.bincount(flat_e, minlength=E)
+        cap = (max(int(counts.max().item()), 1) + 63) // 64 * 64        # padded rows are zero; whole 64-row tiles per expert
+        e_sorted = flat_e[order]
+        rank = torch.arange(T * k, device=a.device) - (torch.cumsum(counts, 0) - counts)[e_sorted]
+        dst = e_sorted * cap + rank                                     # row of the slot in the padded batch
+        xb = torch.zeros(E * cap, H, dtype=BF16, device=a.device)
+        xb[dst] = a[order // k]
+        gu = torch.bmm(xb.view(E, cap, H), w["moe_gate_up_t"])                            # [E, cap, 2I]
+        act = ops.silu_mul(gu.view(E * cap, 2 * I))
+        y = torch.bmm(act.view(E, cap, I), w["moe_down_t"]).view(E * cap, H)
+        ys = torch.empty(T * k, H, dtype=BF16, device=a.device)
+        ys[order] = y[dst]
+        ys = ys.view(T, k, H) * wts_s[:, :, None]
+        out = torch.zeros(T, H, dtype=BF16, device=a.device)
+        for j in range(k):
+            out += ys[:, j]
+        if d.moe_shared_inter > 0:
+            sh = F.linear(ops.silu_mul(F.linear(a, w["moe_shared_gate_up"])), w["moe_shared_down"])
+            out = out + torch.sigmoid(F.linear(a, w["moe_shared_gate"])) * sh
+        return out
 
     def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
                 block_table: torch.Tensor | None = None, use_blas: bool | None = None) -> torch.Tensor:
@@ -410,7 +454,7 @@ class TalkerEngine:
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
         if use_blas is None:
-            use_blas = T > self.max_batch and self.d.moe_experts == 0     # MoE layers: native chunks of <= max_batch rows
+            use_blas = T > self.max_batch
         if use_blas:
             return self.prefill_blas(x, positions, req_of_tok, slot_mapping, bt)
         out = torch.empty_like(x)
