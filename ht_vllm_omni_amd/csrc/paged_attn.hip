@@ -173,58 +173,9 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
     }
 
-#define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
-    {                                                                                                \
-        float s_[PA_U][G], mx_[G];                                                                   \
-        bool ok_[PA_U];                                                                              \
-        _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
-            ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
-            float kf_[16];                                                                           \
-            to_f32<KV>(KR[u], kf_);                                                                  \
-            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
-                float d_ = 0.f;                                                                      \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
-                d_ = group8_sum(d_);       /* 3 DPP steps over the token's 8 lanes */                 \
-                if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
-                d_ = ok_[u] ? d_ : -INFINITY;                                                        \
-                s_[u][g] = d_;                                                                       \
-                mx_[g] = fmaxf(mx_[g], d_);                                                          \
-            }                                                                                        \
-        }                                                                                            \
-        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                              \
-            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx_[g]);                 \
-            m[g] = mx_[g];                                                                           \
-            l[g] *= corr_;                                                                           \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
-        }                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
-            float vf_[16];                                                                           \
-            to_f32<KV>(VR[u], vf_);                                                                  \
-            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
-                float p_ = ok_[u] ? exp2f(s_[u][g] - m[g]) : 0.f;                                    \
-                l[g] += p_;                                                                          \
-                if (KV == OMNI_KV_INT8) p_ *= VS[u];                                                 \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p_, vf_[e], acc[g][e]); \
-            }                                                                                        \
-        }                                                                                            \
-    }
-
-    // ---- main loop, loads one batch ahead
-    constexpr int STRIDE = PA_WAVES * 8 * PA_U;
-    for (int t0 = t_begin + wave * 8; t0 < t_end;) {
-        if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
-        PA_COMPUTE(k0, v0, ks0, vs0, t0)
-        t0 += STRIDE;
-        if (t0 >= t_end) break;
-        if (t0 + STRIDE < t_end) { PA_LOAD(k0, v0, ks0, vs0, t0 + STRIDE) }
-        PA_COMPUTE(k1, v1, ks1, vs1, t0)
-        t0 += STRIDE;
-    }
-#undef PA_LOAD
-#undef PA_COMPUTE
-
-    // ---- fused: the new token's K/V (wave 0 of the split that owns position `cur`)
+    // ---- fused: the new token's K/V (wave 0 of the split that owns position `cur`) -- BEFORE the history loop: its loads,
+    // norm, quantisation and stores overlap the K/V batches already in flight instead of forming a tail after the loop; the
+    // running softmax state of token-group 0 simply starts from this token
     if (FUSED) {
         const int sp_cur = cur / per;
         if (wave == 0 && sp == sp_cur) {
@@ -303,6 +254,57 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             }
         }
     }
+
+#define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
+    {                                                                                                \
+        float s_[PA_U][G], mx_[G];                                                                   \
+        bool ok_[PA_U];                                                                              \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
+            float kf_[16];                                                                           \
+            to_f32<KV>(KR[u], kf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float d_ = 0.f;                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
+                d_ = group8_sum(d_);       /* 3 DPP steps over the token's 8 lanes */                 \
+                if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
+                d_ = ok_[u] ? d_ : -INFINITY;                                                        \
+                s_[u][g] = d_;                                                                       \
+                mx_[g] = fmaxf(mx_[g], d_);                                                          \
+            }                                                                                        \
+        }                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                              \
+            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx_[g]);                 \
+            m[g] = mx_[g];                                                                           \
+            l[g] *= corr_;                                                                           \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            float vf_[16];                                                                           \
+            to_f32<KV>(VR[u], vf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float p_ = ok_[u] ? exp2f(s_[u][g] - m[g]) : 0.f;                                    \
+                l[g] += p_;                                                                          \
+                if (KV == OMNI_KV_INT8) p_ *= VS[u];                                                 \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p_, vf_[e], acc[g][e]); \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    // ---- main loop, loads one batch ahead
+    constexpr int STRIDE = PA_WAVES * 8 * PA_U;
+    for (int t0 = t_begin + wave * 8; t0 < t_end;) {
+        if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
+        PA_COMPUTE(k0, v0, ks0, vs0, t0)
+        t0 += STRIDE;
+        if (t0 >= t_end) break;
+        if (t0 + STRIDE < t_end) { PA_LOAD(k0, v0, ks0, vs0, t0 + STRIDE) }
+        PA_COMPUTE(k1, v1, ks1, vs1, t0)
+        t0 += STRIDE;
+    }
+#undef PA_LOAD
+#undef PA_COMPUTE
 
     // ---- combine: the 8 token-groups of a wave merge in registers (xor-shuffles over lane bits 3..5),
     // then the 4 wave partials go through LDS
