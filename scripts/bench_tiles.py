@@ -85,6 +85,11 @@ def sweep_resid(name, N, K, M=64):
     print(f"{name:14s} N={N:5d} K={K:5d} {wbytes/1e6:5.1f}MB | " + " ".join(out), flush=True)
 
 if __name__ == "__main__":
+    if os.environ.get("BT_ONLY") == "xnorm":
+        sweep("cp qkv", 4096, 1024, L.EPI_BF16, modes=("xnorm",)); sweep("bb qkv", 4096, 2048, L.EPI_BF16, modes=("xnorm",))
+        sweep("cp head", 2048, 1024, L.EPI_F32_BF16RND, modes=("xnorm",)); sweep("lm_head", 3072, 2048, L.EPI_F32_BF16RND, modes=("xnorm",))
+        sweep("cp gate_up gu8", 3072, 1024, L.EPI_SILU_MUL_GU8, modes=("xnorm",)); sweep("bb gate_up gu8", 6144, 2048, L.EPI_SILU_MUL_GU8, modes=("xnorm",))
+        sys.exit(0)
     if os.environ.get("BT_ONLY") == "resid":
         sweep_resid("cp o", 1024, 2048); sweep_resid("cp down", 1024, 3072)
         sweep_resid("bb o", 2048, 2048); sweep_resid("bb down", 2048, 6144)
