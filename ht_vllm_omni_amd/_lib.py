@@ -42,7 +42,7 @@ class TalkerDesc(C.Structure):
         ("moe_experts", i32), ("moe_top_k", i32), ("moe_inter", i32), ("moe_shared_inter", i32), ("moe_norm_topk", i32),
         ("fused_norm", i32), ("cp_fused_norm", i32),
         ("max_batch", i32), ("block_size", i32), ("kv_dtype", i32), ("max_model_len", i32), ("bt_stride", i32),
-        ("k_scale", f32), ("v_scale", f32),
+        ("k_scale", f32), ("v_scale", f32), ("masked_logit", f32),
         ("embed", vp), ("layer", C.POINTER(LayerWeights)), ("final_norm", vp), ("lm_head", vp), ("allowed_mask", vp),
         ("cos_sin", vp), ("cp_proj_w", vp), ("cp_proj_b", vp), ("cp_layer", C.POINTER(LayerWeights)), ("cp_norm", vp),
         ("cp_lm_head", vp), ("cp_embed", vp), ("cp_cos_sin", vp), ("cp_proj_table", vp), ("cp_e0_table", vp),

@@ -307,6 +307,9 @@ static int check_io(const omni_talker* t, const omni_step_io* io) {
     return OMNI_OK;
 }
 
+// value written for masked-out logits (desc.masked_logit: 0 = -inf, the Omni talker's -1e9)
+static inline float mask_fill(const omni_talker* t) { return t->d.masked_logit != 0.0f ? t->d.masked_logit : -INFINITY; }
+
 // dense gate_up weights (layer.wgu): fragment-major engines hold them gate / up interleaved by 8 rows (OMNI_EPI_SILU_MUL_GU8)
 static inline int silu_epi(const omni_talker* t) { return t->d.frag_layout ? OMNI_EPI_SILU_MUL_GU8 : OMNI_EPI_SILU_MUL; }
 
@@ -322,12 +325,12 @@ static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* d
     if (F) {
         // normalised rows go out fragment-major for the GEMM (and row-major too when the caller wants them)
         TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, normed_out, normed_scratch, rows, K, eps, st));
-        return omni_gemm_bf16_ex(normed_scratch, K, w, nullptr, out, rows, N, K, epi, mask,
-                                 OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | (out_frag ? OMNI_LAYOUT_OUT_FRAG : 0), st);
+        return k_gemm_bf16_ex(normed_scratch, K, w, nullptr, out, rows, N, K, epi, mask,
+                              OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | (out_frag ? OMNI_LAYOUT_OUT_FRAG : 0), st, mask_fill(t));
     }
     uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
     TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, nx, nullptr, rows, K, eps, st));
-    return omni_gemm_bf16(nx, K, w, nullptr, out, rows, N, K, epi, mask, st);
+    return k_gemm_bf16_ex(nx, K, w, nullptr, out, rows, N, K, epi, mask, 0, st, mask_fill(t));
 }
 
 // plain GEMM on an activation buffer produced by one of our kernels (fragment-major when the engine runs that layout)
@@ -341,7 +344,7 @@ static int act_gemm(omni_talker* t, const void* x, const void* w, const void* bi
 // into the GEMM that consumes it (omni_gemm_xnorm) and every residual add into the GEMM that produces it (omni_gemm_resid)
 static int xnorm_gemm(omni_talker* t, const uint16_t* r, const float* part, int np, const void* norm_w, void* normed_out,
                       const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask, int out_frag, void* st) {
-    return omni_gemm_xnorm(r, part, np, norm_w, t->d.eps, normed_out, w, out, rows, N, K, epi, mask, out_frag, st);
+    return k_gemm_xnorm(r, part, np, norm_w, t->d.eps, normed_out, w, out, rows, N, K, epi, mask, out_frag, 64, st, mask_fill(t));
 }
 static int resid_gemm(const void* x_frag, const void* w, uint16_t* r, float* part, int rows, int N, int K, void* st) {
     return omni_gemm_resid(x_frag, K, w, nullptr, r, 1, part, nullptr, rows, N, K, OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG, st);
@@ -693,10 +696,10 @@ extern "C" int omni_talker_logits(omni_talker* t, const void* hidden, float* log
     const omni_talker_desc& d = t->d;
     for (int r0 = 0; r0 < R; r0 += 64) {
         const int m = R - r0 < 64 ? R - r0 : 64;
-        TRY(omni_gemm_bf16_ex(reinterpret_cast<const uint16_t*>(hidden) + (size_t)r0 * d.hidden, d.hidden, d.lm_head, nullptr,
-                              logits + (size_t)r0 * d.vocab, m, d.vocab, d.hidden,
-                              round_bf16 ? OMNI_EPI_F32_BF16RND : OMNI_EPI_F32, d.allowed_mask,
-                              d.frag_layout ? OMNI_LAYOUT_W_FRAG : 0, stream));
+        TRY(k_gemm_bf16_ex(reinterpret_cast<const uint16_t*>(hidden) + (size_t)r0 * d.hidden, d.hidden, d.lm_head, nullptr,
+                           logits + (size_t)r0 * d.vocab, m, d.vocab, d.hidden,
+                           round_bf16 ? OMNI_EPI_F32_BF16RND : OMNI_EPI_F32, d.allowed_mask,
+                           d.frag_layout ? OMNI_LAYOUT_W_FRAG : 0, stream, mask_fill(t)));
     }
     return OMNI_OK;
 }

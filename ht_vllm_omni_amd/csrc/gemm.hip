@@ -48,6 +48,7 @@ struct GemmArgs {
     // PRO_XNORM / EPI_RESID: per-row sum-of-squares slabs [np][64 rows] fp32 (deterministic: one slab per producer workgroup)
     const float* part_in; int np_in; float* part_out;
     int pstride;               // rows per slab (64; 128 for the code predictor's two-position pass)
+    float mask_fill;           // logit written where mask[n] == 0 (-inf; the Omni talker writes -1e9)
     int counted;               // use the counted (unpredicated, 2-deep) schedule when K % 512 == 0
 };
 
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float y = (EPI == OMNI_EPI_F32_BF16RND) ? bfround(v[g]) : v[g];
-                    if (a.mask && !a.mask[n + g]) y = -INFINITY;
+                    if (a.mask && !a.mask[n + g]) y = a.mask_fill;
                     po[g] = y;
                 }
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * N + n) = o;
@@ -483,9 +484,10 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
     return OMNI_EINVAL;
 }
 
-extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
-                                 int K, int epilogue, const uint8_t* mask, int layout, void* stream) {
+int k_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
+                   const uint8_t* mask, int layout, void* stream, float mask_fill) {
     GemmArgs a{};
+    a.mask_fill = mask_fill;
     a.pstride = 64;
     a.counted = g_gemm_counted;
     a.wshuf = (layout & OMNI_LAYOUT_W_FRAG) != 0;
@@ -504,6 +506,11 @@ extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const vo
     return dispatch_epi<0>(a, epilogue, (hipStream_t)stream);
 }
 
+extern "C" int omni_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
+                                 int K, int epilogue, const uint8_t* mask, int layout, void* stream) {
+    return k_gemm_bf16_ex(x, ldx, w, bias, out, M, N, K, epilogue, mask, layout, stream, -INFINITY);
+}
+
 extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N,
                               int K, int epilogue, const uint8_t* mask, void* stream) {
     return omni_gemm_bf16_ex(x, ldx, w, bias, out, M, N, K, epilogue, mask, 0, stream);
@@ -515,6 +522,7 @@ extern "C" int omni_gemm_bf16(const void* x, int ldx, const void* w, const void*
 int k_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* r_io, int accumulate, float* partials,
                  int* nparts_out, int M, int N, int K, int layout, int pstride, void* stream) {
     GemmArgs a{};
+    a.mask_fill = -INFINITY;
     OMNI_CHECK_ARG(pstride == 64 || pstride == 128, "omni_gemm_resid: slab stride %d", pstride);
     a.pstride = pstride;
     a.counted = g_gemm_counted;
@@ -542,8 +550,9 @@ extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void
 // normed_out (row-major, optional) receives the normalised rows.  r and W fragment-major.
 int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
                  const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
-                 void* stream) {
+                 void* stream, float mask_fill) {
     GemmArgs a{};
+    a.mask_fill = mask_fill;
     OMNI_CHECK_ARG(pstride == 64 || pstride == 128, "omni_gemm_xnorm: slab stride %d", pstride);
     a.pstride = pstride;
     a.counted = g_gemm_counted;

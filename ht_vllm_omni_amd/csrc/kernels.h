@@ -17,7 +17,10 @@ int k_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* 
                  int* nparts_out, int M, int N, int K, int layout, int pstride, void* stream);
 int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
                  const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
-                 void* stream);
+                 void* stream, float mask_fill = -__builtin_inff());
+// omni_gemm_bf16_ex with the value written for masked-out logits
+int k_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
+                   const uint8_t* mask, int layout, void* stream, float mask_fill);
 // code predictor, positions 0 and 1 of every row in one launch (dense private cache: row b owns block b): qkv rows b
 // (position 0) and row1_off + b (position 1), fragment-major output rows likewise
 int k_attn_pair01(const void* qkv, int row1_off, const void* qnorm_w, const void* knorm_w, const void* cos_sin, float eps,

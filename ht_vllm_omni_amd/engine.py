@@ -101,7 +101,7 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
 class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
-                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
+                 k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, masked_logit: float = 0.0, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
                  fused_norm: bool | None = None):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
@@ -228,6 +228,7 @@ class TalkerEngine:
         desc.max_batch, desc.block_size, desc.kv_dtype = (min(max_batch, 64) if int(n_sub) > 1 else max_batch), block_size, self.kv_code
         desc.max_model_len, desc.bt_stride = d.max_model_len, self.bt_stride
         desc.k_scale, desc.v_scale = k_scale, v_scale
+        desc.masked_logit = float(masked_logit)      # 0: -inf (TTS); -1e9: the Omni talker's finite suppression value
         desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
         desc.layer = C.cast(self._layers, C.POINTER(L.LayerWeights))
         desc.lm_head = (self._lm_head_f if self.frag_layout else self.lm_head).data_ptr()

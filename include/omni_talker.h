@@ -242,6 +242,8 @@ typedef struct omni_talker_desc {
     /* runtime */
     int max_batch, block_size, kv_dtype, max_model_len, bt_stride;
     float k_scale, v_scale;
+    float masked_logit;  /* value written for logits the mask removes: 0 = -inf (Qwen3-TTS compute_logits, qwen3_tts_talker.py:424-443);
+                            the Qwen3-Omni talker writes -1e9 (qwen3_omni.py:1143-1149) -- same picks, finite logits */
     /* weights (device) */
     const void* embed;                 /* bf16 [vocab, H]                    */
     const omni_layer_weights* layer;   /* HOST array [layers]                */

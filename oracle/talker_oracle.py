@@ -325,8 +325,10 @@ class OracleState:
 
 class TalkerOracle:
     def __init__(self, dims, weights: dict, kv_dtype: str = "bf16", num_blocks: int = 64,
-                 block_size: int = 16, k_scale: float = 1.0, v_scale: float = 1.0):
+                 block_size: int = 16, k_scale: float = 1.0, v_scale: float = 1.0, masked_logit: float = float("-inf")):
         self.d, self.w = dims, weights
+        # TTS: -inf (qwen3_tts_talker.py:424-443); the Omni talker suppresses with -1e9 (qwen3_omni.py:1143-1149)
+        self.masked_logit = masked_logit
         self.block_size = block_size
         self.kv = [PagedKV(num_blocks, block_size, dims.kv_heads, dims.head_dim, kv_dtype, k_scale, v_scale)
                    for _ in range(dims.layers)]
@@ -393,7 +395,7 @@ class TalkerOracle:
         y = hidden.to(torch.float32) @ _f32(self.w["lm_head"]).t()
         if round_bf16:
             y = y.to(BF16).to(torch.float32)
-        return y.masked_fill(~self.allowed, float("-inf"))
+        return y.masked_fill(~self.allowed, self.masked_logit)
 
     # ---- code predictor, re-prefill form (code_predictor_vllm.py:480-561)
     def cp_model(self, buf: torch.Tensor) -> torch.Tensor:

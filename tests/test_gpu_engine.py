@@ -12,7 +12,7 @@ from ht_vllm_omni_amd.config import get_dims
 from ht_vllm_omni_amd.sched import BlockPool
 from ht_vllm_omni_amd.weights import make_weights
 from oracle import talker_oracle as O
-from tests.util import BF16, assert_bf16_close, assert_e2e_close, bf16_from_u16
+from tests.util import assert_f32_close, BF16, assert_bf16_close, assert_e2e_close, bf16_from_u16
 
 pytestmark = pytest.mark.gpu
 
@@ -442,6 +442,34 @@ def test_moe_backbone_decode_steps_match_oracle():
         assert_e2e_close(g[same], o[same], mean_tol=8e-3, max_ulps=3, what=f"MoE step {i} logits")
     # a routing near-tie (bf16 router logits) may send a token to a different 4th expert than the oracle's torch.topk
     assert bad_rows <= 2, f"{bad_rows} rows diverged"
+
+
+def test_omni_finite_suppression_value():
+    """The Omni talker's compute_logits writes -1e9 for suppressed tokens instead of -inf (qwen3_omni.py:1143-1149): same
+    picks, finite logits; desc.masked_logit carries the value into the lm_head epilogue of the step and of omni_talker_logits."""
+    d = get_dims("tiny")
+    w = make_weights(d, seed=5, std=0.08, norm_noise=0.1)
+    out = {}
+    for fill in (0.0, -1e9):
+        eng = _engine(d, w, kv_dtype="bf16", num_blocks=16, max_batch=4, masked_logit=fill)
+        orc = O.TalkerOracle(d, w, masked_logit=float("-inf") if fill == 0.0 else fill)
+        h = torch.randn(4, d.hidden, generator=torch.Generator().manual_seed(2)).to(BF16)
+        lg = eng.compute_logits(h.cuda()).cpu()
+        ref = orc.compute_logits(h)
+        masked = ~orc.allowed
+        assert masked.any() and (~masked).any()
+        if fill == 0.0:
+            assert torch.isinf(lg[:, masked]).all() and (lg[:, masked] < 0).all()
+        else:
+            assert (lg[:, masked] == -1e9).all()
+        assert_f32_close(lg[:, ~masked], ref[:, ~masked], atol=0.02, what="unmasked logits")
+        out[fill] = (lg, ops_sample(eng, lg))
+    assert torch.equal(out[0.0][1], out[-1e9][1]), "greedy picks do not depend on the suppression value"
+
+
+def ops_sample(eng, lg):
+    from ht_vllm_omni_amd import ops
+    return ops.sample(lg.cuda(), greedy=True).cpu()
 
 
 def test_omni_talker_real_dims_one_layer():
