@@ -260,3 +260,63 @@ def test_omni_request_prompt_built_on_device_then_decodes_with_queued_text_steps
         assert torch.equal(out.pooler_output[0]["audio_codes"], oc[0:1]), f"audio codes at decode step {stepno}"
         eng.input_ids[0] = int(oi[0]); eng.last_hidden[0] = oh[0].cuda()
     wk.shutdown()
+
+
+def test_engine_core_soak_with_request_churn():
+    """40 requests of mixed prompt / output lengths through an 8-row batch with a tight block pool (preemption by
+    recompute included) and sampled decoding: every request finishes with its length, the pool and the persistent batch
+    come back empty, the captured step is used throughout, and a second run of the same workload reproduces every token
+    (hash RNG keyed by request step: no dependence on batch composition is allowed to leak into the streams... except
+    through the positions of rows -- which the row-independent kernels must not let through)."""
+    from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+    d = get_dims("tiny")
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 40
+    dflt = SamplingParams(temperature=0.9, top_k=20, repetition_penalty=1.05, seed=5)
+
+    def run_once():
+        cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=8, num_gpu_blocks_override=nb, weights=w,
+                          enforce_eager=False, default_sampling_params=dflt)
+        wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+        wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+        wk.engine.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=20)
+        wk.compile_or_warm_up_model()
+        sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=8, max_num_batched_tokens=64,
+                                  max_model_len=d.max_model_len, need_send_cache=False)
+        core = TalkerStageEngine(wk, sched)
+        g = torch.Generator().manual_seed(77)
+        want = {}
+        pending = []
+        for i in range(40):
+            n = int(torch.randint(3, 70, (1,), generator=g))
+            m = int(torch.randint(1, 24, (1,), generator=g))
+            sp = SamplingParams(temperature=0.9, top_k=20, repetition_penalty=1.05, seed=5, max_tokens=m, stop_token_ids=())
+            pe = torch.randn(n, d.hidden, generator=g).to(BF16)
+            pad = torch.randn(d.hidden, generator=g).to(BF16)
+            info = {"talker_prompt_embeds": encode_tensor(pe), "tts_pad_embed": encode_tensor(pad)}
+            pending.append(Request(request_id=f"r{i}", num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp,
+                                   additional_information=info, ignore_eos=True))
+            want[f"r{i}"] = m
+        streams, finished, steps = {}, {}, 0
+        while (pending or sched.has_unfinished_requests()) and steps < 4000:
+            for _ in range(2):                                   # requests keep arriving while others decode
+                if pending:
+                    core.add_request(pending.pop(0))
+            for o in core.step():
+                streams.setdefault(o.request_id, []).extend(o.new_token_ids)
+                if o.finished:
+                    finished[o.request_id] = o.finish_reason
+            steps += 1
+        core.step()                                              # delivers the last finished ids: the runner drops its rows
+        stats = dict(wk.model_runner.cudagraph_stats)
+        free, rows = sched.pool.num_free, list(wk.model_runner.rows)
+        wk.shutdown()
+        return want, streams, finished, steps, stats, free, rows
+
+    want, streams, finished, steps, stats, free, rows = run_once()
+    assert set(finished) == set(want) and all(r == "length" for r in finished.values()), (len(finished), steps)
+    assert all(len(streams[k]) == want[k] for k in want), {k: (len(streams[k]), want[k]) for k in want if len(streams[k]) != want[k]}
+    assert free == nb - 1 and rows == [], (free, rows)
+    assert stats["replays"] > 0
+    _, streams2, *_ = run_once()
+    assert streams2 == streams, "same workload, same seeds -> same token streams"
