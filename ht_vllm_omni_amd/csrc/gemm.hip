@@ -9,9 +9,11 @@
 //   D[n][m]: lane holds m = l&15, n = 4*(l>>4) + reg.
 // Workgroup = 8 waves = one group of NT 16-row n-tiles x MT 16-row m-tiles; grid = (n groups,
 // m splits).  The 8 waves split K (k-steps interleaved w, w+8, ...); when K % 512 == 0 (every talker
-// shape) a wave runs the COUNTED schedule: two k-steps of W and x in flight, no predicated load, so each
-// MFMA group waits only for its own operands (vmcnt(N), not vmcnt(0)); other K take the generic ring
-// loop.  Partial sums combine through LDS.
+// shape) a wave runs the COUNTED schedule: two k-steps of W and x in flight (four for the residual-epilogue tiles), no
+// predicated load, so each MFMA group waits only for its own operands (vmcnt(N), not vmcnt(0)); other K take the generic
+// ring loop.  Partial sums combine through LDS.  M <= 64 (128 with 128-row slabs: the code predictor's pair pass).
+// SiLU epilogues: OMNI_EPI_SILU_MUL pairs a gate tile with its up tile ([gate | up] rows, NT even); OMNI_EPI_SILU_MUL_GU8
+// takes W with gate / up rows interleaved by 8, so ONE tile finishes 8 act columns and NT = 3 fills 256 workgroups.
 // fp32 accumulate, one rounding to bf16 (oracle: talker_oracle.linear / rms_norm).
 //
 // The norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm, see include/omni_talker.h):
