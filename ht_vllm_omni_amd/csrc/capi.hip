@@ -88,14 +88,6 @@ __global__ __launch_bounds__(256) void mtp_finalize_kernel(
     }
 }
 
-__global__ void advance_kernel(int32_t* positions, int32_t* seq_lens, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) {
-        positions[i] += 1;
-        seq_lens[i] += 1;
-    }
-}
-
 __global__ void copy_i32_to_i64_kernel(const int32_t* src, int64_t* dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -708,7 +700,6 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     TRY(check_io(t, io));
     const omni_talker_desc& d = t->d;
     const int B = io->B;
-    hipStream_t st = (hipStream_t)stream;
     // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
     if (d.fused_norm)
@@ -718,11 +709,8 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
                   io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->top_p, io->rep_penalty, io->seen, io->seed,
-                 io->steps, 1, 0, 1, io->input_ids, 1, stream));
-    if (io->advance) {
-        hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, io->positions, io->seq_lens, B);
-        OMNI_CHECK_LAUNCH("advance");
-    }
+                 io->steps, 1, 0, 1, io->input_ids, 1, stream, io->advance ? io->positions : nullptr,
+                 io->advance ? io->seq_lens : nullptr));      // positions / seq_lens += 1 inside the sampler launch
     return OMNI_OK;
 }
 

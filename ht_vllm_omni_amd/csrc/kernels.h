@@ -4,7 +4,7 @@
 
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream);
+             int out_stride, void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr /* per-row counters to bump */);
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
             void* stream);
 // rows of `table` (ids == NULL: rows 0..T-1) -> fragment-major residual stream + slab 0 of the sum(r^2) partials;
@@ -31,7 +31,7 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part /* != NULL: gather_out fragment-major + sum-of-squares slab 0 */,
-                    void* stream);
+                    void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr);
 // rmsnorm with out-of-place residual update: residual_out = bf16(residual + delta) (may alias residual)
 // out (row-major) and/or out_frag (fragment-major, common.cuh frag_off) receive the normalised rows
 int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,

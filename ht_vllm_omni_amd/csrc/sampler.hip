@@ -43,7 +43,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              int32_t* __restrict__ steps, int step_mul, int step_add,
                                                              int inc_steps, int32_t* __restrict__ out_ids, int out_stride,
                                                              const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim,
-                                                             float* __restrict__ gpart) {
+                                                             float* __restrict__ gpart, int32_t* __restrict__ inc0,
+                                                             int32_t* __restrict__ inc1) {
     __shared__ float row[NPT * SMP_THREADS];       // LDS copy of the row: radix fallback only
     __shared__ uint32_t hist[4][256];              // one histogram per radix pass, cleared once
     __shared__ float sval[SMP_THREADS / 64];
@@ -315,13 +316,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
         out_ids[(size_t)b * out_stride] = pick;
         if (sn && pick >= 0 && pick < V) sn[pick] = 1;
         if (steps && inc_steps) steps[b] += 1;
+        if (inc0) inc0[b] += 1;                      // the step's position / sequence-length advance rides along
+        if (inc1) inc1[b] += 1;
     }
 }
 
 int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
-                    int gather_dim, float* gather_part, void* stream) {
+                    int gather_dim, float* gather_part, void* stream, int32_t* inc0, int32_t* inc1) {
     OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
     OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
@@ -334,7 +337,7 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
 #define SMP_LAUNCH(NPT_)                                                                                                  \
     hipLaunchKernelGGL(sample_kernel<NPT_>, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,     \
                        temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids, \
-                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part)
+                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part, inc0, inc1)
     if (V <= 8 * SMP_THREADS) SMP_LAUNCH(8);
     else if (V <= 12 * SMP_THREADS) SMP_LAUNCH(12);
     else SMP_LAUNCH(32);
@@ -345,9 +348,9 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
 
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream) {
+             int out_stride, void* stream, int32_t* inc0, int32_t* inc1) {
     return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
-                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream);
+                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream, inc0, inc1);
 }
 
 extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,

@@ -1,14 +1,15 @@
 """Sum rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes) over the LAST decode step of a bench.py run.
 
 usage: pmc_step_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [note]
-A step = the dispatches after the previous advance_kernel up to and including the last advance_kernel.
+A step = the dispatches after the previous mtp_finalize_kernel (once per step, between the code predictor and the backbone) up to
+and including the last one: the backbone half of one step + the code-predictor half of the next = one step's worth of launches.
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 wide coalesced reads are reported at 1/2); units are KB."""
 import collections, csv, json, re, sys
 
 def last_step(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    adv = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("advance_kernel")]
+    adv = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("mtp_finalize_kernel")]
     assert len(adv) >= 2, "need at least two decode steps in the trace"
     step = rows[adv[-2] + 1: adv[-1] + 1]
     by = collections.defaultdict(float)
