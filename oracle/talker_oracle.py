@@ -44,7 +44,6 @@ Numeric conventions (the GPU path follows the same rounding points):
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 
 import numpy as np

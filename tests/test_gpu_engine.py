@@ -12,7 +12,7 @@ from ht_vllm_omni_amd.config import get_dims
 from ht_vllm_omni_amd.sched import BlockPool
 from ht_vllm_omni_amd.weights import make_weights
 from oracle import talker_oracle as O
-from tests.util import assert_f32_close, BF16, assert_bf16_close, assert_e2e_close, bf16_from_u16
+from tests.util import assert_f32_close, BF16, assert_e2e_close, bf16_from_u16
 
 pytestmark = pytest.mark.gpu
 

@@ -1,7 +1,6 @@
 """Per-op parity: every HIP kernel, called through the C-ABI, against the CPU oracle on the same
 seeded inputs.  Bar: integer/index outputs bit-exact; bf16 outputs within 1 bf16 ulp (same rounding
 points, different fp32 summation order) and fp32 outputs within 1e-3 (north_star tolerance)."""
-import math
 import os
 
 import numpy as np
