@@ -26,14 +26,15 @@ def w3():
     return d, make_weights(d, seed=1234, std=0.02)
 
 
-def _drive(d, w, req_ids, row_of, *, snapshot_kv=False):
+def _drive(d, w, req_ids, row_of, *, snapshot_kv=False, kv="fp8", cp_top_p=1.0):
     """Requests req_ids (global ids: prompt content and length are functions of the id) placed on rows row_of[i]; native
     prefill, STEPS sampled decode steps.  Returns per request: logits / codes / ids of every step (+ touched KV slots)."""
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd import ops
     B = len(req_ids)
-    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=NB, block_size=BS, max_batch=B, device="cuda:0", allow_eos=False)
-    eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+    eng = TalkerEngine(d, w, kv_dtype=kv, num_blocks=NB, block_size=BS, max_batch=B, device="cuda:0", allow_eos=False)
+    eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50,
+                     **({"cp_top_p": cp_top_p} if cp_top_p < 1.0 else {}))
     lens = {q: 32 + (q * 37) % 129 for q in req_ids}
     prompt = {q: (torch.randn(lens[q], d.hidden, generator=torch.Generator().manual_seed(1000 + q)) * 0.05).to(BF16) for q in req_ids}
     pad = {q: (torch.randn(d.hidden, generator=torch.Generator().manual_seed(5000 + q)) * 0.05).to(BF16) for q in req_ids}
@@ -137,3 +138,20 @@ def test_w3_full_size_row_permutation_solo_request_slots_and_replay(w3):
             print(f"request {q}: alone vs batch, step 0: mean |diff| {dd.mean().item():.4g}, max {dd.max().item():.4g}, scale {b[fin].abs().max().item():.3g}")
             # 28 bf16 layers deep, one differing summation order per layer: a few ulps at the largest magnitude
             assert_e2e_close(a, b, mean_tol=3e-2, max_ulps=8, what=f"request {q} alone vs in the batch, step 0")
+
+
+def test_omni_talker_full_size_row_permutation_and_replay():
+    """The same properties for BASELINE config #4's talker: 20 sparse-MoE layers (128 experts, top-8, gated shared expert),
+    16 q / 2 kv heads, int8 KV with per-token scales, code predictor with top-k 50 + top-p 0.8, B = 64."""
+    d = get_dims("omni-talker")
+    w = make_weights(d, seed=1234, std=0.02)
+    reqs = list(range(64))
+    base, extra = _drive(d, w, reqs, list(range(64)), snapshot_kv=True, kv="int8", cp_top_p=0.8)
+    for changed in extra["changed"]:
+        assert changed == extra["want"], (len(changed), len(extra["want"]))
+    again, _ = _drive(d, w, reqs, list(range(64)), kv="int8", cp_top_p=0.8)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(4)).tolist()
+    moved, _ = _drive(d, w, reqs, perm, kv="int8", cp_top_p=0.8)
+    for q in reqs:
+        _same(base[q], again[q], f"replay, request {q}")
+        _same(base[q], moved[q], f"row permutation, request {q} (row {q} -> {perm[q]})")
