@@ -85,6 +85,12 @@ class MI355XARModelRunner:
         self.graphs: dict[int, Any] = {}
         self.engine_output_type = engine_output_type
         self.cudagraph_stats = {"replays": 0, "eager_steps": 0}
+        # per-step text rows as ONE device gather: every request's queue (tailing_text_hidden rows, then its tts_pad row)
+        # is a segment of a table rebuilt only when the batch membership / row order changes; row r of a step reads
+        # table[off[r] + min(pos[r], len[r])] (index len[r] = the pad row)
+        self._tt = None
+        self._tt_rows: list[str] = []
+        self._tt_off = self._tt_len = self._tt_pos = None
 
     # ------------------------------------------------------------------ persistent batch
     def _reset_row(self, r: int) -> None:
@@ -100,14 +106,41 @@ class MI355XARModelRunner:
         n = len(perm)
         if perm == list(range(n)):
             return
+        self._tt_flush()
         idx = torch.as_tensor(perm, device=self.engine.input_ids.device)
         for name in _ROW_BUFFERS:
             buf = getattr(self.engine, name)
             buf[:n] = buf[:n].index_select(0, idx)
         self.rows = [self.rows[i] for i in perm]
 
+    def _tt_flush(self) -> None:
+        """Write the queue positions back to the requests and drop the table (rows are about to change)."""
+        if self._tt is not None:
+            for r, rid in enumerate(self._tt_rows):
+                st = self.requests.get(rid)
+                if st is not None:
+                    st.tail_pos = int(self._tt_pos[r])
+        self._tt = None
+
+    def _tt_build(self) -> None:
+        H = self.d.hidden
+        segs, off, ln, pos, o = [], [], [], [], 0
+        for rid in self.rows:
+            st = self.requests[rid]
+            n = 0 if st.tail is None else int(st.tail.shape[0])
+            if n:
+                segs.append(st.tail.reshape(n, H))
+            segs.append(st.tts_pad.reshape(1, H))
+            off.append(o); ln.append(n); pos.append(st.tail_pos)
+            o += n + 1
+        self._tt = torch.cat(segs, 0) if segs else None
+        self._tt_rows = list(self.rows)
+        self._tt_off, self._tt_len, self._tt_pos = np.asarray(off, np.int64), np.asarray(ln, np.int64), np.asarray(pos, np.int64)
+
     def _update_states(self, so: OmniSchedulerOutput) -> None:
         e = self.engine
+        if so.finished_req_ids or so.preempted_req_ids or so.scheduled_new_reqs:
+            self._tt_flush()
         # drop finished / preempted requests, closing holes with the last row (condense)
         for rid in list(so.finished_req_ids) + list(so.preempted_req_ids):
             if rid not in self.requests:
@@ -185,7 +218,8 @@ class MI355XARModelRunner:
         sched = scheduler_output.num_scheduled_tokens
         # decode-first row order
         dec = [i for i, rid in enumerate(self.rows) if rid in sched and self.requests[rid].in_decode]
-        rest = [i for i in range(len(self.rows)) if i not in set(dec)]
+        decs = set(dec)
+        rest = [i for i in range(len(self.rows)) if i not in decs]
         self._permute_rows(dec + rest)
         nd = len(dec)
         for i in range(nd):
@@ -242,15 +276,11 @@ class MI355XARModelRunner:
 
         # ---- decode rows: text-step queue pop (talker.py:618-629), then the native step
         if nd:
-            text = []
-            for i in range(nd):
-                st = self.requests[self.rows[i]]
-                if st.tail is not None and st.tail_pos < st.tail.shape[0]:
-                    text.append(st.tail[st.tail_pos])
-                    st.tail_pos += 1
-                else:
-                    text.append(st.tts_pad)
-            e.text_step[:nd] = torch.stack(text)
+            if self._tt is None:
+                self._tt_build()
+            idx = self._tt_off[:nd] + np.minimum(self._tt_pos[:nd], self._tt_len[:nd])
+            self._tt_pos[:nd] += 1
+            torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
             self._apply_sampling(self.requests[self.rows[0]].sampling)
             self._run_decode(nd)
         self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans)
@@ -315,9 +345,10 @@ class MI355XARModelRunner:
         nd = len(stt.decode_rows)
         Q = self.d.num_code_groups
         # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550)
-        ids_cpu = e.input_ids[:len(self.rows)].cpu()
+        ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
         hid_cpu = e.last_hidden[:len(self.rows)].cpu()
         codes_cpu = e.audio_codes[:nd].cpu() if nd else None
+        # (pinned staging + one sync was tried: the CPU then reads uncached pinned memory -- 37 ms per step)
         sched = stt.scheduler_output.num_scheduled_tokens
         req_ids, sampled, pooler = [], [], []
         for r, rid in enumerate(self.rows):
@@ -330,8 +361,8 @@ class MI355XARModelRunner:
                 st.num_computed += 1
                 st.output_ids.append(tok)
                 sampled.append([tok])
-                payload["hidden"] = hid_cpu[r:r + 1].clone()
-                payload["audio_codes"] = codes_cpu[r:r + 1].clone()      # frame [c0..c15][t] (talker.py:1642)
+                payload["hidden"] = hid_cpu[r:r + 1]                     # views of this step's own host copies
+                payload["audio_codes"] = codes_cpu[r:r + 1]              # frame [c0..c15][t] (talker.py:1642)
             else:
                 s0, n, hid = stt.prefill_spans[r]
                 payload["hidden"] = hid.cpu()
