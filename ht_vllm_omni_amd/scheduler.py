@@ -52,7 +52,7 @@ _FINISH_REASON = {RequestStatus.FINISHED_STOPPED: "stop", RequestStatus.FINISHED
                   RequestStatus.FINISHED_ABORTED: "abort"}
 
 
-@dataclass
+@dataclass(eq=False)      # identity semantics: requests live in lists / deques that are searched and removed from
 class Request:
     """The fields of vLLM's ``Request`` the path reads, plus the omni payloads (V/request.py)."""
     request_id: str
@@ -183,8 +183,8 @@ class MI355XARScheduler:
             new_blocks = self._allocate(req, req.num_computed_tokens + n)
             if new_blocks is None:          # alone and still no room: leave it for a later step
                 break
-            if req not in self.running:     # it preempted itself out (cannot happen: keep=req), defensive
-                continue
+            if req.request_id in self._preempted:   # it preempted itself out (cannot happen: keep=req), defensive
+                continue                            # (id test: `req not in self.running` compared whole dataclasses, 0.6 ms / step at 64)
             cached.req_ids.append(req.request_id)
             cached.resumed_from_preemption.append(False)
             cached.new_token_ids.append([])

@@ -47,3 +47,29 @@ for _ in range(N):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 print(f"runner wall per step {dt*1e3:.3f} ms  ({B/dt:.0f} tok/s)  execute_model {ex/N*1e3:.3f} ms  sample_tokens {sa/N*1e3:.3f} ms  replays {run.cudagraph_stats}")
+
+# ---- the same through the scheduler (engine-core loop: schedule -> execute_model -> sample_tokens -> update_from_output)
+from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+wk.shutdown()
+wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+wk.engine.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+wk.compile_or_warm_up_model()
+sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=B, max_num_batched_tokens=8192, max_model_len=d.max_model_len,
+                          need_send_cache=False)
+core = TalkerStageEngine(wk, sched)
+sp2 = SamplingParams(temperature=0.9, top_k=50, repetition_penalty=1.05, seed=42, max_tokens=400, stop_token_ids=())
+for r, n in enumerate(lens):
+    info = {"talker_prompt_embeds": encode_tensor((torch.randn(n, d.hidden, generator=g) * 0.05).to(torch.bfloat16)),
+            "tts_pad_embed": encode_tensor((torch.randn(d.hidden, generator=g) * 0.05).to(torch.bfloat16))}
+    core.add_request(Request(request_id=f"s{r}", num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp2,
+                             additional_information=info, ignore_eos=True))
+for _ in range(12): core.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter(); ts = tu = 0.0
+for _ in range(N):
+    a = time.perf_counter(); so = sched.schedule(); b = time.perf_counter()
+    first = wk.execute_model(so); out = first if first is not None else wk.sample_tokens(None)
+    c = time.perf_counter(); sched.update_from_output(so, out); tu += time.perf_counter() - c; ts += b - a
+dt = (time.perf_counter() - t0) / N
+print(f"engine-core loop wall per step {dt*1e3:.3f} ms  ({B/dt:.0f} tok/s)  schedule {ts/N*1e3:.3f} ms  update_from_output {tu/N*1e3:.3f} ms")
