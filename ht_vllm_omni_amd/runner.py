@@ -122,6 +122,12 @@ class MI355XARModelRunner:
                     st.tail_pos = int(self._tt_pos[r])
         self._tt = None
 
+    def text_queue_pos(self, req_id: str) -> int:
+        """How many queued text rows the request has consumed (the live count is kept per row while the batch is stable)."""
+        if self._tt is not None and req_id in self._tt_rows:
+            return int(self._tt_pos[self._tt_rows.index(req_id)])
+        return self.requests[req_id].tail_pos
+
     def _tt_build(self) -> None:
         H = self.d.hidden
         segs, off, ln, pos, o = [], [], [], [], 0

@@ -152,7 +152,7 @@ def test_runner_two_phase_contract_and_state():
     out2 = run.sample_tokens(None)
     assert [c[0] for c in eng.calls[1:]] == ["prefill", "decode"] and eng.calls[2][1] == 1
     assert out2.pooler_output[0]["audio_codes"].shape == (1, d.num_code_groups) and len(out2.sampled_token_ids[1]) == 1
-    assert run.requests["a"].tail_pos == 1                              # one text-step vector popped
+    assert run.text_queue_pos("a") == 1                                 # one text-step vector popped
     # step 3: both decode; a gets a new block; then a finishes with KV transfer
     so3 = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a", "b"], new_block_ids=[([9],), None]),
                               num_scheduled_tokens={"a": 1, "b": 1}, total_num_scheduled_tokens=2)
