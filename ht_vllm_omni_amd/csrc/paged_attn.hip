@@ -117,9 +117,13 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     // sequence end resolve to whatever block the table holds there -- block 0, the null block)
     KVRaw<KV> k0[PA_U], v0[PA_U], k1[PA_U], v1[PA_U];
     float ks0[PA_U], vs0[PA_U], ks1[PA_U], vs1[PA_U];
+    // token groups past the end of the history re-read its LAST row (one hot line) instead of whatever block the table
+    // holds further on: with blocks allocated ahead of the sequence those were real, cold HBM rows -- up to 127 tokens of
+    // wasted traffic per (row, head).  The speculative batch 0 goes out before the length is known and stays unclamped.
+    int t_lim = 0x7FFFFFFF;
 #define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
     _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                       \
-        const int t_ = (T0) + u * PA_WAVES * 8 + tg;                                         \
+        const int t_ = min((T0) + u * PA_WAVES * 8 + tg, t_lim);                             \
         const int bi_ = min(t_ / bs, max_blk);                                               \
         const size_t r_ = ((size_t)bt[bi_] * bs + t_ % bs) * kv_heads + kvh;                 \
         KR[u] = load_row<KV>(a.k_cache, r_, sub);                                            \
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     const int t_begin = sp * per;
     const int cur = seq_len - 1;                  // the token computed this step
     const int t_end = min(FUSED ? cur : seq_len, t_begin + per);
+    t_lim = max(t_end - 1, 0);
     if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
 
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
