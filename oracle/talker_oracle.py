@@ -19,6 +19,11 @@ What it restates (R/ = /root/reference, V/ = R/vllm_omni):
   cache ``[2, num_blocks, block_size, n_kv_heads, head_dim]`` with
   ``slot = block_table[r][p // bs] * bs + p % bs`` (SURVEY Appendix A).
 
+Also restated here (each pinned to the reference module / method named beside the function): the Omni talker's sparse-MoE
+block (HF ``Qwen3OmniMoeTalkerTextSparseMoeBlock``, tests/golden/moe_block.npz), its prompt-embedding builder and decode-side
+text steps (the reference's own ``_thinker_to_talker_prefill`` & co., qwen3_omni.py:650-1060, run on HF ``ResizeMLP`` modules:
+tests/golden/omni_prompt_builder.pt), SnakeBeta (the reference module, snake_beta.npz), KV extraction (kv_extract.npz).
+
 Pinning status: the code predictor is pinned against the reference's own file
 (tests/golden/code_predictor_*.npz, minted by tests/golden/make_fixtures.py); the
 backbone is pinned against HF ``Qwen3Model`` (tests/golden/qwen3_backbone_*.npz).
