@@ -7,9 +7,12 @@ Workload W3 (BASELINE config #3): Qwen3-TTS-1.7B-shaped talker, rando
 whole decode step (code predictor + 28-layer backbone + lm_head + sampler) captured as ONE hipGraph.
 A "step" = one decode step of the batch = 64 speech tokens (64 codec frames of 16 codes).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run,
-                                                         tensor-parallel over RCCL, strong scaling)
-Prints ONE JSON line on rank 0.
+  python bench.py --gpus N --steps K --warmup W
+N > 1 without WORLD_SIZE in the environment: this process (which has made no GPU call) starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits with
+the child's code; under torchrun (WORLD_SIZE set) each rank runs the tensor-parallel step over RCCL (strong scaling).
+The timed window is centred on the BASELINE context (mean ctx 352) whatever --steps is: untimed decode steps advance
+the batch there first, over KV the steps themselves wrote.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -55,7 +58,7 @@ def setup_requests(d, eng, args):
     B, bs = args.batch, 16
     rng = np.random.default_rng(7)
     lens = rng.integers(32, 161, size=B).tolist()
-    total_steps = args.warmup + args.steps + args.ttfa_steps + 4 + args.ctx_extra
+    total_steps = args.warmup + args.steps + args.ttfa_steps + 4 + args.ctx_extra + max(args.target_ctx, 0)   # incl. the untimed advance
     pool = BlockPool(args.num_blocks, bs)
     g = torch.Generator().manual_seed(7)
     bt = torch.zeros(eng.max_batch, eng.bt_stride, dtype=torch.int32)
@@ -80,8 +83,8 @@ def setup_requests(d, eng, args):
     eng.seen.zero_()
     eng.seen[:B, d.codec_pad_id] = 1
     eng.steps.zero_()
-    ids = ops.sample(logits, greedy=False, temperature=s["temperature"], top_k=s["top_k"], rep_penalty=s["rep_penalty"],
-                     seen=eng.seen, seed=s["seed"], steps=eng.steps, inc_steps=True)
+    ids = ops.sample(logits, greedy=bool(s["greedy"]), temperature=s["temperature"], top_k=s["top_k"], rep_penalty=s["rep_penalty"],
+                     seen=eng.seen[:B], seed=s["seed"], steps=eng.steps[:B], inc_steps=True)
     torch.cuda.synchronize()
     prefill_ms = (time.perf_counter() - t0) * 1e3
     eng.input_ids[:B] = ids
@@ -179,13 +182,39 @@ def main():
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1 with --parallel tp: skip the second, untimed-for-`value` "
                     "leg that runs the same step as independent replicas (reported under \"replicas\")")
     ap.add_argument("--ctx-extra", type=int, default=0, help="long-context points: start decoding this many positions later")
+    ap.add_argument("--target-ctx", type=int, default=352, help="mean context of the timed window (W3: 96 + 256); untimed decode "
+                    "steps advance the batch until the window is centred there (0: time from wherever warm-up ends)")
+    ap.add_argument("--master-port", type=int, default=0, help="N > 1 self-launch: rendezvous port (0: pick a free one)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # One process per GPU: start the ranks as CHILDREN of this process, which has not touched the GPU (no exec after
+        # HIP initialisation on this pool), relay rank 0's JSON line, fail when any rank fails.
+        import socket
+        import subprocess
+        port = args.master_port
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        log("self-launch:", " ".join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            log(f"bench.py: the {args.gpus}-rank launch failed (exit {r.returncode}, {len(lines)} JSON line(s))")
+            sys.exit(r.returncode or 1)
+        os.write(json_fd, (lines[-1] + "\n").encode())
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number as {args.gpus} GPUs")
+        sys.exit(2)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.tp_force:
@@ -245,6 +274,13 @@ def main():
     ic_ms = (time.perf_counter() - t0) * 1e3 / n_ic * args.ttfa_steps
     ttfa_ms = prefill_ms + ic_ms
 
+    # ---- centre the timed window on the BASELINE context: untimed decode steps (they write the KV the timed steps read)
+    advance = 0
+    if args.target_ctx > 0:
+        cur = float(eng.seq_lens[:B].float().mean().item())         # context incl. the token of the next step
+        advance = max(0, int(round(args.target_ctx - (cur + args.warmup + (args.steps - 1) / 2.0))))
+        for _ in range(advance):
+            run()
     for _ in range(args.warmup):
         run()
     sync()
@@ -301,6 +337,7 @@ def main():
                    "model": args.model, "kv_cache": args.kv, "batch": B, "mean_ctx": float(np.mean(mean_ctx)),
                    "parallelism": f"{args.parallel}{world}", "hipgraph": graph is not None, "sub_batches": args.sub_batches,
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
+                   "target_ctx": args.target_ctx, "untimed_advance_steps": advance,
                    **({"ctx_extra": args.ctx_extra} if args.ctx_extra else {})},
         "p50_ttfa_ms": ttfa_ms, "ttfa": {"prefill_ms": prefill_ms, "ic_steps": args.ttfa_steps, "ic_ms": ic_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -336,7 +373,7 @@ def main():
             g3 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g3):
                 eng2.decode_step(B)
-            for _ in range(args.warmup + args.ttfa_steps):      # same context as the tensor-parallel leg's timed region
+            for _ in range(args.warmup + args.ttfa_steps + advance):      # same context as the tensor-parallel leg's timed region
                 g3.replay()
             torch.cuda.synchronize()
             run2 = g3.replay
@@ -362,12 +399,23 @@ def main():
     if rank == 0:
         # HBM bytes per step from the PMC passes (rocprofv3 cannot ride along with a timed run: separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary committed under profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
-        if world == 1 and args.model == "tts-1.7b" and os.path.exists(tpath):
+        # `traffic` stays null unless a committed PMC summary of this same command exists AT THIS CONTEXT (within 5 %);
+        # a figure measured at another context is reported beside it, labelled, never as roofline.traffic
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_traffic.json")), reverse=True):
+            if not (world == 1 and args.model == "tts-1.7b"):
+                break
             try:
                 tj = json.load(open(tpath))
-                out["roofline"]["traffic"] = tj["traffic_bytes_per_step"]
-                out["roofline"]["traffic_note"] = "bytes/step, PMC FETCH_SIZE x2 + WRITE_SIZE at mean ctx ~105 (profiles/r01_pmc_step_traffic.json)"
+                tctx = float(tj.get("mean_ctx", 105.0))
+                rel = os.path.relpath(tpath, ROOT)
+                if abs(tctx - float(np.mean(mean_ctx))) <= 0.05 * float(np.mean(mean_ctx)):
+                    out["roofline"]["traffic"] = tj["traffic_bytes_per_step"]
+                    out["roofline"]["traffic_ctx"] = tctx
+                    out["roofline"]["traffic_note"] = f"bytes/step, PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command ({rel})"
+                else:
+                    out["roofline"]["traffic_other_ctx"] = {"bytes_per_step": tj["traffic_bytes_per_step"], "mean_ctx": tctx, "source": rel}
+                break
             except Exception as e:   # noqa: BLE001
                 log(f"traffic file unreadable: {e!r}")
         try:

@@ -51,6 +51,11 @@ class TalkerDesc(C.Structure):
     ]
 
 
+class RowSampling(C.Structure):
+    """omni_row_sampling: per-row device arrays [B] (NULL member = the scalar of StepIO)."""
+    _fields_ = [("greedy", vp), ("temperature", vp), ("top_k", vp), ("top_p", vp), ("rep_penalty", vp), ("seed", vp)]
+
+
 class StepIO(C.Structure):
     _fields_ = [
         ("B", i32), ("input_ids", vp), ("positions", vp), ("seq_lens", vp), ("block_table", vp), ("slot_mapping", vp),
@@ -59,6 +64,7 @@ class StepIO(C.Structure):
         ("greedy", i32), ("temperature", f32), ("top_k", i32), ("rep_penalty", f32), ("seed", u32),
         ("cp_greedy", i32), ("cp_temperature", f32), ("cp_top_k", i32),
         ("advance", i32), ("top_p", f32), ("cp_top_p", f32),
+        ("num_live", vp), ("rows", RowSampling),
     ]
 
 
@@ -86,6 +92,7 @@ SIGNATURES = {
     "omni_paged_attn_prefill": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp]),
     "omni_embed": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "omni_sample": (i32, [vp, i32, i32, i32, i32, f32, i32, f32, f32, vp, u32, vp, i32, i32, i32, vp, vp]),
+    "omni_sample_rows": (i32, [vp, i32, i32, i32, C.POINTER(RowSampling), vp, vp, i32, i32, i32, vp, vp]),
     "omni_talker_scratch_bytes": (i64, [C.POINTER(TalkerDesc)]),
     "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
     "omni_talker_destroy": (None, [vp]),
@@ -106,27 +113,58 @@ SIGNATURES = {
 }
 
 _lib = None
+_product = None
+DEBUG_LIB_PATH = os.path.join(HERE, "libomni_talker_debug.so")
 
 
-def load() -> C.CDLL:
-    """dlopen the library and bind every declared symbol; raises OmniError when absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str, debug: bool) -> C.CDLL:
+    if not os.path.exists(path):
         raise OmniError(
-            f"{LIB_PATH} is missing: build it with `python -m ht_vllm_omni_amd.build` "
+            f"{path} is missing: build it with `python -m ht_vllm_omni_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    # a library older than csrc/ would silently run yesterday's kernels: compare the digest stamped at link time with the
+    # sources that are here (skipped when the sources did not travel, e.g. an installed wheel)
+    stamp, csrc = path + ".digest", os.path.join(HERE, "csrc")
+    if os.path.isdir(csrc) and os.environ.get("OMNI_SKIP_STALE_CHECK") != "1":
+        from .build import sources_digest
+        have = open(stamp).read().strip() if os.path.exists(stamp) else "<no stamp>"
+        if have != sources_digest(debug):
+            raise OmniError(f"{path} is stale: built from other sources than {csrc} (digest {have[:12]}); "
+                            "rebuild with `python -m ht_vllm_omni_amd.build`")
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise OmniError(f"{LIB_PATH} does not export {name}") from e
+            raise OmniError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    """dlopen the product library and bind every declared symbol; raises OmniError when absent or stale.
+    OMNI_TALKER_DEBUG=1 (scripts/ only) selects libomni_talker_debug.so, the same ABI plus the omni_debug_* hooks."""
+    global _lib
+    if _lib is None:
+        dbg = os.environ.get("OMNI_TALKER_DEBUG") == "1"
+        _lib = _open(DEBUG_LIB_PATH if dbg else LIB_PATH, dbg)
+    return _lib
+
+
+class debug_library:
+    """Context manager for the tile-sweep / A-B tests: engines and ops created inside run on libomni_talker_debug.so
+    (same sources, run-time policy knobs); the product library is restored on exit."""
+
+    def __enter__(self) -> C.CDLL:
+        global _lib, _product
+        _product = _lib
+        _lib = _open(DEBUG_LIB_PATH, True)
+        return _lib
+
+    def __exit__(self, *exc) -> None:
+        global _lib
+        _lib = _product
 
 
 def check(rc: int, what: str = "") -> None:

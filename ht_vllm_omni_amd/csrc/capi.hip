@@ -18,7 +18,7 @@ void omni_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* omni_last_error(void) { return g_err; }
-extern "C" int omni_abi_version(void) { return 1; }
+extern "C" int omni_abi_version(void) { return 2; }
 
 #define TRY(expr)                    \
     do {                             \
@@ -310,15 +310,22 @@ static inline int silu_epi(const omni_talker* t) { return t->d.frag_layout ? OMN
 // r = resid_in + delta -> resid_out
 static int norm_gemm(omni_talker* t, const uint16_t* resid_in, const uint16_t* delta, uint16_t* resid_out, const void* norm_w,
                      uint16_t* normed_scratch, void* normed_out, const void* w, void* out, int rows, int N, int K, int epi,
-                     const uint8_t* mask, int out_frag, void* st) {
+                     const uint8_t* mask, int out_frag, void* st, const int32_t* out_live = nullptr) {
     const float eps = t->d.eps;
     const int F = t->d.frag_layout;
     OMNI_CHECK_ARG(resid_out || delta == nullptr, "norm_gemm: delta without resid_out");
     if (F) {
-        // normalised rows go out fragment-major for the GEMM (and row-major too when the caller wants them)
-        TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, normed_out, normed_scratch, rows, K, eps, st));
+        // normalised rows go out fragment-major for the GEMM (and row-major too when the caller wants them; rows past
+        // *out_live keep what normed_out held)
+        TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, normed_out, normed_scratch, rows, K, eps, st, out_live));
         return k_gemm_bf16_ex(normed_scratch, K, w, nullptr, out, rows, N, K, epi, mask,
                               OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | (out_frag ? OMNI_LAYOUT_OUT_FRAG : 0), st, mask_fill(t));
+    }
+    if (normed_out && out_live) {
+        // row-major engine with a gated copy: the GEMM reads the scratch rows, the caller's buffer gets the live rows only
+        TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, normed_scratch, nullptr, rows, K, eps, st));
+        TRY(k_rmsnorm(delta ? resid_out : resid_in, nullptr, nullptr, nullptr, norm_w, normed_out, nullptr, rows, K, eps, st, out_live));
+        return k_gemm_bf16_ex(normed_scratch, K, w, nullptr, out, rows, N, K, epi, mask, 0, st, mask_fill(t));
     }
     uint16_t* nx = normed_out ? reinterpret_cast<uint16_t*>(normed_out) : normed_scratch;
     TRY(k_rmsnorm(nullptr, delta, resid_in, resid_out, norm_w, nx, nullptr, rows, K, eps, st));
@@ -335,8 +342,10 @@ static int act_gemm(omni_talker* t, const void* x, const void* w, const void* bi
 // ---- fused-norm building blocks (desc.fused_norm): the residual stream r stays fragment-major, every RMSNorm is folded
 // into the GEMM that consumes it (omni_gemm_xnorm) and every residual add into the GEMM that produces it (omni_gemm_resid)
 static int xnorm_gemm(omni_talker* t, const uint16_t* r, const float* part, int np, const void* norm_w, void* normed_out,
-                      const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask, int out_frag, void* st) {
-    return k_gemm_xnorm(r, part, np, norm_w, t->d.eps, normed_out, w, out, rows, N, K, epi, mask, out_frag, 64, st, mask_fill(t));
+                      const void* w, void* out, int rows, int N, int K, int epi, const uint8_t* mask, int out_frag, void* st,
+                      const int32_t* num_live = nullptr) {
+    return k_gemm_xnorm(r, part, np, norm_w, t->d.eps, normed_out, w, out, rows, N, K, epi, mask, out_frag, 64, st, mask_fill(t),
+                        num_live);
 }
 static int resid_gemm(const void* x_frag, const void* w, uint16_t* r, float* part, int rows, int N, int K, void* st) {
     return omni_gemm_resid(x_frag, K, w, nullptr, r, 1, part, nullptr, rows, N, K, OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG, st);
@@ -370,8 +379,10 @@ static int cp_forward_fused(omni_talker* t, int B, int p, int* np, void* st) {
 // hidden state), rows [Bp, Bp + B) = position 1 (the layer-0 code embedding), Bp = B rounded up to 16; slabs 128 rows wide.
 // Both inputs exist when the predictor starts, and a row's GEMM result does not depend on the rows beside it: 25 launches
 // instead of 22 + 25.  Position 0 only feeds its K / V (written by the pair attention); its rows ride along.
-static int g_cp_pair01 = 1;
+OMNI_KNOB g_cp_pair01 = 1;
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_cp_pair01(int on) { g_cp_pair01 = on; }
+#endif
 static bool cp_pair01_ok(const omni_talker* t, int B) {
     const omni_talker_desc& d = t->d;
     const int Bp = (B + 15) & ~15;
@@ -450,10 +461,15 @@ static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, vo
 // layer0_ids != NULL and d.cp_e0_table: position-1 input is gathered from the folded table instead of projected.
 static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed, const void* last_hidden,
                               int B, int greedy, float temperature, int top_k, float top_p, uint32_t seed, int32_t* steps,
-                              float* cp_logits_out, void* st) {
+                              float* cp_logits_out, void* st, const uint32_t* row_seed = nullptr) {
     const omni_talker_desc& d = t->d;
     const int Q = d.num_code_groups, Hc = d.cp_hidden;
     if (Q <= 1) return OMNI_OK;
+    // the sub-step sampling parameters are the model's (talker_mtp hard-codes them, qwen3_tts_talker.py:1620-1627); only the
+    // noise stream is per request
+    omni_row_sampling cp_rows{};
+    cp_rows.seed = row_seed;
+    const omni_row_sampling* cpr = row_seed ? &cp_rows : nullptr;
     if (d.cp_fused_norm) {
         int np = 1;
         const bool pair = cp_pair01_ok(t, B);
@@ -507,7 +523,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
             const uint16_t* ptab = (more && d.cp_proj_table)
                                        ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
             TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, top_p, 1.0f, nullptr, seed, steps, Q,
-                                g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, ptab ? t->cp_part : nullptr, st));
+                                g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, ptab ? t->cp_part : nullptr, st, nullptr, nullptr, cpr));
             if (ptab) np = 1;
             if (more && !ptab) {
                 const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
@@ -540,7 +556,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         const uint16_t* ptab = (more && d.cp_proj_table)
                                    ? reinterpret_cast<const uint16_t*>(d.cp_proj_table) + (size_t)(g - 1) * d.codebook * Hc : nullptr;
         TRY(k_sample_gather(t->cp_logits, d.codebook, B, d.codebook, greedy, temperature, top_k, top_p, 1.0f, nullptr, seed, steps, Q,
-                            g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, nullptr, st));
+                            g, 0, t->codes + g, Q, ptab, t->cp_resid, Hc, nullptr, st, nullptr, nullptr, cpr));
         if (more && !ptab) {
             const uint16_t* tab = reinterpret_cast<const uint16_t*>(d.cp_embed) + (size_t)(g - 1) * d.codebook * d.hidden;
             TRY(k_embed(t->codes + g, Q, tab, t->cp_row, B, d.hidden, d.codebook, st));
@@ -576,7 +592,7 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
     // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640): gathered only when no folded table
     if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
     TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->cp_top_p,
-                           io->seed, io->steps, nullptr, stream));
+                           io->seed, io->steps, nullptr, stream, io->rows.seed));
     hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, (const uint16_t*)d.embed,
                        d.vocab, (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds,
                        t->resid, d.fused_norm ? t->part : nullptr, io->audio_codes, d.hidden, Q, d.codebook);
@@ -598,7 +614,8 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
     TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l],
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
-                            d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st));
+                            d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
+                            io->num_live));
     if (d.fused_norm) return resid_gemm(t->attn, w.wo, t->resid, t->part, B, H, hq * D, st);
     TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, B, H, hq * D, st));
     return OMNI_OK;
@@ -704,20 +721,24 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
     if (d.fused_norm)
         TRY(xnorm_gemm(t, t->resid, t->part, d.layers > 0 ? d.hidden / 16 : 1, d.final_norm, io->last_hidden, d.lm_head, io->logits,
-                       B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
+                       B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream, io->num_live));
     else
-    TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
-                  io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream));
+    TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout || io->num_live ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
+                  io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream, io->num_live));
+    const bool any_rows = io->rows.greedy || io->rows.temperature || io->rows.top_k || io->rows.top_p || io->rows.rep_penalty || io->rows.seed;
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->top_p, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream, io->advance ? io->positions : nullptr,
-                 io->advance ? io->seq_lens : nullptr));      // positions / seq_lens += 1 inside the sampler launch
+                 io->advance ? io->seq_lens : nullptr,       // positions / seq_lens += 1 inside the sampler launch
+                 any_rows ? &io->rows : nullptr, io->num_live));
     return OMNI_OK;
 }
 
 // diagnostics: append N trivial launches after every layer phase to price a launch inside the real step
-static int g_extra_trivial = 0;
+OMNI_KNOB g_extra_trivial = 0;
 __global__ void dbg_nop_kernel(int32_t* p) { if (threadIdx.x == 9999) p[0] = 0; }
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
+#endif
 
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(omni_talker_mtp(t, io, stream));

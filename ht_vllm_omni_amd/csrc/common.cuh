@@ -12,6 +12,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 
+// Policy knobs: compile-time constants in libomni_talker.so; run-time variables with omni_debug_* setters only in
+// libomni_talker_debug.so (built with -DOMNI_DEBUG_HOOKS from the same sources + debug.hip; include/omni_talker_debug.h)
+#ifdef OMNI_DEBUG_HOOKS
+#define OMNI_KNOB static int
+#else
+#define OMNI_KNOB static constexpr int
+#endif
+
 // ---- error plumbing (host)
 void omni_set_error(const char* fmt, ...);
 #define OMNI_CHECK_ARG(cond, ...)                \

@@ -52,6 +52,7 @@ struct GemmArgs {
     int pstride;               // rows per slab (64; 128 for the code predictor's two-position pass)
     float mask_fill;           // logit written where mask[n] == 0 (-inf; the Omni talker writes -1e9)
     int counted;               // use the counted (unpredicated, 2-deep) schedule when K % 512 == 0
+    const int32_t* num_live;   // PRO_XNORM normed_out: rows >= *num_live are not written (NULL: all M rows)
 };
 
 // PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
@@ -280,11 +281,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     // re-reads the (L2-hot) fragments of k-steps x, x + gridDim.x, ... of its rows -- a second pass kept out of the main loop so
     // that its waits stay counted, and short (one k-step per wave at most) so that no workgroup column carries a tail
     if (PRO == 2 && a.normed_out != nullptr) {
+        const int nlive = a.num_live ? min(*a.num_live, a.M) - m_base : Mloc;    // h[t+1] of padding rows stays untouched
         for (int ks = blockIdx.x + wave * gridDim.x; ks < nsteps; ks += GEMM_WAVES * gridDim.x) {
             const u32x4 nw = ld16(a.norm_w + ks * 32 + 8 * q);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                if (i * 16 + r < Mloc) {
+                if (i * 16 + r < min(Mloc, nlive)) {
                     const u32x4 v = ld16(a.x + ((size_t)((m_base >> 4) + i) * nsteps + ks) * 512 + lane * 8);
                     *reinterpret_cast<u32x4*>(a.normed_out + (size_t)(m_base + i * 16 + r) * K + ks * 32 + 8 * q) = xnorm_frag(v, nw, rstd[i]);
                 }
@@ -382,9 +384,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 }
 
 
-static int g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1;
+OMNI_KNOB g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1;
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_counted = rn ? 0 : 1; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }   // rn != 0: generic schedule
 extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt; }   // 0 = policy default
+#endif
 
 template <int MT, int NT, int PRO, int EPI>
 static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
@@ -555,9 +559,10 @@ extern "C" int omni_gemm_resid(const void* x, int ldx, const void* w, const void
 // normed_out (row-major, optional) receives the normalised rows.  r and W fragment-major.
 int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
                  const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
-                 void* stream, float mask_fill) {
+                 void* stream, float mask_fill, const int32_t* num_live) {
     GemmArgs a{};
     a.mask_fill = mask_fill;
+    a.num_live = num_live;
     OMNI_CHECK_ARG(pstride == 64 || pstride == 128, "omni_gemm_xnorm: slab stride %d", pstride);
     a.pstride = pstride;
     a.counted = g_gemm_counted;

@@ -2,9 +2,13 @@
 #pragma once
 #include <stdint.h>
 
+#include "../../include/omni_talker.h"
+
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr /* per-row counters to bump */);
+             int out_stride, void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr /* per-row counters to bump */,
+             const omni_row_sampling* rows = nullptr /* per-row parameters override the scalars */,
+             const int32_t* num_live = nullptr /* device: rows >= *num_live are skipped entirely */);
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
             void* stream);
 // rows of `table` (ids == NULL: rows 0..T-1) -> fragment-major residual stream + slab 0 of the sum(r^2) partials;
@@ -17,7 +21,8 @@ int k_gemm_resid(const void* x, int ldx, const void* w, const void* bias, void* 
                  int* nparts_out, int M, int N, int K, int layout, int pstride, void* stream);
 int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps, void* normed_out,
                  const void* w, void* out, int M, int N, int K, int epilogue, const uint8_t* mask, int out_frag, int pstride,
-                 void* stream, float mask_fill = -__builtin_inff());
+                 void* stream, float mask_fill = -__builtin_inff(),
+                 const int32_t* num_live = nullptr /* device: normed_out rows >= *num_live are not written */);
 // omni_gemm_bf16_ex with the value written for masked-out logits
 int k_gemm_bf16_ex(const void* x, int ldx, const void* w, const void* bias, void* out, int M, int N, int K, int epilogue,
                    const uint8_t* mask, int layout, void* stream, float mask_fill);
@@ -31,18 +36,21 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part /* != NULL: gather_out fragment-major + sum-of-squares slab 0 */,
-                    void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr);
+                    void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr, const omni_row_sampling* rows = nullptr,
+                    const int32_t* num_live = nullptr);
 // rmsnorm with out-of-place residual update: residual_out = bf16(residual + delta) (may alias residual)
 // out (row-major) and/or out_frag (fragment-major, common.cuh frag_off) receive the normalised rows
 int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,
-              void* out_frag, int rows, int hidden, float eps, void* stream);
+              void* out_frag, int rows, int hidden, float eps, void* stream,
+              const int32_t* out_live = nullptr /* device: rows >= *out_live skip the row-major `out` write */);
 // internal attention entry points with a fragment-major output option
 int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
                         const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag,
-                        int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream);
+                        int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream,
+                        const int32_t* num_live = nullptr /* device: rows >= *num_live write no KV / slot */);
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,

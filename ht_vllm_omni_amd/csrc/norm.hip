@@ -11,7 +11,7 @@ template <int MAXV>   // MAXV = max 8-element vectors per lane (hidden <= 64*8*M
 __global__ __launch_bounds__(64 * NORM_ROWS_PER_BLOCK) void rmsnorm_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta, const uint16_t* residual, uint16_t* residual_out,
     const uint16_t* __restrict__ w, uint16_t* __restrict__ out, uint16_t* __restrict__ out_frag, int rows, int hidden,
-    float eps) {
+    float eps, const int32_t* __restrict__ out_live) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * NORM_ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -72,14 +72,14 @@ __global__ __launch_bounds__(64 * NORM_ROWS_PER_BLOCK) void rmsnorm_kernel(
                 o[j] = pack_bf2(lo, hi);
             }
             const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-            if (out) *reinterpret_cast<uint4*>(out + (size_t)row * hidden + vi * 8) = ov;
+            if (out && (!out_live || row < *out_live)) *reinterpret_cast<uint4*>(out + (size_t)row * hidden + vi * 8) = ov;
             if (out_frag) *reinterpret_cast<uint4*>(out_frag + frag_off(row, vi * 8, hidden)) = ov;
         }
     }
 }
 
 int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,
-              void* out_frag, int rows, int hidden, float eps, void* stream) {
+              void* out_frag, int rows, int hidden, float eps, void* stream, const int32_t* out_live) {
     OMNI_CHECK_ARG(w && (out || out_frag) && (x || residual), "omni_rmsnorm: null pointer");
     OMNI_CHECK_ARG(!out_frag || hidden % 32 == 0, "omni_rmsnorm: fragment-major output needs hidden %% 32 == 0");
     OMNI_CHECK_ARG(!(delta && !(residual && residual_out)), "omni_rmsnorm: delta needs residual in/out");
@@ -91,13 +91,13 @@ int k_rmsnorm(const void* x, const void* delta, const void* residual, void* resi
     const int nvec = hidden / 8;
     if (nvec <= 64 * 2)
         hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
-                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps);
+                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps, out_live);
     else if (nvec <= 64 * 4)
         hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
-                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps);
+                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps, out_live);
     else
         hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, st, (const uint16_t*)x, (const uint16_t*)delta,
-                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps);
+                           (const uint16_t*)residual, (uint16_t*)residual_out, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)out_frag, rows, hidden, eps, out_live);
     OMNI_CHECK_LAUNCH("omni_rmsnorm");
     return OMNI_OK;
 }

@@ -36,6 +36,7 @@ struct PAArgs {
     int kv_rep;                    // decode kernel: grid.x = kv_heads * kv_rep "virtual" kv heads of q_heads / (kv_heads * kv_rep)
                                    // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
     int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
+    const int32_t* num_live;       // fused decode: rows >= *num_live (padding of a graph bucket) write no KV / slot (NULL: all live)
 };
 
 template <int KV>
@@ -187,9 +188,12 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
             const int pos = a.positions[row];
             const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
             const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
-            if (vh == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+            // rows of a padded graph bucket past the live count may be live PREFILL rows of the persistent batch: they
+            // compute (results discarded) but leave the cache and the slot record alone
+            const bool live = !a.num_live || row < *a.num_live;
+            if (vh == 0 && lane == 0 && a.slot_out && live) a.slot_out[row] = slot;
             const size_t crow = (size_t)slot * kv_heads + kvh;
-            const bool kv_writer = vh % a.kv_rep == 0;      // the other groups of this kv head fold the same values
+            const bool kv_writer = live && vh % a.kv_rep == 0;      // the other groups of this kv head fold the same values
             float* kvs = lds + PA_WAVES * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
             float kx0, kx1;
             head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
     {   // new token: K (norm + rope) and V -> cache and LDS
         const int64_t slot = DENSE ? (int64_t)row * bs + pos : (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
-        if (hsel == 0 && lane == 0 && a.slot_out) a.slot_out[row] = slot;
+        const bool live = DENSE || !a.num_live || row < *a.num_live;      // DENSE = the code predictor's private cache
+        if (hsel == 0 && lane == 0 && a.slot_out && live) a.slot_out[row] = slot;
         const size_t crow = (size_t)slot * kv_heads + kvh;
         float kx0, kx1;
         head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
         const uint16_t v0 = vsrc[lane], v1 = vsrc[lane + 64];
         uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
         uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
-        if (kv_writer) {
+        if (kv_writer && live) {
             kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
             vd[lane] = v0; vd[lane + 64] = v1;
         }
@@ -655,8 +660,10 @@ extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_
     return (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
 }
 
-static int g_pa_int8_max_g = 2;
+OMNI_KNOB g_pa_int8_max_g = 2;
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_int8_max_g(int g) { g_pa_int8_max_g = g; }
+#endif
 template <int KV, bool FUSED>
 static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     PAArgs a = a_in;
@@ -722,18 +729,21 @@ extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const 
     return pa_dispatch(a, B, head_dim, kv_dtype, false, stream);
 }
 
-static int g_small_splitq = 1;
+OMNI_KNOB g_small_splitq = 1;
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_small_splitq(int on) { g_small_splitq = on; }
+#endif
 
 int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
                         const void* cos_sin, float eps, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, int dense_pos,
-                        void* stream) {
+                        void* stream, const int32_t* num_live) {
     PAArgs a{};
     a.out_frag = out_frag;
     a.dense_pos = dense_pos;
+    a.num_live = num_live;
     a.qkv = (const uint16_t*)qkv; a.qnorm_w = (const uint16_t*)qnorm_w; a.knorm_w = (const uint16_t*)knorm_w;
     a.positions = positions; a.cos_sin = (const uint16_t*)cos_sin; a.eps = eps; a.slot_out = slot_out;
     a.k_cache = k_cache; a.v_cache = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;

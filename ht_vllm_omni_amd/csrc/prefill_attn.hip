@@ -221,8 +221,10 @@ static int pf_launch_g(const PFArgs& a, int G, hipStream_t st) {
     return OMNI_OK;
 }
 
-static int g_prefill_mfma = 1;
+OMNI_KNOB g_prefill_mfma = 1;
+#ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_prefill_mfma(int on) { g_prefill_mfma = on; }   // A/B against the per-token VALU path
+#endif
 
 bool k_prefill_mfma_supported(int q_heads, int kv_heads, int head_dim) {
     if (!g_prefill_mfma || head_dim != 128 || kv_heads <= 0 || q_heads % kv_heads) return false;

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              int inc_steps, int32_t* __restrict__ out_ids, int out_stride,
                                                              const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim,
                                                              float* __restrict__ gpart, int32_t* __restrict__ inc0,
-                                                             int32_t* __restrict__ inc1) {
+                                                             int32_t* __restrict__ inc1, const omni_row_sampling rs,
+                                                             const int32_t* __restrict__ num_live) {
     __shared__ float row[NPT * SMP_THREADS];       // LDS copy of the row: radix fallback only
     __shared__ uint32_t hist[4][256];              // one histogram per radix pass, cleared once
     __shared__ float sval[SMP_THREADS / 64];
@@ -52,6 +53,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     __shared__ uint32_t sel_prefix[4], sel_k[4];   // per pass: no barrier needed before the next pass overwrites
     __shared__ uint32_t wtot[4][SMP_THREADS / 64];
     const int b = blockIdx.x;
+    // rows past the live count of a padded graph bucket leave no trace (block-uniform exit, before any barrier)
+    if (num_live && b >= *num_live) return;
+    // per-request sampling parameters (V/worker/gpu_model_runner.py:315-319): a NULL array = the launch-wide scalar
+    if (rs.greedy) greedy = rs.greedy[b];
+    if (rs.temperature) temperature = rs.temperature[b];
+    if (rs.top_k) top_k = rs.top_k[b];
+    if (rs.top_p) top_p = rs.top_p[b];
+    if (rs.rep_penalty) rep_penalty = rs.rep_penalty[b];
+    if (rs.seed) seed = rs.seed[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* src = logits + (size_t)b * ld;
     uint8_t* sn = seen ? seen + (size_t)b * V : nullptr;
@@ -324,12 +334,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
 int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
-                    int gather_dim, float* gather_part, void* stream, int32_t* inc0, int32_t* inc1) {
+                    int gather_dim, float* gather_part, void* stream, int32_t* inc0, int32_t* inc1, const omni_row_sampling* rows,
+                    const int32_t* num_live) {
     OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
+    const omni_row_sampling rs = rows ? *rows : omni_row_sampling{};
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
-    OMNI_CHECK_ARG(greedy || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
-    OMNI_CHECK_ARG(rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
-    OMNI_CHECK_ARG(greedy || !(top_p > 0.f && top_p < 1.f) || (top_k > 0 && top_k <= SMP_PCAP),
+    // scalars are validated when they are the ones in use; per-row arrays are the caller's contract (device memory)
+    OMNI_CHECK_ARG(greedy || rs.greedy || rs.temperature || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
+    OMNI_CHECK_ARG(rs.rep_penalty || rep_penalty > 0.f, "omni_sample: rep_penalty must be > 0");
+    OMNI_CHECK_ARG(greedy || rs.greedy || rs.top_p || rs.top_k || !(top_p > 0.f && top_p < 1.f) || (top_k > 0 && top_k <= SMP_PCAP),
                    "omni_sample: top_p needs 0 < top_k <= %d (got top_k=%d)", SMP_PCAP, top_k);
     OMNI_CHECK_ARG(!gather_table || (gather_out && gather_dim % 8 == 0), "omni_sample: bad gather arguments");
     OMNI_CHECK_ARG(!gather_part || (gather_table && gather_dim % 32 == 0), "omni_sample: bad fragment-major gather arguments");
@@ -337,7 +350,8 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
 #define SMP_LAUNCH(NPT_)                                                                                                  \
     hipLaunchKernelGGL(sample_kernel<NPT_>, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,     \
                        temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids, \
-                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part, inc0, inc1)
+                       out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part, inc0, inc1, rs, \
+                       num_live)
     if (V <= 8 * SMP_THREADS) SMP_LAUNCH(8);
     else if (V <= 12 * SMP_THREADS) SMP_LAUNCH(12);
     else SMP_LAUNCH(32);
@@ -348,9 +362,9 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
 
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream, int32_t* inc0, int32_t* inc1) {
+             int out_stride, void* stream, int32_t* inc0, int32_t* inc1, const omni_row_sampling* rows, const int32_t* num_live) {
     return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
-                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream, inc0, inc1);
+                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream, inc0, inc1, rows, num_live);
 }
 
 extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,
@@ -358,4 +372,12 @@ extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy
                            int inc_steps, int32_t* out_ids, void* stream) {
     return k_sample(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
                     inc_steps, out_ids, 1, stream);
+}
+
+extern "C" int omni_sample_rows(const float* logits, int ld, int B, int V, const omni_row_sampling* rows, uint8_t* seen,
+                                int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids, void* stream) {
+    OMNI_CHECK_ARG(rows && rows->greedy && rows->temperature && rows->top_k && rows->top_p && rows->rep_penalty && rows->seed,
+                   "omni_sample_rows: every per-row array is required");
+    return k_sample(logits, ld, B, V, 1, 1.0f, 0, 1.0f, 1.0f, seen, 0, steps, step_mul, step_add, inc_steps, out_ids, 1, stream,
+                    nullptr, nullptr, rows, nullptr);
 }

@@ -287,6 +287,18 @@ class TalkerEngine:
         self.logits = z(Bm, d.vocab, dt=torch.float32)
         self.seen = z(Bm, d.vocab, dt=torch.uint8)
         self.steps = z(Bm, dt=torch.int32)
+        # per-request sampling parameters as per-row device arrays read inside the captured sampler launch
+        # (V/worker/gpu_model_runner.py:315-319: one SamplingParams + generator per request): a graph serves any mix
+        self.row_greedy = torch.ones(Bm, dtype=torch.int32, device=dev)
+        self.row_temperature = torch.ones(Bm, dtype=torch.float32, device=dev)
+        self.row_top_k = z(Bm, dt=torch.int32)
+        self.row_top_p = torch.ones(Bm, dtype=torch.float32, device=dev)
+        self.row_rep_penalty = torch.ones(Bm, dtype=torch.float32, device=dev)
+        self.row_seed = z(Bm, dt=torch.int32)               # uint32 bit patterns
+        # live decode rows of the step: rows [num_live, B) of a padded graph bucket are inert (no KV write / sample / advance)
+        self.num_live = torch.full((1,), Bm, dtype=torch.int32, device=dev)
+        # launch-wide scalars: the code predictor's model-level parameters (qwen3_tts_talker.py:1620-1627); the layer-0
+        # entries mirror what set_sampling last broadcast into the row arrays
         self.sampling = dict(greedy=1, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seed=0, cp_greedy=1,
                              cp_temperature=0.9, cp_top_k=50, cp_top_p=1.0)
         self._attn_out = self._scratch_view(self.lib.omni_talker_attn_out(self.handle), Bm * H).view(Bm, H)
@@ -305,8 +317,36 @@ class TalkerEngine:
         self._sub = []
 
     # ------------------------------------------------------------------ step
+    ROW_KEYS = ("greedy", "temperature", "top_k", "top_p", "rep_penalty", "seed")
+
     def set_sampling(self, **kw) -> None:
+        """Layer-0 parameters are broadcast to every row's device entry; cp_* are the launch-wide code-predictor scalars
+        (baked into a captured graph: change them before capture)."""
         self.sampling.update(kw)
+        for k in self.ROW_KEYS:
+            if k in kw:
+                self._row_fill(k, slice(None), kw[k])
+
+    def _row_fill(self, key: str, rows, value) -> None:
+        buf = getattr(self, "row_" + key)
+        if key == "seed":
+            value = int(value) & 0xFFFFFFFF
+            value = value - (1 << 32) if value >= (1 << 31) else value      # uint32 bit pattern in an int32 tensor
+        elif key == "greedy":
+            value = int(bool(value))
+        buf[rows] = value
+
+    def set_row_sampling(self, row: int, *, greedy, temperature, top_k, top_p, rep_penalty, seed) -> None:
+        """One request's SamplingParams into its batch row (runner: on admission / row moves ride with _ROW_BUFFERS)."""
+        if not greedy and not temperature > 0.0:
+            raise ValueError("temperature must be > 0 when sampling")
+        if 0.0 < top_p < 1.0 and not 0 < top_k <= 1024:
+            raise ValueError("top_p < 1 needs 0 < top_k <= 1024 on this path")
+        if not rep_penalty > 0.0:
+            raise ValueError("repetition_penalty must be > 0")
+        for k, v in (("greedy", greedy), ("temperature", temperature if temperature > 0 else 1.0), ("top_k", top_k), ("top_p", top_p),
+                     ("rep_penalty", rep_penalty), ("seed", seed)):
+            self._row_fill(k, row, v)
 
     def _io(self, B: int, advance: bool, row0: int = 0) -> L.StepIO:
         io = L.StepIO()
@@ -315,12 +355,16 @@ class TalkerEngine:
                   "inputs_embeds", "audio_codes", "logits", "steps"):
             setattr(io, n, getattr(self, n)[row0:].data_ptr())
         s = self.sampling
-        io.seen = self.seen[row0:].data_ptr() if s["rep_penalty"] != 1.0 else None
+        io.seen = self.seen[row0:].data_ptr()       # always: a row's repetition penalty may differ from its neighbours'
         io.greedy, io.temperature, io.top_k = int(s["greedy"]), float(s["temperature"]), int(s["top_k"])
         io.rep_penalty, io.seed = float(s["rep_penalty"]), int(s["seed"]) & 0xFFFFFFFF
         io.cp_greedy, io.cp_temperature, io.cp_top_k = int(s["cp_greedy"]), float(s["cp_temperature"]), int(s["cp_top_k"])
         io.advance = int(advance)
         io.top_p, io.cp_top_p = float(s.get("top_p", 1.0)), float(s.get("cp_top_p", 1.0))
+        for k in self.ROW_KEYS:
+            setattr(io.rows, k, getattr(self, "row_" + k)[row0:].data_ptr())
+        # sub-batch branches see their own row range: their live count is the bucket (only the runner path pads buckets)
+        io.num_live = self.num_live.data_ptr() if row0 == 0 and self.n_sub == 1 else None
         return io
 
     def decode_step(self, B: int, advance: bool = True) -> None:
@@ -492,6 +536,11 @@ class TalkerEngine:
         """Sampler on arbitrary logits rows (first token after prefill); marks `seen`, increments `steps`."""
         return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, top_p=top_p, rep_penalty=rep_penalty, seen=seen,
                           seed=seed, steps=steps, inc_steps=steps is not None)
+
+    def sample_rows(self, logits: torch.Tensor, rows: torch.Tensor, *, seen=None, steps=None) -> torch.Tensor:
+        """First token after prefill for batch rows `rows` (int64 device indices), each with its own request's parameters."""
+        par = {k: getattr(self, "row_" + k).index_select(0, rows) for k in self.ROW_KEYS}
+        return ops.sample_rows(logits, par, seen=seen, steps=steps, inc_steps=steps is not None)
 
     def code_predictor(self, layer0_ids, layer0_embed, last_hidden, *, greedy=True, temperature=0.9, top_k=50, top_p=1.0, seed=0,
                        steps=None, return_logits=False):

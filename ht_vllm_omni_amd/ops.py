@@ -244,6 +244,19 @@ def sample(logits, *, greedy, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1
     return out
 
 
+def sample_rows(logits, rows: dict, *, seen=None, steps=None, step_mul=1, step_add=0, inc_steps=False):
+    """Sampler with every parameter per row: rows = {greedy int32, temperature f32, top_k int32, top_p f32,
+    rep_penalty f32, seed uint32-as-int32/int64} device tensors [B] (one SamplingParams per request)."""
+    B, V = logits.shape
+    ts = {k: rows[k] for k in ("greedy", "temperature", "top_k", "top_p", "rep_penalty", "seed")}
+    _chk_dev(logits, seen, steps, *ts.values())
+    rs = L.RowSampling(*[t.data_ptr() for t in ts.values()])
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    L.check(L.load().omni_sample_rows(L.ptr(logits), logits.stride(0), B, V, C.byref(rs), L.ptr(seen), L.ptr(steps), step_mul,
+                                      step_add, int(inc_steps), L.ptr(out), L.current_stream()), "omni_sample_rows")
+    return out
+
+
 def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
     """Host-built cos/sin table, bf16 [max_pos][2][head_dim/2]: fp32 cos/sin cast to bf16, the
     HF / reference numerics (qwen3_tts_code_predictor_vllm.py:80-93)."""

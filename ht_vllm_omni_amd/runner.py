@@ -17,6 +17,7 @@ are inert.
 from __future__ import annotations
 
 import logging
+import zlib
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -62,7 +63,13 @@ class _StepState:
     prefill_spans: dict[int, tuple[int, int, torch.Tensor]]  # row -> (start, n, hidden[n,H])
 
 
-_ROW_BUFFERS = ("input_ids", "positions", "seq_lens", "block_table", "last_hidden", "seen", "steps")
+def request_seed(req_id: str, sp: SamplingParams) -> int:
+    """RNG key of a request: its own seed, else one derived from the request id (distinct noise per unseeded request)."""
+    return int(sp.seed) & 0xFFFFFFFF if sp.seed is not None else (zlib.crc32(req_id.encode()) ^ 0x9E3779B9) & 0xFFFFFFFF
+
+
+_ROW_BUFFERS = ("input_ids", "positions", "seq_lens", "block_table", "last_hidden", "seen", "steps",
+                "row_greedy", "row_temperature", "row_top_k", "row_top_p", "row_rep_penalty", "row_seed")
 
 
 class MI355XARModelRunner:
@@ -85,6 +92,7 @@ class MI355XARModelRunner:
         self.graphs: dict[int, Any] = {}
         self.engine_output_type = engine_output_type
         self.cudagraph_stats = {"replays": 0, "eager_steps": 0}
+        self.default_sampling = SamplingParams()        # requests that carry none (worker: the stage's default_sampling_params)
         # per-step text rows as ONE device gather: every request's queue (tailing_text_hidden rows, then its tts_pad row)
         # is a segment of a table rebuilt only when the batch membership / row order changes; row r of a step reads
         # table[off[r] + min(pos[r], len[r])] (index len[r] = the pad row)
@@ -181,7 +189,7 @@ class MI355XARModelRunner:
             if pad is None:
                 raise ValueError(f"request {nr.req_id}: missing tts_pad_embed (prefill must initialise it)")
             st = RequestState(req_id=nr.req_id, prompt_embeds=pe.to(BF16).cpu().contiguous(),
-                              block_ids=list(nr.block_ids[0]), sampling=nr.sampling_params or SamplingParams(),
+                              block_ids=list(nr.block_ids[0]), sampling=nr.sampling_params or self.default_sampling,
                               num_computed=int(nr.num_computed_tokens),
                               tail=None if tail is None else tail.to(device=dev, dtype=BF16).reshape(-1, self.d.hidden),
                               tts_pad=pad.to(device=dev, dtype=BF16).reshape(-1), info=info)
@@ -189,6 +197,13 @@ class MI355XARModelRunner:
             r = len(self.rows)
             self.rows.append(nr.req_id)
             self._reset_row(r)
+            sp = st.sampling
+            # vLLM: a seeded request owns a torch.Generator seeded with it, an unseeded one draws from the global stream
+            # (gpu_model_runner.py:315-319) -- here every request gets its own counter-RNG key: its seed, or one derived
+            # from the request id, so unseeded neighbours never share noise
+            seed = request_seed(nr.req_id, sp)
+            e.set_row_sampling(r, greedy=sp.greedy, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
+                               rep_penalty=sp.repetition_penalty, seed=seed)
             e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=dev)
         # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489)
         c = so.scheduled_cached_reqs
@@ -287,24 +302,19 @@ class MI355XARModelRunner:
             idx = self._tt_off[:nd] + np.minimum(self._tt_pos[:nd], self._tt_len[:nd])
             self._tt_pos[:nd] += 1
             torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
-            self._apply_sampling(self.requests[self.rows[0]].sampling)
             self._run_decode(nd)
         self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans)
         return None
 
-    def _apply_sampling(self, sp: SamplingParams) -> None:
-        self.engine.set_sampling(greedy=int(sp.greedy), temperature=sp.temperature or 1.0, top_k=sp.top_k,
-                                 top_p=sp.top_p, rep_penalty=sp.repetition_penalty, seed=sp.seed or 0)
-
     def _sample_prefill(self, rows: list[int], logits: torch.Tensor) -> torch.Tensor:
+        """First token of the requests whose prompt completed this step, each with ITS request's sampling parameters
+        (the per-row device arrays the decode sampler reads)."""
         e = self.engine
-        sp = self.requests[self.rows[rows[0]]].sampling
         idx = torch.as_tensor(rows, device=logits.device)
         seen = e.seen.index_select(0, idx)
         seen[:, self.d.codec_pad_id] = 1       # prompt ids are codec_pad placeholders (talker.py:603-605)
         steps = torch.zeros(len(rows), dtype=torch.int32, device=logits.device)
-        ids = e.sample(logits, greedy=sp.greedy, temperature=sp.temperature or 1.0, top_k=sp.top_k,
-                       top_p=sp.top_p, rep_penalty=sp.repetition_penalty, seen=seen, seed=sp.seed or 0, steps=steps)
+        ids = e.sample_rows(logits, idx, seen=seen, steps=steps)
         e.seen[idx] = seen
         e.steps[idx] = steps
         return ids
@@ -323,16 +333,18 @@ class MI355XARModelRunner:
         sizes = sizes or sorted({self._bucket(n) for n in range(1, self.max_num_seqs + 1)})
         self.engine.decode_step(min(sizes), advance=False)        # one eager pass loads code objects
         torch.cuda.synchronize()
-        self._graph_sampling = dict(self.engine.sampling)      # sampling params are baked into the captured launches
-        for b in sizes:
+        for b in sizes:      # (layer-0 sampling parameters are per-row device arrays: nothing of them is baked in)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.engine.decode_step(b)
             self.graphs[b] = g
 
     def _run_decode(self, nd: int) -> None:
+        # rows [nd, bucket) of the padded graph may be live PREFILL rows of the persistent batch (decode-first order):
+        # the device-side live count keeps the step off their KV blocks, ids, hidden state and counters
+        self.engine.num_live.fill_(nd)
         g = self.graphs.get(self._bucket(nd)) if self.use_graphs else None
-        if g is not None and self.engine.sampling == getattr(self, "_graph_sampling", None):
+        if g is not None:
             g.replay()
             self.cudagraph_stats["replays"] += 1
         else:

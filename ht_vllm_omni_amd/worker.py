@@ -109,11 +109,10 @@ class MI355XARWorker:
                                                 use_graphs=not getattr(cfg, "enforce_eager", False), prompt_builder=builder)
 
     def compile_or_warm_up_model(self) -> None:
-        # the stage's default_sampling_params (stage_configs/qwen3_tts.yaml:27-34) are baked into the captured step;
-        # a request with other parameters falls back to eager launches
+        # sampling parameters are per-request device rows read inside the captured step (a request without any gets the
+        # stage's default_sampling_params, stage_configs/qwen3_tts.yaml:27-34, on admission): nothing to bake in here
         from .payloads import SamplingParams
-        sp = getattr(self.vllm_config, "default_sampling_params", None) or SamplingParams()
-        self.model_runner._apply_sampling(sp)
+        self.model_runner.default_sampling = getattr(self.vllm_config, "default_sampling_params", None) or SamplingParams()
         self.model_runner.capture_graphs()
 
     # ---- step (executor RPC targets)

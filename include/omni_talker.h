@@ -203,6 +203,24 @@ int omni_sample(const float* logits, int ld, int B, int V, int greedy, float tem
                 float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul,
                 int step_add, int inc_steps, int32_t* out_ids, void* stream);
 
+/* Per-request sampling parameters as per-row device arrays [B] (vLLM keeps one SamplingParams and one seeded
+ * torch.Generator per request: V/worker/gpu_model_runner.py:315-319, sampler call gpu_ar_model_runner.py:455).  A NULL
+ * member falls back to the launch-wide scalar next to it; the arrays are read inside the (graph-captured) sampler
+ * launch, so one captured step serves any mix of requests.  greedy != 0 = argmax (temperature 0 in vLLM terms);
+ * top_p in (0,1) needs 0 < top_k <= 1024 on that row (the host validates at admission). */
+typedef struct omni_row_sampling {
+    const int32_t* greedy;
+    const float* temperature;
+    const int32_t* top_k;
+    const float* top_p;
+    const float* rep_penalty;
+    const uint32_t* seed;
+} omni_row_sampling;
+
+/* omni_sample with every parameter per row (all six arrays required). */
+int omni_sample_rows(const float* logits, int ld, int B, int V, const omni_row_sampling* rows, uint8_t* seen,
+                     int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids, void* stream);
+
 /* ------------------------------------------------------------------ talker engine */
 
 typedef struct omni_layer_weights {
@@ -300,6 +318,11 @@ typedef struct omni_step_io {
     float cp_temperature; int cp_top_k;
     int advance;                  /* !=0: positions/seq_lens += 1 after the step (on device)*/
     float top_p, cp_top_p;        /* nucleus cut after top-k (>= 1 or <= 0: off)            */
+    /* ABI v2 */
+    const int32_t* num_live;      /* device int32 or NULL (= B): rows [*num_live, B) of a padded graph bucket are INERT --
+                                     no KV-cache write, no slot_mapping / last_hidden / input_ids / seen / steps / positions /
+                                     seq_lens update (they may hold live prefill rows of the persistent batch)            */
+    omni_row_sampling rows;       /* layer-0 sampler parameters per row; rows.seed also keys the code predictor's noise    */
 } omni_step_io;
 
 /* The four phases of one decode step.  With TP > 1 the host

@@ -1,4 +1,4 @@
-/* Diagnostic hooks exported by libomni_talker.so next to the ABI of omni_talker.h.  NOT part of the drop-in boundary:
+/* Diagnostic hooks exported ONLY by libomni_talker_debug.so (same sources built with -DOMNI_DEBUG_HOOKS + csrc/debug.hip).  NOT part of the drop-in boundary:
  * they exist so that scripts/ (tile sweeps, same-box A/B runs, launch-cost probes) can flip a policy at run time.
  * Process-global, not thread-safe, defaults = the shipped policy. */
 #pragma once

@@ -460,8 +460,9 @@ class TalkerOracle:
             all_logits.append(logits)
             if do_sample and temperature > 0:
                 st = step if hasattr(step, "__len__") else [step] * B
+                sd = seed if hasattr(seed, "__len__") else [seed] * B      # per-request RNG keys (one generator per request)
                 nxt = torch.tensor([sample_row(logits[b], greedy=False, temperature=max(temperature, 1e-6),
-                                               top_k=top_k, top_p=top_p, seed=seed, step=int(st[b]) * Q + g) for b in range(B)])
+                                               top_k=top_k, top_p=top_p, seed=int(sd[b]), step=int(st[b]) * Q + g) for b in range(B)])
             else:
                 nxt = logits.argmax(-1)
             codes[:, g] = nxt
@@ -505,11 +506,14 @@ class TalkerOracle:
         logits = self.compute_logits(hidden)
         sampled = []
         for b, s in enumerate(states):
-            kw = dict(sampling or {})
+            # `sampling`: one dict for the batch, or one per request (vLLM samples per request, gpu_model_runner.py:315-319);
+            # a per-request dict may carry its own "greedy"
+            kw = dict(sampling[b]) if isinstance(sampling, (list, tuple)) else dict(sampling or {})
+            g_b = bool(kw.pop("greedy", greedy))
             seen = None
             if kw.get("rep_penalty", 1.0) != 1.0:
                 seen = [d.codec_pad_id] * s.prompt_len + s.out_ids   # prompt ids are pad placeholders (talker.py:603-605)
-            tok = sample_row(logits[b], greedy=greedy, seen_ids=seen, step=len(s.out_ids), **kw)
+            tok = sample_row(logits[b], greedy=g_b, seen_ids=seen, step=len(s.out_ids), **kw)
             sampled.append(tok)
             s.seq_len += 1
             s.last_id = tok
@@ -535,10 +539,11 @@ class TalkerOracle:
         logits = self.compute_logits(hl)
         out = []
         for b, s in enumerate(states):
-            kw = dict(sampling or {})
+            kw = dict(sampling[b]) if isinstance(sampling, (list, tuple)) else dict(sampling or {})
+            g_b = bool(kw.pop("greedy", greedy))
             s.prompt_len = seq_after[b]
             seen = [d.codec_pad_id] * s.prompt_len if kw.get("rep_penalty", 1.0) != 1.0 else None
-            tok = sample_row(logits[b], greedy=greedy, seen_ids=seen, step=0, **kw)
+            tok = sample_row(logits[b], greedy=g_b, seen_ids=seen, step=0, **kw)
             s.seq_len = seq_after[b]
             s.last_id = tok
             s.last_hidden = hl[b]

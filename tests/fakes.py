@@ -24,6 +24,13 @@ class FakeEngine:
         self.logits = z(max_batch, d.vocab)
         self.seen = z(max_batch, d.vocab, dtype=torch.uint8)
         self.steps = z(max_batch, dtype=torch.int32)
+        self.row_greedy = torch.ones(max_batch, dtype=torch.int32)
+        self.row_temperature = torch.ones(max_batch)
+        self.row_top_k = z(max_batch, dtype=torch.int32)
+        self.row_top_p = torch.ones(max_batch)
+        self.row_rep_penalty = torch.ones(max_batch)
+        self.row_seed = z(max_batch, dtype=torch.int32)
+        self.num_live = torch.full((1,), max_batch, dtype=torch.int32)
         self.kv_caches = [torch.arange(2 * num_blocks * block_size * d.kv_heads * 4, dtype=torch.float32)
                           .reshape(2, num_blocks, block_size, d.kv_heads, 4) + 1000 * l for l in range(d.layers)]
         self.sampling = {}
@@ -31,6 +38,18 @@ class FakeEngine:
 
     def set_sampling(self, **kw):
         self.sampling.update(kw)
+
+    def set_row_sampling(self, row, *, greedy, temperature, top_k, top_p, rep_penalty, seed):
+        if 0.0 < top_p < 1.0 and not 0 < top_k <= 1024:
+            raise ValueError("top_p < 1 needs 0 < top_k <= 1024 on this path")
+        self.row_greedy[row], self.row_temperature[row], self.row_top_k[row] = int(greedy), temperature or 1.0, top_k
+        self.row_top_p[row], self.row_rep_penalty[row] = top_p, rep_penalty
+        seed &= 0xFFFFFFFF
+        self.row_seed[row] = seed - (1 << 32) if seed >= (1 << 31) else seed
+
+    def sample_rows(self, logits, rows, *, seen=None, steps=None):
+        self.calls.append(("sample_rows", rows.tolist(), self.row_seed[rows].tolist(), self.row_top_k[rows].tolist()))
+        return self.sample(logits, greedy=True, seen=seen, steps=steps)
 
     def prefill(self, x, positions, req_of_tok, slot_mapping, block_table=None):
         self.calls.append(("prefill", x.shape[0], positions.tolist(), req_of_tok.tolist(), slot_mapping.tolist()))
@@ -51,6 +70,7 @@ class FakeEngine:
         return ids
 
     def decode_step(self, B, advance=True):
+        B = min(B, int(self.num_live))          # the native step's contract: rows past the live count are inert
         self.calls.append(("decode", B, self.input_ids[:B].tolist(), self.positions[:B].tolist()))
         self.inputs_embeds[:B] = self.text_step[:B]
         self.audio_codes[:B] = self.input_ids[:B].long()[:, None] + torch.arange(self.d.num_code_groups)[None]

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in omni_talker.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.omni_abi_version() == 1
+    assert lib.omni_abi_version() == 2
     assert lib.omni_last_error() is not None
 
 
@@ -74,11 +74,32 @@ def test_engine_refuses_without_gpu():
 
 
 def test_debug_header_symbols_exported():
-    """include/omni_talker_debug.h (diagnostic hooks, outside the boundary) matches what the library exports."""
+    """include/omni_talker_debug.h (diagnostic hooks, outside the boundary) = what libomni_talker_debug.so exports on top
+    of the full ABI; the product library exports none of them."""
     from ht_vllm_omni_amd import _lib
-    lib = _lib.load()
+    prod = _lib.load()
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "omni_talker_debug.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(omni_debug_[a-z0-9_]+)\s*\(", txt)))
     assert len(names) >= 6
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in omni_talker_debug.h but not exported"
+    with _lib.debug_library() as lib:
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in omni_talker_debug.h but not exported by the debug library"
+        for n in header_functions():
+            assert hasattr(lib, n), f"{n} missing from the debug library"
+    assert _lib.load() is prod
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    assert "omni_debug_" not in out, "diagnostic hooks leaked into the product library"
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """_lib refuses a library whose digest stamp does not match csrc/ (the git-ignored .so may be older)."""
+    from ht_vllm_omni_amd import _lib
+    stamp = _lib.LIB_PATH + ".digest"
+    good = open(stamp).read()
+    try:
+        open(stamp, "w").write("0" * 64 + "\n")
+        with pytest.raises(_lib.OmniError, match="stale"):
+            _lib._open(_lib.LIB_PATH, False)
+    finally:
+        open(stamp, "w").write(good)
+    _lib._open(_lib.LIB_PATH, False)

@@ -29,3 +29,22 @@ def test_bench_line_has_the_contract_fields():
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["unit"] == j["unit"]
+
+
+def test_bench_gpus_n_launches_n_ranks_or_fails_loudly():
+    """VERDICT r1 #4a / ADVICE r1: `python bench.py --gpus N` starts N ranks itself (children of a parent that has made no
+    GPU call) and never reports a 1-rank number under N; a WORLD_SIZE that disagrees with --gpus is refused.  No GPU here:
+    the children die at torch.cuda.set_device and the parent must exit non-zero without printing a JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert "self-launch:" in r.stderr and "--nproc-per-node=2" in r.stderr and "torch.distributed.run" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()

@@ -99,8 +99,6 @@ def test_code_predictor_pair_pass_matches_sequential_and_oracle(model, B):
     position-1 K and V rows in the predictor's cache are bit-identical, the first group's logits are within the same bound."""
     import ctypes as C
     from ht_vllm_omni_amd import _lib as L
-    lib = L.load()
-    lib.omni_debug_cp_pair01.argtypes = [C.c_int]; lib.omni_debug_cp_pair01.restype = None
     d = get_dims(model).with_(layers=1, cp_layers=3, max_model_len=256)
     w = make_weights(d, seed=21, std=0.02)
     g = torch.Generator().manual_seed(B)
@@ -110,17 +108,19 @@ def test_code_predictor_pair_pass_matches_sequential_and_oracle(model, B):
     orc = O.TalkerOracle(d, w)
     ref_codes, ref_lg = orc.code_predictor(code0, e0, lh, do_sample=False, return_logits=True)
     res = {}
-    try:
-        for on in (0, 1):
-            lib.omni_debug_cp_pair01(on)
-            eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
-            for ids in (code0.to(torch.int32).cuda(), None):          # folded e0 table (step path) / explicit embedding (parity entry)
-                codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
-                res[on] = (codes.cpu(), lg.cpu())
-            assert_e2e_close(res[on][1][:, 0], ref_lg[:, 0], what=f"pair={on} logits, group 1")      # 3 layers: ~2.5e-3 either way
-            assert (res[on][0][:, 1] == ref_codes[:, 1]).float().mean().item() >= 0.9
-    finally:
-        lib.omni_debug_cp_pair01(1)
+    with L.debug_library() as lib:      # run-time schedule knob: libomni_talker_debug.so only
+        lib.omni_debug_cp_pair01.argtypes = [C.c_int]; lib.omni_debug_cp_pair01.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_cp_pair01(on)
+                eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
+                for ids in (code0.to(torch.int32).cuda(), None):          # folded e0 table (step path) / explicit embedding (parity entry)
+                    codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
+                    res[on] = (codes.cpu(), lg.cpu())
+                assert_e2e_close(res[on][1][:, 0], ref_lg[:, 0], what=f"pair={on} logits, group 1")      # 3 layers: ~2.5e-3 either way
+                assert (res[on][0][:, 1] == ref_codes[:, 1]).float().mean().item() >= 0.9
+        finally:
+            lib.omni_debug_cp_pair01(1)
     # same library, two schedules: group-1 logits agree to rounding (the pair kernel sums the two scores in another order)
     assert_e2e_close(res[1][1][:, 0], res[0][1][:, 0], what="pair vs sequential logits, group 1")
     err = [(res[on][1][:, 0].float() - ref_lg[:, 0].float()).abs().mean().item() for on in (0, 1)]

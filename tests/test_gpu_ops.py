@@ -171,37 +171,37 @@ def test_gemm_silu_interleaved_gate_up(ops, M, inter, K):
     import ctypes as C
     from ht_vllm_omni_amd import _lib as L
     from ht_vllm_omni_amd.engine import frag_shuffle, gu8_shuffle
-    lib = L.load()
-    lib.omni_debug_tile.argtypes = [C.c_int, C.c_int]; lib.omni_debug_tile.restype = None
-    g = torch.Generator().manual_seed(M + inter + K)
-    x, w = _rand(g, M, K), _rand(g, 2 * inter, K, scale=0.05)
-    ref = ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_SILU_MUL)
-    gu = O.linear(x, w)
-    assert_bf16_close(ref, O.silu_mul(gu[:, :inter], gu[:, inter:]), ulps=2, max_mismatch=0.03, what="paired silu*mul")
-    w8 = gu8_shuffle(w).cuda()
-    Mp = (M + 15) // 16 * 16
-    xp = torch.zeros(Mp, K, dtype=BF16)
-    xp[:M] = x
-    xf = frag_shuffle(xp).cuda()
-    nw = torch.ones(K, dtype=BF16, device="cuda")
-    # residual-stream form of the same rows: r = x, sum(r^2) in one slab, norm weight 1 (rstd != 1: compare with the paired xnorm)
-    part = torch.zeros(K // 16, 64, device="cuda")
-    part[0, :M] = x.float().pow(2).sum(-1).cuda()
-    ref_x = ops.gemm_xnorm(xf, part, K // 16, nw, frag_shuffle(w).cuda(), 1e-6, M=M, epilogue=L.EPI_SILU_MUL)
-    try:
-        for nt in (0, 2, 3, 4):
-            if nt and (inter // 8) % nt:
-                continue
-            for mt in ((0,) if nt == 0 else (1, 2, 4)):
-                lib.omni_debug_tile(nt, mt)
-                out = ops.gemm(x.cuda(), w8, epilogue=L.EPI_SILU_MUL_GU8, layout=L.LAYOUT_W_FRAG)
-                assert torch.equal(out, ref), (nt, mt)
-                out = ops.gemm(xf, w8, epilogue=L.EPI_SILU_MUL_GU8, layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG, M=M)
-                assert torch.equal(out, ref), (nt, mt, "x frag")
-                out = ops.gemm_xnorm(xf, part, K // 16, nw, w8, 1e-6, M=M, epilogue=L.EPI_SILU_MUL_GU8)
-                assert torch.equal(out, ref_x), (nt, mt, "xnorm")
-    finally:
-        lib.omni_debug_tile(0, 0)
+    with L.debug_library() as lib:      # libomni_talker_debug.so: the same sources with run-time tile knobs
+        lib.omni_debug_tile.argtypes = [C.c_int, C.c_int]; lib.omni_debug_tile.restype = None
+        g = torch.Generator().manual_seed(M + inter + K)
+        x, w = _rand(g, M, K), _rand(g, 2 * inter, K, scale=0.05)
+        ref = ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_SILU_MUL)
+        gu = O.linear(x, w)
+        assert_bf16_close(ref, O.silu_mul(gu[:, :inter], gu[:, inter:]), ulps=2, max_mismatch=0.03, what="paired silu*mul")
+        w8 = gu8_shuffle(w).cuda()
+        Mp = (M + 15) // 16 * 16
+        xp = torch.zeros(Mp, K, dtype=BF16)
+        xp[:M] = x
+        xf = frag_shuffle(xp).cuda()
+        nw = torch.ones(K, dtype=BF16, device="cuda")
+        # residual-stream form of the same rows: r = x, sum(r^2) in one slab, norm weight 1 (rstd != 1: compare with the paired xnorm)
+        part = torch.zeros(K // 16, 64, device="cuda")
+        part[0, :M] = x.float().pow(2).sum(-1).cuda()
+        ref_x = ops.gemm_xnorm(xf, part, K // 16, nw, frag_shuffle(w).cuda(), 1e-6, M=M, epilogue=L.EPI_SILU_MUL)
+        try:
+            for nt in (0, 2, 3, 4):
+                if nt and (inter // 8) % nt:
+                    continue
+                for mt in ((0,) if nt == 0 else (1, 2, 4)):
+                    lib.omni_debug_tile(nt, mt)
+                    out = ops.gemm(x.cuda(), w8, epilogue=L.EPI_SILU_MUL_GU8, layout=L.LAYOUT_W_FRAG)
+                    assert torch.equal(out, ref), (nt, mt)
+                    out = ops.gemm(xf, w8, epilogue=L.EPI_SILU_MUL_GU8, layout=L.LAYOUT_W_FRAG | L.LAYOUT_X_FRAG, M=M)
+                    assert torch.equal(out, ref), (nt, mt, "x frag")
+                    out = ops.gemm_xnorm(xf, part, K // 16, nw, w8, 1e-6, M=M, epilogue=L.EPI_SILU_MUL_GU8)
+                    assert torch.equal(out, ref_x), (nt, mt, "xnorm")
+        finally:
+            lib.omni_debug_tile(0, 0)
     with pytest.raises(L.OmniError):
         ops.gemm(x.cuda(), w.cuda(), epilogue=L.EPI_SILU_MUL_GU8)        # row-major W has no interleaved form
 

@@ -131,6 +131,116 @@ def test_worker_runner_matches_oracle(graphs):
     wk.shutdown()
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_mixed_sampling_batch_with_prefill_inside_padded_bucket(graphs):
+    """Rows a2 / a3: four requests with four different SamplingParams share the
+    captured step and each is sampled with ITS parameters and RNG key (oracle: sample_row per request); in the step where
+    three of them decode while the fourth's prompt completes, the bucket-4 graph runs over the fourth's row too -- its KV
+    blocks, first token, hidden state, position and counters must come out exactly as in eager mode / the oracle."""
+    from ht_vllm_omni_amd.runner import request_seed
+    d = get_dims("tiny")
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 64
+    cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w,
+                      enforce_eager=not graphs)
+    wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    wk.engine.set_sampling(cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    run, eng = wk.model_runner, wk.engine
+    sps = {"a": SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0),
+           "b": SamplingParams(temperature=0.8, top_k=10, repetition_penalty=1.1, seed=7),
+           "c": SamplingParams(temperature=1.2, top_k=0, repetition_penalty=1.0, seed=None),
+           "d": SamplingParams(temperature=0.9, top_k=5, top_p=0.9, repetition_penalty=1.3, seed=3)}
+    okw = {k: dict(greedy=sp.greedy, temperature=sp.temperature or 1.0, top_k=sp.top_k, top_p=sp.top_p,
+                   rep_penalty=sp.repetition_penalty, seed=request_seed(k, sp)) for k, sp in sps.items()}
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    pool = BlockPool(nb, bs)
+    g = torch.Generator().manual_seed(31)
+    spec = {"a": 5, "b": 19, "c": 12, "d": 23}
+    prompts = {k: torch.randn(n, d.hidden, generator=g).to(BF16) for k, n in spec.items()}
+    pads = {k: torch.randn(d.hidden, generator=g).to(BF16) for k in spec}
+    ostate = {k: O.OracleState(tail_text=[], tts_pad=pads[k]) for k in spec}
+
+    def new_req(k):
+        pool.allocate(k, spec[k] + 1)
+        info = {"talker_prompt_embeds": encode_tensor(prompts[k]), "tts_pad_embed": encode_tensor(pads[k])}
+        return OmniNewRequestData(req_id=k, prompt_token_ids=[d.codec_pad_id] * spec[k], block_ids=(pool.block_ids(k),),
+                                  sampling_params=sps[k], additional_information=info)
+
+    def cached(keys):
+        nbk = []
+        for k in keys:
+            new = pool.allocate(k, run.requests[k].num_computed + 2)
+            nbk.append((new,) if new else None)
+        return OmniCachedRequestData(req_ids=list(keys), new_block_ids=nbk)
+
+    def force(k, tok, h, got):
+        r = run.rows.index(k)
+        eng.input_ids[r] = tok
+        eng.last_hidden[r] = h.cuda()
+        if got != tok:                                  # keep the repetition-penalty bitmap on the oracle's trajectory too
+            eng.seen[r, got] = 0
+            eng.seen[r, tok] = 1
+
+    def check_token(k, got, tok, logits_row, step):
+        if got != tok:
+            m = O.sample_row_margin(logits_row, step=step, **okw[k])
+            assert m <= 2e-2, f"{k}: sampled {got} != oracle {tok} with score margin {m}"
+
+    def oracle_prefill(keys, out):
+        for k in keys:
+            lg, ids, h = orc.prefill([ostate[k]], [prompts[k]], [pool.block_ids(k)], sampling=[okw[k]])
+            got = out.sampled_token_ids[out.req_id_to_index[k]]
+            assert len(got) == 1
+            check_token(k, got[0], int(ids[0]), lg[0], 0)
+            force(k, int(ids[0]), h[0], got[0])
+
+    def oracle_decode(keys, out):
+        steps = [len(ostate[k].out_ids) for k in keys]
+        ol, oi, oh, oc, osl = orc.decode_step([ostate[k] for k in keys], [pool.block_ids(k) for k in keys],
+                                              sampling=[okw[k] for k in keys])
+        for j, k in enumerate(keys):
+            i = out.req_id_to_index[k]
+            assert torch.equal(out.pooler_output[i]["audio_codes"], oc[j:j + 1]), f"{k}: audio codes"
+            assert_e2e_close(out.pooler_output[i]["hidden"], oh[j:j + 1], mean_tol=6e-3, what=f"{k} hidden")
+            got = out.sampled_token_ids[i][0]
+            check_token(k, got, int(oi[j]), ol[j], steps[j])
+            force(k, int(oi[j]), oh[j], got)
+        return osl
+
+    # step 1: a, b, c prefill whole prompts
+    so = OmniSchedulerOutput(scheduled_new_reqs=[new_req(k) for k in "abc"], num_scheduled_tokens={k: spec[k] for k in "abc"},
+                             total_num_scheduled_tokens=sum(spec[k] for k in "abc"))
+    wk.execute_model(so); out = wk.sample_tokens(None)
+    oracle_prefill("abc", out)
+    # step 2: a, b, c decode (3 live rows in the bucket-4 graph) while d's prompt completes in the SAME step on row 3
+    so = OmniSchedulerOutput(scheduled_new_reqs=[new_req("d")], scheduled_cached_reqs=cached("abc"),
+                             num_scheduled_tokens={"a": 1, "b": 1, "c": 1, "d": spec["d"]}, total_num_scheduled_tokens=3 + spec["d"])
+    wk.execute_model(so); out = wk.sample_tokens(None)
+    oracle_decode("abc", out)
+    oracle_prefill("d", out)
+    rd = run.rows.index("d")
+    assert rd == 3 and int(eng.positions[rd]) == spec["d"] and int(eng.seq_lens[rd]) == spec["d"] + 1 and int(eng.steps[rd]) == 1
+    # d's prompt KV must be exactly what the oracle wrote (the padded row's "decode" must not have touched its blocks)
+    for layer in (0, d.layers - 1):
+        blk = pool.block_ids("d")
+        got_k = eng.kv_caches[layer][0][blk].cpu().view(torch.uint8)
+        ref_k = orc.kv[layer].data[0][blk].view(torch.uint8)
+        assert (got_k[:, : , :, :].reshape(-1)[: spec["d"] * d.kv_heads * d.head_dim] != ref_k.reshape(-1)[: spec["d"] * d.kv_heads * d.head_dim]).float().mean().item() < 0.1
+        tail_rows = got_k.reshape(len(blk) * bs, -1)[spec["d"]:]
+        assert int(tail_rows.abs().sum()) == 0, "slots past d's prompt were written by the padded row's decode step"
+    # steps 3-5: all four decode
+    for _ in range(3):
+        so = OmniSchedulerOutput(scheduled_cached_reqs=cached("abcd"), num_scheduled_tokens={k: 1 for k in "abcd"}, total_num_scheduled_tokens=4)
+        wk.execute_model(so); out = wk.sample_tokens(None)
+        osl = oracle_decode("abcd", out)
+        assert torch.equal(eng.slot_mapping[:4].cpu(), osl)
+    if graphs:
+        assert out.cudagraph_stats["replays"] == 4 and out.cudagraph_stats["eager_steps"] == 0
+    wk.shutdown()
+
+
 def test_engine_core_loop_scheduler_worker_oracle():
     """Row a12 end to end on the GPU: MI355XARScheduler (admission under a token budget, chunked prefill, block
     allocation, stop at max_tokens, KV hand-off + ack) drives MI355XARWorker through TalkerStageEngine; the token

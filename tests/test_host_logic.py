@@ -141,6 +141,8 @@ def test_runner_two_phase_contract_and_state():
     assert len(out.sampled_token_ids[0]) == 1 and out.sampled_token_ids[1] == []      # b still prefilling
     assert out.pooler_output[0]["hidden"].shape == (5, d.hidden) and out.pooler_output[0]["audio_codes"].shape == (5, d.num_code_groups)
     assert int(out.pooler_output[0]["audio_codes"].abs().sum()) == 0                  # prefill rows: zero codes
+    assert eng.calls[1][:2] == ("sample_rows", [0])                     # first token drawn with row 0's (request a's) parameters
+    eng.calls = [c for c in eng.calls if c[0] != "sample_rows"]
     kind, n, pos, req, slots = eng.calls[0]
     assert kind == "prefill" and n == 21 and pos == list(range(5)) + list(range(16))
     assert slots[:5] == [16 + i for i in range(5)] and slots[5:] == [32 + i for i in range(16)]   # slot = block*bs + off
@@ -150,6 +152,7 @@ def test_runner_two_phase_contract_and_state():
                               num_scheduled_tokens={"a": 1, "b": 4}, total_num_scheduled_tokens=5)
     run.execute_model(so2)
     out2 = run.sample_tokens(None)
+    eng.calls = [c for c in eng.calls if c[0] != "sample_rows"]
     assert [c[0] for c in eng.calls[1:]] == ["prefill", "decode"] and eng.calls[2][1] == 1
     assert out2.pooler_output[0]["audio_codes"].shape == (1, d.num_code_groups) and len(out2.sampled_token_ids[1]) == 1
     assert run.text_queue_pos("a") == 1                                 # one text-step vector popped
@@ -173,6 +176,92 @@ def test_runner_two_phase_contract_and_state():
     # no work scheduled
     from ht_vllm_omni_amd.payloads import EMPTY_MODEL_RUNNER_OUTPUT
     assert run.execute_model(OmniSchedulerOutput()) is EMPTY_MODEL_RUNNER_OUTPUT
+
+
+class _FakeGraph:
+    """Stands in for a captured hipGraph of one padded bucket: replay = the step over ALL bucket rows."""
+    def __init__(self, eng, b):
+        self.eng, self.b = eng, b
+
+    def replay(self):
+        self.eng.decode_step(self.b)
+
+
+def _drive_mixed(graphs: bool):
+    """3 decoding requests + a 4th whose prompt completes in the same step (nd = 3 inside the bucket-4 graph), then all
+    four decode: the advisor's round-1 repro (the padded row 3 used to get a spurious decode step)."""
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=graphs)
+    if graphs:
+        run.graphs = {b: _FakeGraph(eng, b) for b in (1, 2, 4)}
+    reqs = [_new_req(d, k, 4 + i, [1 + i]) for i, k in enumerate("abc")]
+    run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=reqs, num_scheduled_tokens={"a": 4, "b": 5, "c": 6}, total_num_scheduled_tokens=15))
+    run.sample_tokens(None)
+    stream = {k: [] for k in "abcd"}
+    so = OmniSchedulerOutput(scheduled_new_reqs=[_new_req(d, "d", 7, [5])],
+                             scheduled_cached_reqs=OmniCachedRequestData(req_ids=list("abc"), new_block_ids=[None] * 3),
+                             num_scheduled_tokens={"a": 1, "b": 1, "c": 1, "d": 7}, total_num_scheduled_tokens=10)
+    run.execute_model(so)
+    out = run.sample_tokens(None)
+    for k in "abcd":
+        stream[k] += out.sampled_token_ids[out.req_id_to_index[k]]
+    pos_d = int(eng.positions[run.rows.index("d")])
+    for _ in range(2):
+        so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=list("abcd"), new_block_ids=[None] * 4),
+                                 num_scheduled_tokens={k: 1 for k in "abcd"}, total_num_scheduled_tokens=4)
+        run.execute_model(so)
+        out = run.sample_tokens(None)
+        for k in "abcd":
+            stream[k] += out.sampled_token_ids[out.req_id_to_index[k]]
+    return stream, pos_d, int(eng.positions[run.rows.index("d")]), out.cudagraph_stats
+
+
+def test_padded_graph_bucket_leaves_prefill_rows_alone():
+    eager, p0e, p1e, _ = _drive_mixed(False)
+    graph, p0g, p1g, stats = _drive_mixed(True)
+    assert stats["replays"] == 3 and stats["eager_steps"] == 0
+    assert p0e == p0g == 7 and p1e == p1g == 9          # d: prompt of 7 -> position 7 after the mixed step, then two decode steps
+    assert graph == eager, (graph, eager)
+
+
+def test_runner_per_request_sampling_rows_follow_their_request():
+    """Row a2 / ADVICE r1: every request's SamplingParams land in ITS batch row (device arrays read by the captured sampler),
+    survive the decode-first permutation and the condense on finish, and unseeded requests get distinct RNG keys."""
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    sps = {"a": SamplingParams(temperature=0.0), "b": SamplingParams(temperature=0.7, top_k=20, top_p=0.9, repetition_penalty=1.2, seed=5),
+           "c": SamplingParams(temperature=1.3, top_k=0, seed=None), "d": SamplingParams(temperature=1.3, top_k=0, seed=None)}
+    reqs = []
+    for i, k in enumerate("abcd"):
+        r = _new_req(d, k, 20 if k == "a" else 3 + i, [1 + 2 * i, 2 + 2 * i])
+        r.sampling_params = sps[k]
+        reqs.append(r)
+    # a prefills in two chunks, the others finish at once -> they become decode rows BEFORE a (rows permute)
+    run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=reqs, num_scheduled_tokens={"a": 16, "b": 4, "c": 5, "d": 6}, total_num_scheduled_tokens=31))
+    run.sample_tokens(None)
+    run.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=list("abcd"), new_block_ids=[None] * 4),
+                                          num_scheduled_tokens={"a": 4, "b": 1, "c": 1, "d": 1}, total_num_scheduled_tokens=7))
+    run.sample_tokens(None)
+    assert run.rows[:3] == ["b", "c", "d"] and run.rows[3] == "a"
+
+    def row(k):
+        r = run.rows.index(k)
+        return (int(eng.row_greedy[r]), round(float(eng.row_temperature[r]), 4), int(eng.row_top_k[r]), round(float(eng.row_top_p[r]), 4),
+                round(float(eng.row_rep_penalty[r]), 4), int(eng.row_seed[r]) & 0xFFFFFFFF)
+    assert row("a")[:5] == (1, 1.0, 50, 1.0, 1.05)
+    assert row("b") == (0, 0.7, 20, 0.9, 1.2, 5)
+    assert row("c")[:5] == (0, 1.3, 0, 1.0, 1.05) and row("c")[5] != row("d")[5]       # unseeded: keys from the request ids
+    # b finishes: the last row moves into its slot with its parameters
+    run.execute_model(OmniSchedulerOutput(finished_req_ids={"b"}, scheduled_cached_reqs=OmniCachedRequestData(req_ids=list("acd"), new_block_ids=[None] * 3),
+                                          num_scheduled_tokens={"a": 1, "c": 1, "d": 1}, total_num_scheduled_tokens=3))
+    run.sample_tokens(None)
+    assert sorted(run.rows) == ["a", "c", "d"] and row("a")[0] == 1 and row("c")[1] == 1.3
+    bad = _new_req(d, "z", 3, [9])
+    bad.sampling_params = SamplingParams(temperature=0.8, top_k=0, top_p=0.5)
+    with pytest.raises(ValueError, match="top_p"):
+        run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[bad], num_scheduled_tokens={"z": 3}, total_num_scheduled_tokens=3))
 
 
 def test_runner_rejects_missing_prompt_embeds_and_overflow():
