@@ -244,10 +244,17 @@ class OmniKVTransferManager:
         self.max_retries, self.backoff_s = max_retries, backoff_s
 
     def extract_kv_cache(self, req_id: str, block_ids: list[int], seq_len: int, kv_caches: list, block_size: int,
-                         cache_dtype: str, custom_metadata: dict | None = None) -> dict | None:
+                         cache_dtype: str, custom_metadata: dict | None = None, kv_scales: list | None = None,
+                         tp_rank: int = 0, tp_size: int = 1) -> dict | None:
+        """kv_scales: the per-(token, kv head) fp32 scale tensors [2, nb, bs, h] of an int8 cache -- they travel as
+        ``layer_blocks["key_scales" / "value_scales"]`` (the reference's payload carries raw bytes + a dtype string only,
+        kv_transfer_manager.py:290-301: without them the receiver cannot dequantise).  Under tensor parallelism every rank
+        holds a slice of the KV heads: metadata says which (``tp_rank``, ``tp_size``)."""
         num_layers = len(kv_caches)
         key_cache: list = [None] * num_layers
         value_cache: list = [None] * num_layers
+        key_scales: list = [None] * num_layers
+        value_scales: list = [None] * num_layers
         for li, layer_kv in enumerate(kv_caches):
             pair = normalize_layer_kv(layer_kv)
             if pair is None:
@@ -262,15 +269,24 @@ class OmniKVTransferManager:
                 fk, fv = fk[:seq_len], fv[:seq_len]
             key_cache[li] = fk.detach().cpu().contiguous()
             value_cache[li] = fv.detach().cpu().contiguous()
+            if kv_scales is not None and kv_scales[li] is not None:
+                sk, sv = kv_scales[li][0][valid].flatten(0, 1), kv_scales[li][1][valid].flatten(0, 1)
+                key_scales[li] = sk[:seq_len].detach().cpu().contiguous()
+                value_scales[li] = sv[:seq_len].detach().cpu().contiguous()
         if not any(k is not None for k in key_cache):
             return None
-        return {"request_id": req_id, "layer_blocks": {"key_cache": key_cache, "value_cache": value_cache},
-                "block_ids": block_ids,
-                "metadata": {"block_size": block_size, "num_layers": num_layers, "dtype": str(cache_dtype),
-                             "seq_len": seq_len, **(custom_metadata or {})}}
+        blocks = {"key_cache": key_cache, "value_cache": value_cache}
+        if kv_scales is not None:
+            blocks.update({"key_scales": key_scales, "value_scales": value_scales})
+        meta = {"block_size": block_size, "num_layers": num_layers, "dtype": str(cache_dtype), "seq_len": seq_len,
+                **(custom_metadata or {})}
+        if tp_size > 1:
+            meta.update({"tp_rank": tp_rank, "tp_size": tp_size})
+        return {"request_id": req_id, "layer_blocks": blocks, "block_ids": block_ids, "metadata": meta}
 
     def handle_finished_requests_kv_transfer(self, finished_reqs: dict[str, dict], kv_caches: list, block_size: int,
-                                             cache_dtype: str, request_id_resolver=None) -> list[str]:
+                                             cache_dtype: str, request_id_resolver=None, kv_scales: list | None = None,
+                                             tp_rank: int = 0, tp_size: int = 1) -> list[str]:
         """Returns the request ids whose blocks the scheduler may now free (kv_extracted_req_ids)."""
         done: list[str] = []
         if not finished_reqs or self.connector is None:
@@ -278,10 +294,14 @@ class OmniKVTransferManager:
         for req_id, data in finished_reqs.items():
             try:
                 payload = self.extract_kv_cache(req_id, list(data.get("block_ids", [])), int(data.get("seq_len", 0)),
-                                                kv_caches, block_size, cache_dtype, data.get("custom_metadata"))
+                                                kv_caches, block_size, cache_dtype, data.get("custom_metadata"),
+                                                kv_scales=kv_scales, tp_rank=tp_rank, tp_size=tp_size)
                 if payload is not None:
                     gid = request_id_resolver(req_id) if request_id_resolver else req_id
+                    payload["request_id"] = gid                      # the resolved transfer id (kv_transfer_manager.py:316)
                     key = f"omni_{self.from_stage}_to_{self.to_stage}_kv_cache_{gid}"
+                    if tp_size > 1:
+                        key += f"_tp{tp_rank}"                       # every rank ships its own KV-head slice
                     ok = False
                     for attempt in range(self.max_retries):
                         ok, _, _ = self.connector.put(self.from_stage, self.to_stage, key, payload)

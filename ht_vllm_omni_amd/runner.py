@@ -44,14 +44,23 @@ class RequestState:
     tail_pos: int = 0
     tts_pad: torch.Tensor | None = None    # [H] device
     info: dict[str, Any] = field(default_factory=dict)
+    codes_hist: list[list[int]] = field(default_factory=list)   # audio codes of every decode step taken (recompute after preemption)
+    recompute: int = 0                     # resumed after preemption: decode inputs appended to the prompt for the KV recompute
+    n_prompt: int = 0                      # prompt rows proper (prompt_embeds may carry `recompute` rebuilt rows behind them)
 
     @property
     def prompt_len(self) -> int:
-        return int(self.prompt_embeds.shape[0])
+        return self.n_prompt or int(self.prompt_embeds.shape[0])
+
+    @property
+    def prefill_len(self) -> int:
+        """Tokens that go through the prefill path: the prompt, plus -- for a request resumed after a recompute
+        preemption -- the inputs of the decode steps it had already taken."""
+        return self.prompt_len + self.recompute
 
     @property
     def in_decode(self) -> bool:
-        return self.num_computed >= self.prompt_len
+        return self.num_computed >= self.prefill_len
 
 
 @dataclass
@@ -86,6 +95,7 @@ class MI355XARModelRunner:
         self.kv_transfer_manager = kv_transfer or OmniKVTransferManager(None)
         self.requests: dict[str, RequestState] = {}
         self.rows: list[str] = []                       # input_batch.req_ids (row order)
+        self.preempted: dict[str, RequestState] = {}    # state of preempted requests (vLLM keeps self.requests across preemption)
         self.execute_model_state: _StepState | None = None
         self.kv_extracted_req_ids: list[str] | None = None
         self.use_graphs = use_graphs
@@ -155,10 +165,15 @@ class MI355XARModelRunner:
         e = self.engine
         if so.finished_req_ids or so.preempted_req_ids or so.scheduled_new_reqs:
             self._tt_flush()
-        # drop finished / preempted requests, closing holes with the last row (condense)
+        # drop finished / preempted requests, closing holes with the last row (condense); a preempted request keeps its
+        # host state (outputs, per-step codes, text queue): its KV is recomputed when the scheduler brings it back
+        for rid in so.finished_req_ids:
+            self.preempted.pop(rid, None)
         for rid in list(so.finished_req_ids) + list(so.preempted_req_ids):
             if rid not in self.requests:
                 continue
+            if rid in so.preempted_req_ids and rid not in so.finished_req_ids:
+                self.preempted[rid] = self.requests[rid]
             r = self.rows.index(rid)
             last = len(self.rows) - 1
             if r != last:
@@ -169,10 +184,13 @@ class MI355XARModelRunner:
             self.rows.pop()
             self._reset_row(last)
             del self.requests[rid]
-        # new requests
+        # new requests (a preempted request re-enters here with fresh blocks and num_computed_tokens = 0)
         for nr in so.scheduled_new_reqs:
             if len(self.rows) >= self.max_num_seqs:
                 raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
+            if nr.req_id in self.preempted:
+                self._resume(nr.req_id, list(nr.block_ids[0]), int(nr.num_computed_tokens))
+                continue
             info = decode_additional_information(nr.additional_information)
             pe = nr.prompt_embeds if nr.prompt_embeds is not None else info.get("talker_prompt_embeds")
             tail = info.get("tailing_text_hidden")
@@ -205,9 +223,15 @@ class MI355XARModelRunner:
             e.set_row_sampling(r, greedy=sp.greedy, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
                                rep_penalty=sp.repetition_penalty, seed=seed)
             e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=dev)
-        # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489)
+        # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489); vLLM's own scheduler brings a
+        # preempted request back HERE, flagged resumed_from_preemption, with its complete new block list (:470-489)
         c = so.scheduled_cached_reqs
         for i, rid in enumerate(c.req_ids):
+            resumed = i < len(c.resumed_from_preemption) and c.resumed_from_preemption[i]
+            if resumed and rid in self.preempted:
+                nb = c.new_block_ids[i] if i < len(c.new_block_ids) else None
+                self._resume(rid, list(nb[0]) if nb else [], int(c.num_computed_tokens[i]) if i < len(c.num_computed_tokens) else 0)
+                continue
             st = self.requests[rid]
             nb = c.new_block_ids[i] if i < len(c.new_block_ids) else None
             if nb:
@@ -216,6 +240,65 @@ class MI355XARModelRunner:
                 dev = e.block_table.device
                 e.block_table[r, len(st.block_ids):len(st.block_ids) + len(new)] = torch.as_tensor(new, dtype=torch.int32, device=dev)
                 st.block_ids.extend(new)
+
+    # ------------------------------------------------------------------ recompute preemption
+    def _rebuild_decode_inputs(self, st: RequestState, J: int) -> torch.Tensor:
+        """The backbone inputs of the first J decode steps the request already took, from what it emitted:
+        x_j = bf16(bf16(embed[c0] + sum_g cp_embed[g-1][c_g]) + text_j) with codes_j = its audio codes of step j (an invalid
+        layer-0 id zeroes the frame's codes but e0 stays the id's embedding) and text_j = its queue entry j or tts_pad --
+        the arithmetic of talker_mtp (qwen3_tts_talker.py:1630-1641), summed in the native kernel's order (e0 first,
+        groups ascending, fp32), so the rows are bit-identical to the ones the decode steps fed the backbone."""
+        e, d = self.engine, self.d
+        dev = e.input_ids.device
+        codes = torch.as_tensor(st.codes_hist[:J], dtype=torch.long, device=dev).reshape(J, d.num_code_groups)
+        c0 = torch.as_tensor(st.output_ids[:J], dtype=torch.long, device=dev)
+        ok = (c0 >= 0) & (c0 < d.vocab)
+        acc = torch.where(ok[:, None], e.embed[c0.clamp(0, d.vocab - 1)].float(), torch.zeros((), device=dev))
+        for g in range(1, d.num_code_groups):
+            acc = acc + e.cp_embed[g - 1][codes[:, g]].float()
+        nt = 0 if st.tail is None else int(st.tail.shape[0])
+        text = torch.stack([st.tail[j] if j < nt else st.tts_pad for j in range(J)])
+        return (acc.to(BF16).float() + text.float()).to(BF16)
+
+    def _resume(self, rid: str, block_ids: list[int], num_computed: int) -> None:
+        """A preempted request comes back: new blocks, KV gone.  Its prefill now covers the prompt AND the inputs of the
+        L - 1 decode steps behind its L emitted tokens; when that completes nothing is sampled -- the row continues as a
+        decode row with input_ids = its last token, h = the hidden state of the last recomputed position, and its
+        position, step counter (RNG key), repetition-penalty bitmap and text-queue cursor where they were."""
+        e = self.engine
+        st = self.preempted.pop(rid)
+        if len(self.rows) >= self.max_num_seqs:
+            raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
+        P = st.prompt_len
+        L = len(st.output_ids)
+        J = max(L - 1, 0)
+        if len(st.codes_hist) < J:
+            raise RuntimeError(f"request {rid}: {len(st.codes_hist)} decode steps recorded, {J} needed to recompute")
+        base = st.prompt_embeds[:P]
+        if J:
+            base = torch.cat([base, self._rebuild_decode_inputs(st, J).cpu()], 0)
+        st.n_prompt, st.recompute, st.prompt_embeds = P, J, base.contiguous()
+        st.block_ids, st.num_computed, st.tail_pos = list(block_ids), int(num_computed), J
+        self.requests[rid] = st
+        r = len(self.rows)
+        self.rows.append(rid)
+        self._reset_row(r)
+        sp = st.sampling
+        e.set_row_sampling(r, greedy=sp.greedy, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
+                           rep_penalty=sp.repetition_penalty, seed=request_seed(rid, sp))
+        e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=e.block_table.device)
+
+    def _restore_decode_row(self, r: int, st: RequestState, hidden_last: torch.Tensor) -> None:
+        e, d = self.engine, self.d
+        L = len(st.output_ids)
+        e.input_ids[r] = int(st.output_ids[-1])
+        e.last_hidden[r] = hidden_last
+        e.positions[r] = st.prefill_len
+        e.seq_lens[r] = st.prefill_len + 1
+        e.steps[r] = L
+        e.seen[r].zero_()
+        ids = [d.codec_pad_id] + [t for t in st.output_ids if 0 <= t < d.vocab]
+        e.seen[r, torch.as_tensor(ids, dtype=torch.long, device=e.seen.device)] = 1
 
     # ------------------------------------------------------------------ phase 1
     @torch.inference_mode()
@@ -226,7 +309,8 @@ class MI355XARModelRunner:
         # [Omni] KV transfer BEFORE updating states (which removes finished requests)
         self.kv_extracted_req_ids = self.kv_transfer_manager.handle_finished_requests_kv_transfer(
             finished_reqs=scheduler_output.finished_requests_needing_kv_transfer, kv_caches=self.kv_caches,
-            block_size=e.block_size, cache_dtype=str(e.kv_dtype)) or None
+            block_size=e.block_size, cache_dtype=str(e.kv_dtype), kv_scales=getattr(e, "kv_scales", None),
+            tp_rank=getattr(e, "tp_rank", 0), tp_size=getattr(e, "tp_size", 1)) or None
         self._update_states(scheduler_output)
         if not scheduler_output.total_num_scheduled_tokens:
             if self.kv_extracted_req_ids:
@@ -237,24 +321,35 @@ class MI355XARModelRunner:
             return EMPTY_MODEL_RUNNER_OUTPUT
 
         sched = scheduler_output.num_scheduled_tokens
-        # decode-first row order
-        dec = [i for i, rid in enumerate(self.rows) if rid in sched and self.requests[rid].in_decode]
+        # a request's scheduled tokens split into a prefill part (prompt, or prompt + recomputed decode inputs after a
+        # preemption) and at most ONE decode token; decode-first row order
+        npre: dict[str, int] = {}
+        dec = []
+        for i, rid in enumerate(self.rows):
+            n = sched.get(rid, 0)
+            if n <= 0:
+                continue
+            st = self.requests[rid]
+            npre[rid] = min(n, max(st.prefill_len - st.num_computed, 0))
+            if n - npre[rid] > 1:
+                raise RuntimeError("decode requests are scheduled one token per step (no spec decode on this path)")
+            if n - npre[rid] == 1:
+                if npre[rid] and not st.output_ids:
+                    raise RuntimeError(f"request {rid}: scheduled past its prompt before its first token was sampled")
+                dec.append(i)
         decs = set(dec)
         rest = [i for i in range(len(self.rows)) if i not in decs]
         self._permute_rows(dec + rest)
         nd = len(dec)
-        for i in range(nd):
-            if sched[self.rows[i]] != 1:
-                raise RuntimeError("decode requests are scheduled one token per step (no spec decode on this path)")
 
         # ---- prefill spans (chunked prefill: a span is any slice of the prompt)
         prefill_done: dict[int, torch.Tensor] = {}
         spans: dict[int, tuple[int, int, torch.Tensor]] = {}
         xs, pos, req, slots, meta = [], [], [], [], []
         bs = e.block_size
-        for r in range(nd, len(self.rows)):
+        for r in range(len(self.rows)):
             rid = self.rows[r]
-            n = sched.get(rid, 0)
+            n = npre.get(rid, 0)
             if n <= 0:
                 continue
             st = self.requests[rid]
@@ -281,7 +376,10 @@ class MI355XARModelRunner:
                 spans[r] = (s0, n, hid[o:o + n])
                 st.num_computed = s0 + n
                 if st.in_decode:
-                    prefill_done[r] = hid[o + n - 1]
+                    if st.output_ids:      # resumed after preemption: nothing to sample, the row picks up where it was
+                        self._restore_decode_row(r, st, hid[o + n - 1])
+                    else:
+                        prefill_done[r] = hid[o + n - 1]
                 o += n
             if prefill_done:
                 rows_done = sorted(prefill_done)
@@ -366,6 +464,7 @@ class MI355XARModelRunner:
         ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
         hid_cpu = e.last_hidden[:len(self.rows)].cpu()
         codes_cpu = e.audio_codes[:nd].cpu() if nd else None
+        codes_list = codes_cpu.tolist() if nd else []
         # (pinned staging + one sync was tried: the CPU then reads uncached pinned memory -- 37 ms per step)
         sched = stt.scheduler_output.num_scheduled_tokens
         req_ids, sampled, pooler = [], [], []
@@ -381,6 +480,7 @@ class MI355XARModelRunner:
                 sampled.append([tok])
                 payload["hidden"] = hid_cpu[r:r + 1]                     # views of this step's own host copies
                 payload["audio_codes"] = codes_cpu[r:r + 1]              # frame [c0..c15][t] (talker.py:1642)
+                st.codes_hist.append(codes_list[r])
             else:
                 s0, n, hid = stt.prefill_spans[r]
                 payload["hidden"] = hid.cpu()

@@ -28,12 +28,15 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                 max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
                 num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
                 connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None,
-                prompt_builder: dict | None = None) -> SimpleNamespace:
+                prompt_builder: dict | None = None, model_path: str | None = None) -> SimpleNamespace:
+    if model_path and isinstance(model, str) and model == "tts-1.7b" and os.path.exists(os.path.join(model_path, "config.json")):
+        from .checkpoint import dims_from_hf_config
+        model = dims_from_hf_config(os.path.join(model_path, "config.json"))          # dimensions come from the checkpoint
     return SimpleNamespace(model=model, kv_cache_dtype=kv_cache_dtype, block_size=block_size, max_num_seqs=max_num_seqs,
                            tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
                            num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
                            enforce_eager=enforce_eager, default_sampling_params=default_sampling_params,
-                           prompt_builder=prompt_builder)
+                           prompt_builder=prompt_builder, model_path=model_path)
 
 
 class MI355XARWorker:
@@ -65,7 +68,15 @@ class MI355XARWorker:
         self.init_free, self.init_total = torch.cuda.mem_get_info(self.device)
 
     def load_model(self) -> None:
+        """Weights, in this order: an explicit dict (tests), a checkpoint directory / .safetensors file in HF naming
+        (``vllm_config.model_path``: the reference's load_weights + hf_to_vllm_mapper, qwen3_tts_talker.py:297-311,
+        1569-1590 -- see checkpoint.py), else seeded random weights of the configured shape (benchmarks)."""
         w = getattr(self.vllm_config, "weights", None)
+        path = getattr(self.vllm_config, "model_path", None)
+        if w is None and path:
+            from .checkpoint import check_against_dims, load_talker_checkpoint
+            w, self.checkpoint_extras = load_talker_checkpoint(path)
+            check_against_dims(w, self.dims)
         self._weights = w if w is not None else make_weights(self.dims, seed=getattr(self.vllm_config, "seed", 1234))
 
     # ---- memory (base.py:78-156): bytes available for the KV cache after weights and step scratch

@@ -33,6 +33,9 @@ class FakeEngine:
         self.num_live = torch.full((1,), max_batch, dtype=torch.int32)
         self.kv_caches = [torch.arange(2 * num_blocks * block_size * d.kv_heads * 4, dtype=torch.float32)
                           .reshape(2, num_blocks, block_size, d.kv_heads, 4) + 1000 * l for l in range(d.layers)]
+        g = torch.Generator().manual_seed(99)
+        self.embed = torch.randn(d.vocab, d.hidden, generator=g).to(BF16)
+        self.cp_embed = torch.randn(d.num_code_groups - 1, d.codebook, d.hidden, generator=g).to(BF16)
         self.sampling = {}
         self.calls = []
 
@@ -77,7 +80,14 @@ class FakeEngine:
         self.slot_mapping[:B] = torch.tensor([int(self.block_table[r, int(self.positions[r]) // self.block_size]) * self.block_size
                                               + int(self.positions[r]) % self.block_size for r in range(B)])
         self.last_hidden[:B] = (self.last_hidden[:B].float() + 1).to(BF16)
-        self.input_ids[:B] = (self.input_ids[:B] % (self.d.codebook - 2)) + 1
+        # next id depends on the id, the position, the step counter and the repetition bitmap: a row restored wrongly
+        # after a preemption forks its stream (the carried hidden state is left out: this fake's prefill and decode are
+        # not the same function, the real engine's are)
+        mix = self.input_ids[:B].long() * 7 + self.positions[:B].long() * 3 + self.steps[:B].long() * 5 \
+            + self.seen[:B].sum(1).long()
+        new = (mix % (self.d.codebook - 2) + 1).to(torch.int32)
+        self.seen[torch.arange(B), new.long()] = 1
+        self.input_ids[:B] = new
         self.steps[:B] += 1
         if advance:
             self.positions[:B] += 1

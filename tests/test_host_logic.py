@@ -337,3 +337,102 @@ def test_mrope_positions_text_only_and_collapse():
         P.collapse_mrope_positions(bad)
     with pytest.raises(ValueError):
         P.collapse_mrope_positions(torch.zeros(2, 5, dtype=torch.int64))
+
+
+# ------------------------------------------------------------------ boundary: entry point + checkpoint loader
+def test_platform_entry_point_is_declared_and_resolves(monkeypatch):
+    """the `vllm_omni.platform_plugins` entry point is SHIPPED (pyproject.toml), names a callable that
+    exists, and that callable returns the platform whose AR worker is ours -- resolved the way the reference's loader
+    does (entry_points(group=...) -> ep.load()() -> qualname; V/platforms/__init__.py:108-148)."""
+    import importlib
+    import os
+    try:
+        import tomllib
+    except ModuleNotFoundError:
+        import tomli as tomllib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    eps = tomllib.load(open(os.path.join(root, "pyproject.toml"), "rb"))["project"]["entry-points"]["vllm_omni.platform_plugins"]
+    assert list(eps.values()) == ["ht_vllm_omni_amd.platform:register"]
+    # installed metadata (pip install -e .) is looked up too when present; otherwise resolve the declared target directly
+    from importlib.metadata import entry_points
+    installed = [ep for ep in entry_points(group="vllm_omni.platform_plugins") if ep.value == "ht_vllm_omni_amd.platform:register"]
+    mod, fn = eps["mi355x"].split(":")
+    register = installed[0].load() if installed else getattr(importlib.import_module(mod), fn)
+    monkeypatch.setenv("HT_OMNI_FORCE_MI355X", "1")
+    qual = register()
+    m, c = qual.rsplit(".", 1)
+    platform = getattr(importlib.import_module(m), c)
+    wm, wc = platform.get_omni_ar_worker_cls().rsplit(".", 1)
+    worker = getattr(importlib.import_module(wm), wc)
+    for meth in ("init_device", "load_model", "determine_available_memory", "initialize_from_config", "compile_or_warm_up_model",
+                 "execute_model", "sample_tokens", "profile"):
+        assert callable(getattr(worker, meth)), meth
+
+
+def test_checkpoint_round_trip_hf_names_to_fused_layout(tmp_path):
+    """VERDICT r1 missing #5: a synthetic checkpoint written in HF Qwen3-TTS naming (split q/k/v and gate/up projections,
+    sharded safetensors + index + config.json) loads back into the engine's fused layout bit-exactly, the dimensions come
+    out of config.json, extras are kept apart, and an unknown talker tensor is an error, not a silent drop."""
+    import json
+    from safetensors.torch import save_file
+    from ht_vllm_omni_amd import checkpoint as CK
+    from ht_vllm_omni_amd.weights import make_weights
+    d = get_dims("tiny")
+    w = make_weights(d, seed=3, norm_noise=0.1)
+    out = tmp_path / "ckpt"
+    CK.export_hf_checkpoint(w, d, str(out), shards=3)
+    names = json.load(open(out / "model.safetensors.index.json"))["weight_map"]
+    assert "talker.model.layers.0.self_attn.q_proj.weight" in names and "talker.code_predictor.lm_head.2.weight" in names
+    assert not any("qkv" in n or "gate_up" in n for n in names)           # HF side has no fused tensors
+    save_file({"speaker_encoder.fc.weight": torch.ones(2, 2), "talker.text_projection.linear_fc1.weight": torch.zeros(3, 3),
+               "talker.model.text_embedding.weight": torch.zeros(4, 3), "talker.model.rotary_emb.inv_freq": torch.zeros(4)},
+              str(out / "extra.safetensors"))
+    idx = json.load(open(out / "model.safetensors.index.json"))
+    for k in ("speaker_encoder.fc.weight", "talker.text_projection.linear_fc1.weight", "talker.model.text_embedding.weight",
+              "talker.model.rotary_emb.inv_freq"):
+        idx["weight_map"][k] = "extra.safetensors"
+    json.dump(idx, open(out / "model.safetensors.index.json", "w"))
+    got, extras = CK.load_talker_checkpoint(str(out))
+    assert set(got) == set(w)
+    for k in w:
+        assert got[k].dtype == BF16 and torch.equal(got[k], w[k]), k
+    assert set(extras) == {"speaker_encoder.fc.weight", "text_projection.linear_fc1.weight", "text_embedding.weight"}
+    d2 = CK.dims_from_hf_config(str(out / "config.json"), max_model_len=d.max_model_len)
+    assert d2.with_(name=d.name) == d
+    CK.check_against_dims(got, d2)
+    with pytest.raises(ValueError, match="wqkv"):
+        CK.check_against_dims(got, d.with_(q_heads=8))
+    with pytest.raises(KeyError, match="unmapped"):
+        CK.map_hf_talker_weights([("talker.model.layers.0.self_attn.bogus.weight", torch.zeros(1))])
+    with pytest.raises(KeyError, match="projections"):
+        CK.map_hf_talker_weights([("talker.model.layers.0.self_attn.q_proj.weight", torch.zeros(2, 2))])
+    # the worker takes the directory: dims from config.json, weights through the mapper
+    from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
+    cfg = make_config(model_path=str(out))
+    assert cfg.model.hidden == d.hidden and cfg.model.num_code_groups == d.num_code_groups
+    wk = MI355XARWorker(cfg)
+    wk.load_model()
+    assert torch.equal(wk._weights["l1.wgu"], w["l1.wgu"]) and "text_embedding.weight" in wk.checkpoint_extras
+
+
+def test_kv_transfer_payload_resolved_id_int8_scales_and_tp_slices():
+    """the payload's request_id is the RESOLVED transfer id (kv_transfer_manager.py:316); an int8 cache
+    ships its per-(token, head) scales so the receiver can dequantise; tensor-parallel ranks put their head slice under
+    their own key."""
+    c = InProcConnector()
+    mgr = OmniKVTransferManager(c, from_stage="0", to_stage="1", backoff_s=0.0)
+    cache = torch.randint(-127, 127, (2, 6, 4, 2, 8), dtype=torch.int8)
+    scales = torch.rand(2, 6, 4, 2)
+    done = mgr.handle_finished_requests_kv_transfer({"local7": {"seq_len": 6, "block_ids": [1, 3]}}, [cache], 4, "int8",
+                                                    request_id_resolver=lambda r: "global-" + r, kv_scales=[scales])
+    assert done == ["local7"]
+    obj, _ = c.get("0", "1", "omni_0_to_1_kv_cache_global-local7")
+    assert obj["request_id"] == "global-local7"
+    ks = obj["layer_blocks"]["key_scales"][0]
+    assert ks.shape == (6, 2) and torch.equal(ks, scales[0][[1, 3]].flatten(0, 1)[:6])
+    deq = obj["layer_blocks"]["key_cache"][0].float() * ks[..., None]
+    assert torch.equal(deq, (cache[0][[1, 3]].flatten(0, 1)[:6].float() * scales[0][[1, 3]].flatten(0, 1)[:6][..., None]))
+    mgr.handle_finished_requests_kv_transfer({"r": {"seq_len": 3, "block_ids": [2]}}, [cache], 4, "int8", kv_scales=[scales],
+                                             tp_rank=1, tp_size=2)
+    obj, _ = c.get("0", "1", "omni_0_to_1_kv_cache_r_tp1")
+    assert obj["metadata"]["tp_rank"] == 1 and obj["metadata"]["tp_size"] == 2

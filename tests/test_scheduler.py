@@ -154,3 +154,85 @@ def test_kv_transfer_criteria_trigger_once_without_stopping():
     toks = core.run()
     assert req.is_finished() and not sched.requests and sched.pool.num_free == 15     # finished later: no second transfer
     assert conn.get("0", "1", "omni_0_to_1_kv_cache_a") is None
+
+
+def _run_engine(num_blocks, n_req=6, max_tokens=14):
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4, num_blocks=num_blocks)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    s = MI355XARScheduler(num_blocks=num_blocks, block_size=16, max_num_seqs=4, max_num_batched_tokens=48, max_model_len=512)
+    core = TalkerStageEngine(_Worker(run), s)
+    for i in range(n_req):
+        core.add_request(_request(d, f"r{i}", 9 + 5 * i, max_tokens=max_tokens, tail=3, seed=i))
+    streams, codes, preempted = {}, {}, 0
+    for _ in range(400):
+        so = s.schedule()
+        preempted += len(so.preempted_req_ids)
+        if so.total_num_scheduled_tokens == 0 and not so.finished_req_ids:
+            if not s.has_unfinished_requests():
+                break
+            continue
+        first = run.execute_model(so)
+        out = first if first is not None else run.sample_tokens(None)
+        for o in s.update_from_output(so, out):
+            streams.setdefault(o.request_id, []).extend(o.new_token_ids)
+            if o.pooling_output is not None and o.new_token_ids and o.pooling_output["audio_codes"].shape[0] == 1 \
+                    and int(o.pooling_output["audio_codes"].abs().sum()) > 0:
+                codes.setdefault(o.request_id, []).append(o.pooling_output["audio_codes"][0].tolist())
+    return streams, codes, preempted, run
+
+
+def test_preempted_request_resumes_where_it_stopped():
+    """a request preempted in its decode phase is RECOMPUTED -- prompt plus the inputs of the decode
+    steps it already took, rebuilt from its emitted codes and text queue -- and continues: same token stream and per-step
+    audio codes as the run that never preempts (the old runner restarted it at the end of the prompt: replayed tokens,
+    RNG keys and text steps from 0)."""
+    ref_streams, ref_codes, p0, _ = _run_engine(num_blocks=64)
+    streams, codes, p1, run = _run_engine(num_blocks=8)            # 7 usable blocks of 16 for up to 4 x (34 + 14) tokens
+    assert p0 == 0 and p1 >= 1, (p0, p1)
+    assert streams == ref_streams
+    assert codes == ref_codes
+    assert all(len(v) == 14 for v in streams.values()) and not run.preempted and not run.requests
+
+
+def test_resume_restores_row_state_and_rebuilds_inputs():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=2)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    from ht_vllm_omni_amd.payloads import OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput
+    req = _request(d, "a", 6, tail=2)
+    nr = OmniNewRequestData(req_id="a", prompt_token_ids=req.prompt_token_ids, block_ids=([1, 2],), sampling_params=req.sampling_params,
+                            additional_information=req.additional_information)
+    run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[nr], num_scheduled_tokens={"a": 6}, total_num_scheduled_tokens=6))
+    toks = run.sample_tokens(None).sampled_token_ids[0]
+    xs = []
+    for _ in range(3):
+        run.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a"], new_block_ids=[None]),
+                                              num_scheduled_tokens={"a": 1}, total_num_scheduled_tokens=1))
+        xs.append(eng.text_step[0].clone())
+        toks += run.sample_tokens(None).sampled_token_ids[0]
+    st = run.requests["a"]
+    state = (int(eng.positions[0]), int(eng.seq_lens[0]), int(eng.steps[0]), int(eng.input_ids[0]), eng.seen[0].clone(), eng.last_hidden[0].clone())
+    assert len(toks) == 4 and len(st.codes_hist) == 3 and state[0] == 9
+    # preempt, then bring it back through vLLM's own route: scheduled_cached_reqs flagged resumed_from_preemption
+    run.execute_model(OmniSchedulerOutput(preempted_req_ids={"a"}))
+    assert run.rows == [] and "a" in run.preempted and "a" not in run.requests
+    eng.calls.clear()
+    so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a"], resumed_from_preemption=[True],
+                                                                         new_block_ids=[([5, 6],)], num_computed_tokens=[0]),
+                             num_scheduled_tokens={"a": 6 + 4}, total_num_scheduled_tokens=10)
+    run.execute_model(so)
+    kind, n, pos, _, slots = eng.calls[0]
+    assert kind == "prefill" and n == 9 and pos == list(range(9)) and slots[:2] == [80, 81]      # prompt + 3 rebuilt inputs, new blocks
+    assert eng.calls[-1][0] == "decode" and not [c for c in eng.calls if c[0] == "sample_rows"]  # nothing sampled at the seam
+    out = run.sample_tokens(None)
+    assert len(out.sampled_token_ids[0]) == 1 and run.text_queue_pos("a") == 4
+    # the rebuilt inputs: embed[c0] + sum of the group embeddings (fp32, in order) -> bf16, + the text step of that step
+    rebuilt = run.requests["a"].prompt_embeds[6:9]
+    for j in range(3):
+        acc = eng.embed[toks[j]].float()
+        for g in range(1, d.num_code_groups):
+            acc = acc + eng.cp_embed[g - 1][st.codes_hist[j][g]].float()
+        want = (acc.to(BF16).float() + xs[j].float()).to(BF16)
+        assert torch.equal(rebuilt[j], want), j
+    assert int(eng.positions[0]) == state[0] + 1 and int(eng.steps[0]) == state[2] + 1
