@@ -22,6 +22,8 @@ LIB_DEBUG = os.path.join(HERE, "libomni_talker_debug.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm_prefill.hip", "norm.hip", "rope_kv.hip", "paged_attn.hip", "prefill_attn.hip", "moe.hip",
            "sampler.hip", "allreduce.hip"]
 DEBUG_ONLY = ["debug.hip"]
+# per-file extra flags
+EXTRA = {"debug.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]
@@ -41,6 +43,7 @@ def sources_digest(debug: bool = False) -> str:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA.items())).encode())
     return h.hexdigest()
 
 
@@ -68,7 +71,7 @@ def _build_one(lib: str, sources: list[str], objdir: str, extra: list[str], forc
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *extra, *EXTRA.get(s, []), "-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]

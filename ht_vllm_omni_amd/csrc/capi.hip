@@ -509,8 +509,8 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         }
         for (int g = 1; g < Q; ++g) {
             const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
-            if (!in_pair) TRY(cp_forward_fused(t, B, g, &np, st));
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
+            if (!in_pair) TRY(cp_forward_fused(t, B, g, &np, st));
             TRY(k_gemm_xnorm(in_pair ? r1 : t->cp_resid, in_pair ? part1 : t->cp_part, np, d.cp_norm, d.eps, nullptr, head, t->cp_logits,
                              B, d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, 0, in_pair ? ps : 64, st));
             if (cp_logits_out) {

@@ -115,3 +115,52 @@ extern "C" int omni_debug_launch(int mode, int blocks, int threads, void* p0, vo
     OMNI_CHECK_LAUNCH("omni_debug_launch");
     return OMNI_OK;
 }
+
+// ---- which XCD does block b of consecutive launches land on?  (the L2 warm-up chain of gemm.hip assumes: the same one
+// for equal b mod 8 as long as every grid in between is a multiple of 8 workgroups)
+__global__ __launch_bounds__(512) void dbg_xcc_kernel(int32_t* out) {
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        out[blockIdx.x + gridDim.x * blockIdx.y] = (int)(x & 0xF);
+    }
+}
+// reps probe launches of (gx, gy) blocks into out[r * gx * gy ...]; between them `odd` blocks of an unrelated kernel
+extern "C" int omni_debug_xcc_probe(int32_t* out, float* scratch, int gx, int gy, int odd, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(dbg_xcc_kernel, dim3(gx, gy), dim3(512), 0, st, out + (size_t)r * gx * gy);
+        if (odd > 0) hipLaunchKernelGGL(dbg_touch_kernel, dim3(odd), dim3(256), 0, st, scratch);
+    }
+    OMNI_CHECK_LAUNCH("omni_debug_xcc_probe");
+    return OMNI_OK;
+}
+
+// ---- dependent chain of small kernels whose first instruction needs a kernel argument: by-value struct (s_load from the
+// kernarg segment) vs leading scalar arguments (this file is built with -amdgpu-kernarg-preload-count=16: they arrive in
+// SGPRs with the wave)
+struct DbgChainArgs { const float* in; float* out; int n; float s; int pad[24]; };
+__global__ __launch_bounds__(512) void dbg_chain_struct_kernel(const DbgChainArgs a) {
+    const int i = blockIdx.x * 512 + threadIdx.x;
+    if (i < a.n) a.out[i] = a.in[i] * a.s + 1.0f;
+}
+__global__ __launch_bounds__(512) void dbg_chain_scalar_kernel(const float* in, float* out, int n, float s) {
+    const int i = blockIdx.x * 512 + threadIdx.x;
+    if (i < n) out[i] = in[i] * s + 1.0f;
+}
+extern "C" int omni_debug_chain(int mode, float* a, float* b, int blocks, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < reps; ++r) {
+        float* src = (r & 1) ? b : a;
+        float* dst = (r & 1) ? a : b;
+        if (mode == 0) {
+            DbgChainArgs x{};
+            x.in = src; x.out = dst; x.n = blocks * 512; x.s = 0.5f;
+            hipLaunchKernelGGL(dbg_chain_struct_kernel, dim3(blocks), dim3(512), 0, st, x);
+        } else {
+            hipLaunchKernelGGL(dbg_chain_scalar_kernel, dim3(blocks), dim3(512), 0, st, (const float*)src, dst, blocks * 512, 0.5f);
+        }
+    }
+    OMNI_CHECK_LAUNCH("omni_debug_chain");
+    return OMNI_OK;
+}

@@ -53,6 +53,7 @@ struct GemmArgs {
     float mask_fill;           // logit written where mask[n] == 0 (-inf; the Omni talker writes -1e9)
     int counted;               // use the counted (unpredicated, 2-deep) schedule when K % 512 == 0
     const int32_t* num_live;   // PRO_XNORM normed_out: rows >= *num_live are not written (NULL: all M rows)
+    int dbg_stage;             // debug library only: leave the kernel after stage N (launch-cost attribution), 0 = run all
 };
 
 // PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
@@ -70,6 +71,12 @@ __device__ __forceinline__ u32x4 xnorm_frag(u32x4 v, u32x4 nw, float rstd) {
 template <int MT, int NT, int PRO, int EPI, bool NTL>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [WAVES][NT*MT*4][64]
+#ifdef OMNI_DEBUG_HOOKS
+#define DBG_STAGE(n) if (a.dbg_stage == (n)) return
+#else
+#define DBG_STAGE(n)
+#endif
+    DBG_STAGE(1);                                                  // 1: empty kernel with this launch geometry
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             r_old = *reinterpret_cast<const uint2*>(a.resid + frag_off(m_base + ml, blockIdx.x * 16 + 4 * (lane >> 4), N));
     }
 
+    DBG_STAGE(2);                                                  // 2: + addressing, slab / old-residual loads issued
     float rstd[MT];
     auto xnorm_rstd = [&]() {
         // part 2 (after the W ring is in flight): fixed-order reduction -> rstd of this workgroup's rows.  row = lane % XROWS:
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         }
     }
 
+    DBG_STAGE(3);                                                  // 3: + main loop (operand loads, normalisation, MFMA)
     // the normalised rows themselves (h[t+1] of the final norm) leave row-major, spread over the n groups: workgroup column x
     // re-reads the (L2-hot) fragments of k-steps x, x + gridDim.x, ... of its rows -- a second pass kept out of the main loop so
     // that its waits stay counted, and short (one k-step per wave at most) so that no workgroup column carries a tail
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 #pragma unroll
             for (int g = 0; g < 4; ++g) lds[(wave * E + (j * MT + i) * 4 + g) * 64 + lane] = acc[j][i][g];
     __syncthreads();
+    DBG_STAGE(4);                                                  // 4: + LDS write of the K partials + barrier
 
     // item = (m-tile i, [n-tile j], lane l): 4 consecutive n (reg 0..3) of one row m
     // OMNI_EPI_SILU_MUL_GU8: every 16-row W tile = 8 gate rows (D lanes 0..31) + the 8 matching up rows (lanes 32..63)
@@ -384,14 +394,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 }
 
 
-OMNI_KNOB g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1;
+OMNI_KNOB g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1, g_gemm_stage = 0;
 #ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_gemm_stage(int stage) { g_gemm_stage = stage; }   // leave every GEMM kernel after stage N (timing only: results are garbage)
 extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_counted = rn ? 0 : 1; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }   // rn != 0: generic schedule
 extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt; }   // 0 = policy default
 #endif
 
 template <int MT, int NT, int PRO, int EPI>
-static int launch_gemm(const GemmArgs& a, int m_splits, hipStream_t st) {
+static int launch_gemm(const GemmArgs& a_in, int m_splits, hipStream_t st) {
+    GemmArgs a = a_in;
+    a.dbg_stage = g_gemm_stage;
     const int groups = (EPI == OMNI_EPI_SILU_MUL || EPI == OMNI_EPI_SILU_MUL_GU8) ? a.N / (8 * NT) : a.N / (16 * NT);
     size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float) + (PRO == 2 ? GEMM_WAVES * 64 * sizeof(float) : 0);
     if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)

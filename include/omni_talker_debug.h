@@ -3,6 +3,7 @@
  * Process-global, not thread-safe, defaults = the shipped policy. */
 #pragma once
 #include <stddef.h>
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -11,12 +12,15 @@ void omni_debug_set(int nt, int generic_schedule, int wgs); /* nt & 1: non-tempo
 void omni_debug_tile(int nt, int mt);                       /* force the GEMM tile (0 = policy)                       */
 void omni_debug_int8_max_g(int g);                         /* int8-KV decode attention: q heads per workgroup (2 | 4) */
 void omni_debug_cp_pair01(int on);                         /* code predictor: positions 0 and 1 as one two-block pass */
+void omni_debug_gemm_stage(int stage);                      /* leave every GEMM kernel after stage 1..4 (timing attribution only) */
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
 void omni_debug_prefill_mfma(int on);                       /* prefill attention on MFMA (off: per-token VALU path)   */
 void omni_debug_extra_trivial(int n);                       /* append n no-op launches per layer phase                */
 int omni_debug_launch(int mode, int blocks, int threads, void* p0, void* p1, int arg, int reps, void* stream);
 int omni_debug_mix(int pattern, float* small, const void* big, size_t big_bytes, int reps, void* stream);
 int omni_debug_cfgmix(int mode, float* p, int reps, void* stream);
+int omni_debug_xcc_probe(int32_t* out, float* scratch, int gx, int gy, int odd, int reps, void* stream); /* XCC id of every block */
+int omni_debug_chain(int mode, float* a, float* b, int blocks, int reps, void* stream);   /* 0: struct kernarg, 1: preloaded scalars */
 #ifdef __cplusplus
 }
 #endif

@@ -374,12 +374,17 @@ class TalkerOracle:
             v = qkv[:, (hq + hkv) * D:].reshape(T, hkv, D)
             q = apply_rope(rms_norm(q, w[p + "qnorm"], d.eps), cos, sin)
             k = apply_rope(rms_norm(k, w[p + "knorm"], d.eps), cos, sin)
+            trace = getattr(self, "trace", None)        # tests: per-layer intermediates (golden G2 pins them to HF Qwen3Model)
+            if trace is not None:
+                trace.append({"layer": li, "q": q.clone(), "k": k.clone(), "v": v.clone()})
             self.kv[li].write(slots, k, v)
             o = torch.empty(T, hq, D, dtype=BF16)
             for r in sorted(set(req_of_tok)):
                 idx = [t for t in range(T) if req_of_tok[t] == r]
                 kk, vv = self.kv[li].gather(block_tables[r], seq_lens_after[r])
                 o[idx] = attention_rows(q[idx], kk, vv, positions[idx], D ** -0.5)
+            if trace is not None:
+                trace[-1]["attn"] = o.reshape(T, hq * D).clone()
             h = resid + linear(o.reshape(T, hq * D), w[p + "wo"])
             resid = h
             a = rms_norm(h, w[p + "ln2"], d.eps)

@@ -15,6 +15,9 @@ input/output tensors are saved.
   snake_beta.npz            reference SnakeBeta module (12 Hz tokenizer decoder) in/out
   omni_stage_processors.pt  reference qwen3_omni.py thinker->talker / talker->code2wav hand-offs in/out
   graph_decoder.json        reference CUDAGraphDecoderWrapper host logic: capture-size tables, bucket lookup, chunk windows
+  qwen3_layer_real.npz      G2: HF Qwen3Model, ONE layer at the 1.7B dims, bf16 and fp32: q / k after norm + RoPE, attention out,
+                            hidden, decode step at ctx 1 / 15 / 16 / 17 / 257
+  kv_quant.npz              G3: cache bytes after fp8 (bit-level OCP e4m3fn encoder, independent of torch) / int8 KV writes
   omni_prompt_builder.pt    reference Qwen3OmniMoeForConditionalGeneration prompt-embedding methods (models/qwen3_omni/
                             qwen3_omni.py) called on a stand-in `self` holding HF's ResizeMLP modules: in/out
 """
@@ -675,10 +678,143 @@ def mint_omni_prompt_builder():
     print("streaming:", [(s_["num_processed_tokens"], s_["out"] if isinstance(s_["out"], str) else tuple(s_["out"].shape)) for s_ in script])
 
 
+# --------------------------------------------------------------------------
+# G2: ONE decoder layer at the real 1.7B dimensions, HF Qwen3Model in bf16 AND fp32, decode step at
+# ctx in {1, 15, 16, 17, 257}: q / k after q/k-norm + RoPE, attention output (o_proj input), final-normed hidden.
+G2_CTX = (1, 15, 16, 17, 257)
+G2_SEED, G2_XSEED, G2_XSTD = 33, 5, 0.5
+
+
+def g2_dims():
+    return get_dims("tts-1.7b").with_(layers=1, cp_layers=1, num_code_groups=2, max_model_len=512)
+
+
+def g2_inputs(d):
+    g = torch.Generator().manual_seed(G2_XSEED)
+    return (torch.randn(max(G2_CTX), d.hidden, generator=g) * G2_XSTD).to(torch.bfloat16)
+
+
+def mint_backbone_layer_real():
+    import transformers.models.qwen3.modeling_qwen3 as MQ
+    from transformers import Qwen3Config, Qwen3Model
+    from transformers.cache_utils import DynamicCache
+    d = g2_dims()
+    w = make_weights(d, seed=G2_SEED, std=0.02, norm_noise=0.1)
+    x = g2_inputs(d)
+    cfg = Qwen3Config(vocab_size=d.vocab, hidden_size=d.hidden, intermediate_size=d.inter, num_hidden_layers=1,
+                      num_attention_heads=d.q_heads, num_key_value_heads=d.kv_heads, head_dim=d.head_dim, rms_norm_eps=d.eps,
+                      rope_theta=d.rope_theta, max_position_embeddings=4096, attention_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    hq, hkv, D = d.q_heads, d.kv_heads, d.head_dim
+    qkv = w["l0.wqkv"]
+    sd = {"embed_tokens.weight": w["embed"], "norm.weight": w["norm"],
+          "layers.0.self_attn.q_proj.weight": qkv[: hq * D], "layers.0.self_attn.k_proj.weight": qkv[hq * D: (hq + hkv) * D],
+          "layers.0.self_attn.v_proj.weight": qkv[(hq + hkv) * D:], "layers.0.self_attn.o_proj.weight": w["l0.wo"],
+          "layers.0.self_attn.q_norm.weight": w["l0.qnorm"], "layers.0.self_attn.k_norm.weight": w["l0.knorm"],
+          "layers.0.input_layernorm.weight": w["l0.ln1"], "layers.0.post_attention_layernorm.weight": w["l0.ln2"],
+          "layers.0.mlp.gate_proj.weight": w["l0.wgu"][: d.inter], "layers.0.mlp.up_proj.weight": w["l0.wgu"][d.inter:],
+          "layers.0.mlp.down_proj.weight": w["l0.wdown"]}
+    rec = {}
+    orig_rope = MQ.apply_rotary_pos_emb
+
+    def rope_spy(q, k, cos, sin, *a, **kw):
+        qo, ko = orig_rope(q, k, cos, sin, *a, **kw)
+        rec["q"], rec["k"] = qo.detach().clone(), ko.detach().clone()       # [1, heads, T, D]
+        return qo, ko
+    MQ.apply_rotary_pos_emb = rope_spy
+    out = dict(seed=np.int64(G2_SEED), xseed=np.int64(G2_XSEED), ctx=np.array(G2_CTX))
+    try:
+        for tag, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+            m = Qwen3Model(cfg).to(dt).eval()
+            missing, unexpected = m.load_state_dict({k: v.to(dt) for k, v in sd.items()}, strict=False)
+            assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+            # `.to(bfloat16)` also rounds the rotary inv_freq BUFFER to bf16 (a transformers quirk: positions > 0 then rotate by
+            # slightly wrong angles; 0.6 absolute error in q at position 256).  vLLM builds its cos / sin cache from fp32
+            # frequencies, as does the reference's own _RotaryEmbedding: restore them.
+            inv = 1.0 / (d.rope_theta ** (torch.arange(0, d.head_dim, 2, dtype=torch.float32) / d.head_dim))
+            m.rotary_emb.inv_freq = inv.clone()
+            if hasattr(m.rotary_emb, "original_inv_freq"):
+                m.rotary_emb.original_inv_freq = inv.clone()
+            m.layers[0].self_attn.o_proj.register_forward_pre_hook(lambda mod, args: rec.__setitem__("attn", args[0].detach().clone()))
+            with torch.inference_mode():
+                for n in G2_CTX:
+                    cache = DynamicCache(config=cfg)
+                    xx = x[None, :n].to(dt)
+                    if n > 1:
+                        m(inputs_embeds=xx[:, : n - 1], past_key_values=cache, use_cache=True)
+                    o = m(inputs_embeds=xx[:, n - 1: n], past_key_values=cache, use_cache=True)
+                    conv = np16 if dt == torch.bfloat16 else (lambda t: t.contiguous().float().numpy())
+                    out[f"{tag}_q{n}"] = conv(rec["q"][0, :, -1])            # [Hq, D]
+                    out[f"{tag}_k{n}"] = conv(rec["k"][0, :, -1])            # [Hkv, D]
+                    out[f"{tag}_attn{n}"] = conv(rec["attn"][0, -1])         # [Hq * D]
+                    out[f"{tag}_h{n}"] = conv(o.last_hidden_state[0, -1])    # [H]
+    finally:
+        MQ.apply_rotary_pos_emb = orig_rope
+    np.savez_compressed(os.path.join(HERE, "qwen3_layer_real.npz"), **out)
+    print("G2 qwen3_layer_real.npz", os.path.getsize(os.path.join(HERE, "qwen3_layer_real.npz")), "bytes")
+
+
+# --------------------------------------------------------------------------
+# G3: cache bytes after fp8 / int8 KV writes.  The fp8 bytes come from a bit-level OCP e4m3fn encoder written
+# here from the format definition (4 exponent bits, bias 7, 3 mantissa bits, no infinities, S.1111.111 = NaN, max 448;
+# round-to-nearest-even, saturating) -- NOT from torch's cast -- so they pin the oracle's fp8_quant and the HIP kernels alike.
+def e4m3fn_encode(x: float) -> int:
+    import math
+    if math.isnan(x):
+        return 0x7F
+    sign = 0x80 if (x < 0 or (x == 0 and math.copysign(1.0, x) < 0)) else 0
+    a = min(abs(x), 448.0)                       # saturating (vLLM scaled_fp8_conversion)
+    if a == 0.0:
+        return sign
+    e = max(math.floor(math.log2(a)), -6)        # subnormals share exponent -6
+    q = a / 2.0 ** (e - 3)                       # in units of the mantissa LSB at this exponent: normal -> [8, 16)
+    r = math.floor(q)
+    frac = q - r
+    if frac > 0.5 or (frac == 0.5 and (r & 1)):
+        r += 1
+    if r == 16:                                  # rounded up into the next binade
+        r, e = 8, e + 1
+    if r < 8:                                    # subnormal (e == -6): exponent field 0, mantissa r
+        return sign | r
+    code = ((e + 7) << 3) | (r - 8)
+    return sign | min(code, 0x7E)                # 0x7E = 448
+
+
+def mint_kv_quant():
+    g = torch.Generator().manual_seed(17)
+    T, H, D, bs = 37, 8, 128, 16
+    k = (torch.randn(T, H, D, generator=g) * 3.0).to(torch.bfloat16)
+    v = (torch.randn(T, H, D, generator=g) * 40.0).to(torch.bfloat16)
+    # boundary values: exact ties, subnormals, the largest finite value and beyond, signed zeros
+    special = torch.tensor([0.0, -0.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 0.0009765625 * 3, 448.0, 464.0, 480.0, 1e4, -1e4, 1.0625, 1.1875,
+                            0.01953125, 240.0, 248.0, 17.0, 18.0, 19.0, -0.4375, 0.46875], dtype=torch.float32).to(torch.bfloat16)
+    k[0, 0, : special.numel()] = special
+    v[1, 3, : special.numel()] = -special
+    block_table = [5, 2, 7]                                  # non-monotonic block ids
+    slots = np.array([block_table[t // bs] * bs + t % bs for t in range(T)], dtype=np.int64)
+    out = dict(block_table=np.array(block_table), slots=slots, block_size=np.int64(bs), k=np16(k), v=np16(v))
+    for name, t, scale in (("k", k, 1.0), ("v", v, 1.0), ("k_s", k, 0.5), ("v_s", v, 2.0)):
+        f = (t.float() / scale).numpy().reshape(-1)           # x / scale in fp32, then the saturating cast
+        out["fp8_" + name] = np.array([e4m3fn_encode(float(z)) for z in f], dtype=np.uint8).reshape(T, H, D)
+    for name, t in (("k", k), ("v", v)):                      # int8: build-defined: per (token, head) absmax / 127
+        f = t.float().numpy().astype(np.float32)
+        amax = np.maximum(np.abs(f).max(-1), np.float32(1e-8)).astype(np.float32)
+        sc = (amax / np.float32(127.0)).astype(np.float32)
+        q = np.clip(np.rint(f / sc[..., None]), -127, 127).astype(np.int8)
+        out["int8_" + name], out["int8_scale_" + name] = q, sc
+    np.savez_compressed(os.path.join(HERE, "kv_quant.npz"), **out)
+    # the 256 codes decode / re-encode to themselves (sanity of the encoder against torch's table of values)
+    allc = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float()
+    for c in range(256):
+        if not torch.isnan(allc[c]):
+            assert e4m3fn_encode(float(allc[c])) == c, c
+    print("G3 kv_quant.npz", os.path.getsize(os.path.join(HERE, "kv_quant.npz")), "bytes")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "g2", "g3"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -697,3 +833,7 @@ if __name__ == "__main__":
         mint_graph_decoder()
     if "op" in which:
         mint_omni_prompt_builder()
+    if "g2" in which:
+        mint_backbone_layer_real()
+    if "g3" in which:
+        mint_kv_quant()

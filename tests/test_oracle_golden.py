@@ -139,3 +139,90 @@ def test_omni_streaming_text_steps_match_reference(omni_prompt_gold):
         if s["cached_after"] is not None:
             assert torch.equal(st["cached"], s["cached_after"])
         assert bool(st.get("finished_flag")) == bool(s["finished_after"] or s["finished_flag"])
+
+
+# ------------------------------------------------------------------ G2 / G3: the backbone half of the oracle
+def _g2_setup():
+    from tests.golden.make_fixtures import G2_CTX, G2_SEED, g2_dims, g2_inputs
+    d = g2_dims()
+    w = make_weights(d, seed=G2_SEED, std=0.02, norm_noise=0.1)
+    return d, w, g2_inputs(d), G2_CTX
+
+
+def _ulp_stats(got: torch.Tensor, ref: torch.Tensor):
+    """(max |diff| in bf16 ulps, fraction bit-identical) for two bf16 tensors; the ulp is that of the reference value's
+    binade, floored at a quarter of the tensor's RMS (sums that cancel to ~0 inherit the error of their terms)."""
+    g, r = got.float(), ref.float()
+    floor = 0.25 * float(r.pow(2).mean().sqrt())
+    ulp = torch.exp2(torch.floor(torch.log2(r.abs().clamp_min(max(floor, 2.0 ** -100)))) - 7)
+    return float(((g - r).abs() / ulp).max()), float((got.view(torch.int16) == ref.view(torch.int16)).float().mean())
+
+
+G2_BT = [[7, 3, 11, 2, 9, 5, 13, 1, 15, 4, 17, 6, 19, 8, 21, 10, 20]]            # 17 non-monotonic blocks cover 257 tokens
+
+
+def g2_check(name: str, n: int, got: torch.Tensor, z) -> None:
+    """One G2 tensor against the fixture.  q / k after q/k-norm + RoPE: the HF bf16 model's rounding points are the
+    oracle's -> bit-identical.  attention output / hidden state: HF's EAGER bf16 attention rounds the scores and P to bf16
+    (matmuls on bf16 tensors), vLLM's attention kernels and this oracle keep them in fp32 -- so those two are measured
+    against HF in FP32: within 1.5 bf16 ulp at the tensor's scale, and no further from it than HF's own bf16 run is
+    (x 1.3)."""
+    ref16 = _bf16(z[f"bf16_{name}{n}"]).reshape(got.shape)
+    ref32 = torch.from_numpy(z[f"f32_{name}{n}"]).reshape(got.shape)
+    if name in ("q", "k"):
+        assert torch.equal(got.view(torch.int16), ref16.view(torch.int16)), (n, name, _ulp_stats(got, ref16))
+        return
+    scale = float(ref32.abs().max())
+    err = float((got.float() - ref32).abs().max())
+    err16 = float((ref16.float() - ref32).abs().max())
+    assert err <= 1.5 * 2.0 ** -7 * scale, (n, name, err, scale)
+    assert err <= 1.3 * err16 + 2.0 ** -9 * scale, (n, name, err, err16)
+
+
+def test_backbone_layer_at_real_dims_matches_hf_qwen3(golden_dir):
+    """VERDICT r1 weak #1 / SURVEY G2: ONE decoder layer at the 1.7B dimensions against HF transformers Qwen3Model in bf16
+    and fp32, decode step at ctx 1 / 15 / 16 / 17 / 257 (page edges of the 16-token blocks and a 17-block context),
+    per-layer q / k after norm + RoPE, attention output, final-normed hidden state (bounds: g2_check)."""
+    z = np.load(os.path.join(golden_dir, "qwen3_layer_real.npz"))
+    d, w, x, ctxs = _g2_setup()
+    assert tuple(z["ctx"].tolist()) == tuple(ctxs)
+    for n in ctxs:
+        orc = O.TalkerOracle(d, w, kv_dtype="bf16", num_blocks=24, block_size=16)
+        if n > 1:
+            orc.backbone(x[: n - 1], torch.arange(n - 1), [0] * (n - 1), G2_BT, [n - 1])
+        orc.trace = []
+        h = orc.backbone(x[n - 1: n], torch.tensor([n - 1]), [0], G2_BT, [n])
+        tr = orc.trace[0]
+        for name, got in (("q", tr["q"][0]), ("k", tr["k"][0]), ("attn", tr["attn"][0]), ("h", h[0])):
+            g2_check(name, n, got, z)
+
+
+def test_kv_quant_bytes_match_the_format_definitions(golden_dir):
+    """G3: what the oracle writes into an fp8 / int8 cache, byte for byte, against expectations minted WITHOUT torch's
+    cast (fp8: a bit-level OCP e4m3fn encoder from the format definition, saturating, ties to even; int8: the build's own
+    per-(token, head) absmax / 127 rule) -- exact ties, subnormals, +-0, 448 and beyond included -- and the slot rule
+    slot = block_table[pos // bs] * bs + pos % bs."""
+    z = np.load(os.path.join(golden_dir, "kv_quant.npz"))
+    k, v = _bf16(z["k"]).reshape(z["fp8_k"].shape), _bf16(z["v"]).reshape(z["fp8_v"].shape)
+    T, H, D = k.shape
+    bs, bt = int(z["block_size"]), z["block_table"].tolist()
+    slots = torch.tensor([O.slot_of(bt, t, bs) for t in range(T)])
+    assert slots.tolist() == z["slots"].tolist()
+    for ks, vs, kn, vn in ((1.0, 1.0, "fp8_k", "fp8_v"), (0.5, 2.0, "fp8_k_s", "fp8_v_s")):
+        kv = O.PagedKV(max(bt) + 1, bs, H, D, "fp8", k_scale=ks, v_scale=vs)
+        kv.write(slots, k, v)
+        got_k = kv.data[0].view(torch.uint8).reshape(-1, H, D)[slots]
+        got_v = kv.data[1].view(torch.uint8).reshape(-1, H, D)[slots]
+        # +-0 both encode a zero: compare with the sign bit of zeros masked
+        for got, want in ((got_k, z[kn]), (got_v, z[vn])):
+            want = torch.from_numpy(want)
+            nz = (want & 0x7F) != 0
+            assert torch.equal(got[nz], want[nz]) and bool(((got[~nz] & 0x7F) == 0).all())
+        untouched = torch.ones(kv.data.shape[1] * bs, dtype=torch.bool)
+        untouched[slots] = False
+        assert int(kv.data[0].view(torch.uint8).reshape(-1, H, D)[untouched].sum()) == 0      # no other slot written
+    kv = O.PagedKV(max(bt) + 1, bs, H, D, "int8")
+    kv.write(slots, k, v)
+    for half, qn, sn in ((0, "int8_k", "int8_scale_k"), (1, "int8_v", "int8_scale_v")):
+        assert torch.equal(kv.data[half].reshape(-1, H, D)[slots], torch.from_numpy(z[qn]))
+        assert torch.equal(kv.scales[half].reshape(-1, H)[slots], torch.from_numpy(z[sn]))
