@@ -33,6 +33,11 @@ class LayerWeights(C.Structure):
                                   "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate")]
 
 
+class ArPeers(C.Structure):
+    """omni_ar_peers: peer-mapped partial buffers + flag words of a tensor-parallel group."""
+    _fields_ = [("world", i32), ("rank", i32), ("data", vp * 8), ("flags", vp * 8), ("epoch", vp), ("error", vp)]
+
+
 class TalkerDesc(C.Structure):
     _fields_ = [
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
@@ -48,6 +53,7 @@ class TalkerDesc(C.Structure):
         ("cp_lm_head", vp), ("cp_embed", vp), ("cp_cos_sin", vp), ("cp_proj_table", vp), ("cp_e0_table", vp),
         ("k_cache", C.POINTER(vp)), ("v_cache", C.POINTER(vp)), ("k_scales", C.POINTER(vp)), ("v_scales", C.POINTER(vp)),
         ("scratch", vp), ("scratch_bytes", i64),
+        ("ar_attn", C.POINTER(ArPeers)), ("ar_mlp", C.POINTER(ArPeers)),
     ]
 
 
@@ -93,6 +99,11 @@ SIGNATURES = {
     "omni_embed": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "omni_sample": (i32, [vp, i32, i32, i32, i32, f32, i32, f32, f32, vp, u32, vp, i32, i32, i32, vp, vp]),
     "omni_sample_rows": (i32, [vp, i32, i32, i32, C.POINTER(RowSampling), vp, vp, i32, i32, i32, vp, vp]),
+    "omni_allreduce_resid": (i32, [C.POINTER(ArPeers), vp, i32, vp, i32, vp, i32, i32, vp]),
+    "omni_ar_alloc": (i32, [i64, C.POINTER(vp), vp]),
+    "omni_ar_open": (i32, [vp, C.POINTER(vp)]),
+    "omni_ar_close": (i32, [vp]),
+    "omni_ar_free": (i32, [vp]),
     "omni_talker_scratch_bytes": (i64, [C.POINTER(TalkerDesc)]),
     "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
     "omni_talker_destroy": (None, [vp]),

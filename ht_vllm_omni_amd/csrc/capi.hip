@@ -111,6 +111,8 @@ struct omni_talker {
     int64_t* cp_slots;
     std::vector<uint16_t*> cp_k, cp_v;
     int32_t* pf_seq;   // prefill scratch
+    omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
+    bool has_ar;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -255,6 +257,17 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
     } else {
         t->k_scales.assign(desc->layers, nullptr);
         t->v_scales.assign(desc->layers, nullptr);
+    }
+    t->has_ar = desc->ar_attn != nullptr && desc->ar_mlp != nullptr;
+    if (t->has_ar) {
+        t->ar_attn = *desc->ar_attn;
+        t->ar_mlp = *desc->ar_mlp;
+        if (!desc->fused_norm || desc->moe_experts > 0 || t->ar_attn.world != t->ar_mlp.world || t->ar_attn.rank != t->ar_mlp.rank ||
+            t->ar_attn.world < 1 || t->ar_attn.world > 8 || !t->ar_attn.data[t->ar_attn.rank] || !t->ar_mlp.data[t->ar_mlp.rank]) {
+            omni_set_error("omni_talker_create: peer-mapped all-reduce needs fused_norm, a dense backbone and consistent peer tables");
+            delete t;
+            return nullptr;
+        }
     }
     size_t total = 0;
     carve(t, reinterpret_cast<char*>(desc->scratch), &total);
@@ -616,6 +629,14 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
                             io->num_live));
+    if (d.fused_norm && t->has_ar) {
+        // tensor-parallel rank on the norm-free stream: partial o_proj -> this rank's peer-mapped buffer (fragment-major),
+        // then ONE launch sums the ranks' partials, adds into r and writes the sum(r^2) slabs
+        void* mine = const_cast<void*>(t->ar_attn.data[t->ar_attn.rank]);
+        TRY(omni_gemm_bf16_ex(t->attn, hq * D, w.wo, nullptr, mine, B, H, hq * D, OMNI_EPI_BF16, nullptr,
+                              OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | OMNI_LAYOUT_OUT_FRAG, st));
+        return omni_allreduce_resid(&t->ar_attn, t->resid, 1, t->part, 64, nullptr, B, H, st);
+    }
     if (d.fused_norm) return resid_gemm(t->attn, w.wo, t->resid, t->part, B, H, hq * D, st);
     TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, B, H, hq * D, st));
     return OMNI_OK;
@@ -695,6 +716,12 @@ extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int
         const omni_layer_weights& w = t->layer[layer];
         TRY(xnorm_gemm(t, t->resid, t->part, d.hidden / 16, w.ln2, nullptr, w.wgu, t->act, io->B, d.inter, d.hidden,
                        silu_epi(t), nullptr, 1, stream));
+        if (t->has_ar) {
+            void* mine = const_cast<void*>(t->ar_mlp.data[t->ar_mlp.rank]);
+            TRY(omni_gemm_bf16_ex(t->act, d.inter, w.wdown, nullptr, mine, io->B, d.hidden, d.inter, OMNI_EPI_BF16, nullptr,
+                                  OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG | OMNI_LAYOUT_OUT_FRAG, stream));
+            return omni_allreduce_resid(&t->ar_mlp, t->resid, 1, t->part, 64, nullptr, io->B, d.hidden, stream);
+        }
         return resid_gemm(t->act, w.wdown, t->resid, t->part, io->B, d.hidden, d.inter, stream);
     }
     return layer_mlp_rows(t, layer, io->B, stream);

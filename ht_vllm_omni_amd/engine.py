@@ -102,23 +102,30 @@ class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
                  k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, masked_logit: float = 0.0, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
-                 fused_norm: bool | None = None):
+                 fused_norm: bool | None = None, peer_allreduce=None):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
         self.d, self.device = dims, torch.device(device)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         self.tp_path = tp_size > 1 or tp_force      # tp_force: run the collective path on a 1-rank group (tests)
+        # tp_comm.PeerAllReduce (peer-mapped one-shot all-reduce fused with the residual add): the tensor-parallel rank then
+        # keeps the norm-free stream and the whole step is one native call; None = RCCL all-reduces between the phase calls
+        self.ar = peer_allreduce
         assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
         self.kv_dtype = kv_dtype
         self.frag_layout = bool(frag_layout)
         # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm): single-rank decode only -- the tensor-parallel
         # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
-        self.fused_norm = (self.frag_layout and not self.tp_path and dims.moe_experts == 0) if fused_norm is None else bool(fused_norm)
+        self.fused_norm = (self.frag_layout and (not self.tp_path or self.ar is not None) and dims.moe_experts == 0) \
+            if fused_norm is None else bool(fused_norm)
         if dims.moe_experts > 0 and (self.fused_norm or not self.frag_layout or tp_size > 1):
             raise ValueError("the sparse-MoE backbone runs the separate-norm, fragment-major, single-rank path")
-        if self.fused_norm and (self.tp_path or not self.frag_layout):
-            raise ValueError("fused_norm needs frag_layout and a single rank")
+        if self.fused_norm and ((self.tp_path and self.ar is None) or not self.frag_layout):
+            raise ValueError("fused_norm needs frag_layout and a single rank (or the peer-mapped all-reduce)")
+        if self.ar is not None and (not self.fused_norm or self.ar.world != tp_size or self.ar.rank != tp_rank or self.ar.hidden != dims.hidden
+                                    or self.ar.rows16 < (max_batch + 15) // 16 * 16):
+            raise ValueError("peer_allreduce does not match this engine (world / rank / hidden / rows, fused_norm)")
         self.kv_code = L.KV_CODES[kv_dtype]
         self.block_size, self.num_blocks, self.max_batch = block_size, num_blocks, max_batch
         self.hq_l = dims.q_heads // tp_size
@@ -244,6 +251,8 @@ class TalkerEngine:
         desc.k_cache, desc.v_cache = C.cast(self._kc, pvp), C.cast(self._vc, pvp)
         if self._ks is not None:
             desc.k_scales, desc.v_scales = C.cast(self._ks, pvp), C.cast(self._vs, pvp)
+        if self.ar is not None:
+            desc.ar_attn, desc.ar_mlp = C.pointer(self.ar.peers[0]), C.pointer(self.ar.peers[1])
         nbytes = self.lib.omni_talker_scratch_bytes(C.byref(desc))
         if nbytes < 0:
             raise L.OmniError("omni_talker_scratch_bytes: " + self.lib.omni_last_error().decode())
@@ -392,7 +401,7 @@ class TalkerEngine:
                 cur.wait_event(ev)
             return
         io = self._io(B, advance)
-        if not self.tp_path:
+        if not self.tp_path or self.ar is not None:
             L.check(self.lib.omni_talker_decode_step(self.handle, C.byref(io), st), "omni_talker_decode_step")
             return
         import torch.distributed as dist

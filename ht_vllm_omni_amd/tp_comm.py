@@ -1,0 +1,114 @@
+"""Tensor-parallel communication of the decode step: peer-mapped one-shot all-reduce (csrc/allreduce.hip) set up over
+torch.distributed.
+
+The reference gets its tensor-parallel group from vLLM (``init_worker_distributed_environment`` at
+V/worker/gpu_ar_worker.py:69-75) and all-reduces inside ``RowParallelLinear`` over NCCL/RCCL.  Here every rank of the group
+allocates two partial buffers ([rows16, H] bf16, fragment-major: one for the o_proj, one for the down_proj all-reduce) and
+one control block (arrival flags, epoch, error word) in fine-grained device memory, publishes their hipIpc handles with
+``all_gather_object`` and maps the peers' -- after which the all-reduces are plain kernel launches of the native decode step
+(captured into its hipGraph).  RCCL stays the transport for prefill-sized messages and for the one-time self-check.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+CTL_BYTES = 256          # uint32 flags[8] | uint32 epoch, ticket | int32 error (64-byte aligned pieces)
+FLAGS_OFF, EPOCH_OFF, ERROR_OFF = 0, 64, 128
+
+
+class PeerAllReduce:
+    def __init__(self, rank: int, world: int, rows: int, hidden: int):
+        if not 1 <= world <= 8:
+            raise ValueError("peer all-reduce: world size 1..8 (one xGMI hop to every peer)")
+        self.lib = L.load()
+        self.rank, self.world, self.hidden = rank, world, hidden
+        self.rows16 = (rows + 15) // 16 * 16
+        self.nbytes = self.rows16 * hidden * 2
+        self._own: list[int] = []
+        self._opened: list[int] = []
+        self.handles = []
+        for nb in (self.nbytes, self.nbytes, CTL_BYTES):
+            p, h = C.c_void_p(), (C.c_char * 64)()
+            L.check(self.lib.omni_ar_alloc(nb, C.byref(p), h), "omni_ar_alloc")
+            self._own.append(p.value)
+            self.handles.append(bytes(h))
+        self.data = [[None] * world, [None] * world]        # [buffer][rank] device pointers valid in this process
+        self.ctl = [None] * world
+        self.data[0][rank], self.data[1][rank], self.ctl[rank] = self._own
+        self.peers = None
+
+    # ---- wiring
+    def connect(self, group=None) -> "PeerAllReduce":
+        """Exchange the hipIpc handles over the (already initialised) process group and map every peer."""
+        import torch.distributed as dist
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, self.handles, group=group)
+        for r, hs in enumerate(gathered):
+            if r == self.rank:
+                continue
+            ptrs = []
+            for h in hs:
+                p = C.c_void_p()
+                L.check(self.lib.omni_ar_open(C.create_string_buffer(h, 64), C.byref(p)), "omni_ar_open")
+                self._opened.append(p.value)
+                ptrs.append(p.value)
+            self.data[0][r], self.data[1][r], self.ctl[r] = ptrs
+        dist.barrier(group=group)
+        return self._finish()
+
+    @staticmethod
+    def link_local(members: list["PeerAllReduce"]) -> None:
+        """All ranks inside ONE process (tests on a single GPU): peers are plain device pointers."""
+        for m in members:
+            for o in members:
+                m.data[0][o.rank], m.data[1][o.rank], m.ctl[o.rank] = o._own
+            m._finish()
+
+    def _finish(self) -> "PeerAllReduce":
+        self.peers = []
+        for b in (0, 1):
+            s = L.ArPeers()
+            s.world, s.rank = self.world, self.rank
+            for r in range(self.world):
+                s.data[r] = self.data[b][r]
+                s.flags[r] = self.ctl[r] + FLAGS_OFF
+            s.epoch = self.ctl[self.rank] + EPOCH_OFF
+            s.error = self.ctl[self.rank] + ERROR_OFF
+            self.peers.append(s)
+        return self
+
+    # ---- views / calls
+    def buffer(self, which: int) -> torch.Tensor:
+        """This rank's partial buffer as a [rows16, H] bf16 tensor (fragment-major bytes)."""
+        return _device_tensor(self.data[which][self.rank], self.rows16 * self.hidden, torch.bfloat16).view(self.rows16, self.hidden)
+
+    def error(self) -> int:
+        return int(_device_tensor(self.ctl[self.rank] + ERROR_OFF, 1, torch.int32).item())
+
+    def all_reduce(self, which: int, *, r_io=None, accumulate=True, partials=None, out=None, M: int) -> None:
+        """Launch on the current stream: sum of data[which] over the ranks (+ residual add / slabs / row-major copy)."""
+        L.check(self.lib.omni_allreduce_resid(C.byref(self.peers[which]), L.ptr(r_io), int(accumulate), L.ptr(partials),
+                                              64 if partials is None else partials.shape[-1], L.ptr(out), M, self.hidden,
+                                              L.current_stream()), "omni_allreduce_resid")
+
+    def close(self) -> None:
+        for p in self._opened:
+            self.lib.omni_ar_close(p)
+        for p in self._own:
+            self.lib.omni_ar_free(p)
+        self._opened, self._own = [], []
+
+
+def _device_tensor(ptr: int, n: int, dtype) -> torch.Tensor:
+    """A torch view of device memory this module allocated through the C-ABI (no ownership: PeerAllReduce frees it)."""
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    typestr = {torch.bfloat16: "<u2", torch.int32: "<i4", torch.uint32: "<u4", torch.float32: "<f4", torch.uint8: "|u1"}[dtype]
+
+    class _Holder:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+    t = torch.as_tensor(_Holder(), device="cuda")
+    return t.view(dtype) if t.dtype != dtype and t.element_size() == itemsize else t

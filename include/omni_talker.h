@@ -221,6 +221,32 @@ typedef struct omni_row_sampling {
 int omni_sample_rows(const float* logits, int ld, int B, int V, const omni_row_sampling* rows, uint8_t* seen,
                      int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids, void* stream);
 
+/* One-shot all-reduce of the tensor-parallel decode step over peer-mapped buffers, fused with the residual add and the
+ * sum-of-squares slabs of the norm-free stream (the reference initialises vLLM's tensor-parallel group at
+ * V/worker/gpu_ar_worker.py:69-75 and all-reduces inside RowParallelLinear; SURVEY 5.8 / 8e: 56 messages of <= 256 KiB per
+ * step are latency-bound on a ring).  One process per GPU: every rank allocates its partial buffers and its flag words with
+ * omni_ar_alloc (fine-grained device memory + hipIpc handle), exchanges the 64-byte handles out of band
+ * (torch.distributed) and maps the peers' with omni_ar_open.
+ *   data[p]  : rank p's partial [M16, H] bf16, FRAGMENT-major (written by the GEMM before the call: OMNI_LAYOUT_OUT_FRAG)
+ *   flags[p] : rank p's uint32[8] arrival words; epoch: this rank's uint32[2] (epoch, ticket); error: this rank's int32,
+ *              set when a peer failed to arrive within the spin bound (the kernel then carries on: never a hung GPU)
+ * omni_allreduce_resid: sum over ranks in rank order (fp32, one rounding: identical bits on every rank);
+ *   r_io (fragment-major residual stream, may be NULL) = bf16((accumulate ? r_io : 0) + sum), partials[H/16][pstride] slabs of
+ *   sum(r^2) (may be NULL), out_rowmajor (bf16 [M, H], may be NULL) = the sum itself.  M <= 64, H % 32 == 0. */
+typedef struct omni_ar_peers {
+    int world, rank;
+    const void* data[8];
+    uint32_t* flags[8];
+    uint32_t* epoch;
+    int32_t* error;
+} omni_ar_peers;
+int omni_allreduce_resid(const omni_ar_peers* peers, void* r_io, int accumulate, float* partials, int pstride, void* out_rowmajor,
+                         int M, int H, void* stream);
+int omni_ar_alloc(int64_t bytes, void** ptr, void* ipc_handle64);   /* zero-filled; handle = hipIpcMemHandle_t bytes */
+int omni_ar_open(const void* ipc_handle64, void** ptr);
+int omni_ar_close(void* ptr);
+int omni_ar_free(void* ptr);
+
 /* ------------------------------------------------------------------ talker engine */
 
 typedef struct omni_layer_weights {
@@ -288,6 +314,12 @@ typedef struct omni_talker_desc {
     /* scratch (device), sized by omni_talker_scratch_bytes() */
     void* scratch;
     int64_t scratch_bytes;
+    /* ABI v2: tensor-parallel ranks with peer-mapped partial buffers (both NULL: the host all-reduces omni_talker_attn_out /
+     * omni_talker_mlp_out between the phase calls).  Same flags / epoch / error words in both, different data buffers: the
+     * o_proj and down_proj all-reduces alternate.  With them a tensor-parallel rank runs fused_norm = 1 and
+     * omni_talker_decode_step is the whole step (the all-reduces are launches of the step, captured with it). */
+    const omni_ar_peers* ar_attn;
+    const omni_ar_peers* ar_mlp;
 } omni_talker_desc;
 
 typedef struct omni_talker omni_talker;
