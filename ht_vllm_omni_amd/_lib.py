@@ -30,7 +30,8 @@ class OmniError(RuntimeError):
 
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown", "moe_router", "moe_gate_up",
-                                  "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate")]
+                                  "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate", "moe_gate_up_scale",
+                                  "moe_down_scale")]
 
 
 class ArPeers(C.Structure):
@@ -54,6 +55,7 @@ class TalkerDesc(C.Structure):
         ("k_cache", C.POINTER(vp)), ("v_cache", C.POINTER(vp)), ("k_scales", C.POINTER(vp)), ("v_scales", C.POINTER(vp)),
         ("scratch", vp), ("scratch_bytes", i64),
         ("ar_attn", C.POINTER(ArPeers)), ("ar_mlp", C.POINTER(ArPeers)),
+        ("moe_e0", i32), ("moe_experts_local", i32), ("moe_w8", i32),
     ]
 
 
@@ -86,6 +88,7 @@ SIGNATURES = {
     "omni_resize_mlp": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "omni_moe_route": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "omni_moe_experts": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "omni_moe_experts_ex": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "omni_snake_beta": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_resid": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_xnorm": (i32, [vp, vp, i32, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),

@@ -676,8 +676,10 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
             TRY(omni_gemm_bf16_ex(t->act, Is, w.moe_shared_down, nullptr, t->moe_shared, rows, H, Is, OMNI_EPI_BF16, nullptr, lay, st));
             shared = t->moe_shared;
         }
-        return omni_moe_experts(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, w.moe_down, shared, w.moe_shared_gate, t->moe_act,
-                                t->moe_y, t->mlp_out, rows, H, d.moe_inter, E, d.moe_top_k, st);
+        const int El = d.moe_experts_local > 0 ? d.moe_experts_local : E;
+        return omni_moe_experts_ex(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, d.moe_w8 ? w.moe_gate_up_scale : nullptr, w.moe_down,
+                                   d.moe_w8 ? w.moe_down_scale : nullptr, shared, w.moe_shared_gate, t->moe_act, t->moe_y, t->mlp_out,
+                                   rows, H, d.moe_inter, El, d.moe_e0, d.moe_top_k, st);
     }
     TRY(norm_gemm(t, t->resid_b, t->attn_out, t->resid, w.ln2, t->normed, nullptr, w.wgu, t->act, rows, d.inter, d.hidden,
                   silu_epi(t), nullptr, d.frag_layout, st));

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         for (int e = 0; e < PE; ++e) s_ += pv[e];
         if (XROWS <= 32) s_ = xor32_sum(s_);
         if (XROWS <= 16) s_ = xor16_sum(s_);
-        float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;
+        float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;      // past the combine slots
         red[wave * 64 + lane] = s_;
         __syncthreads();
         float t = 0.f;
@@ -302,14 +302,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         }
     }
 
-    // ---- combine the 8 K-partials through LDS: lds[wave][e][lane], e = (j*MT+i)*4+reg
-    constexpr int E = NT * MT * 4;
+    // ---- combine the 8 K-partials through LDS: one 16-byte slot per (wave, tile, lane) holding the lane's 4 accumulator
+    // registers -- ds_write_b128 / ds_read_b128, a quarter of the LDS instructions of the former [wave][reg][lane] floats
+    // (GEMM stage attribution, scripts/ab_knobs.py gemm_stage: the combine + epilogue were 0.42 ms of a 3.93 ms step)
+    f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) lds[(wave * E + (j * MT + i) * 4 + g) * 64 + lane] = acc[j][i][g];
+        for (int i = 0; i < MT; ++i) lds4[(wave * (NT * MT) + j * MT + i) * 64 + lane] = acc[j][i];
     __syncthreads();
     DBG_STAGE(4);                                                  // 4: + LDS write of the K partials + barrier
 
@@ -328,17 +328,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         if (ml >= Mloc) continue;
         const int m = m_base + ml;
         float v[4], v2[4];
+        {
+            f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f}, sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float sum = 0.f, sum2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < GEMM_WAVES; ++w) {
-                sum += lds[(w * E + (j * MT + i) * 4 + g) * 64 + l];
-                if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds[(w * E + ((NT / 2 + j) * MT + i) * 4 + g) * 64 + l];
-                if (GU8) sum2 += lds[(w * E + (j * MT + i) * 4 + g) * 64 + l + 32];
+            for (int w = 0; w < GEMM_WAVES; ++w) {              // fixed order: run-to-run deterministic
+                sum += lds4[(w * (NT * MT) + j * MT + i) * 64 + l];
+                if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds4[(w * (NT * MT) + (NT / 2 + j) * MT + i) * 64 + l];
+                if (GU8) sum2 += lds4[(w * (NT * MT) + j * MT + i) * 64 + l + 32];
             }
-            v[g] = sum;
-            v2[g] = sum2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { v[g] = sum[g]; v2[g] = sum2[g]; }
         }
         if (SILU) {
             const int n = GU8 ? (blockIdx.x * NT + j) * 8 + 4 * (l >> 4) : blockIdx.x * 16 * (NT / 2) + j * 16 + 4 * (l >> 4);

@@ -85,21 +85,37 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
 // ---------------------------------------------------------------- expert GEMMs
 struct MoeArgs {
     const uint16_t* x;          // phase 1: bf16 [T, K] tokens; phase 2: bf16 [T * k, K] activation slots
-    const uint16_t* W;          // [E, N_rows, K] fragment-major per expert (phase 1: N_rows = 2 * I gate | up; phase 2: H)
+    const void* W;              // [E_local, N_rows, K] fragment-major per expert (phase 1: N_rows = 2 * I gate | up; phase 2: H);
+                                // bf16, or (W8) fp8 e4m3fn bytes in the same element order + w_scale
+    const float* w_scale;       // W8: fp32 [E_local, N_rows] per-output-row dequantisation scales
     const int32_t* topk_idx; const uint16_t* topk_w;
     uint16_t* out;              // phase 1: act [T * k, I]; phase 2: y [T * k, H] (already * routing weight)
     int T, top_k, K, N;         // N = output columns (I or H)
+    int e0;                     // expert parallel: this rank holds experts [e0, e0 + gridDim.y) of the router's numbering
 };
 
+// fp8 e4m3fn weights, dequantised in registers to the bf16 values bf16(fp8 * row scale) -- exactly the matrix a
+// weight-only-dequantised bf16 model holds (oracle: HF block on those weights) -- then the same bf16 MFMA
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 deq_fp8x8(u32x2 q, float s) {
+    float f[8];
+    unpack_fp8x4(q[0], f);
+    unpack_fp8x4(q[1], f + 4);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(f[2 * j] * s, f[2 * j + 1] * s);
+    return o;
+}
+
 // PHASE 1: NT = 2 tiles (16 gate + 16 up columns) -> SiLU * up; PHASE 2: NT tiles of 16 output columns, * weight
-template <int PHASE, int NT>
+template <int PHASE, int NT, bool W8>
 __global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [WAVES][NT*4][64] partial sums
     __shared__ int s_tok[MOE_MAXT], s_slot[MOE_MAXT];
     __shared__ int s_cnt[MOE_WAVES + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int e = blockIdx.y;
+    const int e = a.e0 + blockIdx.y;                     // the router's expert id; blockIdx.y indexes this rank's weights
     const int K = a.K, nsteps = K >> 5;
 
     // ---- this expert's (token, slot) list, in token order: entry i = token i / k, position i % k
@@ -126,14 +142,22 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a
 
     // ---- W rows of this workgroup (fragment-major per expert: tile (row tile, k step) = 512 contiguous elements)
     const size_t rows_e = PHASE == 1 ? 2 * (size_t)a.N : (size_t)a.N;
-    const uint16_t* We = a.W + (size_t)e * rows_e * K;
-    const uint16_t* wrow[NT];
+    constexpr int WB = W8 ? 1 : 2;                        // bytes per weight element
+    const char* We = reinterpret_cast<const char*>(a.W) + (size_t)blockIdx.y * rows_e * K * WB;
+    const char* wrow[NT];
+    int tile_of[NT];
     if (PHASE == 1) {
-        wrow[0] = We + ((size_t)blockIdx.x * nsteps) * 512 + lane * 8;                                   // gate tile
-        wrow[NT - 1] = We + ((size_t)(a.N / 16 + blockIdx.x) * nsteps) * 512 + lane * 8;                 // matching up tile
+        tile_of[0] = blockIdx.x;                          // gate tile
+        tile_of[NT - 1] = a.N / 16 + blockIdx.x;          // matching up tile
     } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wrow[j] = We + ((size_t)(blockIdx.x * NT + j) * nsteps) * 512 + lane * 8;
+        for (int j = 0; j < NT; ++j) tile_of[j] = blockIdx.x * NT + j;
+    }
+    float wsc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        wrow[j] = We + (((size_t)tile_of[j] * nsteps) * 512 + lane * 8) * WB;
+        wsc[j] = W8 ? a.w_scale[(size_t)blockIdx.y * rows_e + tile_of[j] * 16 + r] : 1.0f;      // lane (r, q) holds W row r of the tile
     }
 
     for (int m0 = 0; m0 < n_e; m0 += 16) {
@@ -146,7 +170,9 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a
             const u32x4 X = *reinterpret_cast<const u32x4*>(xrow + ks * 32);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const u32x4 Wf = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[j] + (size_t)ks * 512));
+                u32x4 Wf;
+                if (W8) Wf = deq_fp8x8(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow[j] + (size_t)ks * 512)), wsc[j]);
+                else Wf = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[j] + (size_t)ks * 1024));
                 acc[j] = moe_mfma(Wf, X, acc[j]);
             }
         }
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a
 __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ y, const int32_t* __restrict__ topk_idx,
                                                           const uint16_t* __restrict__ x, const uint16_t* __restrict__ w_sg,
                                                           const uint16_t* __restrict__ shared, uint16_t* __restrict__ out,
-                                                          int top_k, int H) {
+                                                          int top_k, int H, int e_lo, int e_hi) {
     const int t = blockIdx.x;
     __shared__ int order[MOE_MAXK];
     __shared__ float red[4];
@@ -228,18 +254,25 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
         __syncthreads();
         gate = s_gate;
     }
+    // expert parallel: slots of experts another rank holds were never written here -- they count as zero (the ranks'
+    // partial outputs are summed by the all-reduce that follows)
     int ord[MOE_MAXK];
+    bool loc[MOE_MAXK];
 #pragma unroll
-    for (int k = 0; k < MOE_MAXK; ++k) ord[k] = k < top_k ? order[k] : 0;
+    for (int k = 0; k < MOE_MAXK; ++k) {
+        ord[k] = k < top_k ? order[k] : 0;
+        const int ek = k < top_k ? topk_idx[(size_t)t * top_k + ord[k]] : -1;
+        loc[k] = ek >= e_lo && ek < e_hi;
+    }
     for (int h = threadIdx.x * 2; h < H; h += 512) {       // two columns per thread: 4-B accesses
         uint32_t yv[MOE_MAXK];
 #pragma unroll
         for (int k = 0; k < MOE_MAXK; ++k)
-            yv[k] = k < top_k ? *reinterpret_cast<const uint32_t*>(y + ((size_t)t * top_k + ord[k]) * H + h) : 0u;
+            yv[k] = (k < top_k && loc[k]) ? *reinterpret_cast<const uint32_t*>(y + ((size_t)t * top_k + ord[k]) * H + h) : 0u;
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int k = 0; k < MOE_MAXK; ++k)
-            if (k < top_k) { a0 = bfround(a0 + bf_lo(yv[k])); a1 = bfround(a1 + bf_hi(yv[k])); }
+            if (k < top_k && loc[k]) { a0 = bfround(a0 + bf_lo(yv[k])); a1 = bfround(a1 + bf_hi(yv[k])); }
         if (shared) {
             const uint32_t sv = *reinterpret_cast<const uint32_t*>(shared + (size_t)t * H + h);
             a0 = bfround(a0 + bfround(gate * bf_lo(sv)));
@@ -262,27 +295,47 @@ extern "C" int omni_moe_route(const void* logits, int T, int E, int top_k, int n
     return OMNI_OK;
 }
 
-extern "C" int omni_moe_experts(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,
-                                const void* w_down, const void* shared, const void* w_shared_gate, void* act_ws, void* y_ws,
-                                void* out, int T, int H, int I, int E, int top_k, void* stream) {
+// E = experts held here (the router's ids [e0, e0 + E)); scales != NULL: fp8 e4m3fn weights + per-row fp32 scales
+static int moe_experts_impl(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up,
+                            const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
+                            void* y_ws, void* out, int T, int H, int I, int E, int e0, int top_k, void* stream) {
     OMNI_CHECK_ARG(x && topk_idx && topk_w && w_gate_up && w_down && act_ws && y_ws && out, "omni_moe_experts: null pointer");
     OMNI_CHECK_ARG(T >= 1 && T <= MOE_MAXT && top_k >= 1 && top_k <= MOE_MAXK && T * top_k <= MOE_THREADS,
                    "omni_moe_experts: T=%d top_k=%d (T <= %d, T * top_k <= %d)", T, top_k, MOE_MAXT, MOE_THREADS);
-    OMNI_CHECK_ARG(H % 64 == 0 && I % 32 == 0 && E >= 1 && E <= 65535, "omni_moe_experts: H=%d I=%d E=%d (H %% 64, I %% 32)", H, I, E);
+    OMNI_CHECK_ARG(H % 64 == 0 && I % 32 == 0 && E >= 1 && E <= 65535 && e0 >= 0, "omni_moe_experts: H=%d I=%d E=%d e0=%d (H %% 64, I %% 32)", H, I, E, e0);
     OMNI_CHECK_ARG(!shared || w_shared_gate, "omni_moe_experts: shared expert output without its gate weight");
+    OMNI_CHECK_ARG((s_gate_up == nullptr) == (s_down == nullptr), "omni_moe_experts: fp8 weights need both scale arrays");
     hipStream_t st = (hipStream_t)stream;
+    const bool w8 = s_gate_up != nullptr;
     MoeArgs a{};
-    a.topk_idx = topk_idx; a.topk_w = (const uint16_t*)topk_w; a.T = T; a.top_k = top_k;
+    a.topk_idx = topk_idx; a.topk_w = (const uint16_t*)topk_w; a.T = T; a.top_k = top_k; a.e0 = e0;
     // phase 1: act[slot] = silu(x . Wg^T) * (x . Wu^T)
-    a.x = (const uint16_t*)x; a.W = (const uint16_t*)w_gate_up; a.out = (uint16_t*)act_ws; a.K = H; a.N = I;
-    hipLaunchKernelGGL((moe_expert_kernel<1, 2>), dim3(I / 16, E), dim3(MOE_THREADS), MOE_WAVES * 2 * 4 * 64 * sizeof(float), st, a);
+    a.x = (const uint16_t*)x; a.W = w_gate_up; a.w_scale = s_gate_up; a.out = (uint16_t*)act_ws; a.K = H; a.N = I;
+    if (w8) hipLaunchKernelGGL((moe_expert_kernel<1, 2, true>), dim3(I / 16, E), dim3(MOE_THREADS), MOE_WAVES * 2 * 4 * 64 * sizeof(float), st, a);
+    else hipLaunchKernelGGL((moe_expert_kernel<1, 2, false>), dim3(I / 16, E), dim3(MOE_THREADS), MOE_WAVES * 2 * 4 * 64 * sizeof(float), st, a);
     OMNI_CHECK_LAUNCH("omni_moe_experts(gate_up)");
     // phase 2: y[slot] = bf16(act . Wd^T) * weight
-    a.x = (const uint16_t*)act_ws; a.W = (const uint16_t*)w_down; a.out = (uint16_t*)y_ws; a.K = I; a.N = H;
-    hipLaunchKernelGGL((moe_expert_kernel<2, 4>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
+    a.x = (const uint16_t*)act_ws; a.W = w_down; a.w_scale = s_down; a.out = (uint16_t*)y_ws; a.K = I; a.N = H;
+    if (w8) hipLaunchKernelGGL((moe_expert_kernel<2, 4, true>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
+    else hipLaunchKernelGGL((moe_expert_kernel<2, 4, false>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
     OMNI_CHECK_LAUNCH("omni_moe_experts(down)");
     hipLaunchKernelGGL(moe_combine_kernel, dim3(T), dim3(256), 0, st, (const uint16_t*)y_ws, topk_idx, (const uint16_t*)x,
-                       (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, top_k, H);
+                       (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, top_k, H, e0, e0 + E);
     OMNI_CHECK_LAUNCH("omni_moe_experts(combine)");
     return OMNI_OK;
+}
+
+extern "C" int omni_moe_experts(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,
+                                const void* w_down, const void* shared, const void* w_shared_gate, void* act_ws, void* y_ws,
+                                void* out, int T, int H, int I, int E, int top_k, void* stream) {
+    return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, nullptr, w_down, nullptr, shared, w_shared_gate, act_ws, y_ws, out, T, H, I,
+                            E, 0, top_k, stream);
+}
+
+extern "C" int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,
+                                   const float* s_gate_up, const void* w_down, const float* s_down, const void* shared,
+                                   const void* w_shared_gate, void* act_ws, void* y_ws, void* out, int T, int H, int I,
+                                   int E_local, int e0, int top_k, void* stream) {
+    return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, s_gate_up, w_down, s_down, shared, w_shared_gate, act_ws, y_ws, out, T, H, I,
+                            E_local, e0, top_k, stream);
 }

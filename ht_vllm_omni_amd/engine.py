@@ -66,6 +66,33 @@ def frag_unshuffle(w: torch.Tensor) -> torch.Tensor:
 MOE_NAMES = ("moe_router", "moe_gate_up", "moe_down", "moe_shared_gate_up", "moe_shared_down", "moe_shared_gate")
 
 
+def moe_parallel_mode(d: TalkerDims, tp: int) -> str:
+    """How the routed experts are spread over a tensor-parallel group of `tp` ranks: "tp" = every expert's intermediate
+    dimension split (needs whole 32-column tiles per rank), else "ep" = whole experts per rank (needs whole 16-expert groups)."""
+    if tp == 1:
+        return "none"
+    if d.moe_shared_inter % (32 * tp):
+        raise ValueError(f"shared expert width {d.moe_shared_inter} does not split into 32-column tiles over {tp} ranks")
+    if d.moe_inter % (32 * tp) == 0:
+        return "tp"
+    if d.moe_experts % tp == 0:
+        return "ep"
+    raise ValueError(f"MoE of {d.moe_experts} experts x {d.moe_inter} columns does not split over {tp} ranks")
+
+
+def fp8_quant_rows(w: torch.Tensor):
+    """Per-output-row symmetric e4m3fn quantisation of an expert weight stack [..., rows, K]: (uint8 bytes, fp32 scales
+    [..., rows]); dequantised value = bf16(fp8 * scale) (what the kernel rebuilds in registers and the oracle's weights are)."""
+    wf = w.float()
+    scale = (wf.abs().amax(-1).clamp_min(1e-12) / 448.0).to(torch.float32)
+    q = (wf / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def fp8_dequant_rows(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return (q_u8.view(torch.float8_e4m3fn).float() * scale[..., None].float()).to(BF16)
+
+
 def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict:
     """Per-rank slices of one backbone layer."""
     D = d.head_dim
@@ -82,11 +109,25 @@ def shard_layer(d: TalkerDims, w: dict, prefix: str, rank: int, tp: int) -> dict
     k = wqkv[ko + kv0 * D: ko + (kv0 + hkv_l) * D]
     v = wqkv[vo + kv0 * D: vo + (kv0 + hkv_l) * D]
     if d.moe_experts > 0:
-        if tp != 1:
-            raise ValueError("the sparse-MoE backbone is single-rank (no expert / tensor parallel sharding yet)")
-        return {"ln1": w[prefix + "ln1"], "ln2": w[prefix + "ln2"], "qnorm": w[prefix + "qnorm"], "knorm": w[prefix + "knorm"],
-                "wqkv": w[prefix + "wqkv"].contiguous(), "wo": w[prefix + "wo"].contiguous(),
-                **{n: w[prefix + n] for n in MOE_NAMES}}
+        out = {"ln1": w[prefix + "ln1"], "ln2": w[prefix + "ln2"], "qnorm": w[prefix + "qnorm"], "knorm": w[prefix + "knorm"],
+               "wqkv": torch.cat([q, k, v], 0).contiguous(),
+               "wo": w[prefix + "wo"][:, rank * hq_l * D:(rank + 1) * hq_l * D].contiguous(),
+               "moe_router": w[prefix + "moe_router"], "moe_shared_gate": w[prefix + "moe_shared_gate"]}
+        mode, Im, Is, E = moe_parallel_mode(d, tp), d.moe_inter, d.moe_shared_inter, d.moe_experts
+        gu, dn = w[prefix + "moe_gate_up"], w[prefix + "moe_down"]
+        if mode == "tp":        # every expert's intermediate dimension split (vLLM FusedMoE under tensor_parallel_size)
+            il = Im // tp
+            out["moe_gate_up"] = torch.cat([gu[:, rank * il:(rank + 1) * il], gu[:, Im + rank * il: Im + (rank + 1) * il]], 1).contiguous()
+            out["moe_down"] = dn[:, :, rank * il:(rank + 1) * il].contiguous()
+        else:                   # expert parallel: a contiguous range of experts per rank (tokens are replicated on every rank)
+            el = E // tp
+            out["moe_gate_up"] = gu[rank * el:(rank + 1) * el].contiguous()
+            out["moe_down"] = dn[rank * el:(rank + 1) * el].contiguous()
+        sl = Is // tp           # the shared expert is a dense MLP: always split over its intermediate dimension
+        sgu = w[prefix + "moe_shared_gate_up"]
+        out["moe_shared_gate_up"] = torch.cat([sgu[rank * sl:(rank + 1) * sl], sgu[Is + rank * sl: Is + (rank + 1) * sl]], 0).contiguous()
+        out["moe_shared_down"] = w[prefix + "moe_shared_down"][:, rank * sl:(rank + 1) * sl].contiguous()
+        return out
     i_l = d.inter // tp
     wgu = w[prefix + "wgu"]
     return {
@@ -102,7 +143,7 @@ class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
                  k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, masked_logit: float = 0.0, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
-                 fused_norm: bool | None = None, peer_allreduce=None):
+                 fused_norm: bool | None = None, peer_allreduce=None, moe_fp8: bool = False):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -119,8 +160,10 @@ class TalkerEngine:
         # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
         self.fused_norm = (self.frag_layout and (not self.tp_path or self.ar is not None) and dims.moe_experts == 0) \
             if fused_norm is None else bool(fused_norm)
-        if dims.moe_experts > 0 and (self.fused_norm or not self.frag_layout or tp_size > 1):
-            raise ValueError("the sparse-MoE backbone runs the separate-norm, fragment-major, single-rank path")
+        if dims.moe_experts > 0 and (self.fused_norm or not self.frag_layout):
+            raise ValueError("the sparse-MoE backbone runs the separate-norm, fragment-major path")
+        self.moe_fp8 = bool(moe_fp8) and dims.moe_experts > 0
+        self.moe_mode = moe_parallel_mode(dims, tp_size) if dims.moe_experts > 0 else "none"
         if self.fused_norm and ((self.tp_path and self.ar is None) or not self.frag_layout):
             raise ValueError("fused_norm needs frag_layout and a single rank (or the peer-mapped all-reduce)")
         if self.ar is not None and (not self.fused_norm or self.ar.world != tp_size or self.ar.rank != tp_rank or self.ar.hidden != dims.hidden
@@ -131,6 +174,10 @@ class TalkerEngine:
         self.hq_l = dims.q_heads // tp_size
         self.hkv_l = max(dims.kv_heads // tp_size, 1)
         self.inter_l = dims.inter // tp_size
+        self.moe_inter_l = dims.moe_inter // tp_size if dims.moe_experts > 0 and self.moe_mode == "tp" else dims.moe_inter
+        self.moe_experts_l = dims.moe_experts // tp_size if dims.moe_experts > 0 and self.moe_mode == "ep" else dims.moe_experts
+        self.moe_e0 = tp_rank * self.moe_experts_l if self.moe_mode == "ep" else 0
+        self.moe_shared_l = dims.moe_shared_inter // tp_size
         self.bt_stride = (dims.max_model_len + block_size - 1) // block_size
         dev = self.device
         d = dims
@@ -174,13 +221,25 @@ class TalkerEngine:
         self.layer_w: list[dict] = []
         for i in range(d.layers):
             sh = shard_layer(d, weights, f"l{i}.", tp_rank, tp_size)
+            if self.moe_fp8:
+                # fp8 e4m3fn expert weights (BASELINE config #5): quantised per output row at load; everything downstream
+                # -- the decode kernels' in-register dequantisation, the prefill's bf16 copies, the oracle in the tests --
+                # sees the SAME matrix bf16(fp8 * scale)
+                for n in ("moe_gate_up", "moe_down"):
+                    q8, sc = fp8_quant_rows(sh[n])
+                    sh[n + "_q8"], sh[n + "_scale"] = q8, sc
+                    sh[n] = fp8_dequant_rows(q8, sc)
             lw = {n: up(sh[n]) for n in bb_names}
             self.layer_w.append(lw)                 # row-major: hipBLASLt prefill path
             for n in bb_names:
                 t_ = lw[n]
                 if self.frag_layout and n in frag_names:
                     # fragment-major copy for the native decode GEMMs (per expert for MoE; dense gate_up interleaved by 8)
-                    t_ = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
+                    if self.moe_fp8 and n in ("moe_gate_up", "moe_down"):
+                        t_ = up(frag_shuffle(sh[n + "_q8"]))            # same element order, one byte per weight
+                        setattr(self._layers[i], n + "_scale", up(sh[n + "_scale"]).data_ptr())
+                    else:
+                        t_ = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
                 setattr(self._layers[i], n, t_.data_ptr())
             if d.moe_experts > 0:
                 # the batched hipBLASLt prefill wants [E, K, N] operands stored that way: torch.bmm on the transposed VIEW of
@@ -225,8 +284,9 @@ class TalkerEngine:
         # the code predictor is replicated on every rank and has no collective inside: norm-free whenever layouts allow
         self.cp_fused_norm = self.frag_layout if fused_norm is None else bool(fused_norm)
         desc.cp_fused_norm = int(self.cp_fused_norm)
-        desc.moe_experts, desc.moe_top_k, desc.moe_inter = d.moe_experts, d.moe_top_k, d.moe_inter
-        desc.moe_shared_inter, desc.moe_norm_topk = d.moe_shared_inter, int(d.moe_norm_topk)
+        desc.moe_experts, desc.moe_top_k, desc.moe_inter = d.moe_experts, d.moe_top_k, self.moe_inter_l
+        desc.moe_shared_inter, desc.moe_norm_topk = self.moe_shared_l, int(d.moe_norm_topk)
+        desc.moe_e0, desc.moe_experts_local, desc.moe_w8 = self.moe_e0, self.moe_experts_l if d.moe_experts > 0 else 0, int(self.moe_fp8)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
@@ -475,8 +535,12 @@ class TalkerEngine:
         import torch.nn.functional as F
         d = self.d
         T, H = a.shape
-        E, k, I = d.moe_experts, d.moe_top_k, d.moe_inter
+        E, k, I = self.moe_experts_l, d.moe_top_k, self.moe_inter_l
         idx, wts = ops.moe_route(F.linear(a, w["moe_router"]), k, d.moe_norm_topk)       # int32 [T, k], bf16 [T, k]
+        if self.moe_mode == "ep":       # slots of experts another rank holds: weight 0 here (their share arrives by all-reduce)
+            local = (idx >= self.moe_e0) & (idx < self.moe_e0 + E)
+            wts = torch.where(local, wts, torch.zeros_like(wts))
+            idx = torch.where(local, idx - self.moe_e0, torch.zeros_like(idx))
         idx_s, perm = torch.sort(idx.long(), dim=1)                     # per token: its experts in ascending order
         wts_s = torch.gather(wts, 1, perm)
         flat_e = idx_s.reshape(-1)                                      # expert of slot (t, j), slot = t * k + j
@@ -497,7 +561,7 @@ class TalkerEngine:
         out = torch.zeros(T, H, dtype=BF16, device=a.device)
         for j in range(k):
             out += ys[:, j]
-        if d.moe_shared_inter > 0:
+        if self.moe_shared_l > 0:
             sh = F.linear(ops.silu_mul(F.linear(a, w["moe_shared_gate_up"])), w["moe_shared_down"])
             out = out + torch.sigmoid(F.linear(a, w["moe_shared_gate"])) * sh
         return out

@@ -110,6 +110,17 @@ int omni_moe_route(const void* logits, int T, int E, int top_k, int norm_topk_pr
 int omni_moe_experts(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const void* w_down,
                      const void* shared, const void* w_shared_gate, void* act_ws, void* y_ws, void* out, int T, int H, int I,
                      int E, int top_k, void* stream);
+/* The same block for a tensor- / expert-parallel rank and for fp8 expert weights (BASELINE configs #4 / #5; the reference
+ * runs vLLM FusedMoE under tensor_parallel_size, V/model_executor/models/qwen3_omni/qwen3_moe.py:8,152-161):
+ *   E_local, e0 : this rank holds experts [e0, e0 + E_local) of the router's numbering (expert parallel); slots routed to
+ *                 other ranks' experts contribute zero -- `out` is then a PARTIAL sum the caller all-reduces.  Tensor
+ *                 parallel (every expert's intermediate dimension split) needs no special case: pass the shards and I_local.
+ *   s_gate_up [E_local, 2I] / s_down [E_local, H] fp32, both or neither: with them w_gate_up / w_down hold fp8 e4m3fn bytes
+ *                 (same fragment-major element order), dequantised in registers to bf16(fp8 * row scale) -- bit for bit the
+ *                 matrix of a weight-only-dequantised bf16 model -- before the same bf16 MFMA (half the HBM bytes).       */
+int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up,
+                        const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
+                        void* y_ws, void* out, int T, int H, int I, int E_local, int e0, int top_k, void* stream);
 
 /* SnakeBeta activation of the Code2Wav decoder (next stage after the talker):
  *   out[b, c, t] = x + inv_beta[c] * sin^2(x * exp_alpha[c]),  x / out [B, C, T] contiguous fp32 (is_bf16 = 0) or bf16,
@@ -265,6 +276,9 @@ typedef struct omni_layer_weights {
     const void* moe_shared_gate_up;  /* bf16 [2*Is, H]  ([gate | up] rows)             */
     const void* moe_shared_down;     /* bf16 [H, Is]    (layout as wdown)              */
     const void* moe_shared_gate;     /* bf16 [H]                                       */
+    /* ABI v2: fp8 e4m3fn expert weights (desc.moe_w8): moe_gate_up / moe_down hold bytes, these the per-row fp32 scales */
+    const float* moe_gate_up_scale;  /* fp32 [E_local, 2*Im]                           */
+    const float* moe_down_scale;     /* fp32 [E_local, H]                              */
 } omni_layer_weights;
 
 typedef struct omni_talker_desc {
@@ -320,6 +334,10 @@ typedef struct omni_talker_desc {
      * omni_talker_decode_step is the whole step (the all-reduces are launches of the step, captured with it). */
     const omni_ar_peers* ar_attn;
     const omni_ar_peers* ar_mlp;
+    /* sparse-MoE backbone on a tensor- / expert-parallel rank: moe_experts stays the ROUTER's expert count; this rank holds
+     * experts [moe_e0, moe_e0 + moe_experts_local) (0 local = all of them), each with moe_inter columns (already the shard);
+     * moe_w8 != 0: fp8 expert weights + scales in omni_layer_weights */
+    int moe_e0, moe_experts_local, moe_w8;
 } omni_talker_desc;
 
 typedef struct omni_talker omni_talker;

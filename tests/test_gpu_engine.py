@@ -156,7 +156,7 @@ def test_code_predictor_omni_style_no_projection_top_p():
 
 
 def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_blocks=64, graph=False, seed=0,
-              mean_tol=4e-3, engine_kw=None):
+              mean_tol=4e-3, engine_kw=None, max_ulps=2.0):
     """Prefill + n_steps decode steps on GPU engine and oracle; returns per-step records."""
     bs = 16
     B = len(prompt_lens)
@@ -188,7 +188,7 @@ def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_
     hid = eng.prefill(x.cuda(), pos.cuda(), req.cuda(), slots.cuda())
     last = torch.tensor(np.cumsum(prompt_lens) - 1)
     hl = hid[last.cuda()]
-    assert_e2e_close(hl, o_h, mean_tol=mean_tol, what="prefill hidden")
+    assert_e2e_close(hl, o_h, mean_tol=mean_tol, max_ulps=max_ulps, what="prefill hidden")
     lg = eng.compute_logits(hl)
     rec = {"prefill_logits": (lg.cpu(), o_logits)}
     # hand the ORACLE's first token / hidden to the engine so later steps compare like for like
@@ -242,19 +242,42 @@ def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_
         eng.last_hidden[:B] = oh.cuda()
     rec["steps"] = steps
     rec["engine"], rec["oracle"] = eng, orc
+    rec["first"] = (o_ids, o_h)
     return rec
 
 
-def _check(rec, *, mean_tol=4e-3):
+def _codes_equal_up_to_near_ties(rec, i, w, tie=2.0 ** -6):
+    """Audio codes of step i: bit-exact, except that a row may leave the oracle's greedy path at a group whose two best
+    (bf16-rounded) code-predictor logits are within `tie` of each other -- an argmax over near-equal values is decided by
+    the summation order; everything after that group in the row follows a different input and is not compared."""
+    got, ref = rec["steps"][i]["codes"]
+    if torch.equal(got, ref):
+        return
+    orc = rec["oracle"]
+    ids_prev, h_prev = rec["first"] if i == 0 else (rec["steps"][i - 1]["ids"][1], rec["steps"][i - 1]["hidden"][1])
+    bad = (got != ref).any(1).nonzero().flatten().tolist()
+    _, lg = orc.code_predictor(ids_prev[bad], w["embed"][ids_prev[bad]], h_prev[bad], do_sample=False, return_logits=True)
+    for j, b in enumerate(bad):
+        gfirst = int((got[b] != ref[b]).nonzero()[0])
+        assert gfirst >= 1, f"step {i} row {b}: layer-0 code differs"
+        top = torch.topk(lg[j, gfirst - 1].float(), 2).values
+        assert float(top[0] - top[1]) <= tie, f"step {i} row {b}: code group {gfirst} differs without a near-tie (margin {float(top[0] - top[1]):.4g})"
+    assert len(bad) <= max(1, got.shape[0] // 8), f"step {i}: {len(bad)} rows left the greedy path"
+
+
+def _check(rec, *, mean_tol=4e-3, max_ulps=2.0, weights=None):
     lg, ol = rec["prefill_logits"]
-    assert_e2e_close(lg, ol, mean_tol=mean_tol, what="prefill logits")
+    assert_e2e_close(lg, ol, mean_tol=mean_tol, max_ulps=max_ulps, what="prefill logits")
     for i, st in enumerate(rec["steps"]):
         assert torch.equal(st["slots"][0], st["slots"][1]), f"step {i}: slot mapping must be bit-exact"
-        assert torch.equal(st["codes"][0], st["codes"][1]), f"step {i}: audio codes must be bit-exact"
+        if weights is None:
+            assert torch.equal(st["codes"][0], st["codes"][1]), f"step {i}: audio codes must be bit-exact"
+        else:
+            _codes_equal_up_to_near_ties(rec, i, weights)
         g, o = st["logits"]
         assert torch.equal(torch.isinf(g), torch.isinf(o)), f"step {i}: codec mask pattern"
-        assert_e2e_close(g, o, mean_tol=mean_tol, what=f"step {i} logits")
-        assert_e2e_close(st["hidden"][0], st["hidden"][1], mean_tol=mean_tol, what=f"step {i} hidden")
+        assert_e2e_close(g, o, mean_tol=mean_tol, max_ulps=max_ulps, what=f"step {i} logits")
+        assert_e2e_close(st["hidden"][0], st["hidden"][1], mean_tol=mean_tol, max_ulps=max_ulps, what=f"step {i} hidden")
         ids_g, ids_o = st["ids"]
         for b in range(ids_o.shape[0]):
             if ids_g[b] != ids_o[b]:
@@ -491,7 +514,8 @@ def test_omni_talker_real_dims_one_layer():
     assert diverged <= 6, f"{diverged} of 128 rows took a different expert / code at a near-tie"
 
 
-@pytest.mark.parametrize("model,tp", [("tiny", 2), ("tts-1.7b-1layer", 8), ("tts-1.7b-1layer", 4)])
+@pytest.mark.parametrize("model,tp", [("tiny", 2), ("tts-1.7b-1layer", 8), ("tts-1.7b-1layer", 4), ("omni-talker-1layer", 2),
+                                      ("omni-talker-1layer-fp8w", 8)])
 def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
     """Tensor parallel on ONE GPU: all rank engines of a TP group (sharded qkv / o / gate_up / down, one
     KV head each, replicated code predictor) are driven phase by phase, the two all-reduces of every layer replaced by
@@ -499,16 +523,31 @@ def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
     unsharded oracle.  (The RCCL all-reduce itself: test_tp_collective_path_captured_in_hipgraph, 1-rank group.)"""
     import ctypes as C
     from ht_vllm_omni_amd import _lib as L
+    kv, moe_fp8, ow = "bf16", False, None
     if model == "tiny":
         d = get_dims("tiny")
         w = make_weights(d, seed=17, std=0.06, norm_noise=0.1)
+    elif model.startswith("omni-talker"):
+        # BASELINE config #4: the Omni talker's real layer shape (sparse MoE: 128 experts top-8 of width 384 + shared 768,
+        # 16 q / 2 kv heads) under TP = 2 with int8 KV -- experts split over their intermediate dimension (192 columns per
+        # rank); config #5's regime: 8 ranks = expert parallel (16 experts per rank), fp8 e4m3fn expert weights, fp8 KV
+        from ht_vllm_omni_amd.engine import fp8_dequant_rows, fp8_quant_rows, moe_parallel_mode
+        d = get_dims("omni-talker").with_(layers=1, cp_layers=1, num_code_groups=3, max_model_len=256)
+        w = make_weights(d, seed=17, std=0.02)
+        moe_fp8 = model.endswith("fp8w")
+        kv = "fp8" if moe_fp8 else "int8"
+        assert moe_parallel_mode(d, tp) == ("ep" if tp == 8 else "tp")
+        if moe_fp8:                                   # the oracle computes on the dequantised matrices the engine's kernels rebuild
+            ow = dict(w)
+            for n in ("l0.moe_gate_up", "l0.moe_down"):
+                ow[n] = fp8_dequant_rows(*fp8_quant_rows(w[n]))
     else:                                             # real layer shapes: TP = 8 -> 2 q heads / 1 kv head / 768 columns per rank
         d = get_dims("tts-1.7b").with_(layers=1, cp_layers=1, num_code_groups=3, max_model_len=256)
         w = make_weights(d, seed=17, std=0.02)
     bs, nb, n_steps = 16, 32, 3
     prompt_lens = [5, 17, 33]
     B = len(prompt_lens)
-    orc = O.TalkerOracle(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs)
+    orc = O.TalkerOracle(d, ow or w, kv_dtype=kv, num_blocks=nb, block_size=bs)
     pool = BlockPool(nb, bs)
     g = torch.Generator().manual_seed(0)
     prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in prompt_lens]
@@ -518,12 +557,21 @@ def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
     bts = [pool.block_ids(f"r{r}") for r in range(B)]
     states = [O.OracleState(tail_text=[], tts_pad=pads[r]) for r in range(B)]
     _, o_ids, o_h = orc.prefill(states, prompts, bts, greedy=True, sampling={})
-    engs = [_engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=B, tp_rank=r, tp_size=tp) for r in range(tp)]
+    engs = [_engine(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs, max_batch=B, tp_rank=r, tp_size=tp, moe_fp8=moe_fp8) for r in range(tp)]
     lib = engs[0].lib
+    moe = d.moe_experts > 0
+
+    def kv_head_slice(e, r):                             # more ranks than KV heads: heads replicate (vLLM QKVParallelLinear)
+        h0 = r * e.hkv_l if tp <= d.kv_heads else r // (tp // d.kv_heads)
+        return slice(h0, h0 + e.hkv_l)
+
     for r, e in enumerate(engs):
-        assert e.tp_path and e.hq_l == d.q_heads // tp and e.hkv_l == d.kv_heads // tp and not e.fused_norm and e.cp_fused_norm
+        assert e.tp_path and e.hq_l == d.q_heads // tp and e.hkv_l == max(d.kv_heads // tp, 1) and not e.fused_norm and e.cp_fused_norm
         for li in range(d.layers):                       # this rank's KV head of the prefilled cache
-            e.kv_caches[li].copy_(orc.kv[li].data[:, :, :, r * e.hkv_l:(r + 1) * e.hkv_l].cuda())
+            src = orc.kv[li].data.view(torch.uint8) if kv == "fp8" else orc.kv[li].data
+            e.kv_caches[li].copy_(src[:, :, :, kv_head_slice(e, r)].cuda())
+            if kv == "int8":
+                e.kv_scales[li].copy_(orc.kv[li].scales[:, :, :, kv_head_slice(e, r)].cuda())
         bt = torch.zeros(e.max_batch, e.bt_stride, dtype=torch.int32)
         for q in range(B):
             bt[q, :len(bts[q])] = torch.tensor(bts[q])
@@ -559,8 +607,11 @@ def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
         for r, e in enumerate(engs):
             assert torch.equal(e.slot_mapping[:B].cpu(), osl), f"step {s} rank {r}: slots"
             assert torch.equal(e.audio_codes[:B].cpu(), oc), f"step {s} rank {r}: codes"
-            assert_e2e_close(e.logits[:B].cpu(), ol, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} logits")
-            assert_e2e_close(e.last_hidden[:B].cpu(), oh, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} hidden")
+            # sparse MoE: a routing near-tie may send a row to another k-th expert than torch.topk's (cf. the single-rank MoE test)
+            rows = torch.ones(B, dtype=torch.bool) if not moe else ((e.logits[:B].cpu().nan_to_num(neginf=0) - ol.nan_to_num(neginf=0)).abs().amax(1) < 0.25)
+            assert int(rows.sum()) >= B - 1
+            assert_e2e_close(e.logits[:B].cpu()[rows], ol[rows], mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} logits")
+            assert_e2e_close(e.last_hidden[:B].cpu()[rows], oh[rows], mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} hidden")
         assert torch.equal(engs[0].logits[:B], engs[1].logits[:B]), "ranks must agree bit for bit (replicated tail)"
         for e in engs:                                   # stay on the oracle's trajectory
             e.input_ids[:B] = oi.to(torch.int32).cuda()
@@ -568,7 +619,11 @@ def test_tp_sharded_engines_in_lockstep_match_oracle(model, tp):
     # each rank's cache holds its own KV head of the new tokens
     for li in range(d.layers):
         for r, e in enumerate(engs):
-            assert_e2e_close(e.kv_caches[li].cpu(), orc.kv[li].data[:, :, :, r * e.hkv_l:(r + 1) * e.hkv_l], what=f"kv layer {li} rank {r}")
+            if kv == "bf16":
+                assert_e2e_close(e.kv_caches[li].cpu(), orc.kv[li].data[:, :, :, kv_head_slice(e, r)], what=f"kv layer {li} rank {r}")
+            else:
+                ref = (orc.kv[li].data.view(torch.uint8) if kv == "fp8" else orc.kv[li].data)[:, :, :, kv_head_slice(e, r)]
+                assert (e.kv_caches[li].cpu() != ref).float().mean().item() < 0.15, f"kv bytes layer {li} rank {r}"
 
 
 def test_decode_is_run_to_run_deterministic():

@@ -691,3 +691,52 @@ def _moe_oracle_with_routing(x, w, idx, wts):
     sgu = O.linear(x, w["shared_gate_up"])
     shared = torch.sigmoid(O.linear(x, w["shared_gate"])) * O.linear(O.silu_mul(sgu[:, :Is], sgu[:, Is:]), w["shared_down"])
     return out + shared
+
+
+@pytest.mark.parametrize("H,E,K,I,Is,T,ep", [(64, 16, 4, 32, 64, 9, 2), (1024, 128, 8, 384, 768, 64, 8)])
+def test_moe_experts_expert_parallel_and_fp8_weights(ops, H, E, K, I, Is, T, ep):
+    """omni_moe_experts_ex (BASELINE configs #4 / #5): (a) expert parallel -- every rank runs the block on its E / ep experts,
+    slots of foreign experts count as zero, and the ranks' partial outputs add up to the single-rank block; (b) fp8 e4m3fn
+    expert weights with per-row scales, dequantised in registers: bit-comparable to the bf16 kernel (and within the oracle
+    bound) on the weight matrix bf16(fp8 * scale)."""
+    import ctypes as C
+    from ht_vllm_omni_amd import _lib as L
+    from ht_vllm_omni_amd.engine import fp8_dequant_rows, fp8_quant_rows, frag_shuffle
+    from tests.util import assert_e2e_close, make_moe_weights
+    lib = L.load()
+    w = make_moe_weights(H, E, I, Is, seed=3 * E + ep)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, H, generator=g).to(BF16).cuda()
+    logits = ops.gemm(x, w["router"].cuda())
+    idx, wts = ops.moe_route(logits, K, False)
+
+    def run(gu, dn, sgu, sdn, e0, El, with_shared):
+        act = torch.empty(T * K, I, dtype=BF16, device="cuda")
+        y = torch.zeros(T * K, H, dtype=BF16, device="cuda")
+        out = torch.empty(T, H, dtype=BF16, device="cuda")
+        shared = None
+        if with_shared:
+            shared = ops.gemm(ops.gemm(x, w["shared_gate_up"].cuda(), epilogue=L.EPI_SILU_MUL), w["shared_down"].cuda())
+        L.check(lib.omni_moe_experts_ex(L.ptr(x), L.ptr(idx), L.ptr(wts), L.ptr(gu), L.ptr(sgu), L.ptr(dn), L.ptr(sdn), L.ptr(shared),
+                                        L.ptr(w["shared_gate"].cuda()) if with_shared else None, L.ptr(act), L.ptr(y), L.ptr(out), T, H, I,
+                                        El, e0, K, L.current_stream()), "omni_moe_experts_ex")
+        return out
+
+    full = run(frag_shuffle(w["gate_up"]).cuda(), frag_shuffle(w["down"]).cuda(), None, None, 0, E, True)
+    El = E // ep
+    parts = [run(frag_shuffle(w["gate_up"][r * El:(r + 1) * El]).cuda(), frag_shuffle(w["down"][r * El:(r + 1) * El]).cuda(), None, None,
+                 r * El, El, r == 0) for r in range(ep)]             # the shared expert rides on rank 0 in this test
+    tot = sum(p.float() for p in parts).to(BF16)
+    scale = max(1.0, float(full.float().abs().max()))
+    assert_e2e_close(tot.cpu(), full.cpu(), mean_tol=2e-3 * scale, max_ulps=3, what="sum of expert-parallel partials")
+    # fp8 weights: same kernel arithmetic on bf16(fp8 * scale)
+    q_gu, s_gu = fp8_quant_rows(w["gate_up"])
+    q_dn, s_dn = fp8_quant_rows(w["down"])
+    deq_gu, deq_dn = fp8_dequant_rows(q_gu, s_gu), fp8_dequant_rows(q_dn, s_dn)
+    got8 = run(frag_shuffle(q_gu).cuda(), frag_shuffle(q_dn).cuda(), s_gu.cuda(), s_dn.cuda(), 0, E, True)
+    ref8 = run(frag_shuffle(deq_gu).cuda(), frag_shuffle(deq_dn).cuda(), None, None, 0, E, True)
+    assert torch.equal(got8, ref8), "in-register dequantisation must reproduce the dequantised bf16 matrix bit for bit"
+    w8 = dict(w, gate_up=deq_gu, down=deq_dn)
+    ref_o = _moe_oracle_with_routing(x.cpu(), w8, idx.cpu().long(), wts.cpu())
+    assert_e2e_close(got8.cpu(), ref_o, mean_tol=5e-4 * max(1.0, float(ref_o.float().abs().max())), max_ulps=2, what="fp8-weight experts vs oracle")
+    assert float((got8.float() - full.float()).abs().mean()) > 0          # the quantisation is really in effect

@@ -32,8 +32,10 @@ def test_full_depth_w3_two_decode_steps_match_oracle():
     d = get_dims("tts-1.7b").with_(max_model_len=512)
     w = make_weights(d, seed=1234, std=0.02)
     lens = [33, 47, 16, 60, 38, 21, 52, 44]
-    rec = _scenario(d, w, "fp8", prompt_lens=lens, n_steps=2, num_blocks=64, mean_tol=4e-3)
-    _check(rec, mean_tol=4e-3)
+    # 28 layers of bf16 rounding: isolated elements drift up to ~5 ulp at the tensor's scale (measured 0.156 at |h| ~ 4), the
+    # mean stays at a few 1e-4
+    rec = _scenario(d, w, "fp8", prompt_lens=lens, n_steps=2, num_blocks=64, mean_tol=4e-3, max_ulps=8.0)
+    _check(rec, mean_tol=4e-3, max_ulps=8.0, weights=w)
     devs = []
     for st in rec["steps"]:
         g, o = st["logits"]
@@ -61,7 +63,7 @@ def test_config2_0p6b_decode_bf16_kv_matches_oracle():
     g = torch.Generator().manual_seed(2)
     lens = torch.randint(8, 70, (16,), generator=g).tolist()
     rec = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=2e-3)
-    _check(rec, mean_tol=2e-3)
+    _check(rec, mean_tol=2e-3, weights=w)         # 16 rows x 15 greedy argmaxes per step: near-ties may flip (checked as such)
     assert rec["engine"].kv_caches[0].dtype == torch.bfloat16
 
 

@@ -430,3 +430,84 @@ def test_engine_core_soak_with_request_churn():
     assert stats["replays"] > 0
     _, streams2, *_ = run_once()
     assert streams2 == streams, "same workload, same seeds -> same token streams"
+
+
+def test_chunk_streamer_fed_by_the_real_runner_ships_the_oracles_frames():
+    """SURVEY 8f rank 1 on the GPU (f1 had no -m gpu test): scheduler + worker + runner with graphs, the per-step
+    audio codes of the native step go through CodecChunkStreamer and the connector under {req}_{stage}_{chunk}; every shipped
+    window must hold exactly the ORACLE's frames of that request in the reference's layout (codebook-major, left context +
+    new frames, chunk sizes by the load-dependent initial-chunk rule), the last chunk flagged finished."""
+    from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+    from ht_vllm_omni_amd.stage_input_processors import CodecChunkStreamer
+    d = get_dims("tiny")
+    Q = d.num_code_groups
+    w = make_weights(d, seed=9, std=0.06, norm_noise=0.1)
+    bs, nb = 16, 64
+    n_out = {"a": 13, "b": 7, "c": 10}
+    cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=4, num_gpu_blocks_override=nb, weights=w, enforce_eager=False)
+    wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    wk.engine.set_sampling(cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    run, eng = wk.model_runner, wk.engine
+    chunk_conn = InProcConnector()
+    streamer = CodecChunkStreamer(codec_chunk_frames=4, codec_left_context_frames=2, max_num_seqs=4, num_quantizers=Q, connector=chunk_conn)
+    sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=4, max_num_batched_tokens=64, max_model_len=d.max_model_len,
+                              chunk_streamer=streamer)
+    core = TalkerStageEngine(wk, sched)
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    g = torch.Generator().manual_seed(8)
+    spec = {"a": 9, "b": 21, "c": 14}
+    prompts = {k: torch.randn(n, d.hidden, generator=g).to(BF16) for k, n in spec.items()}
+    pads = {k: torch.randn(d.hidden, generator=g).to(BF16) for k in spec}
+    ostate = {k: O.OracleState(tail_text=[], tts_pad=pads[k]) for k in spec}
+    for k, n in spec.items():
+        sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0, max_tokens=n_out[k], stop_token_ids=())
+        info = {"talker_prompt_embeds": encode_tensor(prompts[k]), "tts_pad_embed": encode_tensor(pads[k])}
+        core.add_request(Request(request_id=k, num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp,
+                                 additional_information=info))
+    frames = {k: [] for k in spec}               # the oracle's audio codes per decode step
+    prefilled = set()
+    for step in range(60):
+        outs = core.step()
+        decoding = [o.request_id for o in outs if o.request_id in prefilled and o.new_token_ids]
+        if decoding:
+            ol, oi, oh, oc, _ = orc.decode_step([ostate[k] for k in decoding], [sched.pool.block_ids(k) for k in decoding])
+        for o in outs:
+            k = o.request_id
+            if not o.new_token_ids:
+                continue
+            if k not in prefilled:
+                _, ids, h = orc.prefill([ostate[k]], [prompts[k]], [sched.pool.block_ids(k)])
+                tok, hid = int(ids[0]), h[0]
+                prefilled.add(k)
+            else:
+                j = decoding.index(k)
+                tok, hid = int(oi[j]), oh[j]
+                frames[k].append(oc[j].tolist())
+                assert torch.equal(o.pooling_output["audio_codes"], oc[j:j + 1]), f"{k}: audio codes at step {step}"
+            assert o.new_token_ids[0] == tok, (k, step)
+            if k in run.requests:
+                eng.last_hidden[run.rows.index(k)] = hid.cuda()
+        if not sched.has_unfinished_requests():
+            break
+    assert all(len(frames[k]) == n_out[k] - 1 for k in spec)
+    # what the connector received: per request the chunks' NEW frames tile the oracle's frame sequence exactly (no gap, no
+    # replay), each chunk's left context is the frames right before its new ones, the last chunk is flagged finished
+    for k in spec:
+        F = frames[k]
+        covered, chunk_id, sent_finished = 0, 0, False
+        while f"{k}_0_{chunk_id}" in chunk_conn.store:
+            payload, _ = chunk_conn.get("0", "1", f"{k}_0_{chunk_id}")
+            lc = payload["left_context_size"]
+            codes = torch.tensor(payload["code_predictor_codes"]).reshape(Q, -1).t().tolist()     # codebook-major -> frames
+            new = codes[lc:]
+            assert 0 <= lc <= 2 and len(new) >= 1 and not sent_finished
+            assert new == F[covered:covered + len(new)], f"{k} chunk {chunk_id}: new frames differ from the oracle's"
+            assert codes[:lc] == F[covered - lc:covered], f"{k} chunk {chunk_id}: left context"
+            covered += len(new)
+            sent_finished = bool(payload["finished"])
+            chunk_id += 1
+        assert covered == len(F) and chunk_id >= 2 and sent_finished, (k, covered, len(F), chunk_id)
+        assert k not in streamer.code_prompt_token_ids          # state dropped when the request finished
+    wk.shutdown()
