@@ -565,6 +565,96 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
 }
 
+// ---- code predictor, position p <= 15 of every row (dense private cache: row b owns block b): ONE wave per (row, q head)
+// with the work laid out so that almost nothing is serial -- the general small kernel above spends ~1.5 k dependent
+// instructions per wave (16 dims per lane, 8 tokens per pass, 28-step output reduction), 5.2 us for 17 keys, 70 launches a
+// step.  Here:
+//   scores   lane = (token t = lane / 4, quarter = lane % 4): 32 dims of K_t per lane (4 x 16-B loads), q transposed through
+//            LDS, 32 FMAs, 2 DPP steps over the quarter -> all <= 16 history scores at once;
+//   softmax  max / sum over the token lanes: 4 exchange steps each (the new token's score is wave-uniform);
+//   PV       lane = output dims (2 l, 2 l + 1): p_t arrives by v_readlane (wave-uniform operand), V_t as ONE 4-byte load per
+//            token -- no cross-lane reduction of the output at all.
+// q / k-norm + RoPE keep the (l, l + 64) pairing of head_norm_rope.  Every load of the kernel is issued before the first use.
+__global__ __launch_bounds__(256) void attn_tiny_dense_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ qnorm_w,
+                                                              const uint16_t* __restrict__ knorm_w, const uint16_t* __restrict__ cos_sin,
+                                                              float eps, uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                              uint16_t* __restrict__ out, int npairs, int q_heads, int kv_heads, int bs,
+                                                              int pos, float sm_scale, int out_frag) {
+    __shared__ float sq[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= npairs) return;                        // whole waves leave: no workgroup barrier below
+    const int row = pair / q_heads, h = pair - row * q_heads;
+    const int ratio = q_heads / kv_heads, kvh = h / ratio;
+    const int nslots = q_heads + 2 * kv_heads;
+    const int t = lane >> 2, qd = lane & 3;            // score phase: token, quarter of the head dimension
+    // ---- all loads up front
+    const size_t hrow = ((size_t)row * bs + t) * kv_heads + kvh;             // history row t (t < 16 <= bs: valid address)
+    u32x4 kq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kq[j] = *reinterpret_cast<const u32x4*>(k_cache + hrow * 128 + qd * 32 + j * 8);
+    uint32_t vq[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        vq[u] = *reinterpret_cast<const uint32_t*>(v_cache + (((size_t)row * bs + u) * kv_heads + kvh) * 128 + 2 * lane);
+    const uint16_t* qsrc = qkv + ((size_t)row * nslots + h) * 128;
+    const uint16_t* ksrc = qkv + ((size_t)row * nslots + q_heads + kvh) * 128;
+    const uint16_t* vsrc = qkv + ((size_t)row * nslots + q_heads + kv_heads + kvh) * 128;
+    const uint32_t vnew = *reinterpret_cast<const uint32_t*>(vsrc + 2 * lane);
+    const uint16_t* cs = cos_sin + (size_t)pos * 128;
+    float q0, q1, k0, k1;
+    head_norm_rope(qsrc, qnorm_w, cs, eps, lane, q0, q1);
+    head_norm_rope(ksrc, knorm_w, cs, eps, lane, k0, k1);
+    // ---- the new token's K / V into the private cache (one writer per kv head)
+    if (h % ratio == 0) {
+        const size_t crow = (((size_t)row * bs + pos) * kv_heads + kvh) * 128;
+        k_cache[crow + lane] = f2bf(k0);
+        k_cache[crow + 64 + lane] = f2bf(k1);
+        *reinterpret_cast<uint32_t*>(v_cache + crow + 2 * lane) = vnew;
+    }
+    const float qs = sm_scale * LOG2E;
+    const float s_new = wave_sum(fmaf(q0 * qs, k0, (q1 * qs) * k1));        // wave-uniform
+    // ---- history scores: q through LDS into the (token, quarter) layout
+    sq[wave][lane] = q0 * qs;
+    sq[wave][lane + 64] = q1 * qs;
+    __builtin_amdgcn_wave_barrier();                   // other lanes' writes are read below (same wave: LDS executes in order)
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(&sq[wave][qd * 32 + j * 8]);
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(&sq[wave][qd * 32 + j * 8 + 4]);
+        d = fmaf(qa[0], bf_lo(kq[j][0]), d); d = fmaf(qa[1], bf_hi(kq[j][0]), d);
+        d = fmaf(qa[2], bf_lo(kq[j][1]), d); d = fmaf(qa[3], bf_hi(kq[j][1]), d);
+        d = fmaf(qb[0], bf_lo(kq[j][2]), d); d = fmaf(qb[1], bf_hi(kq[j][2]), d);
+        d = fmaf(qb[2], bf_lo(kq[j][3]), d); d = fmaf(qb[3], bf_hi(kq[j][3]), d);
+    }
+    d += dpp_f<OMNI_DPP_XOR1>(d);
+    d += dpp_f<OMNI_DPP_XOR2>(d);                      // the 4 quarter lanes of token t now hold s_t
+    const float s = t < pos ? d : -INFINITY;
+    // ---- softmax over the history tokens (lane bits 2..5) and the new token
+    float m = fmaxf(s, dpp_f<OMNI_DPP_HALF_MIRROR>(s));    // lanes i <-> 7 - i: the other token of the 8-lane group
+    m = fmaxf(m, dpp_f<OMNI_DPP_MIRROR>(m));               // the other half of the row: 4 tokens
+    m = xor32_max(xor16_max(m));
+    m = fmaxf(m, s_new);
+    const float p = exp2f(s - m);                          // 0 for masked tokens
+    const float p_new = exp2f(s_new - m);
+    float l = p + dpp_f<OMNI_DPP_HALF_MIRROR>(p);
+    l += dpp_f<OMNI_DPP_MIRROR>(l);
+    l = xor32_sum(xor16_sum(l));                           // each of the 16 tokens exactly once (the mirrors pair DIFFERENT tokens)
+    const float inv = 1.0f / (l + p_new);
+    // ---- PV in the (2 l, 2 l + 1) layout: p_t is wave-uniform after a readlane
+    float o0 = p_new * bf_lo(vnew), o1 = p_new * bf_hi(vnew);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float pu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 4 * u));
+        o0 = fmaf(pu, bf_lo(vq[u]), o0);
+        o1 = fmaf(pu, bf_hi(vq[u]), o1);
+    }
+    const int col = h * 128 + 2 * lane;
+    uint16_t* op = out_frag ? out + frag_off(row, col, q_heads * 128) : out + (size_t)row * q_heads * 128 + col;
+    *reinterpret_cast<uint32_t*>(op) = pack_bf2(o0 * inv, o1 * inv);
+}
+
 // ---- code predictor, positions 0 and 1 of every row in ONE launch (both inputs are known when the pass starts: the
 // talker's last hidden state and the layer-0 code embedding).  One wave per (row, q head): position 0 attends to itself
 // only (output = its V row, exactly), position 1 to both; the position-0 K is rebuilt from the qkv rows by every wave
@@ -729,9 +819,10 @@ extern "C" int omni_paged_attn_decode(const void* q, const void* k_cache, const 
     return pa_dispatch(a, B, head_dim, kv_dtype, false, stream);
 }
 
-OMNI_KNOB g_small_splitq = 1;
+OMNI_KNOB g_small_splitq = 1, g_small_tiny = 1;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_small_splitq(int on) { g_small_splitq = on; }
+extern "C" void omni_debug_small_tiny(int on) { g_small_tiny = on; }
 #endif
 
 int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
@@ -760,6 +851,14 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
         const int G = q_heads / kv_heads;
         hipStream_t st = (hipStream_t)stream;
         a.nsplit = 1;
+        if (dense && g_small_tiny) {
+            const int npairs = B * q_heads;
+            hipLaunchKernelGGL(attn_tiny_dense_kernel, dim3((npairs + 3) / 4), dim3(256), 0, st, a.qkv, a.qnorm_w, a.knorm_w, a.cos_sin, eps,
+                               (uint16_t*)k_cache, (uint16_t*)v_cache, a.out, npairs, q_heads, kv_heads, block_size, dense_pos, sm_scale,
+                               out_frag);
+            OMNI_CHECK_LAUNCH("omni_attn_decode_fused(tiny dense)");
+            return OMNI_OK;
+        }
         if (g_small_splitq && G > 1) {
             const int npairs = B * q_heads;
             dim3 grid((npairs + 3) / 4), block(256);

@@ -201,6 +201,13 @@ class MI355XARModelRunner:
                 prompt, upd = self.prompt_builder.from_info(info)     # qwen3_omni.py:678-809
                 pe, tail, pad = prompt.embeds, upd.get("trailing_text_hidden"), prompt.tts_pad
                 info.update(upd)
+            elif pe is None and getattr(self.prompt_builder, "from_info", None) is not None and (info.get("text") or info.get("input_ids") is not None):
+                # Qwen3-TTS request (text / task_type / speaker / voice_clone_prompt): _build_prompt_embeds on the device
+                # (prompt_builder_tts.TTSTalkerPromptBuilder = qwen3_tts_talker.py:1211-1567)
+                tp = self.prompt_builder.from_info(info)
+                pe, tail, pad = tp.embeds, tp.trailing_text_hidden, tp.tts_pad
+                if tp.ref_code is not None:
+                    info.update({"ref_code": tp.ref_code, "ref_code_len": tp.ref_code_len})
             if pe is None or pe.ndim != 2 or pe.shape[1] != self.d.hidden:
                 raise ValueError(f"request {nr.req_id}: missing talker_prompt_embeds [T,{self.d.hidden}]")
             dev = e.input_ids.device

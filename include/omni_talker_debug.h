@@ -14,6 +14,7 @@ void omni_debug_int8_max_g(int g);                         /* int8-KV decode att
 void omni_debug_cp_pair01(int on);                         /* code predictor: positions 0 and 1 as one two-block pass */
 void omni_debug_gemm_stage(int stage);                      /* leave every GEMM kernel after stage 1..4 (timing attribution only) */
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
+void omni_debug_small_tiny(int on);                         /* code-predictor attention: the (token, quarter) / readlane kernel */
 void omni_debug_prefill_mfma(int on);                       /* prefill attention on MFMA (off: per-token VALU path)   */
 void omni_debug_extra_trivial(int n);                       /* append n no-op launches per layer phase                */
 int omni_debug_launch(int mode, int blocks, int threads, void* p0, void* p1, int arg, int reps, void* stream);

@@ -725,3 +725,70 @@ def omni_text_step_streaming(state: dict, n_thinker_output_ids: int, tts_eos_pro
         x = fresh
     state["fresh"] = None
     return resize_mlp(x.to(BF16), w_text)
+
+
+# --------------------------------------------------------------------------
+# Prompt-embedding builder of the Qwen3-TTS talker (reference:
+# qwen3_tts_talker.py:1160-1209 _generate_icl_prompt, 1211-1567 _build_prompt_embeds).  Token ids in (the tokenizer and the
+# speaker encoder run before this point), embeddings out.  Pinned by tests/golden/tts_prompt_builder.pt (the reference's own
+# method on a stand-in self).  w = {"text_embedding" [Vt, Ht], "text_projection" {fc1_w, fc1_b, fc2_w, fc2_b},
+# "codec_embed" [V, H], "cp_embed" [Q-1, Vc, H]}; ids = {tts_bos, tts_eos, tts_pad, codec_nothink, codec_think,
+# codec_think_bos, codec_think_eos, codec_pad, codec_bos}.
+# --------------------------------------------------------------------------
+def tts_talker_prompt(w: dict, ids: dict, task_type: str, input_ids, *, language_id=None, speaker_id=None, speaker_embed=None,
+                      instruct_ids=None, ref_ids=None, ref_code=None, in_context_mode: bool = False,
+                      non_streaming_mode: bool | None = None):
+    """-> (talker_prompt [P, H], trailing_text_hidden [T, H], tts_pad_embed [1, H], ref_code_len | None), all bf16."""
+    if non_streaming_mode is None:
+        non_streaming_mode = task_type in ("CustomVoice", "VoiceDesign")                 # talker.py:1226-1230
+    input_ids = torch.as_tensor(input_ids, dtype=torch.long).reshape(-1)
+    emb = lambda t: w["codec_embed"][torch.as_tensor(t, dtype=torch.long)]              # noqa: E731  embed_input_ids
+    proj = lambda t: resize_mlp(w["text_embedding"][torch.as_tensor(t, dtype=torch.long)], w["text_projection"])   # noqa: E731
+    tts_bos, tts_eos, tts_pad = (r[None] for r in proj([ids["tts_bos"], ids["tts_eos"], ids["tts_pad"]]))          # 1245-1252
+    if language_id is None:                                                              # 1270-1286
+        pre = [ids["codec_nothink"], ids["codec_think_bos"], ids["codec_think_eos"]]
+    else:
+        pre = [ids["codec_think"], ids["codec_think_bos"], int(language_id), ids["codec_think_eos"]]
+    codec_input_0, codec_input_1 = emb(pre), emb([ids["codec_pad"], ids["codec_bos"]])
+    if task_type == "Base":
+        spk = speaker_embed.to(BF16).reshape(1, -1)
+    elif task_type == "CustomVoice":
+        spk = emb([int(speaker_id)])
+    elif task_type == "VoiceDesign":
+        spk = None
+    else:
+        raise ValueError(f"Unsupported task_type={task_type}")
+    codec_input = torch.cat([codec_input_0] + ([spk] if spk is not None else []) + [codec_input_1], 0)
+    role = proj(input_ids[:3])                                                           # <|im_start|>assistant\n
+    n = codec_input.shape[0]
+    codec_prefix = torch.cat([tts_pad.expand(n - 2, -1), tts_bos], 0) + codec_input[:-1]
+    prompt = torch.cat([role, codec_prefix], 0)
+    ref_code_len = None
+    if task_type == "Base" and in_context_mode:                                          # _generate_icl_prompt
+        ref_code = torch.as_tensor(ref_code, dtype=torch.long)
+        ref_code_len = int(ref_code.shape[0])
+        ref_ids = torch.as_tensor(ref_ids, dtype=torch.long).reshape(-1)
+        text_embed = torch.cat([proj(torch.cat([ref_ids[3:-2], input_ids[3:-5]])), tts_eos], 0)
+        Q = ref_code.shape[1]
+        parts = [emb(ref_code[:, 0])[:, None]] + [w["cp_embed"][i - 1][ref_code[:, i]][:, None] for i in range(1, Q)]
+        codec_sum = torch.cat([emb([ids["codec_bos"]]), torch.cat(parts, 1).sum(1)], 0)  # bf16 sum over the Q groups
+        tl, cl = text_embed.shape[0], codec_sum.shape[0]
+        if non_streaming_mode:
+            icl = torch.cat([text_embed + emb([ids["codec_pad"]] * tl), codec_sum + tts_pad], 0)
+            trailing = tts_pad
+        elif tl > cl:
+            icl, trailing = text_embed[:cl] + codec_sum, text_embed[cl:]
+        else:
+            icl = torch.cat([text_embed] + [tts_pad] * (cl - tl), 0) + codec_sum
+            trailing = tts_pad
+        prompt = torch.cat([prompt, icl], 0)
+    elif non_streaming_mode:                                                             # 1424-1445
+        text_all = torch.cat([proj(input_ids[3:-5]), tts_eos], 0)
+        prompt = torch.cat([prompt, text_all + emb([ids["codec_pad"]] * text_all.shape[0]), tts_pad + emb([ids["codec_bos"]])], 0)
+        trailing = tts_pad
+    else:                                                                                # 1446-1455
+        prompt = torch.cat([prompt, proj(input_ids[3:4]) + codec_input[-1:]], 0)
+        trailing = torch.cat([proj(input_ids[4:-5]), tts_eos], 0)
+    if instruct_ids is not None and len(instruct_ids):
+        prompt = torch.cat([proj(torch.as_tensor(instruct_ids, dtype=torch.long).reshape(-1)), prompt], 0)
+    return prompt, trailing, tts_pad, ref_code_len

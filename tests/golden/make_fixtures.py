@@ -18,6 +18,8 @@ input/output tensors are saved.
   qwen3_layer_real.npz      G2: HF Qwen3Model, ONE layer at the 1.7B dims, bf16 and fp32: q / k after norm + RoPE, attention out,
                             hidden, decode step at ctx 1 / 15 / 16 / 17 / 257
   kv_quant.npz              G3: cache bytes after fp8 (bit-level OCP e4m3fn encoder, independent of torch) / int8 KV writes
+  tts_prompt_builder.pt     reference Qwen3TTSTalkerForConditionalGeneration._build_prompt_embeds / _generate_icl_prompt on a
+                            stand-in `self` (reference ResizeMLP, table tokenizer): every task type / mode, in/out
   omni_prompt_builder.pt    reference Qwen3OmniMoeForConditionalGeneration prompt-embedding methods (models/qwen3_omni/
                             qwen3_omni.py) called on a stand-in `self` holding HF's ResizeMLP modules: in/out
 """
@@ -529,13 +531,13 @@ def install_auto_stubs():
         def __getattr__(self, name):
             if name.startswith("__"):
                 raise AttributeError(name)
-            c = _Meta(name, (), {})
+            c = _Meta(name, (), {"__init__": lambda self_, *a, **k: None})      # instantiable with any arguments (class-level uses)
             setattr(self, name, c)
             return c
 
     class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         def find_spec(self, fullname, path, target=None):
-            if fullname.split(".")[0] in ("vllm", "vllm_omni", "flash_attn") and fullname not in sys.modules:
+            if fullname.split(".")[0] in ("vllm", "vllm_omni", "flash_attn", "soundfile", "librosa") and fullname not in sys.modules:
                 return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
             return None
 
@@ -811,10 +813,118 @@ def mint_kv_quant():
     print("G3 kv_quant.npz", os.path.getsize(os.path.join(HERE, "kv_quant.npz")), "bytes")
 
 
+# --------------------------------------------------------------------------
+def mint_tts_prompt_builder():
+    """Known answers of the Qwen3-TTS talker's prompt-embedding builder: the reference's own `_build_prompt_embeds` /
+    `_generate_icl_prompt` (qwen3_tts_talker.py:1160-1567) bound to a stand-in `self` whose text_projection is the reference's
+    Qwen3TTSTalkerResizeMLP (bf16, CPU, seeded), with a table tokenizer (text -> fixed ids: the real tokenizer is a checkpoint
+    asset) -- every task type, streaming / non-streaming text, language tags, dialect override, instruct prefix, x-vector-only
+    and in-context voice cloning (text longer / shorter than the reference codes)."""
+    install_auto_stubs()
+    # the file's relative imports resolve inside a scratch package whose path is the reference directory (read in place);
+    # the 12 Hz tokenizer module (audio codec, librosa / soundfile) is not needed by the prompt builder: placeholder
+    pkg = "refq3tts_talker_pkg"
+    pm = types.ModuleType(pkg)
+    pm.__path__ = [os.path.join(V, "model_executor/models/qwen3_tts")]
+    sys.modules[pkg] = pm
+    _stub(pkg + ".qwen3_tts_tokenizer", Qwen3TTSTokenizer=object)
+    mod = load_by_path(pkg + ".qwen3_tts_talker", os.path.join(V, "model_executor/models/qwen3_tts/qwen3_tts_talker.py"), package=pkg)
+    Cls = mod.Qwen3TTSTalkerForConditionalGeneration
+    NS = types.SimpleNamespace
+    g = torch.Generator().manual_seed(77)
+    Vt, Ht, H, Vc, Q, Cb = 96, 48, 32, 80, 4, 40
+    ids = dict(tts_bos=90, tts_eos=91, tts_pad=92, codec_nothink=60, codec_think=61, codec_think_bos=62, codec_think_eos=63,
+               codec_pad=64, codec_bos=65)
+    IM_START, ASSIST, NL, IM_END, USER = 1, 2, 3, 4, 5
+    text_emb = torch.nn.Embedding(Vt, Ht)
+    tp = mod.Qwen3TTSTalkerResizeMLP(Ht, Ht, H, "silu", bias=True)
+    with torch.no_grad():
+        text_emb.weight.copy_(torch.randn(Vt, Ht, generator=g) * 0.5)
+        for p_ in tp.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.2 if p_.ndim == 2 else 0.1))
+    text_emb, tp = text_emb.to(torch.bfloat16).eval(), tp.to(torch.bfloat16).eval()
+    table = (torch.randn(Vc, H, generator=g) * 0.5).to(torch.bfloat16)
+    cp_tabs = [(torch.randn(Cb, H, generator=g) * 0.5).to(torch.bfloat16) for _ in range(Q - 1)]
+    vocab_text = {}
+
+    def tok(text, return_tensors="pt", padding=False):
+        return {"input_ids": torch.tensor([vocab_text[text]], dtype=torch.long)}
+
+    tcfg = NS(codec_nothink_id=ids["codec_nothink"], codec_think_id=ids["codec_think"], codec_think_bos_id=ids["codec_think_bos"],
+              codec_think_eos_id=ids["codec_think_eos"], codec_pad_id=ids["codec_pad"], codec_bos_id=ids["codec_bos"],
+              codec_language_id={"english": 70, "chinese": 71, "sichuan_dialect": 72}, spk_id={"Vivian": 75, "Eric": 76},
+              spk_is_dialect={"eric": "sichuan_dialect"}, num_code_groups=Q)
+    cfg = NS(tts_bos_token_id=ids["tts_bos"], tts_eos_token_id=ids["tts_eos"], tts_pad_token_id=ids["tts_pad"])
+    fake = NS(config=cfg, talker_config=tcfg, text_embedding=text_emb, text_projection=tp, embed_input_ids=lambda t: table[t],
+              code_predictor=NS(get_input_embeddings=lambda: [lambda t, tab=tab: tab[t] for tab in cp_tabs]),
+              parameters=lambda: iter([text_emb.weight]), _get_tokenizer=lambda: tok,
+              _build_assistant_text=Cls._build_assistant_text, _build_ref_text=Cls._build_ref_text,
+              _build_instruct_text=Cls._build_instruct_text)
+    for name in ("_build_prompt_embeds", "_generate_icl_prompt"):
+        setattr(fake, name, types.MethodType(getattr(Cls, name), fake))
+
+    def text_ids(n):
+        return [10 + int(x) for x in torch.randint(0, 40, (n,), generator=g)]
+
+    def register(text, body):
+        a = [IM_START, ASSIST, NL] + body + [IM_END, NL, IM_START, ASSIST, NL]
+        vocab_text[Cls._build_assistant_text(text)] = a
+        return a
+
+    cases = []
+    spec = [
+        dict(name="custom_nonstreaming", task="CustomVoice", n=9, info=dict(speaker=["Vivian"])),
+        dict(name="custom_streaming_english", task="CustomVoice", n=7, info=dict(speaker=["vivian"], language=["English"], non_streaming_mode=[False])),
+        dict(name="custom_dialect_override", task="CustomVoice", n=5, info=dict(speaker=["Eric"], language=["Auto"])),
+        dict(name="design_instruct", task="VoiceDesign", n=6, info=dict(instruct=["a calm low voice"], language=["chinese"])),
+        dict(name="design_streaming", task="VoiceDesign", n=4, info=dict(non_streaming_mode=[False])),
+        dict(name="base_xvector_streaming", task="Base", n=8, info=dict(x_vector_only_mode=[True]), spk=True),
+        dict(name="base_xvector_nonstreaming", task="Base", n=3, info=dict(x_vector_only_mode=[True], non_streaming_mode=[True]), spk=True),
+        dict(name="base_icl_text_longer", task="Base", n=12, info={}, spk=True, icl=dict(ref_n=5, codes=6)),
+        dict(name="base_icl_codes_longer", task="Base", n=3, info={}, spk=True, icl=dict(ref_n=2, codes=11)),
+        dict(name="base_icl_nonstreaming", task="Base", n=4, info=dict(non_streaming_mode=[True]), spk=True, icl=dict(ref_n=3, codes=5)),
+    ]
+    with torch.no_grad():
+        for sp in spec:
+            text = "text-" + sp["name"]
+            a = register(text, text_ids(sp["n"]))
+            info = dict(text=[text], **sp["info"])
+            c = {"name": sp["name"], "task_type": sp["task"], "input_ids": a, "info": {k: v for k, v in sp["info"].items()}}
+            if "instruct" in info:
+                ins = [IM_START, USER, NL] + text_ids(5) + [IM_END, NL]
+                vocab_text[Cls._build_instruct_text(info["instruct"][0])] = ins
+                c["instruct_ids"] = ins
+            if sp.get("spk"):
+                emb = (torch.randn(H, generator=g) * 0.5).to(torch.bfloat16)
+                vcp = {"ref_spk_embedding": emb}
+                c["speaker_embed"] = emb
+                if "icl" in sp:
+                    ref_text = "ref-" + sp["name"]
+                    rid = [IM_START, ASSIST, NL] + text_ids(sp["icl"]["ref_n"]) + [IM_END, NL]
+                    vocab_text[Cls._build_ref_text(ref_text)] = rid
+                    codes = torch.randint(0, Cb, (sp["icl"]["codes"], Q), generator=g)
+                    vcp.update({"ref_code": codes, "icl_mode": True})
+                    info["ref_text"] = [ref_text]
+                    c["ref_ids"], c["ref_code"] = rid, codes
+                info["voice_clone_prompt"] = [vcp]
+            prompt, trailing, pad, rlen, rcode = fake._build_prompt_embeds(task_type=sp["task"], info_dict=info)
+            c.update(out_prompt=prompt.clone(), out_trailing=trailing.clone(), out_tts_pad=pad.clone(), out_ref_code_len=rlen)
+            cases.append(c)
+    w = {"text_embedding": text_emb.weight.detach().clone(),
+         "text_projection": {"fc1_w": tp.linear_fc1.weight.detach().clone(), "fc1_b": tp.linear_fc1.bias.detach().clone(),
+                             "fc2_w": tp.linear_fc2.weight.detach().clone(), "fc2_b": tp.linear_fc2.bias.detach().clone()},
+         "codec_embed": table, "cp_embed": torch.stack(cp_tabs)}
+    out = {"ids": ids, "weights": w, "cases": cases, "language_ids": dict(tcfg.codec_language_id), "speaker_ids": dict(tcfg.spk_id),
+           "spk_is_dialect": dict(tcfg.spk_is_dialect)}
+    path = os.path.join(HERE, "tts_prompt_builder.pt")
+    torch.save(out, path)
+    print("tts_prompt_builder.pt", os.path.getsize(path), "bytes;", [(c["name"], tuple(c["out_prompt"].shape), tuple(c["out_trailing"].shape)) for c in cases])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "g2", "g3"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "tp", "g2", "g3"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -833,6 +943,8 @@ if __name__ == "__main__":
         mint_graph_decoder()
     if "op" in which:
         mint_omni_prompt_builder()
+    if "tp" in which:
+        mint_tts_prompt_builder()
     if "g2" in which:
         mint_backbone_layer_real()
     if "g3" in which:

@@ -26,8 +26,10 @@ def _ref_allreduce(parts, r, accumulate=True):
     return s, out
 
 
-@pytest.mark.parametrize("world,M,H", [(2, 64, 2048), (3, 37, 1024), (2, 5, 256), (1, 64, 512)])
+@pytest.mark.parametrize("world,M,H", [(2, 64, 2048), (2, 37, 1024), (2, 5, 256), (1, 64, 512)])
 def test_one_shot_allreduce_residual_and_slabs(world, M, H):
+    # (all ranks in ONE process here: beyond two concurrently spinning streams the HIP runtime starts sharing hardware queues
+    #  and a waiting rank blocks the one it waits for until the spin bound -- real ranks are one process per GPU)
     from ht_vllm_omni_amd.engine import frag_shuffle, frag_unshuffle
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
     ars = [PeerAllReduce(r, world, 64, H) for r in range(world)]

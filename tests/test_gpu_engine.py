@@ -246,10 +246,11 @@ def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_
     return rec
 
 
-def _codes_equal_up_to_near_ties(rec, i, w, tie=2.0 ** -6):
+def _codes_equal_up_to_near_ties(rec, i, w, tie_ulps=3.0):
     """Audio codes of step i: bit-exact, except that a row may leave the oracle's greedy path at a group whose two best
-    (bf16-rounded) code-predictor logits are within `tie` of each other -- an argmax over near-equal values is decided by
-    the summation order; everything after that group in the row follows a different input and is not compared."""
+    (bf16-rounded) code-predictor logits are within `tie_ulps` bf16 ulps of each other -- after 5 predictor layers the two
+    pipelines' logits differ by 1-2 ulp, so an argmax over values that close is decided by the summation order; everything
+    after that group in the row follows a different input and is not compared."""
     got, ref = rec["steps"][i]["codes"]
     if torch.equal(got, ref):
         return
@@ -261,7 +262,8 @@ def _codes_equal_up_to_near_ties(rec, i, w, tie=2.0 ** -6):
         gfirst = int((got[b] != ref[b]).nonzero()[0])
         assert gfirst >= 1, f"step {i} row {b}: layer-0 code differs"
         top = torch.topk(lg[j, gfirst - 1].float(), 2).values
-        assert float(top[0] - top[1]) <= tie, f"step {i} row {b}: code group {gfirst} differs without a near-tie (margin {float(top[0] - top[1]):.4g})"
+        tie = tie_ulps * 2.0 ** (int(np.floor(np.log2(max(float(top[0].abs()), 1e-30)))) - 7)
+        assert float(top[0] - top[1]) <= tie, f"step {i} row {b}: code group {gfirst} differs without a near-tie (margin {float(top[0] - top[1]):.4g} > {tie:.4g})"
     assert len(bad) <= max(1, got.shape[0] // 8), f"step {i}: {len(bad)} rows left the greedy path"
 
 

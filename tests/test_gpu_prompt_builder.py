@@ -108,3 +108,46 @@ def test_streaming_text_steps_match_reference(gold, builder):
         if s["cached_after"] is not None:
             assert torch.equal(st["cached"].cpu(), s["cached_after"])
         assert bool(st.get("finished_flag")) == bool(s["finished_after"] or s["finished_flag"])
+
+
+# ------------------------------------------------------------------ Qwen3-TTS flavour (prompt_builder_tts)
+def test_tts_prompt_builder_matches_reference_fixture_and_oracle(golden_dir):
+    """TTSTalkerPromptBuilder (one batched omni_resize_mlp + device gathers) against the known answers minted from the
+    reference's own _build_prompt_embeds / _generate_icl_prompt (tests/golden/tts_prompt_builder.pt): every task type / mode;
+    row counts exact, embeddings within one bf16 rounding of the projection GEMMs; request-level resolution (language tag,
+    dialect override, speaker id, mode defaults) through from_info."""
+    import os
+    from ht_vllm_omni_amd.prompt_builder_tts import TTSPromptIds, TTSTalkerPromptBuilder
+    from tests.test_oracle_golden import tts_case_kwargs
+    g = torch.load(os.path.join(golden_dir, "tts_prompt_builder.pt"), weights_only=True)
+    i = g["ids"]
+    ids = TTSPromptIds(tts_bos=i["tts_bos"], tts_eos=i["tts_eos"], tts_pad=i["tts_pad"], codec_nothink=i["codec_nothink"],
+                       codec_think=i["codec_think"], codec_think_bos=i["codec_think_bos"], codec_think_eos=i["codec_think_eos"],
+                       codec_pad=i["codec_pad"], codec_bos=i["codec_bos"], language_ids=g["language_ids"], speaker_ids=g["speaker_ids"],
+                       spk_is_dialect=g["spk_is_dialect"])
+    b = TTSTalkerPromptBuilder(g["weights"], ids, "cuda")
+    for c in g["cases"]:
+        p = b.build(c["task_type"], c["input_ids"], **tts_case_kwargs(g, c))
+        assert p.embeds.shape == c["out_prompt"].shape and p.trailing_text_hidden.shape == c["out_trailing"].shape, c["name"]
+        assert p.ref_code_len == c["out_ref_code_len"], c["name"]
+        assert_bf16_close(p.embeds.cpu(), c["out_prompt"], ulps=1, max_mismatch=0.03, what=c["name"] + " prompt")
+        assert_bf16_close(p.trailing_text_hidden.cpu(), c["out_trailing"], ulps=1, max_mismatch=0.03, what=c["name"] + " trailing")
+        assert_bf16_close(p.tts_pad.cpu(), c["out_tts_pad"], ulps=1, max_mismatch=0.03, what=c["name"] + " tts_pad")
+        # the request-level path: the same case as additional_information with tokenised fields
+        info = dict(c["info"], task_type=[c["task_type"]], input_ids=c["input_ids"])
+        if "instruct_ids" in c:
+            info["instruct_ids"] = c["instruct_ids"]
+        if "speaker_embed" in c:
+            vcp = {"ref_spk_embedding": c["speaker_embed"]}
+            if "ref_code" in c:
+                vcp.update(ref_code=c["ref_code"], icl_mode=True)
+                info["ref_ids"] = c["ref_ids"]
+            info["voice_clone_prompt"] = [vcp]
+        p2 = b.from_info(info)
+        assert torch.equal(p2.embeds, p.embeds) and torch.equal(p2.trailing_text_hidden, p.trailing_text_hidden), c["name"]
+    with pytest.raises(ValueError, match="speaker"):
+        b.from_info({"task_type": ["CustomVoice"], "input_ids": g["cases"][0]["input_ids"]})
+    with pytest.raises(ValueError, match="Unsupported speaker"):
+        b.from_info({"task_type": ["CustomVoice"], "input_ids": g["cases"][0]["input_ids"], "speaker": ["nobody"]})
+    with pytest.raises(ValueError, match="tokenizer"):
+        b.from_info({"task_type": ["VoiceDesign"], "text": ["hello"]})

@@ -452,8 +452,9 @@ def test_chunk_streamer_fed_by_the_real_runner_ships_the_oracles_frames():
     run, eng = wk.model_runner, wk.engine
     chunk_conn = InProcConnector()
     streamer = CodecChunkStreamer(codec_chunk_frames=4, codec_left_context_frames=2, max_num_seqs=4, num_quantizers=Q, connector=chunk_conn)
+    wk.model_runner.kv_transfer_manager = OmniKVTransferManager(InProcConnector())
     sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=4, max_num_batched_tokens=64, max_model_len=d.max_model_len,
-                              chunk_streamer=streamer)
+                              chunk_streamer=streamer, need_send_cache=True)      # finished requests keep their blocks until acked
     core = TalkerStageEngine(wk, sched)
     orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
     g = torch.Generator().manual_seed(8)
@@ -489,7 +490,7 @@ def test_chunk_streamer_fed_by_the_real_runner_ships_the_oracles_frames():
             assert o.new_token_ids[0] == tok, (k, step)
             if k in run.requests:
                 eng.last_hidden[run.rows.index(k)] = hid.cuda()
-        if not sched.has_unfinished_requests():
+        if not sched.has_unfinished_requests() and not sched.waiting_for_transfer_free and not sched.requests_needing_kv_transfer:
             break
     assert all(len(frames[k]) == n_out[k] - 1 for k in spec)
     # what the connector received: per request the chunks' NEW frames tile the oracle's frame sequence exactly (no gap, no

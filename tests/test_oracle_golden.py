@@ -226,3 +226,38 @@ def test_kv_quant_bytes_match_the_format_definitions(golden_dir):
     for half, qn, sn in ((0, "int8_k", "int8_scale_k"), (1, "int8_v", "int8_scale_v")):
         assert torch.equal(kv.data[half].reshape(-1, H, D)[slots], torch.from_numpy(z[qn]))
         assert torch.equal(kv.scales[half].reshape(-1, H)[slots], torch.from_numpy(z[sn]))
+
+
+# ------------------------------------------------------------------ Qwen3-TTS prompt-embedding builder
+def tts_case_kwargs(g, c):
+    """Resolve a fixture case to the builder's id-level arguments the way the reference resolves them from the request
+    (language tag / dialect override: qwen3_tts_talker.py:1254-1269; speaker id: 1458-1466; defaults: 1226-1230)."""
+    info = c["info"]
+    lang = (info.get("language") or ["Auto"])[0]
+    language_id = None
+    if lang.lower() != "auto":
+        language_id = g["language_ids"].get(lang.lower())
+    speaker_id = None
+    if c["task_type"] == "CustomVoice":
+        spk = info["speaker"][0].lower()
+        speaker_id = {k.lower(): v for k, v in g["speaker_ids"].items()}[spk]
+        if language_id is None and lang.lower() in ("chinese", "auto") and g["spk_is_dialect"].get(spk):
+            language_id = g["language_ids"][g["spk_is_dialect"][spk]]
+    nsm = info.get("non_streaming_mode")
+    return dict(language_id=language_id, speaker_id=speaker_id, speaker_embed=c.get("speaker_embed"), instruct_ids=c.get("instruct_ids"),
+                ref_ids=c.get("ref_ids"), ref_code=c.get("ref_code"), in_context_mode="ref_code" in c,
+                non_streaming_mode=None if nsm is None else bool(nsm[0]))
+
+
+def test_tts_prompt_builder_matches_reference_method(golden_dir):
+    """oracle.tts_talker_prompt == the reference's _build_prompt_embeds / _generate_icl_prompt (run on the reference's own
+    ResizeMLP module, CPU bf16) for every task type and mode: same row counts, embeddings within one bf16 rounding of the
+    module's GEMMs (bit-identical where no projection is involved)."""
+    g = torch.load(os.path.join(golden_dir, "tts_prompt_builder.pt"), weights_only=True)
+    for c in g["cases"]:
+        prompt, trailing, pad, rlen = O.tts_talker_prompt(g["weights"], g["ids"], c["task_type"], c["input_ids"], **tts_case_kwargs(g, c))
+        assert prompt.shape == c["out_prompt"].shape and trailing.shape == c["out_trailing"].shape, c["name"]
+        assert rlen == c["out_ref_code_len"], c["name"]
+        assert_bf16_close(prompt, c["out_prompt"], ulps=1, max_mismatch=0.02, what=c["name"] + " prompt")
+        assert_bf16_close(trailing, c["out_trailing"], ulps=1, max_mismatch=0.02, what=c["name"] + " trailing")
+        assert_bf16_close(pad, c["out_tts_pad"], ulps=1, max_mismatch=0.02, what=c["name"] + " tts_pad")
