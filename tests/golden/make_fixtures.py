@@ -832,7 +832,7 @@ def mint_tts_prompt_builder():
     Cls = mod.Qwen3TTSTalkerForConditionalGeneration
     NS = types.SimpleNamespace
     g = torch.Generator().manual_seed(77)
-    Vt, Ht, H, Vc, Q, Cb = 96, 48, 32, 80, 4, 40
+    Vt, Ht, H, Vc, Q, Cb = 96, 64, 32, 80, 4, 40          # Ht / H multiples of 32 / 16: the device projection's tile sizes
     ids = dict(tts_bos=90, tts_eos=91, tts_pad=92, codec_nothink=60, codec_think=61, codec_think_bos=62, codec_think_eos=63,
                codec_pad=64, codec_bos=65)
     IM_START, ASSIST, NL, IM_END, USER = 1, 2, 3, 4, 5

@@ -17,6 +17,14 @@ from tests.util import BF16, assert_e2e_close
 pytestmark = pytest.mark.gpu
 
 
+def _rank_streams(world):
+    """One stream per in-process "rank".  The ranks' kernels WAIT for each other, so they must sit on different hardware
+    queues: two pool streams of equal priority may share one (then the waiting kernel blocks its peer until the spin bound);
+    streams of different priority never do -- hence at most two in-process ranks."""
+    assert world <= 2
+    return [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)][:world]
+
+
 def _ref_allreduce(parts, r, accumulate=True):
     acc = torch.zeros_like(parts[0], dtype=torch.float32)
     for p in parts:                                  # rank order, fp32
@@ -34,7 +42,7 @@ def test_one_shot_allreduce_residual_and_slabs(world, M, H):
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
     ars = [PeerAllReduce(r, world, 64, H) for r in range(world)]
     PeerAllReduce.link_local(ars)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = _rank_streams(world)
     g = torch.Generator().manual_seed(world * 1000 + M)
     M16 = 64
     r0 = torch.zeros(M16, H, dtype=BF16)
@@ -109,7 +117,7 @@ def test_tp_engines_on_peer_allreduce_match_oracle(tp):      # share a queue and
     PeerAllReduce.link_local(ars)
     engs = [TalkerEngine(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, max_batch=B, tp_rank=r, tp_size=tp, peer_allreduce=ars[r])
             for r in range(tp)]
-    streams = [torch.cuda.Stream() for _ in range(tp)]
+    streams = _rank_streams(tp)
     for r, e in enumerate(engs):
         assert e.tp_path and e.fused_norm and e.hkv_l == d.kv_heads // tp
         for li in range(d.layers):
