@@ -15,6 +15,7 @@ SnakeBeta activation inside it is `omni_snake_beta`).
 """
 from __future__ import annotations
 
+import bisect
 import logging
 
 import torch
@@ -42,24 +43,20 @@ class HipGraphDecoderWrapper:
     @staticmethod
     def compute_capture_sizes(codec_chunk_frames: int = 0, codec_left_context_frames: int = 0, decode_chunk_size: int = 300,
                               decode_left_context: int = 25) -> list[int]:
-        """Buckets with a high hit rate (cuda_graph_decoder_wrapper.py:52-78): the streaming window sizes (chunk, chunk +
-        left context), the full non-streaming chunk (decode_chunk_size + decode_left_context) and the powers of two up to it
-        (initial streaming chunks, the last non-streaming chunk)."""
-        sizes: set[int] = set()
+        """Bucket lengths worth a graph (the reference's table, cuda_graph_decoder_wrapper.py:52-78, pinned by
+        tests/golden/graph_decoder.json): every power of two from 2 to 256 that a full non-streaming window
+        (decode_chunk_size + decode_left_context frames) can hold, that window itself, and the two streaming window lengths
+        (a bare chunk; a chunk with its left context)."""
+        full = decode_chunk_size + decode_left_context
+        buckets = {1 << e for e in range(1, 9) if (1 << e) <= full} | {full}
         if codec_chunk_frames > 0:
-            sizes.add(codec_chunk_frames)
-            if codec_left_context_frames > 0:
-                sizes.add(codec_chunk_frames + codec_left_context_frames)
-        top = decode_chunk_size + decode_left_context
-        sizes.add(top)
-        sizes.update(p for p in (2, 4, 8, 16, 32, 64, 128, 256) if p <= top)
-        return sorted(sizes)
+            buckets |= {codec_chunk_frames} | ({codec_chunk_frames + codec_left_context_frames} if codec_left_context_frames > 0 else set())
+        return sorted(buckets)
 
     def _get_padded_size(self, actual_size: int) -> int | None:
-        for size in self.capture_sizes:
-            if actual_size <= size:
-                return size
-        return None
+        """Smallest captured bucket that holds `actual_size` frames (capture_sizes is kept sorted)."""
+        i = bisect.bisect_left(self.capture_sizes, actual_size)
+        return self.capture_sizes[i] if i < len(self.capture_sizes) else None
 
     def warmup(self, device: torch.device, dtype: torch.dtype = torch.long, codec_chunk_frames: int = 0,
                codec_left_context_frames: int = 0) -> None:
@@ -111,17 +108,19 @@ class HipGraphDecoderWrapper:
         self.stats["replays"] += 1
         return self.static_outputs[size][..., : n * self.decoder.total_upsample].clone()
 
+    @staticmethod
+    def chunk_windows(total: int, chunk_size: int, left_context_size: int):
+        """(first frame, last frame + 1, context frames) of every window of a non-streaming decode: consecutive chunks, each
+        preceded by `left_context_size` frames of its predecessor -- except that a chunk starting within the first
+        `left_context_size` frames takes everything before it (…wrapper.py:154-177)."""
+        for start in range(0, total, chunk_size):
+            ctx = left_context_size if start > left_context_size else start
+            yield start - ctx, min(start + chunk_size, total), ctx
+
     def chunked_decode_with_cudagraph(self, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
-        """Non-streaming decode in chunks with a left context whose samples are dropped (…wrapper.py:154-177)."""
-        wavs = []
-        start, total = 0, codes.shape[-1]
+        """Non-streaming decode window by window; the samples of each window's context frames are dropped."""
         up = self.decoder.total_upsample
-        while start < total:
-            end = min(start + chunk_size, total)
-            ctx = left_context_size if start - left_context_size > 0 else start
-            wav = self.decode(codes[..., start - ctx:end])
-            wavs.append(wav[..., ctx * up:])
-            start = end
-        return torch.cat(wavs, dim=-1)
+        return torch.cat([self.decode(codes[..., lo:hi])[..., ctx * up:]
+                          for lo, hi, ctx in self.chunk_windows(codes.shape[-1], chunk_size, left_context_size)], dim=-1)
 
     chunked_decode = chunked_decode_with_cudagraph

@@ -1,11 +1,14 @@
 #!/bin/bash
-# usage: scripts/prof_pmc.sh <tag>  -- FETCH_SIZE and WRITE_SIZE passes (separate runs) of a 3-step bench
+# usage: scripts/prof_pmc.sh <tag>  -- FETCH_SIZE and WRITE_SIZE passes (separate runs) of a 3-step bench AT THE HEADLINE CONTEXT
+# (bench.py advances the batch to mean ctx 352 with untimed steps first); writes gpurun_out/pmc_<tag>_step_traffic.json with
+# the mean context of the measured step, which bench.py reads back as roofline.traffic only when its own context matches
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o p -- python3 bench.py --steps 3 --warmup 1 --ttfa-steps 3 --no-cpu-baseline --device-weights > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o p -- python3 bench.py --steps 3 --warmup 1 --ttfa-steps 3 --no-cpu-baseline --device-weights > gpurun_out/pmc_${tag}_$c.json 2> gpurun_out/pmc_${tag}_$c.log
 done
 f=$(find gpurun_out/pmc_${tag}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 w=$(find gpurun_out/pmc_${tag}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python3 scripts/pmc_step_traffic.py "$f" "$w" gpurun_out/pmc_${tag}_step_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the last decode step of bench.py --steps 3 --warmup 1 --ttfa-steps 3 --no-cpu-baseline --device-weights; FETCH_SIZE doubled per MI355X_MICROARCH.md; mean ctx ~105"
+ctx=$(python3 -c "import json,sys; print(json.loads(open('gpurun_out/pmc_${tag}_FETCH_SIZE.json').read().strip().splitlines()[-1])['config']['mean_ctx'])")
+python3 scripts/pmc_step_traffic.py "$f" "$w" gpurun_out/pmc_${tag}_step_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the last decode step of bench.py --steps 3 --warmup 1 --ttfa-steps 3 --no-cpu-baseline --device-weights; FETCH_SIZE doubled per MI355X_MICROARCH.md" "$ctx"
 rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
