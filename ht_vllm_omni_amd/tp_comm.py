@@ -47,6 +47,12 @@ class PeerAllReduce:
         import torch.distributed as dist
         gathered = [None] * self.world
         dist.all_gather_object(gathered, self.handles, group=group)
+        self.map_peers(gathered)
+        dist.barrier(group=group)
+        return self
+
+    def map_peers(self, gathered: list) -> "PeerAllReduce":
+        """Map every peer's buffers from the gathered hipIpc handles (local work only: no collective inside)."""
         for r, hs in enumerate(gathered):
             if r == self.rank:
                 continue
@@ -57,7 +63,6 @@ class PeerAllReduce:
                 self._opened.append(p.value)
                 ptrs.append(p.value)
             self.data[0][r], self.data[1][r], self.ctl[r] = ptrs
-        dist.barrier(group=group)
         return self._finish()
 
     @staticmethod

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("OMNI_TALKER_DEBUG", "1")   # omni_debug_* hooks live in libomni_talker_debug.so
 import sys, ctypes as C, torch
 sys.path.insert(0, "/root/repo")
 from tests.test_gpu_engine import _engine, get_dims, make_weights, O, BF16

@@ -1,4 +1,5 @@
 """A/B of the end-to-end prefill deviation from the oracle: MFMA prefill attention vs the per-token VALU path."""
+import os as _os; _os.environ.setdefault("OMNI_TALKER_DEBUG", "1")   # omni_debug_* hooks live in libomni_talker_debug.so
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
