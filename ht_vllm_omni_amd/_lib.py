@@ -39,6 +39,16 @@ class ArPeers(C.Structure):
     _fields_ = [("world", i32), ("rank", i32), ("data", vp * 8), ("flags", vp * 8), ("epoch", vp), ("error", vp)]
 
 
+class TileGemm(C.Structure):
+    """omni_tile_gemm: one large-M MFMA GEMM / conv-as-GEMM launch (include/omni_talker.h)."""
+    _fields_ = [("x", vp), ("x_rows", i64), ("ldx", i32), ("seg_len", i32), ("seg_rows", i32), ("row_off", i32),
+                ("w", vp), ("bias", vp), ("scale", vp), ("act", i32), ("resid", vp), ("ldr", i32), ("out", vp), ("ldo", i32),
+                ("out2", vp), ("ldo2", i32), ("snake_alpha", vp), ("snake_inv_beta", vp), ("M", i32), ("N", i32), ("K", i32)]
+
+
+TILE_ACT_NONE, TILE_ACT_GELU, TILE_ACT_SILU_MUL_GU8 = 0, 1, 2
+
+
 class TalkerDesc(C.Structure):
     _fields_ = [
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
@@ -90,6 +100,7 @@ SIGNATURES = {
     "omni_moe_experts": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omni_moe_experts_ex": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "omni_snake_beta": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "omni_gemm_tile": (i32, [C.POINTER(TileGemm), vp]),
     "omni_gemm_resid": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_xnorm": (i32, [vp, vp, i32, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,

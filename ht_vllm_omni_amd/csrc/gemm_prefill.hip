@@ -1,0 +1,294 @@
+// Large-M bf16 GEMM on the matrix cores: out[M, N] = epilogue(x[M, K] . W[N, K]^T), fp32 accumulate.
+//
+// The prefill-side counterpart of gemm.hip's weight-streaming skinny kernel: at M = 512 ... 600 k rows the op is MFMA-bound, so a
+// workgroup owns a 256-row x BN-column output tile, stages 64-deep slices of both operands in LDS and reuses every fragment
+// 4 - 8 times from registers.  Built for two callers:
+//   * talker prefill (engine.prefill_native): the four per-layer GEMMs on the SAME fragment-major weights the decode step
+//     streams (OMNI_LAYOUT_W_FRAG; gate_up in its 8-row interleave with SiLU(gate) * up fused) -- weights are stored once;
+//   * Code2Wav decoder (codec.hip / code2wav.py): activations are TIME-major [T, C], so a causal dilated conv1d is this GEMM
+//     over overlapping row windows of x -- K = taps x C_in split into `seg_len`-wide segments, segment s of output row m
+//     reading x row m + row_off + s * seg_rows -- with no im2col buffer, and a transposed conv of stride s / kernel 2s is
+//     the GEMM [T, 2 C_in] x [2 C_in, s * C_out] whose row-major output IS the up-sampled [T * s, C_out] signal.
+//
+// Data movement.  Both operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per wave instruction, no VGPR
+// staging): W fragments are contiguous 1 KB runs of the fragment-major matrix; x fragments are gathered by the per-lane
+// SOURCE address (lane (c, q) fetches 16 B of row c at k-offset 8q), which leaves the LDS image fragment-major too --
+// every ds_read_b128 is lane-linear, conflict-free, no swizzle.  Rows outside [0, x_rows) (the causal left padding, the
+// M tail) and k-steps past K are out of range of the buffer descriptor and read as zero.  Two LDS buffers; the loads of
+// slice t + 1 are issued before the MFMAs of slice t, one counted wait + barrier per slice.
+// MFMA v_mfma_f32_16x16x32_bf16 with W as the A operand: D[n][m], lane holds m = l & 15, n = 4 (l >> 4) + reg.
+// Epilogue: (acc + bias) -> GELU -> * scale -> bf16, transposed through LDS so that global stores are 16 B per lane along
+// n (whole 128 / 192 / 256-byte row pieces); on the way out: SiLU(gate) * up for the interleaved gate_up layout, the
+// residual add (bf16(resid + y), the rounding points of a bf16 torch module), and an optional second output
+// snake(out) = out + inv_beta * sin^2(alpha * out) -- the activation in front of the NEXT conv, so that no stand-alone
+// activation pass runs over the 24 kHz-rate tensors.
+// Workgroups are dealt to the 8 XCDs in contiguous chunks of the (n block, m block) order, m fastest: the workgroups that
+// share an L2 share a W panel.
+#include "common.cuh"
+#include "kernels.h"
+
+#define TG_WAVES 8
+#define TG_THREADS (TG_WAVES * 64)
+#define TG_BM 256
+#define TG_OOB 0x80000000u           // byte offset beyond any descriptor (num_records < 2^31): reads as zero
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct TileArgs {
+    const uint16_t* x; int64_t x_rows; int ldx;
+    int seg_len, seg_rows, row_off;
+    const uint16_t* W; const float* bias; const float* scale;
+    const uint16_t* resid; int ldr;
+    uint16_t* out; int ldo;
+    uint16_t* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
+    int M, N, K;
+    int act;                         // OMNI_TILE_ACT_*
+    int mblocks, nblocks;
+};
+
+__device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float tg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+// WAVES_N x (8 / WAVES_N) waves; a wave owns WN n-tiles x WM m-tiles of 16 x 16; BN = WAVES_N * WN * 16, BM = 256.
+template <int WAVES_N, int WN, int WM, bool GU8>
+__global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a) {
+    constexpr int WAVES_M = TG_WAVES / WAVES_N;
+    static_assert(WAVES_M * WM * 16 == TG_BM, "tile rows");
+    constexpr int NTILES = WAVES_N * WN, MTILES = WAVES_M * WM;           // 16-row tiles of the workgroup
+    constexpr int FW = NTILES * 2, FX = MTILES * 2, F = FW + FX;          // 1 KB fragments per 64-deep slice
+    constexpr int BUF = F * 1024;                                         // bytes per LDS buffer
+    constexpr int NLW = (FW + TG_WAVES - 1) / TG_WAVES, NLX = FX / TG_WAVES; // LDS-DMA instructions per wave and slice
+    constexpr int PITCH = WN * 32 + 16;                                   // epilogue image: bytes per row (16 B pad)
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];      // max(2 * BUF, 8 * WM * 16 * PITCH)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int c = lane & 15, q = lane >> 4;
+
+    // XCD-aware tile order (bijective for any grid size): the hardware deals workgroup ids round-robin over the 8 XCDs
+    int tile;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, per = nwg >> 3, rem = nwg & 7;
+        tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    }
+    const int n_blk = tile / a.mblocks, m_blk = tile - n_blk * a.mblocks;
+    const int m0 = m_blk * TG_BM, n0 = n_blk * (NTILES * 16);
+    const int nsteps = a.K >> 5;                                          // 32-deep k-steps
+    const int nslices = (nsteps + 1) >> 1;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(a.x_rows * a.ldx * 2), 0x00020000);
+
+    // ---- staging.  Slice image: W fragment f = (n tile f >> 1, sub-step f & 1) at f KB, x fragment g likewise at (FW + g) KB.
+    // Wave w issues W fragments w + 8 i (i < NLW, guarded when FW is no multiple of 8) and x fragments w + 8 i (i < NLX).
+    // Kept per owned fragment: the lane's byte offset at slice 0 (W) / the lane's row and byte offset (x).
+    unsigned wbase[NLW];
+    int xrow[NLX], xbyte[NLX];
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int f = wave + TG_WAVES * i;
+        const int n16 = (n0 >> 4) + (f >> 1);
+        wbase[i] = (f < FW && n16 * 16 < a.N) ? (unsigned)(((size_t)n16 * nsteps + (f & 1)) * 1024 + lane * 16) : TG_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+        const int g = wave + TG_WAVES * i;
+        xrow[i] = m0 + (g >> 1) * 16 + c + a.row_off;
+        xbyte[i] = (xrow[i] * a.ldx + 8 * q) * 2;        // wraps out of the descriptor for rows < 0 (never used then)
+    }
+    // segment walk of the two k-steps of the NEXT slice to stage (slices are staged in order): k = seg * seg_len + cs
+    int seg0 = 0, cs0 = 0;
+    const int seg_row_bytes = a.seg_rows * a.ldx * 2;
+    const int sub = wave & 1;                           // the k sub-step of every fragment this wave stages (f & 1 == w & 1)
+    auto stage = [&](int buf, int slice) {
+        int seg1 = seg0, cs1 = cs0 + 32;
+        if (cs1 >= a.seg_len) { cs1 -= a.seg_len; ++seg1; }
+        const int shift = (sub ? seg1 : seg0) * a.seg_rows;
+        const int add = sub ? seg1 * seg_row_bytes + cs1 * 2 : seg0 * seg_row_bytes + cs0 * 2;
+        const bool live = slice * 2 + sub < nsteps;
+        uint8_t* base = lds + buf * BUF + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            if (FW % TG_WAVES != 0 && wave + TG_WAVES * i >= FW) continue;
+            const unsigned off = (live && wbase[i] != TG_OOB) ? wbase[i] + (unsigned)slice * 2048u : TG_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(base + i * (TG_WAVES * 1024)), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLX; ++i) {
+            const int r = xrow[i] + shift;
+            const unsigned off = (live && r >= 0 && r < (int)a.x_rows) ? (unsigned)(xbyte[i] + add) : TG_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(base + (FW + i * TG_WAVES) * 1024), 16, off, 0, 0, 0);
+        }
+        cs0 = cs1 + 32; seg0 = seg1;
+        if (cs0 >= a.seg_len) { cs0 -= a.seg_len; ++seg0; }
+    };
+
+    f32x4 acc[WN][WM];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const uint8_t* wb = lds + buf * BUF + (wn * WN) * 2048 + lane * 16;
+        const uint8_t* xb = lds + buf * BUF + FW * 1024 + (wm * WM) * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 wf[WN], xf[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) xf[i] = *reinterpret_cast<const u32x4*>(xb + i * 2048 + s * 1024);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + s * 1024);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i) acc[j][i] = tg_mfma(wf[j], xf[i], acc[j][i]);
+            __builtin_amdgcn_sched_barrier(0);       // keep the next sub-step's 12 fragment reads behind these MFMAs' registers
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int t = 0; t < nslices; ++t) {
+        if (t + 1 < nslices) stage((t + 1) & 1, t + 1);          // in flight behind this slice's 64 MFMAs
+        compute(t & 1);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue, register side: bias / GELU / scale in fp32, one rounding, transposed into this wave's LDS image [m][n]
+    uint8_t* img = lds + wave * (WM * 16 * PITCH);
+    const int nw0 = n0 + wn * WN * 16;                    // first column of this wave
+    const int mw0 = m0 + wm * WM * 16;                    // first row of this wave
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = nw0 + j * 16 + 4 * q;
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, sc = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (n < a.N) {
+            if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[j][i][e] + b[e];
+                if (a.act == OMNI_TILE_ACT_GELU) v[e] = tg_gelu(v[e]);
+                v[e] *= sc[e];
+            }
+            uint2 pk;
+            pk.x = pack_bf2(v[0], v[1]);
+            pk.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(img + (i * 16 + c) * PITCH + (j * 16 + 4 * q) * 2) = pk;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- epilogue, row side: 16-byte pieces along n
+    if (GU8) {
+        // tile j of a row = [8 gate | 8 up] -> 8 act columns at (n / 2)
+        constexpr int PER_ROW = WN;
+        for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
+            const int row = idx / PER_ROW, j = idx - row * PER_ROW;
+            const int m = mw0 + row, n = nw0 + j * 16;
+            if (m >= a.M || n >= a.N) continue;
+            const u32x4 g = *reinterpret_cast<const u32x4*>(img + row * PITCH + j * 32);
+            const u32x4 u = *reinterpret_cast<const u32x4*>(img + row * PITCH + j * 32 + 16);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
+                o[e] = pack_bf2(g0 / (1.0f + __expf(-g0)) * bf_lo(u[e]), g1 / (1.0f + __expf(-g1)) * bf_hi(u[e]));
+            }
+            *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
+        }
+    } else {
+        constexpr int PER_ROW = WN * 2;
+        for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
+            const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
+            const int m = mw0 + row, n = nw0 + ch * 8;
+            if (m >= a.M || n >= a.N) continue;
+            u32x4 y = *reinterpret_cast<const u32x4*>(img + row * PITCH + ch * 16);
+            if (a.resid) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(a.resid + (size_t)m * a.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = pack_bf2(bf_lo(r[e]) + bf_lo(y[e]), bf_hi(r[e]) + bf_hi(y[e]));
+            }
+            if (a.out) *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = y;
+            if (a.out2) {
+                const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
+                const f32x4 ib0 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n), ib1 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n + 4);
+                u32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float al_lo = e < 2 ? al0[2 * e] : al1[2 * e - 4], al_hi = e < 2 ? al0[2 * e + 1] : al1[2 * e - 3];
+                    const float ib_lo = e < 2 ? ib0[2 * e] : ib1[2 * e - 4], ib_hi = e < 2 ? ib0[2 * e + 1] : ib1[2 * e - 3];
+                    const float v0 = bf_lo(y[e]), v1 = bf_hi(y[e]);
+                    const float s0 = __sinf(v0 * al_lo), s1 = __sinf(v1 * al_hi);
+                    z[e] = pack_bf2(v0 + ib_lo * s0 * s0, v1 + ib_hi * s1 * s1);
+                }
+                *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = z;
+            }
+        }
+    }
+}
+
+template <int WAVES_N, int WN, int WM, bool GU8>
+static int launch_tile(TileArgs a, hipStream_t st) {
+    constexpr int BN = WAVES_N * WN * 16;
+    constexpr int F = (WAVES_N * WN + (TG_WAVES / WAVES_N) * WM) * 2;
+    constexpr int EPI_BYTES = TG_WAVES * WM * 16 * (WN * 32 + 16);
+    constexpr int LDS_BYTES = 2 * F * 1024 > EPI_BYTES ? 2 * F * 1024 : EPI_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    a.mblocks = (a.M + TG_BM - 1) / TG_BM;
+    a.nblocks = (a.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<WAVES_N, WN, WM, GU8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { omni_set_error("omni_gemm_tile: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tile_kernel<WAVES_N, WN, WM, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), LDS_BYTES, st, a);
+    OMNI_CHECK_LAUNCH("omni_gemm_tile");
+    return OMNI_OK;
+}
+
+extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
+    OMNI_CHECK_ARG(g && g->x && g->w && (g->out || g->out2), "omni_gemm_tile: null argument");
+    OMNI_CHECK_ARG(g->M > 0 && g->N > 0 && g->N % 16 == 0 && g->K > 0 && g->K % 32 == 0, "omni_gemm_tile: M=%d N=%d K=%d (N %% 16, K %% 32)", g->M, g->N, g->K);
+    const int seg_len = g->seg_len > 0 ? g->seg_len : g->K;
+    OMNI_CHECK_ARG(seg_len % 32 == 0 && g->K % seg_len == 0, "omni_gemm_tile: seg_len=%d must divide K=%d and be a multiple of 32", seg_len, g->K);
+    OMNI_CHECK_ARG(g->ldx % 8 == 0 && g->ldx >= seg_len, "omni_gemm_tile: ldx=%d (>= seg_len, multiple of 8)", g->ldx);
+    OMNI_CHECK_ARG(g->x_rows > 0 && g->x_rows * (int64_t)g->ldx * 2 < (int64_t)TG_OOB, "omni_gemm_tile: x of %lld rows x %d exceeds the 2 GB descriptor", (long long)g->x_rows, g->ldx);
+    OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
+    const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
+    OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
+    OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2), "omni_gemm_tile: SiLU-mul takes out only");
+    OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
+    const int nout = gu8 ? g->N / 2 : g->N;
+    OMNI_CHECK_ARG((!g->out || (g->ldo >= nout && g->ldo % 8 == 0)) && (!g->resid || (g->ldr >= nout && g->ldr % 8 == 0)) &&
+                   (!g->out2 || (g->ldo2 >= nout && g->ldo2 % 8 == 0)), "omni_gemm_tile: ldo / ldr / ldo2 (>= N, multiple of 8)");
+    TileArgs a;
+    a.x = (const uint16_t*)g->x; a.x_rows = g->x_rows; a.ldx = g->ldx;
+    a.seg_len = seg_len; a.seg_rows = g->seg_rows; a.row_off = g->row_off;
+    a.W = (const uint16_t*)g->w; a.bias = g->bias; a.scale = g->scale;
+    a.resid = (const uint16_t*)g->resid; a.ldr = g->ldr;
+    a.out = (uint16_t*)g->out; a.ldo = g->ldo;
+    a.out2 = (uint16_t*)g->out2; a.ldo2 = g->ldo2; a.snake_alpha = g->snake_alpha; a.snake_inv_beta = g->snake_inv_beta;
+    a.M = g->M; a.N = g->N; a.K = g->K; a.act = g->act;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = g->N;
+    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st) : launch_tile<1, 8, 2, true>(a, st);
+    if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st);
+    if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st);
+    if (N % 128 == 0) return launch_tile<1, 8, 2, false>(a, st);
+    if (N % 96 == 0) return launch_tile<1, 6, 2, false>(a, st);
+    return N > 128 ? launch_tile<2, 8, 4, false>(a, st) : launch_tile<1, 8, 2, false>(a, st);
+}

@@ -263,3 +263,40 @@ def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
     freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
     return torch.stack((freqs.cos(), freqs.sin()), dim=1).to(BF16).contiguous()
+
+
+def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bias=None, scale=None, act: int = L.TILE_ACT_NONE,
+              resid=None, out=None, out2=None, snake=None, taps: int = 1, dilation: int = 1, row_off: int | None = None,
+              want_out: bool = True):
+    """omni_gemm_tile: out[M, N] = epilogue(A . W^T) on the matrix cores, A = x for taps == 1, else the causal conv window
+    A[m] = [x[m + row_off], x[m + row_off + dilation], ...] (taps rows of x.shape[1] channels; row_off defaults to
+    -(taps - 1) * dilation; rows outside x read as zero).  x bf16 [rows, C] row-major (row stride = x.stride(0)); w_frag bf16
+    [N, taps * C] fragment-major (engine.frag_shuffle); bias / scale fp32 [N]; resid bf16 [M, N]; snake = (alpha, inv_beta)
+    fp32 [N] -> out2 = snake(out).  Returns out (or (out, out2))."""
+    assert x.dtype == BF16 and w_frag.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
+    rows, Cin = x.shape
+    N, K = w_frag.shape
+    assert K == taps * Cin, (K, taps, Cin)
+    M = rows if M is None else M
+    gu8 = act == L.TILE_ACT_SILU_MUL_GU8
+    nout = N // 2 if gu8 else N
+    g = L.TileGemm()
+    g.x, g.x_rows, g.ldx = x.data_ptr(), rows, x.stride(0)
+    g.seg_len, g.seg_rows = Cin, dilation
+    g.row_off = (-(taps - 1) * dilation if row_off is None else row_off) if taps > 1 or row_off is not None else 0
+    g.w, g.bias, g.scale, g.act = w_frag.data_ptr(), L.ptr(bias), L.ptr(scale), act
+    if resid is not None:
+        assert resid.dtype == BF16 and resid.stride(1) == 1
+        g.resid, g.ldr = resid.data_ptr(), resid.stride(0)
+    if want_out:
+        out = torch.empty(M, nout, dtype=BF16, device=x.device) if out is None else out
+        g.out, g.ldo = out.data_ptr(), out.stride(0)
+    if snake is not None:
+        out2 = torch.empty(M, nout, dtype=BF16, device=x.device) if out2 is None else out2
+        g.out2, g.ldo2 = out2.data_ptr(), out2.stride(0)
+        g.snake_alpha, g.snake_inv_beta = snake[0].data_ptr(), snake[1].data_ptr()
+    g.M, g.N, g.K = M, N, K
+    L.check(L.load().omni_gemm_tile(C.byref(g), L.current_stream()), "omni_gemm_tile")
+    if snake is not None:
+        return (out, out2) if want_out else out2
+    return out

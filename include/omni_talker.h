@@ -122,6 +122,35 @@ int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk
                         const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
                         void* y_ws, void* out, int T, int H, int I, int E_local, int e0, int top_k, void* stream);
 
+/* Large-M bf16 GEMM on the matrix cores (csrc/gemm_prefill.hip): out[M, N] = epilogue(x[M, K] . W[N, K]^T), fp32 accumulate.
+ * The prefill GEMMs of the talker (replaces the F.linear calls vLLM's Qwen3 layers make under
+ * vllm_omni/worker/gpu_model_runner.py:1305-1328 for prompt tokens) and every convolution of the Code2Wav decoder
+ * (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:174-224: causal conv1d / transposed conv on TIME-major activations).
+ *   x        bf16 row-major, x_rows rows of ldx elements.  K is K / seg_len segments; segment s of output row m reads columns
+ *            [0, seg_len) of x row (m + row_off + s * seg_rows); rows outside [0, x_rows) read as zero (causal padding).
+ *            Plain GEMM: seg_len = 0 (or K), seg_rows = row_off = 0.  conv1d, kernel k, dilation d, C_in channels:
+ *            K = k * C_in, seg_len = C_in, seg_rows = d, row_off = -(k - 1) * d.
+ *   w        bf16 [N, K] fragment-major (OMNI_LAYOUT_W_FRAG); N % 16 == 0, K % 32 == 0, seg_len % 32 == 0.
+ *   bias / scale  fp32 [N] or NULL.  y = bf16(act(acc + bias) * scale).
+ *   act      OMNI_TILE_ACT_NONE | _GELU (erf) | _SILU_MUL_GU8 (w rows interleaved as OMNI_EPI_SILU_MUL_GU8; out is [M, N / 2]).
+ *   resid    bf16 [M, ldr] or NULL: out = bf16(resid + y).
+ *   out2     bf16 [M, ldo2] or NULL: snake(out) = out + inv_beta[n] * sin^2(alpha[n] * out) (the SnakeBeta in front of the next
+ *            conv, fp32 [N] parameters as omni_snake_beta); out may be NULL when only out2 is wanted.                          */
+#define OMNI_TILE_ACT_NONE 0
+#define OMNI_TILE_ACT_GELU 1
+#define OMNI_TILE_ACT_SILU_MUL_GU8 2
+typedef struct omni_tile_gemm {
+    const void* x; int64_t x_rows; int ldx;
+    int seg_len, seg_rows, row_off;
+    const void* w; const float* bias; const float* scale;
+    int act;
+    const void* resid; int ldr;
+    void* out; int ldo;
+    void* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
+    int M, N, K;
+} omni_tile_gemm;
+int omni_gemm_tile(const omni_tile_gemm* g, void* stream);
+
 /* SnakeBeta activation of the Code2Wav decoder (next stage after the talker):
  *   out[b, c, t] = x + inv_beta[c] * sin^2(x * exp_alpha[c]),  x / out [B, C, T] contiguous fp32 (is_bf16 = 0) or bf16,
  *   exp_alpha = exp(alpha), inv_beta = 1 / (exp(beta) + 1e-9) fp32 [C].

@@ -1,0 +1,70 @@
+"""omni_gemm_tile vs hipBLASLt (torch F.linear) on the talker's prefill shapes and the Code2Wav conv shapes: TFLOP/s each,
+interleaved rounds in one process (random operands)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from ht_vllm_omni_amd import ops, _lib as L
+from ht_vllm_omni_amd.engine import frag_shuffle, gu8_shuffle
+
+BF16 = torch.bfloat16
+dev = "cuda"
+
+
+def timed(fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+    M = int(os.environ.get("M", 6400))
+    rows = []
+    for name, N, K, gu in (("qkv", 4096, 2048, False), ("o", 2048, 2048, False), ("gate_up", 12288, 2048, True), ("down", 2048, 6144, False)):
+        x = torch.randn(M, K, device=dev).to(BF16)
+        w = (torch.randn(N, K, device=dev) * 0.03).to(BF16)
+        wf = gu8_shuffle(w) if gu else frag_shuffle(w)
+        flops = 2.0 * M * N * K
+        if gu:
+            a = lambda: ops.gemm_tile(x, wf, act=L.TILE_ACT_SILU_MUL_GU8)
+            b = lambda: ops.silu_mul(F.linear(x, w))
+        else:
+            a = lambda: ops.gemm_tile(x, wf)
+            b = lambda: F.linear(x, w)
+        ta, tb = [], []
+        for _ in range(5):
+            ta.append(timed(a, 20)); tb.append(timed(b, 20))
+        ta, tb = min(ta), min(tb)
+        rows.append((f"prefill {name} M={M} N={N} K={K}", ta, tb, flops))
+    # Code2Wav decoder shapes at a 325-frame window (T4 = 1300 rows after the 2 x 2 upsample)
+    T4 = 1300
+    for name, T, Cin, Cout, taps, dil in (("dec.conv7 1024->1536", T4, 1024, 1536, 7, 1), ("blk0 res conv7 768 d3", T4 * 8, 768, 768, 7, 3),
+                                          ("blk1 res conv7 384 d9", T4 * 40, 384, 384, 7, 9), ("blk2 res conv7 192 d1", T4 * 160, 192, 192, 7, 1),
+                                          ("blk3 res conv7 96 d3", T4 * 480, 96, 96, 7, 3), ("blk3 res conv1 96", T4 * 480, 96, 96, 1, 1),
+                                          ("blk0 transconv 1536->768 s8", T4, 1536, 768 * 8, 2, 1), ("blk3 transconv 192->96 s3", T4 * 160, 192, 96 * 3, 2, 1)):
+        x = torch.randn(T, Cin, device=dev).to(BF16)
+        w = (torch.randn(Cout, taps * Cin, device=dev) * 0.03).to(BF16)
+        wf = frag_shuffle(w)
+        flops = 2.0 * T * Cout * taps * Cin
+        a = lambda: ops.gemm_tile(x, wf, taps=taps, dilation=dil)
+        if taps == 1 or name.startswith("blk0 transconv") or name.startswith("blk3 transconv"):
+            xu = torch.randn(T, taps * Cin, device=dev).to(BF16)
+            b = lambda: F.linear(xu, w)                                     # the same GEMM on an im2col'd operand (copy not timed)
+        else:
+            w3 = w.view(Cout, taps, Cin).permute(0, 2, 1).contiguous()
+            xt = x.T.contiguous()[None]
+            b = lambda: F.conv1d(F.pad(xt, ((taps - 1) * dil, 0)), w3, dilation=dil)     # MIOpen, channel-major as the reference runs it
+        ta, tb = [], []
+        for _ in range(3):
+            ta.append(timed(a, 10)); tb.append(timed(b, 10))
+        rows.append((f"code2wav {name} T={T}", min(ta), min(tb), flops))
+    for name, ta, tb, fl in rows:
+        print(f"{name:52s} tile {ta * 1e6:9.1f} us {fl / ta * 1e-12:7.1f} TF | torch {tb * 1e6:9.1f} us {fl / tb * 1e-12:7.1f} TF | x{tb / ta:.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""omni_gemm_tile (csrc/gemm_prefill.hip): the large-M MFMA GEMM / conv-as-GEMM kernel against fp64 references built from
+the SAME bf16 operands -- plain GEMMs at every tile configuration (N = 256 k, 192 k, 128 k, 96 k, ragged), odd k-step
+counts, M tails; causal dilated conv1d windows and the transposed-conv mapping against torch.nn.functional on fp64; every
+epilogue (bias, GELU, scale, residual, snake second output, interleaved SiLU-mul).  Bound: one bf16 rounding of an fp32
+accumulation -- |got - ref| <= 2^-8 |ref| + tiny (half an ulp) + the accumulation-order slack 2^-16 * sum|a_k b_k|."""
+import pytest
+import torch
+
+from tests.util import BF16
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from ht_vllm_omni_amd import ops
+    from ht_vllm_omni_amd import _lib as L
+    from ht_vllm_omni_amd.engine import frag_shuffle, gu8_shuffle
+    return ops, L, frag_shuffle, gu8_shuffle
+
+
+def _close(got, ref, mag, what):
+    """got bf16, ref fp64 exact value of the pre-rounding quantity, mag = sum of |terms| (accumulation-order slack)."""
+    g = got.double().cpu()
+    tol = ref.abs() * 2.0 ** -8 + mag * 2.0 ** -16 + 1e-30
+    bad = (g - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} off; worst {((g - ref).abs() / tol).max().item():.2f} x bound"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 2048), (257, 192, 96), (513, 384, 672), (640, 128, 64),
+                                   (1111, 96, 672), (255, 288, 96), (70, 48, 32), (900, 272, 160), (6400, 2048, 2048)])
+def test_plain_gemm_every_tile_configuration(M, N, K):
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF16)
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda())
+    ref = x.double() @ w.double().T
+    mag = x.double().abs() @ w.double().abs().T
+    _close(out, ref, mag, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("Cin,Cout,taps,dil,T", [(96, 96, 7, 1, 700), (96, 96, 7, 9, 531), (192, 192, 7, 3, 400), (512, 1024, 3, 1, 77),
+                                                  (768, 768, 7, 9, 290), (96, 96, 1, 1, 333)])
+def test_causal_dilated_conv1d_as_windowed_gemm(Cin, Cout, taps, dil, T):
+    """y[t, co] = b[co] + sum_{j, ci} w[co, ci, j] x[t - (taps - 1 - j) dil, ci]  -- Qwen3TTSTokenizerV2CausalConvNet
+    (modeling_qwen3_tts_tokenizer_v2.py:174-207: left padding (k - 1) d, stride 1) on time-major activations."""
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(Cin + taps * 13 + dil)
+    x = torch.randn(T, Cin, generator=g).to(BF16)
+    w = (torch.randn(Cout, Cin, taps, generator=g) * 0.05).to(BF16)
+    b = torch.randn(Cout, generator=g)
+    wk = w.permute(0, 2, 1).reshape(Cout, taps * Cin).contiguous()            # K index = tap * Cin + ci
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.cuda(), taps=taps, dilation=dil)
+    xp = torch.nn.functional.pad(x.double().T[None], ((taps - 1) * dil, 0))
+    ref = torch.nn.functional.conv1d(xp, w.double(), b.double(), dilation=dil)[0].T
+    mag = torch.nn.functional.conv1d(xp.abs(), w.double().abs(), b.double().abs(), dilation=dil)[0].T
+    _close(out, ref, mag, f"conv k{taps} d{dil} {Cin}->{Cout}")
+
+
+@pytest.mark.parametrize("Cin,Cout,s,T", [(192, 96, 3, 300), (384, 192, 4, 161), (1536, 768, 8, 40), (768, 384, 5, 97)])
+def test_transposed_conv_stride_s_kernel_2s_as_one_gemm(Cin, Cout, s, T):
+    """Qwen3TTSTokenizerV2CausalTransConvNet (…:210-224): ConvTranspose1d(k = 2 s, stride s), last s samples dropped.
+    y[s i + r] = x[i] w[:, :, r] + x[i - 1] w[:, :, r + s]  ->  A[i] = [x[i - 1] | x[i]], W rows n = r * Cout + co: the row-major
+    [T, s * Cout] output is the [T * s, Cout] signal."""
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(Cin + s)
+    x = torch.randn(T, Cin, generator=g).to(BF16)
+    w = (torch.randn(Cin, Cout, 2 * s, generator=g) * 0.05).to(BF16)         # ConvTranspose1d weight [Cin, Cout, k]
+    b = torch.randn(Cout, generator=g)
+    wk = torch.cat([w[:, :, s:], w[:, :, :s]], dim=0)                         # [2 Cin (x[i-1] | x[i]), Cout, s (phase r)]
+    wk = wk.permute(2, 1, 0).reshape(s * Cout, 2 * Cin).contiguous()
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.repeat(s).cuda(), taps=2, dilation=1)
+    ref = torch.nn.functional.conv_transpose1d(x.double().T[None], w.double(), b.double(), stride=s)[0, :, : T * s].T
+    mag = torch.nn.functional.conv_transpose1d(x.double().abs().T[None], w.double().abs(), b.double().abs(), stride=s)[0, :, : T * s].T
+    _close(out.view(T * s, Cout), ref, mag, f"transconv s{s} {Cin}->{Cout}")
+
+
+def test_epilogues_gelu_scale_residual_and_snake_second_output():
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 700, 192, 192
+    x = torch.randn(M, K, generator=g).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.08).to(BF16)
+    b, sc = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    r = torch.randn(M, N, generator=g).to(BF16)
+    al, ib = torch.rand(N, generator=g) + 0.5, torch.rand(N, generator=g) + 0.5
+    acc = x.double() @ w.double().T + b.double()
+    mag = x.double().abs() @ w.double().abs().T + b.double().abs()
+    # GELU * scale
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), act=L.TILE_ACT_GELU)
+    _close(out, torch.nn.functional.gelu(acc) * sc.double(), mag * sc.double() * 1.2 + 1e-3, "gelu * scale")
+    # residual: bf16(resid + bf16(acc + b)); snake of that as the second output
+    out, out2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()))
+    y = acc.float().to(BF16)                                                   # the kernel's first rounding (fp32 acc: may differ by 1 ulp)
+    ref = r.double() + y.double()
+    got = out.double().cpu()
+    assert ((got - ref).abs() <= ref.abs() * 2.0 ** -8 + y.double().abs() * 2.0 ** -7 + 1e-6).all()
+    z = out.cpu().float()
+    ref2 = z.double() + ib.double() * torch.sin(z.double() * al.double()) ** 2
+    assert ((out2.double().cpu() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 2e-3).all()       # __sinf: abs error ~1e-6 x |arg|
+    only2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()), want_out=False)
+    assert torch.equal(only2, out2)
+
+
+@pytest.mark.parametrize("M,I,K", [(333, 3072, 1024), (6400, 6144, 2048), (100, 64, 64)])
+def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
+    """The decode step's gate_up weight as it lies in HBM (gate / up rows interleaved by 8, fragment-major) serves the
+    prefill GEMM: act = SiLU(bf16 gate) * bf16 up, one rounding -- ops.silu_mul's convention."""
+    ops, L, frag_shuffle, gu8_shuffle = _ops()
+    g = torch.Generator().manual_seed(I)
+    x = torch.randn(M, K, generator=g).to(BF16)
+    w = (torch.randn(2 * I, K, generator=g) * 0.03).to(BF16)
+    out = ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8)
+    assert out.shape == (M, I)
+    gu = (x.double() @ w.double().T)
+    mag = x.double().abs() @ w.double().abs().T
+    ga, up = gu[:, :I].float().to(BF16).double(), gu[:, I:].float().to(BF16).double()
+    ref = ga / (1 + torch.exp(-ga)) * up
+    slack = (mag[:, :I] * up.abs() + mag[:, I:] * ga.abs()) * 2.0 ** -7 + 1e-6   # a 1-ulp flip of either rounded factor
+    assert ((out.double().cpu() - ref).abs() <= ref.abs() * 2.0 ** -8 + slack).all()
+
+
+def test_rejects_bad_shapes():
+    ops, L, frag_shuffle, _ = _ops()
+    from ht_vllm_omni_amd._lib import OmniError
+    x = torch.zeros(64, 48, dtype=BF16, device="cuda")
+    with pytest.raises(OmniError):
+        ops.gemm_tile(x, torch.zeros(32, 48, dtype=BF16, device="cuda"))            # K % 32
+    with pytest.raises(OmniError):
+        ops.gemm_tile(torch.zeros(64, 64, dtype=BF16, device="cuda"), torch.zeros(24, 64, dtype=BF16, device="cuda"))   # N % 16
