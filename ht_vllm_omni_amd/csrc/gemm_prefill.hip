@@ -29,8 +29,8 @@
 
 #define TG_WAVES 8
 #define TG_THREADS (TG_WAVES * 64)
-#define TG_BM 256
 #define TG_OOB 0x80000000u           // byte offset beyond any descriptor (num_records < 2^31): reads as zero
+#define TG_LDS_MAX (160 * 1024)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -53,17 +53,31 @@ __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
 
 __device__ __forceinline__ float tg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
-// WAVES_N x (8 / WAVES_N) waves; a wave owns WN n-tiles x WM m-tiles of 16 x 16; BN = WAVES_N * WN * 16, BM = 256.
+// Geometry of one instantiation: 8 waves (two per SIMD: while one issues its LDS-DMA pieces -- 60 - 180 cycles each -- or waits
+// for fragments, the other feeds the matrix pipe) as WAVES_N x (8 / WAVES_N); a wave owns WN n-tiles x WM m-tiles of 16 x 16
+// (acc = WN * WM * 4 of its 256 registers); BN = WAVES_N * WN * 16, BM = (8 / WAVES_N) * WM * 16.
+template <int WAVES_N, int WN, int WM>
+struct TileGeom {
+    static constexpr int WAVES_M = TG_WAVES / WAVES_N;
+    static constexpr int NTILES = WAVES_N * WN, MTILES = WAVES_M * WM;
+    static constexpr int BN = NTILES * 16, BM = MTILES * 16;
+    static constexpr int SLICE = (NTILES + MTILES) * 1024;                   // one 32-deep slice of both operands
+    static constexpr int NLW = (NTILES + TG_WAVES - 1) / TG_WAVES, NLX = MTILES / TG_WAVES;   // LDS-DMA per wave and slice
+    static constexpr bool W_RAGGED = NTILES % TG_WAVES != 0;                 // some waves issue a dummy W load (uniform counts)
+    static constexpr int NBUF = (TG_LDS_MAX - (W_RAGGED ? TG_WAVES * 1024 : 0)) / SLICE >= 4 ? 4 : 3;
+    static constexpr int PITCH = WN * 32 + 16;                               // epilogue image: bytes per row (16 B pad)
+    static constexpr int EPI_BYTES = TG_WAVES * WM * 16 * PITCH;
+    static constexpr int RING_BYTES = NBUF * SLICE + (W_RAGGED ? TG_WAVES * 1024 : 0);
+    static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+    static_assert(MTILES % TG_WAVES == 0 && WN % 2 == 0 && LDS_BYTES <= TG_LDS_MAX, "geometry");
+};
+
 template <int WAVES_N, int WN, int WM, bool GU8>
 __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a) {
-    constexpr int WAVES_M = TG_WAVES / WAVES_N;
-    static_assert(WAVES_M * WM * 16 == TG_BM, "tile rows");
-    constexpr int NTILES = WAVES_N * WN, MTILES = WAVES_M * WM;           // 16-row tiles of the workgroup
-    constexpr int FW = NTILES * 2, FX = MTILES * 2, F = FW + FX;          // 1 KB fragments per 64-deep slice
-    constexpr int BUF = F * 1024;                                         // bytes per LDS buffer
-    constexpr int NLW = (FW + TG_WAVES - 1) / TG_WAVES, NLX = FX / TG_WAVES; // LDS-DMA instructions per wave and slice
-    constexpr int PITCH = WN * 32 + 16;                                   // epilogue image: bytes per row (16 B pad)
-    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];      // max(2 * BUF, 8 * WM * 16 * PITCH)
+    using G = TileGeom<WAVES_N, WN, WM>;
+    constexpr int NTILES = G::NTILES, SLICE = G::SLICE, NLW = G::NLW, NLX = G::NLX, NBUF = G::NBUF, PITCH = G::PITCH;
+    constexpr int INFLIGHT = NBUF - 2;                                        // slices still landing when slice t + 1 is awaited
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,55 +92,50 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
     }
     const int n_blk = tile / a.mblocks, m_blk = tile - n_blk * a.mblocks;
-    const int m0 = m_blk * TG_BM, n0 = n_blk * (NTILES * 16);
-    const int nsteps = a.K >> 5;                                          // 32-deep k-steps
-    const int nslices = (nsteps + 1) >> 1;
+    const int m0 = m_blk * G::BM, n0 = n_blk * G::BN;
+    const int nsteps = a.K >> 5;                                              // 32-deep slices
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(a.x_rows * a.ldx * 2), 0x00020000);
 
-    // ---- staging.  Slice image: W fragment f = (n tile f >> 1, sub-step f & 1) at f KB, x fragment g likewise at (FW + g) KB.
-    // Wave w issues W fragments w + 8 i (i < NLW, guarded when FW is no multiple of 8) and x fragments w + 8 i (i < NLX).
-    // Kept per owned fragment: the lane's byte offset at slice 0 (W) / the lane's row and byte offset (x).
+    // ---- staging.  Slice image: W tile f at f KB, x tile g at (NTILES + g) KB.  Wave w issues W tiles w + 8 i (i < NLW; a wave
+    // without an i-th tile loads zeros into a spare KB so that every wave has the same count in flight) and x tiles w + 8 i.
     unsigned wbase[NLW];
     int xrow[NLX], xbyte[NLX];
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
         const int f = wave + TG_WAVES * i;
-        const int n16 = (n0 >> 4) + (f >> 1);
-        wbase[i] = (f < FW && n16 * 16 < a.N) ? (unsigned)(((size_t)n16 * nsteps + (f & 1)) * 1024 + lane * 16) : TG_OOB;
+        const int n16 = (n0 >> 4) + f;
+        wbase[i] = (f < NTILES && n16 * 16 < a.N) ? (unsigned)((size_t)n16 * nsteps * 1024 + lane * 16) : TG_OOB;
     }
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
         const int g = wave + TG_WAVES * i;
-        xrow[i] = m0 + (g >> 1) * 16 + c + a.row_off;
+        xrow[i] = m0 + g * 16 + c + a.row_off;
         xbyte[i] = (xrow[i] * a.ldx + 8 * q) * 2;        // wraps out of the descriptor for rows < 0 (never used then)
     }
-    // segment walk of the two k-steps of the NEXT slice to stage (slices are staged in order): k = seg * seg_len + cs
-    int seg0 = 0, cs0 = 0;
+    int seg = 0, cs = 0;                                  // segment walk of the NEXT slice to stage: k = seg * seg_len + cs
     const int seg_row_bytes = a.seg_rows * a.ldx * 2;
-    const int sub = wave & 1;                           // the k sub-step of every fragment this wave stages (f & 1 == w & 1)
-    auto stage = [&](int buf, int slice) {
-        int seg1 = seg0, cs1 = cs0 + 32;
-        if (cs1 >= a.seg_len) { cs1 -= a.seg_len; ++seg1; }
-        const int shift = (sub ? seg1 : seg0) * a.seg_rows;
-        const int add = sub ? seg1 * seg_row_bytes + cs1 * 2 : seg0 * seg_row_bytes + cs0 * 2;
-        const bool live = slice * 2 + sub < nsteps;
-        uint8_t* base = lds + buf * BUF + wave * 1024;
+    auto stage = [&](int slice) {                         // slices are staged in order, one call each
+        const int buf = slice % NBUF;
+        const bool live = slice < nsteps;
+        const int shift = seg * a.seg_rows, add = seg * seg_row_bytes + cs * 2;
+        uint8_t* base = lds + buf * SLICE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
-            if (FW % TG_WAVES != 0 && wave + TG_WAVES * i >= FW) continue;
-            const unsigned off = (live && wbase[i] != TG_OOB) ? wbase[i] + (unsigned)slice * 2048u : TG_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(base + i * (TG_WAVES * 1024)), 16, off, 0, 0, 0);
+            const bool mine = !G::W_RAGGED || wave + TG_WAVES * i < NTILES;
+            const unsigned off = (live && mine && wbase[i] != TG_OOB) ? wbase[i] + (unsigned)slice * 1024u : TG_OOB;
+            uint8_t* dst = mine ? base + i * (TG_WAVES * 1024) : lds + NBUF * SLICE + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)dst, 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             const int r = xrow[i] + shift;
             const unsigned off = (live && r >= 0 && r < (int)a.x_rows) ? (unsigned)(xbyte[i] + add) : TG_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(base + (FW + i * TG_WAVES) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(base + (NTILES + i * TG_WAVES) * 1024), 16, off, 0, 0, 0);
         }
-        cs0 = cs1 + 32; seg0 = seg1;
-        if (cs0 >= a.seg_len) { cs0 -= a.seg_len; ++seg0; }
+        cs += 32;
+        if (cs >= a.seg_len) { cs = 0; ++seg; }
     };
 
     f32x4 acc[WN][WM];
@@ -135,31 +144,47 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 #pragma unroll
         for (int i = 0; i < WM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
-        const uint8_t* wb = lds + buf * BUF + (wn * WN) * 2048 + lane * 16;
-        const uint8_t* xb = lds + buf * BUF + FW * 1024 + (wm * WM) * 2048 + lane * 16;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 wf[WN], xf[WM];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) xf[i] = *reinterpret_cast<const u32x4*>(xb + i * 2048 + s * 1024);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + s * 1024);
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int i = 0; i < WM; ++i) acc[j][i] = tg_mfma(wf[j], xf[i], acc[j][i]);
-            __builtin_amdgcn_sched_barrier(0);       // keep the next sub-step's 12 fragment reads behind these MFMAs' registers
-        }
+    // ---- main loop.  Per slice a wave reads WM x fragments + WN W fragments and issues WN * WM MFMAs, in two halves of the W
+    // tiles.  The wait for slice t + 1 and the workgroup barrier sit BETWEEN the halves of slice t; right after it the wave
+    // reads the x fragments and the first W half of slice t + 1 into the other register set, so that LDS latency hides behind
+    // the second half's MFMAs, and the second W half is read at the top of the next slice behind the first half's MFMAs.
+    // NBUF-deep ring, slice t + NBUF - 1 staged at the top of slice t: NBUF - 2 slices stay in flight across every barrier
+    // (counted vmcnt, never 0 inside the loop).  lgkmcnt(0) before the barrier retires this wave's reads of the buffer that
+    // the next top-of-slice staging overwrites.
+    constexpr int HW = WN / 2;
+    auto lds_w = [&](int slice, int j) {
+        return *reinterpret_cast<const u32x4*>(lds + (slice % NBUF) * SLICE + (wn * WN + j) * 1024 + lane * 16);
     };
+    auto lds_x = [&](int slice, int i) {
+        return *reinterpret_cast<const u32x4*>(lds + (slice % NBUF) * SLICE + (NTILES + wm * WM + i) * 1024 + lane * 16);
+    };
+    u32x4 xa[WM], xb[WM], w0[HW], w1[HW];
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s) stage(s);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT * (NLW + NLX)) : "memory");
+#pragma unroll
+    for (int i = 0; i < WM; ++i) xa[i] = lds_x(0, i);
+#pragma unroll
+    for (int j = 0; j < HW; ++j) w0[j] = lds_w(0, j);
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int t = 0; t < nslices; ++t) {
-        if (t + 1 < nslices) stage((t + 1) & 1, t + 1);          // in flight behind this slice's 64 MFMAs
-        compute(t & 1);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#define TG_SLICE(T, XCUR, XNEXT)                                                                             \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < HW; ++j) w1[j] = lds_w((T), HW + j);                           \
+        stage((T) + NBUF - 1);                                                                               \
+        _Pragma("unroll") for (int j = 0; j < HW; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) acc[j][i] = tg_mfma(w0[j], XCUR[i], acc[j][i]);   \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT * (NLW + NLX)) : "memory"); \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) XNEXT[i] = lds_x((T) + 1, i);                         \
+        _Pragma("unroll") for (int j = 0; j < HW; ++j) w0[j] = lds_w((T) + 1, j);                            \
+        _Pragma("unroll") for (int j = 0; j < HW; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) acc[HW + j][i] = tg_mfma(w1[j], XCUR[i], acc[HW + j][i]); \
     }
+    for (int t = 0; t < nsteps; t += 2) {                // an odd slice count runs one slice of zeros (staged out of range)
+        TG_SLICE(t, xa, xb)
+        TG_SLICE(t + 1, xb, xa)
+    }
+#undef TG_SLICE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is dead: its tail loads (zeros) landed
 
     // ---- epilogue, register side: bias / GELU / scale in fp32, one rounding, transposed into this wave's LDS image [m][n]
     uint8_t* img = lds + wave * (WM * 16 * PITCH);
@@ -241,21 +266,17 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 
 template <int WAVES_N, int WN, int WM, bool GU8>
 static int launch_tile(TileArgs a, hipStream_t st) {
-    constexpr int BN = WAVES_N * WN * 16;
-    constexpr int F = (WAVES_N * WN + (TG_WAVES / WAVES_N) * WM) * 2;
-    constexpr int EPI_BYTES = TG_WAVES * WM * 16 * (WN * 32 + 16);
-    constexpr int LDS_BYTES = 2 * F * 1024 > EPI_BYTES ? 2 * F * 1024 : EPI_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    a.mblocks = (a.M + TG_BM - 1) / TG_BM;
-    a.nblocks = (a.N + BN - 1) / BN;
+    using G = TileGeom<WAVES_N, WN, WM>;
+    a.mblocks = (a.M + G::BM - 1) / G::BM;
+    a.nblocks = (a.N + G::BN - 1) / G::BN;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<WAVES_N, WN, WM, GU8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) { omni_set_error("omni_gemm_tile: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<WAVES_N, WN, WM, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_tile_kernel<WAVES_N, WN, WM, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), G::LDS_BYTES, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_tile");
     return OMNI_OK;
 }
@@ -285,10 +306,11 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     a.M = g->M; a.N = g->N; a.K = g->K; a.act = g->act;
     hipStream_t st = (hipStream_t)stream;
     const int N = g->N;
-    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st) : launch_tile<1, 8, 2, true>(a, st);
+    // <waves along n, n tiles per wave, m tiles per wave>: 256 x 256 | 192 x 256 | 128 x 512 | 96 x 512 output tiles
+    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st) : launch_tile<1, 8, 4, true>(a, st);
     if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st);
     if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st);
-    if (N % 128 == 0) return launch_tile<1, 8, 2, false>(a, st);
-    if (N % 96 == 0) return launch_tile<1, 6, 2, false>(a, st);
-    return N > 128 ? launch_tile<2, 8, 4, false>(a, st) : launch_tile<1, 8, 2, false>(a, st);
+    if (N % 128 == 0) return launch_tile<1, 8, 4, false>(a, st);
+    if (N % 96 == 0) return launch_tile<1, 6, 4, false>(a, st);
+    return N > 128 ? launch_tile<2, 8, 4, false>(a, st) : launch_tile<1, 8, 4, false>(a, st);
 }
