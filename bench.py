@@ -51,7 +51,7 @@ def build_engine(args, rank, world):
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
                        device=f"cuda:{torch.cuda.current_device()}", tp_rank=0 if args.parallel == "dp" else rank,
                        tp_size=1 if args.parallel == "dp" else world, allow_eos=False,
-                       n_sub=args.sub_batches, tp_force=args.tp_force, peer_allreduce=ar)
+                       n_sub=args.sub_batches, tp_force=args.tp_force, peer_allreduce=ar, prefill_gemm=args.prefill_gemm)
     return d, w, eng
 
 
@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--allreduce", choices=("oneshot", "rccl"), default="oneshot",
                     help="N > 1 tensor parallel: peer-mapped one-shot all-reduce inside the native step (self-checked against RCCL "
                          "at start-up, falls back to it) or RCCL all-reduces between the phase calls")
+    ap.add_argument("--prefill-gemm", choices=("tile", "blas"), default="tile", help="GEMMs of the TTFA prefill: omni_gemm_tile on "
+                    "the decode step's fragment-major weights (stored once) | hipBLASLt on row-major copies")
     ap.add_argument("--ctx-extra", type=int, default=0, help="long-context points: start decoding this many positions later")
     ap.add_argument("--target-ctx", type=int, default=352, help="mean context of the timed window (W3: 96 + 256); untimed decode "
                     "steps advance the batch until the window is centred there (0: time from wherever warm-up ends)")
@@ -418,6 +420,7 @@ def main():
                                if args.model == "tts-1.7b" else f"{args.model} {args.kv} B={B}",
                    "model": args.model, "kv_cache": args.kv, "batch": B, "mean_ctx": float(np.mean(mean_ctx)),
                    "parallelism": f"{args.parallel}{world}", "allreduce": getattr(args, "allreduce_used", "none"),
+                   "prefill_gemm": "omni_gemm_tile (hand-written MFMA)" if args.prefill_gemm == "tile" else "hipBLASLt",
                    "hipgraph": graph is not None, "sub_batches": args.sub_batches,
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
                    "target_ctx": args.target_ctx, "untimed_advance_steps": advance,

@@ -143,7 +143,7 @@ class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
                  k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, masked_logit: float = 0.0, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
-                 fused_norm: bool | None = None, peer_allreduce=None, moe_fp8: bool = False):
+                 fused_norm: bool | None = None, peer_allreduce=None, moe_fp8: bool = False, prefill_gemm: str = "tile"):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -156,6 +156,11 @@ class TalkerEngine:
         assert dims.q_heads % tp_size == 0 and dims.inter % tp_size == 0
         self.kv_dtype = kv_dtype
         self.frag_layout = bool(frag_layout)
+        # GEMMs of the all-tokens-at-once prefill: "tile" = omni_gemm_tile on the decode step's fragment-major weights (stored
+        # once); "blas" = hipBLASLt on row-major copies (another 2.8 GB at the 1.7B shape); "both" keeps both sets (tests / A-B)
+        if prefill_gemm not in ("tile", "blas", "both"):
+            raise ValueError(f"prefill_gemm={prefill_gemm!r}")
+        self.prefill_gemm = prefill_gemm if self.frag_layout else "blas"
         # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm): single-rank decode only -- the tensor-parallel
         # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
         self.fused_norm = (self.frag_layout and (not self.tp_path or self.ar is not None) and dims.moe_experts == 0) \
@@ -229,17 +234,24 @@ class TalkerEngine:
                     q8, sc = fp8_quant_rows(sh[n])
                     sh[n + "_q8"], sh[n + "_scale"] = q8, sc
                     sh[n] = fp8_dequant_rows(q8, sc)
-            lw = {n: up(sh[n]) for n in bb_names}
-            self.layer_w.append(lw)                 # row-major: hipBLASLt prefill path
+            # row-major copies: norms always; the dense GEMM weights only for the hipBLASLt prefill; MoE tensors for its batched path
+            dense = ("wqkv", "wo", "wgu", "wdown")
+            lw = {n: up(sh[n]) for n in bb_names if self.prefill_gemm != "tile" or n not in dense}
+            self.layer_w.append(lw)
             for n in bb_names:
-                t_ = lw[n]
                 if self.frag_layout and n in frag_names:
-                    # fragment-major copy for the native decode GEMMs (per expert for MoE; dense gate_up interleaved by 8)
+                    # fragment-major copy for the native GEMMs (per expert for MoE; dense gate_up interleaved by 8)
                     if self.moe_fp8 and n in ("moe_gate_up", "moe_down"):
                         t_ = up(frag_shuffle(sh[n + "_q8"]))            # same element order, one byte per weight
                         setattr(self._layers[i], n + "_scale", up(sh[n + "_scale"]).data_ptr())
                     else:
-                        t_ = up(gu8_shuffle(lw[n]) if n == "wgu" else frag_shuffle(lw[n]))
+                        src = lw[n] if n in lw else sh[n].to(dev)       # shuffled on the device; the row-major temporary is dropped
+                        t_ = up(gu8_shuffle(src) if n == "wgu" else frag_shuffle(src))
+                        del src
+                    if n in dense:
+                        lw[n + "_f"] = t_
+                else:
+                    t_ = lw[n]
                 setattr(self._layers[i], n, t_.data_ptr())
             if d.moe_experts > 0:
                 # the batched hipBLASLt prefill wants [E, K, N] operands stored that way: torch.bmm on the transposed VIEW of
@@ -485,14 +497,19 @@ class TalkerEngine:
             L.check(self.lib.omni_talker_layer_mlp(self.handle, C.byref(io), l, st), "omni_talker_layer_mlp")
         L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
 
-    def prefill_blas(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
-                     block_table: torch.Tensor | None = None) -> torch.Tensor:
-        """Prefill with the four plain per-layer GEMMs on hipBLASLt (torch.nn.functional.linear; bf16 in, fp32
-        accumulate, one rounding -- the same convention as the skinny kernel) and everything else on the native
-        kernels (norm, q/k-norm + RoPE + KV write, causal paged attention).  All T tokens in one pass per layer
-        instead of max_batch-row chunks that each re-stream the weights."""
+    def prefill_wide(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
+                     block_table: torch.Tensor | None = None, gemm: str | None = None) -> torch.Tensor:
+        """Prefill of all T prompt tokens in one pass per layer (instead of max_batch-row chunks that each re-stream the
+        weights): norm, q/k-norm + RoPE + KV write, causal paged attention on the native kernels; the four per-layer GEMMs
+        either on omni_gemm_tile (gemm = "tile": the decode step's fragment-major weights, SiLU(gate) * up fused into the
+        gate_up epilogue) or on hipBLASLt (gemm = "blas": torch.nn.functional.linear on row-major copies).  Both: bf16 in,
+        fp32 accumulate, one rounding -- the skinny kernel's convention."""
         import torch.nn.functional as F
         d = self.d
+        gemm = ("tile" if self.prefill_gemm in ("tile", "both") else "blas") if gemm is None else gemm
+        if (gemm == "tile" and self.prefill_gemm == "blas") or (gemm == "blas" and self.prefill_gemm == "tile"):
+            raise L.OmniError(f"this engine was built with prefill_gemm={self.prefill_gemm!r}: no weights for the {gemm} prefill")
+        tile = gemm == "tile"
         bt = self.block_table if block_table is None else block_table
         D, hq, hkv = d.head_dim, self.hq_l, self.hkv_l
         resid = x.clone()
@@ -500,7 +517,7 @@ class TalkerEngine:
         for l in range(d.layers):
             w = self.layer_w[l]
             a = ops.rmsnorm(None, w["ln1"], d.eps, delta=delta, residual=resid)
-            qkv = F.linear(a, w["wqkv"])
+            qkv = ops.gemm_tile(a, w["wqkv_f"]) if tile else F.linear(a, w["wqkv"])
             kc, vc = self.kv_caches[l][0], self.kv_caches[l][1]
             ks = self.kv_scales[l] if self.kv_scales is not None else None
             q = ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], positions, self.cos_sin, slot_mapping, kc, vc,
@@ -511,19 +528,22 @@ class TalkerEngine:
                                        block_size=self.block_size, kv_dtype=self.kv_code, k_scale=self._desc.k_scale,
                                        v_scale=self._desc.v_scale, k_scales=None if ks is None else ks[0],
                                        v_scales=None if ks is None else ks[1])
-            o = F.linear(o, w["wo"])
+            o = ops.gemm_tile(o, w["wo_f"]) if tile else F.linear(o, w["wo"])
             if self.tp_path:
                 torch.distributed.all_reduce(o, group=self.tp_group)
             a = ops.rmsnorm(None, w["ln2"], d.eps, delta=o, residual=resid)
             if d.moe_experts > 0:
                 delta = self._moe_mlp_blas(a, w)
+            elif tile:
+                delta = ops.gemm_tile(ops.gemm_tile(a, w["wgu_f"], act=L.TILE_ACT_SILU_MUL_GU8), w["wdown_f"])
             else:
-                gu = F.linear(a, w["wgu"])
-                act = ops.silu_mul(gu)
-                delta = F.linear(act, w["wdown"])
+                delta = F.linear(ops.silu_mul(F.linear(a, w["wgu"])), w["wdown"])
             if self.tp_path:
                 torch.distributed.all_reduce(delta, group=self.tp_group)
         return ops.rmsnorm(None, self.final_norm, d.eps, delta=delta, residual=resid)
+
+    def prefill_blas(self, x, positions, req_of_tok, slot_mapping, block_table=None):
+        return self.prefill_wide(x, positions, req_of_tok, slot_mapping, block_table, gemm="blas")
 
     def _moe_mlp_blas(self, a: torch.Tensor, w: dict) -> torch.Tensor:
         """Sparse-MoE MLP over T prompt rows (a = normalised rows, bf16 [T, H]) with the expert GEMMs as TWO batched hipBLASLt
@@ -567,14 +587,16 @@ class TalkerEngine:
         return out
 
     def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
-                block_table: torch.Tensor | None = None, use_blas: bool | None = None) -> torch.Tensor:
-        """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H]."""
+                block_table: torch.Tensor | None = None, use_blas: bool | None = None, gemm: str | None = None) -> torch.Tensor:
+        """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H].  use_blas (historic name) selects the
+        all-tokens-per-layer pass (prefill_wide; its GEMMs per `gemm` / the engine's prefill_gemm) over max_batch-row chunks
+        on the decode kernels; default: wide when T > max_batch."""
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
         if use_blas is None:
             use_blas = T > self.max_batch
         if use_blas:
-            return self.prefill_blas(x, positions, req_of_tok, slot_mapping, bt)
+            return self.prefill_wide(x, positions, req_of_tok, slot_mapping, bt, gemm=gemm)
         out = torch.empty_like(x)
         st = L.current_stream()
         if not self.tp_path:

@@ -364,14 +364,15 @@ def test_real_dims_one_layer():
     _check(rec, mean_tol=1e-3)      # BASELINE weight scale: logits within 1e-3 in the mean, 1-2 bf16 ulp max
 
 
-def test_prefill_blas_path_matches_native_and_oracle():
-    """Prefill with hipBLASLt GEMMs (all tokens per layer at once) == native skinny-GEMM chunks == oracle."""
+def test_prefill_wide_paths_match_chunked_native_and_oracle():
+    """All-tokens-per-layer prefill with omni_gemm_tile on the fragment-major decode weights == the same pass with hipBLASLt
+    GEMMs on row-major copies == native skinny-GEMM chunks == oracle."""
     d = get_dims("tiny")
     w = make_weights(d, seed=12, std=0.06, norm_noise=0.1)
     bs, nb = 16, 64
     lens = [5, 40, 17, 64]
     for kv in ("bf16", "fp8"):
-        engs = [_engine(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs, max_batch=8) for _ in range(2)]
+        engs = [_engine(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs, max_batch=8, prefill_gemm="both") for _ in range(3)]
         orc = O.TalkerOracle(d, w, kv_dtype=kv, num_blocks=nb, block_size=bs)
         pool = BlockPool(nb, bs)
         g = torch.Generator().manual_seed(1)
@@ -385,17 +386,23 @@ def test_prefill_blas_path_matches_native_and_oracle():
         pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32).cuda()
         req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32).cuda()
         outs = []
-        for e, blas in zip(engs, (False, True)):
+        for e, (wide, gemm) in zip(engs, ((False, None), (True, "tile"), (True, "blas"))):
             for r in range(len(lens)):
                 e.block_table[r, :len(bts[r])] = torch.tensor(bts[r], dtype=torch.int32)
-            outs.append(e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=blas))
+            outs.append(e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=wide, gemm=gemm))
         last = torch.tensor(np.cumsum(lens) - 1)
         for h in outs:
             assert_e2e_close(h[last.cuda()], o_h, mean_tol=6e-3, max_ulps=3, what=f"prefill hidden {kv}")
-        assert_e2e_close(outs[0], outs[1], mean_tol=6e-3, max_ulps=3, what="blas vs native prefill")
+        assert_e2e_close(outs[0], outs[1], mean_tol=9e-3, max_ulps=4, what="tile vs chunked prefill")      # two implementations, each within 6e-3 of the oracle
+        assert_e2e_close(outs[1], outs[2], mean_tol=9e-3, max_ulps=4, what="tile vs blas prefill")
         for li in range(d.layers):
             a, b = engs[0].kv_caches[li].cpu(), engs[1].kv_caches[li].cpu()
             assert (a != b).float().mean().item() < 0.1, "KV written by both prefill paths"
+    # the default engine keeps ONE copy of the dense GEMM weights and refuses the path it has no weights for
+    e = _engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=8)
+    assert e.prefill_gemm == "tile" and "wqkv" not in e.layer_w[0] and "wqkv_f" in e.layer_w[0]
+    with pytest.raises(L.OmniError):
+        e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=True, gemm="blas")
 
 
 def test_tp_collective_path_captured_in_hipgraph():
