@@ -42,7 +42,7 @@ class ArPeers(C.Structure):
 class TileGemm(C.Structure):
     """omni_tile_gemm: one large-M MFMA GEMM / conv-as-GEMM launch (include/omni_talker.h)."""
     _fields_ = [("x", vp), ("x_rows", i64), ("ldx", i32), ("seg_len", i32), ("seg_rows", i32), ("row_off", i32),
-                ("w", vp), ("bias", vp), ("scale", vp), ("act", i32), ("resid", vp), ("ldr", i32), ("out", vp), ("ldo", i32),
+                ("w", vp), ("bias", vp), ("scale", vp), ("act", i32), ("resid", vp), ("ldr", i32), ("out_f32", vp), ("ldf", i32), ("out", vp), ("ldo", i32),
                 ("out2", vp), ("ldo2", i32), ("snake_alpha", vp), ("snake_inv_beta", vp), ("M", i32), ("N", i32), ("K", i32)]
 
 
@@ -101,6 +101,13 @@ SIGNATURES = {
     "omni_moe_experts_ex": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "omni_snake_beta": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_tile": (i32, [C.POINTER(TileGemm), vp]),
+    # include/omni_codec.h
+    "omni_codec_rvq_embed": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "omni_codec_rmsnorm": (i32, [vp, i32, vp, f32, vp, i32, i32, vp]),
+    "omni_codec_rope": (i32, [vp, i32, i32, i32, i32, i32, f32, vp]),
+    "omni_codec_window_attn": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "omni_codec_dwconv_ln": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
+    "omni_codec_out_conv": (i32, [vp, vp, f32, vp, i32, i32, i32, vp]),
     "omni_gemm_resid": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_xnorm": (i32, [vp, vp, i32, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,

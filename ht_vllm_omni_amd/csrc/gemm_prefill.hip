@@ -17,11 +17,11 @@
 // M tail) and k-steps past K are out of range of the buffer descriptor and read as zero.  Two LDS buffers; the loads of
 // slice t + 1 are issued before the MFMAs of slice t, one counted wait + barrier per slice.
 // MFMA v_mfma_f32_16x16x32_bf16 with W as the A operand: D[n][m], lane holds m = l & 15, n = 4 (l >> 4) + reg.
-// Epilogue: (acc + bias) -> GELU -> * scale -> bf16, transposed through LDS so that global stores are 16 B per lane along
-// n (whole 128 / 192 / 256-byte row pieces); on the way out: SiLU(gate) * up for the interleaved gate_up layout, the
-// residual add (bf16(resid + y), the rounding points of a bf16 torch module), and an optional second output
-// snake(out) = out + inv_beta * sin^2(alpha * out) -- the activation in front of the NEXT conv, so that no stand-alone
-// activation pass runs over the 24 kHz-rate tensors.
+// Epilogue: y = (acc + bias) -> GELU -> * scale (+ fp32 residual) in fp32, transposed through LDS so that global stores are whole
+// row pieces; on the way out SiLU(gate) * up for the interleaved gate_up layout, and up to three stores of y: fp32 (a residual
+// STREAM kept in fp32: snake's sin(alpha x) turns a bf16 ulp of x ~ 16 into a phase error of 0.1 rad), bf16 (the next GEMM's
+// operand) and bf16(snake(y)) = y + inv_beta * sin^2(alpha * y) -- the activation in front of the NEXT conv, so that no
+// stand-alone activation pass runs over the 24 kHz-rate tensors.
 // Workgroups are dealt to the 8 XCDs in contiguous chunks of the (n block, m block) order, m fastest: the workgroups that
 // share an L2 share a W panel.
 #include "common.cuh"
@@ -39,7 +39,8 @@ struct TileArgs {
     const uint16_t* x; int64_t x_rows; int ldx;
     int seg_len, seg_rows, row_off;
     const uint16_t* W; const float* bias; const float* scale;
-    const uint16_t* resid; int ldr;
+    const float* resid; int ldr;
+    float* out_f32; int ldf;
     uint16_t* out; int ldo;
     uint16_t* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;
@@ -65,8 +66,7 @@ struct TileGeom {
     static constexpr int NLW = (NTILES + TG_WAVES - 1) / TG_WAVES, NLX = MTILES / TG_WAVES;   // LDS-DMA per wave and slice
     static constexpr bool W_RAGGED = NTILES % TG_WAVES != 0;                 // some waves issue a dummy W load (uniform counts)
     static constexpr int NBUF = (TG_LDS_MAX - (W_RAGGED ? TG_WAVES * 1024 : 0)) / SLICE >= 4 ? 4 : 3;
-    static constexpr int PITCH = WN * 32 + 16;                               // epilogue image: bytes per row (16 B pad)
-    static constexpr int EPI_BYTES = TG_WAVES * WM * 16 * PITCH;
+    static constexpr int EPI_BYTES = TG_WAVES * WM * 16 * ((WN / 2) * 64 + 16);   // fp32 image of half the wave's n tiles
     static constexpr int RING_BYTES = NBUF * SLICE + (W_RAGGED ? TG_WAVES * 1024 : 0);
     static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
     static_assert(MTILES % TG_WAVES == 0 && WN % 2 == 0 && LDS_BYTES <= TG_LDS_MAX, "geometry");
@@ -75,7 +75,7 @@ struct TileGeom {
 template <int WAVES_N, int WN, int WM, bool GU8>
 __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a) {
     using G = TileGeom<WAVES_N, WN, WM>;
-    constexpr int NTILES = G::NTILES, SLICE = G::SLICE, NLW = G::NLW, NLX = G::NLX, NBUF = G::NBUF, PITCH = G::PITCH;
+    constexpr int NTILES = G::NTILES, SLICE = G::SLICE, NLW = G::NLW, NLX = G::NLX, NBUF = G::NBUF;
     constexpr int INFLIGHT = NBUF - 2;                                        // slices still landing when slice t + 1 is awaited
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
 
@@ -186,81 +186,97 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 #undef TG_SLICE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is dead: its tail loads (zeros) landed
 
-    // ---- epilogue, register side: bias / GELU / scale in fp32, one rounding, transposed into this wave's LDS image [m][n]
-    uint8_t* img = lds + wave * (WM * 16 * PITCH);
-    const int nw0 = n0 + wn * WN * 16;                    // first column of this wave
+    // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image [m][n] in
+    // fp32, half of the wave's n tiles at a time (64 rows x 64 columns x 4 B + pad = 17 KB per wave).  Row side: 8 columns per
+    // lane (32 B of the image), + fp32 residual, then up to three stores of the SAME fp32 value: fp32 (the residual stream),
+    // bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand) -- each rounded once.
+    constexpr int HT = WN / 2;                            // n tiles per pass
+    constexpr int IPITCH = HT * 64 + 16;                  // bytes per image row
+    uint8_t* img = lds + wave * (WM * 16 * IPITCH);
     const int mw0 = m0 + wm * WM * 16;                    // first row of this wave
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = nw0 + j * 16 + 4 * q;
-        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, sc = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (n < a.N) {
-            if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
-            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-        }
+    for (int half = 0; half < 2; ++half) {
+        const int nh0 = n0 + wn * WN * 16 + half * HT * 16;   // first column of this pass
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[j][i][e] + b[e];
-                if (a.act == OMNI_TILE_ACT_GELU) v[e] = tg_gelu(v[e]);
-                v[e] *= sc[e];
+        for (int jj = 0; jj < HT; ++jj) {
+            const int j = half * HT + jj;
+            const int n = nh0 + jj * 16 + 4 * q;
+            f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, sc = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (n < a.N) {
+                if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
             }
-            uint2 pk;
-            pk.x = pack_bf2(v[0], v[1]);
-            pk.y = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(img + (i * 16 + c) * PITCH + (j * 16 + 4 * q) * 2) = pk;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- epilogue, row side: 16-byte pieces along n
-    if (GU8) {
-        // tile j of a row = [8 gate | 8 up] -> 8 act columns at (n / 2)
-        constexpr int PER_ROW = WN;
-        for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
-            const int row = idx / PER_ROW, j = idx - row * PER_ROW;
-            const int m = mw0 + row, n = nw0 + j * 16;
-            if (m >= a.M || n >= a.N) continue;
-            const u32x4 g = *reinterpret_cast<const u32x4*>(img + row * PITCH + j * 32);
-            const u32x4 u = *reinterpret_cast<const u32x4*>(img + row * PITCH + j * 32 + 16);
-            u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
-                o[e] = pack_bf2(g0 / (1.0f + __expf(-g0)) * bf_lo(u[e]), g1 / (1.0f + __expf(-g1)) * bf_hi(u[e]));
-            }
-            *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
-        }
-    } else {
-        constexpr int PER_ROW = WN * 2;
-        for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
-            const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
-            const int m = mw0 + row, n = nw0 + ch * 8;
-            if (m >= a.M || n >= a.N) continue;
-            u32x4 y = *reinterpret_cast<const u32x4*>(img + row * PITCH + ch * 16);
-            if (a.resid) {
-                const u32x4 r = *reinterpret_cast<const u32x4*>(a.resid + (size_t)m * a.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = pack_bf2(bf_lo(r[e]) + bf_lo(y[e]), bf_hi(r[e]) + bf_hi(y[e]));
-            }
-            if (a.out) *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = y;
-            if (a.out2) {
-                const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
-                const f32x4 ib0 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n), ib1 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n + 4);
-                u32x4 z;
+            for (int i = 0; i < WM; ++i) {
+                f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float al_lo = e < 2 ? al0[2 * e] : al1[2 * e - 4], al_hi = e < 2 ? al0[2 * e + 1] : al1[2 * e - 3];
-                    const float ib_lo = e < 2 ? ib0[2 * e] : ib1[2 * e - 4], ib_hi = e < 2 ? ib0[2 * e + 1] : ib1[2 * e - 3];
-                    const float v0 = bf_lo(y[e]), v1 = bf_hi(y[e]);
-                    const float s0 = __sinf(v0 * al_lo), s1 = __sinf(v1 * al_hi);
-                    z[e] = pack_bf2(v0 + ib_lo * s0 * s0, v1 + ib_hi * s1 * s1);
+                    float t = acc[j][i][e] + b[e];
+                    if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
+                    v[e] = t * sc[e];
                 }
-                *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = z;
+                *reinterpret_cast<f32x4*>(img + (i * 16 + c) * IPITCH + (jj * 16 + 4 * q) * 4) = v;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (GU8) {
+            // tile jj of a row = [8 gate | 8 up] -> 8 act columns at n / 2: SiLU(bf16 gate) * bf16 up, one rounding (ops.silu_mul)
+            for (int idx = lane; idx < WM * 16 * HT; idx += 64) {
+                const int row = idx / HT, jj = idx - row * HT;
+                const int m = mw0 + row, n = nh0 + jj * 16;
+                if (m >= a.M || n >= a.N) continue;
+                const float* gp = reinterpret_cast<const float*>(img + row * IPITCH + jj * 64);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g0 = bfround(gp[2 * e]), g1 = bfround(gp[2 * e + 1]);
+                    const float u0 = bfround(gp[8 + 2 * e]), u1 = bfround(gp[8 + 2 * e + 1]);
+                    o[e] = pack_bf2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+                }
+                *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
+            }
+        } else {
+            constexpr int PER_ROW = HT * 2;               // 8-column pieces per image row
+            for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
+                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
+                const int m = mw0 + row, n = nh0 + ch * 8;
+                if (m >= a.M || n >= a.N) continue;
+                f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
+                f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
+                if (a.resid) {
+                    const float* rp = a.resid + (size_t)m * a.ldr + n;
+                    y0 += *reinterpret_cast<const f32x4*>(rp);
+                    y1 += *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+                if (a.out_f32) {
+                    float* op = a.out_f32 + (size_t)m * a.ldf + n;
+                    *reinterpret_cast<f32x4*>(op) = y0;
+                    *reinterpret_cast<f32x4*>(op + 4) = y1;
+                }
+                if (a.out) {
+                    u32x4 o;
+                    o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
+                    o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
+                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                }
+                if (a.out2) {
+                    const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
+                    const f32x4 ib0 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n), ib1 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n + 4);
+                    f32x4 z0, z1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s0 = __sinf(y0[e] * al0[e]), s1 = __sinf(y1[e] * al1[e]);
+                        z0[e] = y0[e] + ib0[e] * s0 * s0;
+                        z1[e] = y1[e] + ib1[e] * s1 * s1;
+                    }
+                    u32x4 o;
+                    o[0] = pack_bf2(z0[0], z0[1]); o[1] = pack_bf2(z0[2], z0[3]);
+                    o[2] = pack_bf2(z1[0], z1[1]); o[3] = pack_bf2(z1[2], z1[3]);
+                    *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -282,7 +298,7 @@ static int launch_tile(TileArgs a, hipStream_t st) {
 }
 
 extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
-    OMNI_CHECK_ARG(g && g->x && g->w && (g->out || g->out2), "omni_gemm_tile: null argument");
+    OMNI_CHECK_ARG(g && g->x && g->w && (g->out || g->out2 || g->out_f32), "omni_gemm_tile: null argument");
     OMNI_CHECK_ARG(g->M > 0 && g->N > 0 && g->N % 16 == 0 && g->K > 0 && g->K % 32 == 0, "omni_gemm_tile: M=%d N=%d K=%d (N %% 16, K %% 32)", g->M, g->N, g->K);
     const int seg_len = g->seg_len > 0 ? g->seg_len : g->K;
     OMNI_CHECK_ARG(seg_len % 32 == 0 && g->K % seg_len == 0, "omni_gemm_tile: seg_len=%d must divide K=%d and be a multiple of 32", seg_len, g->K);
@@ -291,16 +307,18 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
     const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
     OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
-    OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2), "omni_gemm_tile: SiLU-mul takes out only");
+    OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2 && !g->out_f32), "omni_gemm_tile: SiLU-mul takes out only");
     OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
     const int nout = gu8 ? g->N / 2 : g->N;
-    OMNI_CHECK_ARG((!g->out || (g->ldo >= nout && g->ldo % 8 == 0)) && (!g->resid || (g->ldr >= nout && g->ldr % 8 == 0)) &&
-                   (!g->out2 || (g->ldo2 >= nout && g->ldo2 % 8 == 0)), "omni_gemm_tile: ldo / ldr / ldo2 (>= N, multiple of 8)");
+    OMNI_CHECK_ARG((!g->out || (g->ldo >= nout && g->ldo % 8 == 0)) && (!g->resid || (g->ldr >= nout && g->ldr % 4 == 0)) &&
+                   (!g->out2 || (g->ldo2 >= nout && g->ldo2 % 8 == 0)) && (!g->out_f32 || (g->ldf >= nout && g->ldf % 4 == 0)),
+                   "omni_gemm_tile: ldo / ldr / ldo2 / ldf (>= N; multiples of 8 (bf16) / 4 (fp32))");
     TileArgs a;
     a.x = (const uint16_t*)g->x; a.x_rows = g->x_rows; a.ldx = g->ldx;
     a.seg_len = seg_len; a.seg_rows = g->seg_rows; a.row_off = g->row_off;
     a.W = (const uint16_t*)g->w; a.bias = g->bias; a.scale = g->scale;
-    a.resid = (const uint16_t*)g->resid; a.ldr = g->ldr;
+    a.resid = g->resid; a.ldr = g->ldr;
+    a.out_f32 = g->out_f32; a.ldf = g->ldf;
     a.out = (uint16_t*)g->out; a.ldo = g->ldo;
     a.out2 = (uint16_t*)g->out2; a.ldo2 = g->ldo2; a.snake_alpha = g->snake_alpha; a.snake_inv_beta = g->snake_inv_beta;
     a.M = g->M; a.N = g->N; a.K = g->K; a.act = g->act;

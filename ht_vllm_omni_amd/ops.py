@@ -266,13 +266,15 @@ def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
 
 
 def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bias=None, scale=None, act: int = L.TILE_ACT_NONE,
-              resid=None, out=None, out2=None, snake=None, taps: int = 1, dilation: int = 1, row_off: int | None = None,
-              want_out: bool = True):
-    """omni_gemm_tile: out[M, N] = epilogue(A . W^T) on the matrix cores, A = x for taps == 1, else the causal conv window
-    A[m] = [x[m + row_off], x[m + row_off + dilation], ...] (taps rows of x.shape[1] channels; row_off defaults to
-    -(taps - 1) * dilation; rows outside x read as zero).  x bf16 [rows, C] row-major (row stride = x.stride(0)); w_frag bf16
-    [N, taps * C] fragment-major (engine.frag_shuffle); bias / scale fp32 [N]; resid bf16 [M, N]; snake = (alpha, inv_beta)
-    fp32 [N] -> out2 = snake(out).  Returns out (or (out, out2))."""
+              resid=None, out=None, out_f32=None, out2=None, snake=None, taps: int = 1, dilation: int = 1,
+              row_off: int | None = None, want: str = "b"):
+    """omni_gemm_tile: y[M, N] = act(A . W^T + bias) * scale (+ resid) on the matrix cores, A = x for taps == 1, else the
+    causal conv window A[m] = [x[m + row_off], x[m + row_off + dilation], ...] (taps rows of x.shape[1] channels; row_off
+    defaults to -(taps - 1) * dilation; rows outside x read as zero).  x bf16 [rows, C] (row stride = x.stride(0)); w_frag bf16
+    [N, taps * C] fragment-major (engine.frag_shuffle); bias / scale fp32 [N]; resid fp32 [M, N].
+    `want` names the outputs: "f" = fp32 y, "b" = bf16(y), "s" = bf16(snake(y)) with snake = (alpha, inv_beta) fp32 [N];
+    given buffers (out_f32 / out / out2) are used, missing ones allocated.  Returns them in the order of `want` (a single
+    tensor when one is wanted)."""
     assert x.dtype == BF16 and w_frag.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
     rows, Cin = x.shape
     N, K = w_frag.shape
@@ -286,17 +288,25 @@ def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bi
     g.row_off = (-(taps - 1) * dilation if row_off is None else row_off) if taps > 1 or row_off is not None else 0
     g.w, g.bias, g.scale, g.act = w_frag.data_ptr(), L.ptr(bias), L.ptr(scale), act
     if resid is not None:
-        assert resid.dtype == BF16 and resid.stride(1) == 1
+        assert resid.dtype == torch.float32 and resid.stride(1) == 1
         g.resid, g.ldr = resid.data_ptr(), resid.stride(0)
-    if want_out:
-        out = torch.empty(M, nout, dtype=BF16, device=x.device) if out is None else out
-        g.out, g.ldo = out.data_ptr(), out.stride(0)
-    if snake is not None:
-        out2 = torch.empty(M, nout, dtype=BF16, device=x.device) if out2 is None else out2
-        g.out2, g.ldo2 = out2.data_ptr(), out2.stride(0)
-        g.snake_alpha, g.snake_inv_beta = snake[0].data_ptr(), snake[1].data_ptr()
+    res = []
+    for k in want:
+        if k == "f":
+            out_f32 = torch.empty(M, nout, dtype=torch.float32, device=x.device) if out_f32 is None else out_f32
+            g.out_f32, g.ldf = out_f32.data_ptr(), out_f32.stride(0)
+            res.append(out_f32)
+        elif k == "b":
+            out = torch.empty(M, nout, dtype=BF16, device=x.device) if out is None else out
+            g.out, g.ldo = out.data_ptr(), out.stride(0)
+            res.append(out)
+        elif k == "s":
+            out2 = torch.empty(M, nout, dtype=BF16, device=x.device) if out2 is None else out2
+            g.out2, g.ldo2 = out2.data_ptr(), out2.stride(0)
+            g.snake_alpha, g.snake_inv_beta = snake[0].data_ptr(), snake[1].data_ptr()
+            res.append(out2)
+        else:
+            raise ValueError(want)
     g.M, g.N, g.K = M, N, K
     L.check(L.load().omni_gemm_tile(C.byref(g), L.current_stream()), "omni_gemm_tile")
-    if snake is not None:
-        return (out, out2) if want_out else out2
-    return out
+    return res[0] if len(res) == 1 else tuple(res)

@@ -131,11 +131,13 @@ int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk
  *            Plain GEMM: seg_len = 0 (or K), seg_rows = row_off = 0.  conv1d, kernel k, dilation d, C_in channels:
  *            K = k * C_in, seg_len = C_in, seg_rows = d, row_off = -(k - 1) * d.
  *   w        bf16 [N, K] fragment-major (OMNI_LAYOUT_W_FRAG); N % 16 == 0, K % 32 == 0, seg_len % 32 == 0.
- *   bias / scale  fp32 [N] or NULL.  y = bf16(act(acc + bias) * scale).
- *   act      OMNI_TILE_ACT_NONE | _GELU (erf) | _SILU_MUL_GU8 (w rows interleaved as OMNI_EPI_SILU_MUL_GU8; out is [M, N / 2]).
- *   resid    bf16 [M, ldr] or NULL: out = bf16(resid + y).
- *   out2     bf16 [M, ldo2] or NULL: snake(out) = out + inv_beta[n] * sin^2(alpha[n] * out) (the SnakeBeta in front of the next
- *            conv, fp32 [N] parameters as omni_snake_beta); out may be NULL when only out2 is wanted.                          */
+ *   bias / scale  fp32 [N] or NULL.  y = act(acc + bias) * scale (+ resid), all fp32.
+ *   act      OMNI_TILE_ACT_NONE | _GELU (erf) | _SILU_MUL_GU8 (w rows interleaved as OMNI_EPI_SILU_MUL_GU8; out is [M, N / 2],
+ *            = SiLU(bf16 gate) * bf16 up as omni_silu_mul; no other output).
+ *   resid    fp32 [M, ldr] or NULL (may alias out_f32: the residual stream updated in place).
+ *   out_f32  fp32 [M, ldf] or NULL: y.   out  bf16 [M, ldo] or NULL: bf16(y).
+ *   out2     bf16 [M, ldo2] or NULL: bf16(snake(y)), snake(y) = y + inv_beta[n] * sin^2(alpha[n] * y) (the SnakeBeta in front of
+ *            the next conv, fp32 [N] parameters as omni_snake_beta).  At least one output.                                    */
 #define OMNI_TILE_ACT_NONE 0
 #define OMNI_TILE_ACT_GELU 1
 #define OMNI_TILE_ACT_SILU_MUL_GU8 2
@@ -144,7 +146,8 @@ typedef struct omni_tile_gemm {
     int seg_len, seg_rows, row_off;
     const void* w; const float* bias; const float* scale;
     int act;
-    const void* resid; int ldr;
+    const float* resid; int ldr;
+    float* out_f32; int ldf;
     void* out; int ldo;
     void* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;

@@ -920,11 +920,68 @@ def mint_tts_prompt_builder():
     torch.save(out, path)
     print("tts_prompt_builder.pt", os.path.getsize(path), "bytes;", [(c["name"], tuple(c["out_prompt"].shape), tuple(c["out_trailing"].shape)) for c in cases])
 
+# --------------------------------------------------------------------------
+def mint_code2wav():
+    """The reference's own Qwen3TTSTokenizerV2Decoder (tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:912-1043) at the
+    tiny configuration of tests/codec_util.py with that file's seeded weights (load_state_dict, strict), fp32 on CPU as the
+    Code2Wav stage runs it (qwen3_tts_code2wav.py:71-75 loads torch_dtype=float32): waveforms of three code sequences, the
+    stage boundaries inside forward() for the longest one, and chunked_decode with a small window.  The one adaptation is
+    for the installed transformers (5.x renamed create_*_mask's `input_embeds` argument and dropped `cache_position`)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from codec_util import TINY_CODEC, make_codec_state
+    install_vllm_stubs()
+    pkg = "reftok12"
+    pk = types.ModuleType(pkg)
+    pk.__path__ = [os.path.join(V, "model_executor/models/qwen3_tts/tokenizer_12hz")]
+    sys.modules[pkg] = pk
+    cfgm = load_by_path(pkg + ".configuration_qwen3_tts_tokenizer_v2", os.path.join(pk.__path__[0], "configuration_qwen3_tts_tokenizer_v2.py"), pkg)
+    mod = load_by_path(pkg + ".modeling_qwen3_tts_tokenizer_v2", os.path.join(pk.__path__[0], "modeling_qwen3_tts_tokenizer_v2.py"), pkg)
+
+    def adapt(fn):
+        def f(**kw):
+            kw["inputs_embeds"] = kw.pop("input_embeds")
+            kw.pop("cache_position", None)
+            return fn(**kw)
+        return f
+    mod.create_causal_mask = adapt(mod.create_causal_mask)
+    mod.create_sliding_window_causal_mask = adapt(mod.create_sliding_window_causal_mask)
+    cfg = cfgm.Qwen3TTSTokenizerV2DecoderConfig(**TINY_CODEC)
+    cfg._attn_implementation = "eager"
+    dec = mod.Qwen3TTSTokenizerV2Decoder(cfg).eval()
+    seed = 11
+    missing, unexpected = dec.load_state_dict(make_codec_state(TINY_CODEC, seed), strict=True)
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(5)
+    out = {"seed": np.int64(seed), "total_upsample": np.int64(int(dec.total_upsample))}
+    taps = {}
+    hooks = []
+    orig_decode = dec.quantizer.decode
+    dec.quantizer.decode = lambda c: taps.setdefault("quantized", orig_decode(c))      # decode() is no forward(): no hook
+    hooks.append(dec.pre_conv.register_forward_hook(lambda m, i, o: taps.__setitem__("pre_conv", o)))
+    hooks.append(dec.pre_transformer.register_forward_hook(lambda m, i, o: taps.__setitem__("pre_transformer", o.last_hidden_state)))
+    hooks.append(dec.upsample[-1][-1].register_forward_hook(lambda m, i, o: taps.__setitem__("upsampled", o)))
+    for bi in range(len(dec.decoder)):
+        hooks.append(dec.decoder[bi].register_forward_hook(lambda m, i, o, bi=bi: taps.__setitem__(f"decoder{bi}", o)))
+    with torch.no_grad():
+        for i, T in enumerate((1, 7, 30)):
+            codes = torch.randint(0, TINY_CODEC["codebook_size"], (1, TINY_CODEC["num_quantizers"], T), generator=g)
+            taps.clear()
+            wav = dec(codes)
+            out[f"codes{i}"], out[f"wav{i}"] = codes.numpy(), wav.numpy()
+        for k, v in taps.items():
+            out["tap_" + k] = v.detach().numpy()
+        dec.quantizer.decode = orig_decode
+        out["wav_chunked"] = dec.chunked_decode(codes, chunk_size=8, left_context_size=3).numpy()
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "code2wav_tiny.npz"), **out)
+    print("code2wav tiny:", {k: v.shape for k, v in out.items() if k.startswith(("wav", "tap"))})
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "tp", "g2", "g3"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "tp", "g2", "g3", "c2w"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -949,3 +1006,5 @@ if __name__ == "__main__":
         mint_backbone_layer_real()
     if "g3" in which:
         mint_kv_quant()
+    if "c2w" in which:
+        mint_code2wav()

@@ -12,9 +12,11 @@ HDR = os.path.join(ROOT, "include", "omni_talker.h")
 
 
 def header_functions():
-    txt = open(HDR).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", txt)))
+    names = set()
+    for h in (HDR, os.path.join(ROOT, "include", "omni_codec.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_header_symbols_exported_and_bound():
@@ -23,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     names = header_functions()
     assert len(names) >= 25
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in omni_talker.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert lib.omni_abi_version() == 2
     assert lib.omni_last_error() is not None

@@ -1,0 +1,141 @@
+"""Code2Wav decoder on the HIP kernels (ht_vllm_omni_amd/code2wav.py) against
+  * the reference's own decoder outputs (tests/golden/code2wav_tiny.npz: fp32 torch module on CPU) -- waveform and every
+    stage boundary, at the tolerance bf16 GEMM operands allow, and
+  * oracle/code2wav_oracle.py (pinned to the same fixture by tests/test_code2wav_oracle.py) at the real architecture's depth
+    (MID_CODEC: 8 transformer layers, window 72, 4 decoder blocks with rates 8 / 5 / 4 / 3), plus chunked decode, the hipGraph
+    wrapper around the real decoder and the stage's request parsing / context trimming.
+Tolerances: the product computes with bf16 GEMM operands and fp32 accumulation / residual streams; the reference computes fp32.
+Measured on the fixture: |wav - ref| mean 1.9e-3, max 8e-3 at a signal of mean |wav| 0.15 (1.2 %); asserted at 2.5x that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.code2wav_oracle import Code2WavOracle
+from tests.codec_util import MID_CODEC, TINY_CODEC, make_codec_state, total_upsample
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(cfg, sd):
+    from ht_vllm_omni_amd.code2wav import Code2WavDecoder
+    return Code2WavDecoder(cfg, sd)
+
+
+def _tm(t):            # time-major device tensor -> channel-major fp32 on the host
+    return t.float().cpu().T
+
+
+def test_tiny_decoder_matches_the_reference_module_outputs(golden_dir):
+    z = np.load(os.path.join(golden_dir, "code2wav_tiny.npz"))
+    sd = make_codec_state(TINY_CODEC, int(z["seed"]))
+    dec = _decoder(TINY_CODEC, sd)
+    assert dec.total_upsample == int(z["total_upsample"])
+    worst = {}
+    for i in range(3):
+        codes = torch.from_numpy(z[f"codes{i}"]).cuda()
+        taps = {}
+        wav = dec.forward(codes, taps)
+        ref = torch.from_numpy(z[f"wav{i}"])
+        assert wav.shape == ref.shape and wav.dtype == torch.float32
+        d = (wav.cpu() - ref).abs()
+        worst[f"wav{i}"] = (d.mean().item(), d.max().item())
+        assert d.mean().item() <= 5e-3 and d.max().item() <= 5e-2, (i, d.mean().item(), d.max().item())
+    for k in ("quantized", "pre_conv", "upsampled", "decoder0", "decoder1", "decoder2", "decoder3"):
+        ref = torch.from_numpy(z["tap_" + k])[0]
+        got = _tm(taps[k])
+        assert got.shape == ref.shape, k
+        d = (got - ref).abs()
+        scale = ref.abs().mean().item()
+        worst[k] = (d.mean().item() / scale, d.max().item() / scale)
+        assert d.mean().item() <= 2e-2 * scale and d.max().item() <= 0.15 * scale, (k, worst[k])      # measured <= 1.1 % / 6 %
+    ref = torch.from_numpy(z["tap_pre_transformer"])[0]
+    d = (taps["pre_transformer"].float().cpu() - ref).abs()
+    assert d.mean().item() <= 1e-2 * ref.abs().mean().item(), "pre_transformer"
+    print("code2wav tiny vs reference (mean, max):", worst)
+
+
+def test_tiny_decoder_chunked_decode_and_batch(golden_dir):
+    z = np.load(os.path.join(golden_dir, "code2wav_tiny.npz"))
+    sd = make_codec_state(TINY_CODEC, int(z["seed"]))
+    dec = _decoder(TINY_CODEC, sd)
+    codes = torch.from_numpy(z["codes2"]).cuda()
+    wav = dec.chunked_decode(codes, chunk_size=8, left_context_size=3)
+    d = (wav.cpu() - torch.from_numpy(z["wav_chunked"])).abs()
+    assert wav.shape == (1, 1, 30 * 48) and d.mean().item() <= 5e-3 and d.max().item() <= 5e-2
+    both = dec(torch.cat([codes, codes.flip(-1)], 0))                     # batch of 2 = two independent decodes
+    assert both.shape == (2, 1, 30 * 48) and torch.equal(both[0], dec(codes)[0]) and torch.equal(both[1], dec(codes.flip(-1))[0])
+    with pytest.raises(ValueError):
+        dec(codes[:, :3])
+
+
+@pytest.mark.parametrize("T", [1, 13, 50])
+def test_mid_size_decoder_matches_the_oracle(T):
+    """Real depth (8 layers, window 72 > and < T, rates 8 x 5 x 4 x 3 x 2 x 2 = 1920) at a quarter of the real widths: against the
+    fp32 oracle and, tighter, against the oracle run with the product's rounding points."""
+    sd = make_codec_state(MID_CODEC, 3)
+    dec = _decoder(MID_CODEC, sd)
+    g = torch.Generator().manual_seed(T)
+    codes = torch.randint(0, MID_CODEC["codebook_size"], (1, MID_CODEC["num_quantizers"], T), generator=g)
+    wav = dec(codes.cuda()).cpu()
+    assert total_upsample(MID_CODEC) == 1920 and wav.shape == (1, 1, T * 1920)
+    ref32 = Code2WavOracle(MID_CODEC, sd)(codes)
+    ref16 = Code2WavOracle(MID_CODEC, sd, bf16_points=True)(codes)
+    sig = ref32.abs().mean().item()
+    d32, d16, dor = (wav - ref32).abs(), (wav - ref16).abs(), (ref16 - ref32).abs()
+    # measured at T = 13 (scripts/diag_code2wav.py): signal 0.198; HIP vs fp32 0.0048 mean / 0.028 max; HIP vs the oracle with the
+    # product's rounding points 0.0028 / 0.019; that oracle vs fp32 0.0047 / 0.026 -- the bf16-operand effect itself
+    assert d32.mean().item() <= 0.06 * sig and d32.max().item() <= 0.12, (d32.mean().item(), d32.max().item(), sig)
+    assert d16.mean().item() <= 0.04 * sig and d16.max().item() <= 0.10, (d16.mean().item(), d16.max().item(), sig)
+    assert d32.mean().item() <= 2.0 * dor.mean().item() + 1e-4, "the HIP path is no further from fp32 than bf16 operands make it"
+
+
+def test_window_attention_longer_than_the_window():
+    """T = 200 > window 72 with two 64-key chunks per query: the transformer output against the oracle's."""
+    sd = make_codec_state(MID_CODEC, 4)
+    dec = _decoder(MID_CODEC, sd)
+    codes = torch.randint(0, MID_CODEC["codebook_size"], (1, MID_CODEC["num_quantizers"], 200), generator=torch.Generator().manual_seed(9))
+    taps, otaps = {}, {}
+    dec.forward(codes.cuda(), taps)
+    Code2WavOracle(MID_CODEC, sd).forward(codes, otaps)
+    ref = otaps["pre_transformer"]
+    d = (taps["pre_transformer"].float().cpu() - ref).abs()
+    assert d.mean().item() <= 1e-2 * ref.abs().mean().item() and d.max().item() <= 0.1 * ref.abs().max().item()
+
+
+def test_hipgraph_wrapper_around_the_real_decoder():
+    """cuda_graph_decoder_wrapper.py's contract with the real network under it: replayed buckets == eager decode, padding does
+    not leak (causal network: trailing zero-code frames cannot change earlier samples)."""
+    sd = make_codec_state(TINY_CODEC, 1)
+    dec = _decoder(TINY_CODEC, sd)
+    g = torch.Generator().manual_seed(2)
+    codes = torch.randint(0, 64, (1, 4, 21), generator=g).cuda()
+    eager = dec.chunked_decode(codes, chunk_size=8, left_context_size=3)
+    dec.enable_cudagraph(capture_sizes=[4, 8, 11, 16])
+    assert sorted(dec._graph.graphs) == [4, 8, 11, 16]
+    graphed = dec.chunked_decode(codes, chunk_size=8, left_context_size=3)
+    assert dec._graph.stats["replays"] == 3 and dec._graph.stats["eager"] == 0
+    assert torch.equal(graphed, eager)
+    dec.disable_cudagraph()
+
+
+def test_stage_forward_request_parsing_and_context_trim():
+    from ht_vllm_omni_amd.code2wav import MI355XCode2Wav
+    sd = make_codec_state(TINY_CODEC, 1)
+    dec = _decoder(TINY_CODEC, sd)
+    stage = MI355XCode2Wav(dec, output_sample_rate=24000)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(0, 64, (4, 9), generator=g)
+    b = torch.randint(0, 64, (4, 6), generator=g)
+    ids = torch.cat([a.reshape(-1), b.reshape(-1), torch.tensor([1, 2, 3])]).cuda()       # third request: malformed (3 % 4 != 0)
+    out = stage(ids, seq_token_counts=[36, 24, 3], runtime_additional_information=[{}, {"left_context_size": torch.tensor([2])}, {}])
+    wa, wb, wc = out["model_outputs"]
+    assert [int(s) for s in out["sr"]] == [24000] * 3
+    assert torch.equal(wa.cpu(), dec(a[None].cuda()).reshape(-1).cpu())
+    full_b = dec(b[None].cuda()).reshape(-1).cpu()
+    assert torch.equal(wb.cpu(), full_b[int(2 / 6 * full_b.shape[0]):]) and wb.shape[0] == 4 * 48
+    assert wc.numel() == 0
+    assert stage(torch.zeros(0, dtype=torch.long))["model_outputs"][0].numel() == 0
+    with pytest.raises(ValueError):
+        stage(torch.full((8,), 64).cuda())

@@ -75,31 +75,34 @@ def test_transposed_conv_stride_s_kernel_2s_as_one_gemm(Cin, Cout, s, T):
     _close(out.view(T * s, Cout), ref, mag, f"transconv s{s} {Cin}->{Cout}")
 
 
-def test_epilogues_gelu_scale_residual_and_snake_second_output():
+def test_epilogues_gelu_scale_fp32_residual_stream_and_snake_output():
     ops, L, frag_shuffle, _ = _ops()
     g = torch.Generator().manual_seed(5)
     M, N, K = 700, 192, 192
     x = torch.randn(M, K, generator=g).to(BF16)
     w = (torch.randn(N, K, generator=g) * 0.08).to(BF16)
     b, sc = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
-    r = torch.randn(M, N, generator=g).to(BF16)
+    r = torch.randn(M, N, generator=g) * 4
     al, ib = torch.rand(N, generator=g) + 0.5, torch.rand(N, generator=g) + 0.5
     acc = x.double() @ w.double().T + b.double()
     mag = x.double().abs() @ w.double().abs().T + b.double().abs()
-    # GELU * scale
+    # GELU * scale -> bf16
     out = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), act=L.TILE_ACT_GELU)
     _close(out, torch.nn.functional.gelu(acc) * sc.double(), mag * sc.double() * 1.2 + 1e-3, "gelu * scale")
-    # residual: bf16(resid + bf16(acc + b)); snake of that as the second output
-    out, out2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()))
-    y = acc.float().to(BF16)                                                   # the kernel's first rounding (fp32 acc: may differ by 1 ulp)
-    ref = r.double() + y.double()
-    got = out.double().cpu()
-    assert ((got - ref).abs() <= ref.abs() * 2.0 ** -8 + y.double().abs() * 2.0 ** -7 + 1e-6).all()
-    z = out.cpu().float()
-    ref2 = z.double() + ib.double() * torch.sin(z.double() * al.double()) ** 2
-    assert ((out2.double().cpu() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 2e-3).all()       # __sinf: abs error ~1e-6 x |arg|
-    only2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()), want_out=False)
-    assert torch.equal(only2, out2)
+    # y = acc * scale + resid: fp32 stream (in place on the residual buffer), bf16 copy, snake of the fp32 value
+    stream = r.clone().cuda()
+    f, o, s2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), resid=stream, out_f32=stream,
+                             snake=(al.cuda(), ib.cuda()), want="fbs")
+    assert f.data_ptr() == stream.data_ptr()
+    ref = acc * sc.double() + r.double()
+    tol = mag * sc.double() * 2.0 ** -16 + ref.abs() * 2.0 ** -22 + 1e-6
+    assert ((f.double().cpu() - ref).abs() <= tol).all()
+    assert torch.equal(o.cpu(), f.cpu().to(BF16))                                  # one rounding of the same fp32 value
+    z = f.double().cpu()
+    ref2 = z + ib.double() * torch.sin(z * al.double()) ** 2
+    assert ((s2.double().cpu() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 1e-4 + 4e-6 * z.abs()).all()   # __sinf argument error
+    only = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()), want="s")
+    assert torch.equal(only, s2)
 
 
 @pytest.mark.parametrize("M,I,K", [(333, 3072, 1024), (6400, 6144, 2048), (100, 64, 64)])
