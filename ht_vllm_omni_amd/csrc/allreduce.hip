@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void allreduce_resid_kernel(const ArArgs a) {
     if (a.world > 1) {
         if (blockIdx.x == 0 && threadIdx.x < a.world)
             __hip_atomic_store(a.flags[threadIdx.x] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x < a.world) {
+        // a peer that failed to arrive once (error word set) is not waited for again: a dead rank costs ONE timeout, not one
+        // per all-reduce of every remaining step; the caller reads the error word and voids the results
+        if (threadIdx.x < a.world && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             const uint32_t* f = a.flags[a.rank] + threadIdx.x;
             uint32_t spins = 0;
             while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {

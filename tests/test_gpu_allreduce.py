@@ -86,6 +86,12 @@ def test_missing_peer_times_out_instead_of_hanging():
     ars[0].all_reduce(0, out=out, M=4)               # rank 1 never launches
     torch.cuda.synchronize()
     assert ars[0].error() == 2                       # 1 + index of the absent peer
+    import time
+    t0 = time.perf_counter()
+    for _ in range(50):                              # the error is sticky: later launches do not wait for the dead peer again
+        ars[0].all_reduce(0, out=out, M=4)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5 and ars[0].error() == 2
     for a in ars:
         a.close()
 
