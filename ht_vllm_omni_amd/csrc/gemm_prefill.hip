@@ -45,7 +45,7 @@ struct TileArgs {
     uint16_t* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;
     int act;                         // OMNI_TILE_ACT_*
-    int mblocks, nblocks;
+    int mblocks, nblocks, band;
 };
 
 __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
@@ -91,7 +91,16 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         const int xcd = id & 7, slot = id >> 3, per = nwg >> 3, rem = nwg & 7;
         tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
     }
-    const int n_blk = tile / a.mblocks, m_blk = tile - n_blk * a.mblocks;
+    // tile order: bands of `band` m blocks, n-major inside a band, so that an XCD's contiguous chunk of ~nwg / 8 tiles is a compact
+    // 2-D block (~sqrt x sqrt) of the tile grid: it touches the fewest distinct W and x panels (L2 misses go to the MALL / HBM)
+    int n_blk, m_blk;
+    {
+        const int per_band = a.band * a.nblocks;
+        const int b = tile / per_band, r = tile - b * per_band;
+        const int h = min(a.band, a.mblocks - b * a.band);            // rows of this (possibly last, shorter) band
+        n_blk = r / h;
+        m_blk = b * a.band + (r - n_blk * h);
+    }
     const int m0 = m_blk * G::BM, n0 = n_blk * G::BN;
     const int nsteps = a.K >> 5;                                              // 32-deep slices
 
@@ -171,13 +180,17 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
     {                                                                                                        \
         _Pragma("unroll") for (int j = 0; j < HW; ++j) w1[j] = lds_w((T), HW + j);                           \
         stage((T) + NBUF - 1);                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int j = 0; j < HW; ++j)                                                       \
             _Pragma("unroll") for (int i = 0; i < WM; ++i) acc[j][i] = tg_mfma(w0[j], XCUR[i], acc[j][i]);   \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT * (NLW + NLX)) : "memory"); \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) XNEXT[i] = lds_x((T) + 1, i);                         \
         _Pragma("unroll") for (int j = 0; j < HW; ++j) w0[j] = lds_w((T) + 1, j);                            \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int j = 0; j < HW; ++j)                                                       \
             _Pragma("unroll") for (int i = 0; i < WM; ++i) acc[HW + j][i] = tg_mfma(w1[j], XCUR[i], acc[HW + j][i]); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
     }
     for (int t = 0; t < nsteps; t += 2) {                // an odd slice count runs one slice of zeros (staged out of range)
         TG_SLICE(t, xa, xb)
@@ -285,6 +298,12 @@ static int launch_tile(TileArgs a, hipStream_t st) {
     using G = TileGeom<WAVES_N, WN, WM>;
     a.mblocks = (a.M + G::BM - 1) / G::BM;
     a.nblocks = (a.N + G::BN - 1) / G::BN;
+    {
+        const int per_xcd = (a.mblocks * a.nblocks + 7) / 8;
+        int band = 1;
+        while (band * band < per_xcd) ++band;                         // ~sqrt(tiles per XCD)
+        a.band = band < 1 ? 1 : (band > a.mblocks ? a.mblocks : band);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<WAVES_N, WN, WM, GU8>),
