@@ -233,7 +233,8 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         }
         __builtin_amdgcn_wave_barrier();
         if (GU8) {
-            // tile jj of a row = [8 gate | 8 up] -> 8 act columns at n / 2: SiLU(bf16 gate) * bf16 up, one rounding (ops.silu_mul)
+            // tile jj of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
+            // torch's F.silu(g) * u on bf16 tensors (omni_silu_mul, oracle silu_mul)
             for (int idx = lane; idx < WM * 16 * HT; idx += 64) {
                 const int row = idx / HT, jj = idx - row * HT;
                 const int m = mw0 + row, n = nh0 + jj * 16;
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
                 for (int e = 0; e < 4; ++e) {
                     const float g0 = bfround(gp[2 * e]), g1 = bfround(gp[2 * e + 1]);
                     const float u0 = bfround(gp[8 + 2 * e]), u1 = bfround(gp[8 + 2 * e + 1]);
-                    o[e] = pack_bf2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+                    const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));   // torch: F.silu(bf16) is bf16
+                    o[e] = pack_bf2(s0 * u0, s1 * u1);
                 }
                 *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
             }

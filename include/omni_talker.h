@@ -133,7 +133,7 @@ int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk
  *   w        bf16 [N, K] fragment-major (OMNI_LAYOUT_W_FRAG); N % 16 == 0, K % 32 == 0, seg_len % 32 == 0.
  *   bias / scale  fp32 [N] or NULL.  y = act(acc + bias) * scale (+ resid), all fp32.
  *   act      OMNI_TILE_ACT_NONE | _GELU (erf) | _SILU_MUL_GU8 (w rows interleaved as OMNI_EPI_SILU_MUL_GU8; out is [M, N / 2],
- *            = SiLU(bf16 gate) * bf16 up as omni_silu_mul; no other output).
+ *            = bf16(bf16(SiLU(bf16 gate)) * bf16 up), omni_silu_mul's rounding points; no other output).
  *   resid    fp32 [M, ldr] or NULL (may alias out_f32: the residual stream updated in place).
  *   out_f32  fp32 [M, ldf] or NULL: y.   out  bf16 [M, ldo] or NULL: bf16(y).
  *   out2     bf16 [M, ldo2] or NULL: bf16(snake(y)), snake(y) = y + inv_beta[n] * sin^2(alpha[n] * y) (the SnakeBeta in front of

@@ -118,7 +118,7 @@ class Code2WavOracle:
             a = _r(self.rms_norm(h, p + "post_attention_layernorm"), bf)
             g = _r(a @ self.w(p + "mlp.gate_proj.weight").T, bf)
             u = _r(a @ self.w(p + "mlp.up_proj.weight").T, bf)
-            m = _r(F.silu(g) * u, bf)
+            m = _r(_r(F.silu(g), bf) * u, bf)
             h = h + (m @ self.w(p + "mlp.down_proj.weight").T) * self.sd[p + "mlp_layer_scale.scale"]
         h = _r(self.rms_norm(h, "pre_transformer.norm"), bf)
         return _r(h @ self.w("pre_transformer.output_proj.weight").T + self.sd["pre_transformer.output_proj.bias"], bf)

@@ -6,7 +6,7 @@ import os
 
 def _latest():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    files = sorted(glob.glob(os.path.join(root, "r01_v*_bench.json")), key=lambda p: int(os.path.basename(p).split("_v")[1].split("_")[0]))
+    files = sorted(glob.glob(os.path.join(root, "r[0-9][0-9]_bench_steps20*.json")))       # newest round's line at the driver's flags
     assert files, "no committed bench line under profiles/"
     return json.load(open(files[-1]))
 

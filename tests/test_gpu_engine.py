@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from ht_vllm_omni_amd import _lib as L
 from ht_vllm_omni_amd.config import get_dims
 from ht_vllm_omni_amd.sched import BlockPool
 from ht_vllm_omni_amd.weights import make_weights

@@ -108,7 +108,7 @@ def test_epilogues_gelu_scale_fp32_residual_stream_and_snake_output():
 @pytest.mark.parametrize("M,I,K", [(333, 3072, 1024), (6400, 6144, 2048), (100, 64, 64)])
 def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     """The decode step's gate_up weight as it lies in HBM (gate / up rows interleaved by 8, fragment-major) serves the
-    prefill GEMM: act = SiLU(bf16 gate) * bf16 up, one rounding -- ops.silu_mul's convention."""
+    prefill GEMM: act = bf16(bf16(SiLU(bf16 gate)) * bf16 up) -- ops.silu_mul's (= torch bf16) rounding points."""
     ops, L, frag_shuffle, gu8_shuffle = _ops()
     g = torch.Generator().manual_seed(I)
     x = torch.randn(M, K, generator=g).to(BF16)
@@ -116,11 +116,14 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     out = ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8)
     assert out.shape == (M, I)
     gu = (x.double() @ w.double().T)
-    mag = x.double().abs() @ w.double().abs().T
-    ga, up = gu[:, :I].float().to(BF16).double(), gu[:, I:].float().to(BF16).double()
-    ref = ga / (1 + torch.exp(-ga)) * up
-    slack = (mag[:, :I] * up.abs() + mag[:, I:] * ga.abs()) * 2.0 ** -7 + 1e-6   # a 1-ulp flip of either rounded factor
-    assert ((out.double().cpu() - ref).abs() <= ref.abs() * 2.0 ** -8 + slack).all()
+    ga, up = gu[:, :I].float().to(BF16), gu[:, I:].float().to(BF16)
+    ref = torch.nn.functional.silu(ga) * up                       # torch bf16 semantics: silu rounds, the product rounds
+    same = (out.cpu() == ref).float().mean().item()
+    assert same >= 0.995, same                                    # the rest: 1-ulp flips of gate / up at fp32 accumulation-order ties
+    assert ((out.cpu().float() - ref.float()).abs() <= ref.float().abs() * 2.0 ** -6 + 1e-3).all()
+    from ht_vllm_omni_amd.engine import frag_shuffle as _fs
+    plain = ops.gemm_tile(x.cuda(), _fs(w).cuda())                # the same GEMM without the epilogue, through omni_silu_mul
+    assert torch.equal(out, ops.silu_mul(plain))
 
 
 def test_rejects_bad_shapes():
