@@ -164,3 +164,67 @@ extern "C" int omni_debug_chain(int mode, float* a, float* b, int blocks, int re
     OMNI_CHECK_LAUNCH("omni_debug_chain");
     return OMNI_OK;
 }
+
+// ---- what does a grid barrier cost inside ONE persistent launch?  (The alternative to a kernel boundary for the code predictor's
+// chain of dependent steps.)  `blocks` workgroups of 512 threads, all co-resident (blocks <= 256, one per CU), run `iters` steps of
+// { out[i] = in[j] * s + 1 with j on ANOTHER workgroup's slice (a real cross-XCD hand-off), grid barrier }.
+//   mode 0: one counter: release-add at agent scope, every workgroup's thread 0 polls it
+//   mode 1: as 0, the pollers s_sleep between polls
+//   mode 2: hierarchical: one counter per XCD (its 32 workgroups), the last arriver of an XCD adds to the global one; the pollers
+//           read the global counter
+//   mode 3 / 4: as 0 / 2 with the exchanged values moved by sc1 (L2-bypassing) stores and loads instead of release / acquire fences
+// Bounded spins: a workgroup that never sees its peers sets err and moves on (a wrong number, not a hung GPU).
+#define DBG_GBAR_BOUND (1u << 20)
+__global__ __launch_bounds__(512) void dbg_gbar_kernel(float* a, float* b, unsigned* ctr /* [0] global, [8 + 16 x] per XCD */, int* err,
+                                                       int iters, int mode) {
+    const int nwg = gridDim.x, w = blockIdx.x, tid = threadIdx.x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7;
+    // workgroups of this XCD: ids congruent mod 8 (round-robin dealing), so nwg / 8 each when nwg % 8 == 0
+    const unsigned per_xcd = (unsigned)nwg >> 3;
+    for (int it = 0; it < iters; ++it) {
+        const float* src = (it & 1) ? b : a;
+        float* dst = (it & 1) ? a : b;
+        const int j = ((w + 37) % nwg) * 512 + tid;                       // a slice some other workgroup (other XCD) wrote last step
+        if (mode >= 3) {
+            // coherent-by-access: the exchanged values bypass the XCD-private L2 in both directions (sc1 store / sc1 load), no cache
+            // write-back or invalidate at the barrier -- what a tuned persistent kernel would do for its activations
+            const float v = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 0.5f + 1.0f;
+            __hip_atomic_store(dst + w * 512 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores have left the CU
+        } else {
+            dst[w * 512 + tid] = __builtin_nontemporal_load(src + j) * 0.5f + 1.0f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // this workgroup's stores visible beyond its XCD's L2
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned target = (unsigned)(it + 1) * (unsigned)nwg;
+            if (mode == 2 || mode == 4) {
+                unsigned* xc = ctr + 8 + 16 * xcc;
+                const unsigned prev = __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev + 1 == (unsigned)(it + 1) * per_xcd)
+                    __hip_atomic_fetch_add(ctr, per_xcd, mode == 2 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_fetch_add(ctr, 1u, mode < 3 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned spins = 0;
+            const bool dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;     // sticky: one timeout, not one per step
+            while (!dead && (int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                if (mode == 1) __builtin_amdgcn_s_sleep(2);
+                if (++spins > DBG_GBAR_BOUND) { atomicExch(err, 1 + it); break; }
+            }
+        }
+        __syncthreads();
+        if (mode < 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines before reading the peers' slices
+    }
+}
+extern "C" int omni_debug_grid_barrier_chain(int mode, float* a, float* b, unsigned* counters, int* err, int blocks, int iters, void* stream) {
+    OMNI_CHECK_ARG(blocks > 0 && blocks <= 256 && blocks % 8 == 0 && mode >= 0 && mode <= 4, "omni_debug_grid_barrier_chain: blocks=%d mode=%d", blocks, mode);
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(counters, 0, 8 * 64 + 64, st);
+    hipMemsetAsync(err, 0, 4, st);
+    hipLaunchKernelGGL(dbg_gbar_kernel, dim3(blocks), dim3(512), 0, st, a, b, counters, err, iters, mode);
+    OMNI_CHECK_LAUNCH("omni_debug_grid_barrier_chain");
+    return OMNI_OK;
+}

@@ -22,6 +22,11 @@ int omni_debug_mix(int pattern, float* small, const void* big, size_t big_bytes,
 int omni_debug_cfgmix(int mode, float* p, int reps, void* stream);
 int omni_debug_xcc_probe(int32_t* out, float* scratch, int gx, int gy, int odd, int reps, void* stream); /* XCC id of every block */
 int omni_debug_chain(int mode, float* a, float* b, int blocks, int reps, void* stream);   /* 0: struct kernarg, 1: preloaded scalars */
+/* One persistent launch of `blocks` (<= 256, multiple of 8) co-resident workgroups running `iters` steps of { cross-workgroup hand-off;
+ * grid barrier } -- the in-kernel alternative to a kernel boundary (mode 0: one counter; 1: + s_sleep between polls; 2: per-XCD
+ * counters feeding the global one).  counters: >= 576 zeroable bytes; err: int32 set when a spin ran out (bounded: no hang). */
+int omni_debug_grid_barrier_chain(int mode, float* a, float* b, unsigned* counters, int* err, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
