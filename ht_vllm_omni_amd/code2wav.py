@@ -20,7 +20,6 @@ There is no CPU path: the constructor needs the HIP library and a GPU.
 """
 from __future__ import annotations
 
-import ctypes as C
 import logging
 import math
 from dataclasses import dataclass, fields
