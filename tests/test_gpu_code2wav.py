@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle.code2wav_oracle import Code2WavOracle
-from tests.codec_util import MID_CODEC, TINY_CODEC, make_codec_state, total_upsample
+from tests.codec_util import FULL_CODEC, MID_CODEC, TINY_CODEC, make_codec_state, total_upsample
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,32 @@ def test_mid_size_decoder_matches_the_oracle(T):
     assert d32.mean().item() <= 0.06 * sig and d32.max().item() <= 0.12, (d32.mean().item(), d32.max().item(), sig)
     assert d16.mean().item() <= 0.04 * sig and d16.max().item() <= 0.10, (d16.mean().item(), d16.max().item(), sig)
     assert d32.mean().item() <= 2.0 * dor.mean().item() + 1e-4, "the HIP path is no further from fp32 than bf16 operands make it"
+
+
+def test_full_architecture_decoder_matches_the_oracle_in_fp32_torch_on_the_gpu():
+    """The released architecture's sizes (latent 1024, 8 x 1024-wide layers with 16 heads, codebooks of 2048 x 16, decoder
+    1536 -> 768 -> 384 -> 192 -> 96 channels: every tile configuration of omni_gemm_tile at its real shape, the 1024-channel
+    depthwise conv, 624 k-row tensors) with random-init weights: the HIP decoder against the oracle's functional restatement run in
+    fp32 torch ops on the same GPU (an independent implementation: MIOpen / hipBLASLt), stage by stage and at the waveform."""
+    sd = make_codec_state(FULL_CODEC, 7, device="cuda")
+    dec = _decoder(FULL_CODEC, sd)
+    T = 20
+    codes = torch.randint(0, FULL_CODEC["codebook_size"], (1, FULL_CODEC["num_quantizers"], T), generator=torch.Generator().manual_seed(1)).cuda()
+    orc = Code2WavOracle(FULL_CODEC, {})
+    orc.sd = {k: v.float() for k, v in sd.items()}                       # weights stay on the GPU: torch ops run there
+    taps, otaps = {}, {}
+    wav = dec.forward(codes, taps)
+    ref = orc.forward(codes, otaps)
+    assert wav.shape == ref.shape == (1, 1, T * 1920)
+    for k in ("quantized", "pre_conv", "pre_transformer", "upsampled", "decoder1", "decoder2", "decoder3", "decoder4"):
+        r = otaps[k]
+        g = taps[k].float()
+        g = g if g.shape == r.shape else g.T
+        rel = ((g - r).abs().mean() / r.abs().mean()).item()
+        assert rel <= 0.04, (k, rel)                                      # smooth growth 0.1 % -> ~2 % as at the mid size
+    d = (wav - ref).abs()
+    sig = ref.abs().mean().item()
+    assert d.mean().item() <= 0.08 * sig and d.max().item() <= 0.2, (d.mean().item(), d.max().item(), sig)
 
 
 def test_window_attention_longer_than_the_window():
