@@ -212,3 +212,25 @@ def export_hf_checkpoint(w: dict, d: TalkerDims, out_dir: str, shards: int = 2) 
         index["weight_map"].update({k: fn for k in part})
     json.dump(index, open(os.path.join(out_dir, "model.safetensors.index.json"), "w"))
     json.dump(hf_config_from_dims(d), open(os.path.join(out_dir, "config.json"), "w"))
+
+
+def load_code2wav_checkpoint(path: str) -> tuple[dict, dict]:
+    """The speech tokenizer's DECODER out of a Qwen3-TTS checkpoint: (decoder_config dict, state dict under the decoder's own
+    parameter names) for ``code2wav.Code2WavDecoder``.  ``path`` is the model directory or its ``speech_tokenizer/`` sub-directory
+    (qwen3_tts_code2wav.py:59-75 resolves ``speech_tokenizer/config.json`` and loads the whole tokenizer in fp32); the tokenizer
+    model's tensors are named ``decoder.…`` / ``encoder.…`` (Qwen3TTSTokenizerV2Model, modeling_qwen3_tts_tokenizer_v2.py:1073-1100):
+    only the ``decoder.`` ones are read, the prefix is stripped, dtype fp32 as stored."""
+    d = os.path.join(path, "speech_tokenizer") if os.path.isdir(os.path.join(path, "speech_tokenizer")) else path
+    with open(os.path.join(d, "config.json")) as f:
+        cfg = json.load(f)
+    dec_cfg = dict(cfg.get("decoder_config") or {})
+    if "num_quantizers" not in dec_cfg:
+        raise ValueError("speech_tokenizer decoder_config.num_quantizers not found")
+    dec_cfg.setdefault("output_sample_rate", cfg.get("output_sample_rate", 24000))
+    state = {}
+    for name, t in iter_safetensors(d):
+        if name.startswith("decoder."):
+            state[name[len("decoder."):]] = t.to(torch.float32)
+    if not state:
+        raise ValueError(f"no decoder.* tensors under {d}")
+    return dec_cfg, state

@@ -78,3 +78,29 @@ def test_decoder_has_no_cpu_path():
     from ht_vllm_omni_amd._lib import OmniError
     with pytest.raises(OmniError, match="no CPU fallback"):
         Code2WavDecoder(TINY_CODEC, {})
+
+
+def test_code2wav_checkpoint_loader_reads_the_decoder_of_a_speech_tokenizer_directory(tmp_path):
+    """A synthetic speech_tokenizer/ directory (config.json + model.safetensors with decoder.* and encoder.* tensors): the loader
+    returns the decoder's config and ONLY its tensors, prefix stripped, bit-exact."""
+    import json, os
+    from safetensors.torch import save_file
+    from ht_vllm_omni_amd.checkpoint import load_code2wav_checkpoint
+    from tests.codec_util import make_codec_state
+    sd = make_codec_state(TINY_CODEC, 5)
+    st = tmp_path / "model" / "speech_tokenizer"
+    os.makedirs(st)
+    tensors = {"decoder." + k: v.contiguous() for k, v in sd.items()}
+    tensors["encoder.layers.0.weight"] = torch.zeros(4, 4)
+    save_file(tensors, str(st / "model.safetensors"))
+    json.dump({"decoder_config": {**TINY_CODEC, "upsample_rates": list(TINY_CODEC["upsample_rates"]),
+                                  "upsampling_ratios": list(TINY_CODEC["upsampling_ratios"])}, "output_sample_rate": 24000,
+               "encoder_config": {}}, open(st / "config.json", "w"))
+    for root in (tmp_path / "model", st):
+        cfg, state = load_code2wav_checkpoint(str(root))
+        assert set(state) == set(sd) and all(torch.equal(state[k], sd[k]) for k in sd)
+        c = Code2WavConfig.from_dict(cfg)
+        assert c.total_upsample == 48 and c.num_quantizers == 4 and c.output_sample_rate == 24000
+    json.dump({"decoder_config": {}}, open(st / "config.json", "w"))
+    with pytest.raises(ValueError, match="num_quantizers"):
+        load_code2wav_checkpoint(str(st))
