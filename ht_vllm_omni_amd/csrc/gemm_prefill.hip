@@ -63,13 +63,15 @@ struct TileGeom {
     static constexpr int NTILES = WAVES_N * WN, MTILES = WAVES_M * WM;
     static constexpr int BN = NTILES * 16, BM = MTILES * 16;
     static constexpr int SLICE = (NTILES + MTILES) * 1024;                   // one 32-deep slice of both operands
-    static constexpr int NLW = (NTILES + TG_WAVES - 1) / TG_WAVES, NLX = MTILES / TG_WAVES;   // LDS-DMA per wave and slice
+    static constexpr int NLW = (NTILES + TG_WAVES - 1) / TG_WAVES, NLX = (MTILES + TG_WAVES - 1) / TG_WAVES;   // LDS-DMA per wave and slice
     static constexpr bool W_RAGGED = NTILES % TG_WAVES != 0;                 // some waves issue a dummy W load (uniform counts)
-    static constexpr int NBUF = (TG_LDS_MAX - (W_RAGGED ? TG_WAVES * 1024 : 0)) / SLICE >= 4 ? 4 : 3;
+    static constexpr bool X_RAGGED = MTILES % TG_WAVES != 0;                 // likewise for x (the 64-row tile of the small-M geometry)
+    static constexpr bool RAGGED = W_RAGGED || X_RAGGED;
+    static constexpr int NBUF = (TG_LDS_MAX - (RAGGED ? TG_WAVES * 1024 : 0)) / SLICE >= 4 ? 4 : 3;
     static constexpr int EPI_BYTES = TG_WAVES * WM * 16 * ((WN / 2) * 64 + 16);   // fp32 image of half the wave's n tiles
-    static constexpr int RING_BYTES = NBUF * SLICE + (W_RAGGED ? TG_WAVES * 1024 : 0);
+    static constexpr int RING_BYTES = NBUF * SLICE + (RAGGED ? TG_WAVES * 1024 : 0);
     static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-    static_assert(MTILES % TG_WAVES == 0 && WN % 2 == 0 && LDS_BYTES <= TG_LDS_MAX, "geometry");
+    static_assert(WN % 2 == 0 && LDS_BYTES <= TG_LDS_MAX, "geometry");
 };
 
 template <int WAVES_N, int WN, int WM, bool GU8>
@@ -139,9 +141,11 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         }
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
+            const bool mine = !G::X_RAGGED || wave + TG_WAVES * i < G::MTILES;
             const int r = xrow[i] + shift;
-            const unsigned off = (live && r >= 0 && r < (int)a.x_rows) ? (unsigned)(xbyte[i] + add) : TG_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(base + (NTILES + i * TG_WAVES) * 1024), 16, off, 0, 0, 0);
+            const unsigned off = (live && mine && r >= 0 && r < (int)a.x_rows) ? (unsigned)(xbyte[i] + add) : TG_OOB;
+            uint8_t* dst = mine ? base + (NTILES + i * TG_WAVES) * 1024 : lds + NBUF * SLICE + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)dst, 16, off, 0, 0, 0);
         }
         cs += 32;
         if (cs >= a.seg_len) { cs = 0; ++seg; }
@@ -328,6 +332,7 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
     const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
     OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
+    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 2, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
     OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2 && !g->out_f32), "omni_gemm_tile: SiLU-mul takes out only");
     OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
     const int nout = gu8 ? g->N / 2 : g->N;
@@ -345,7 +350,16 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     a.M = g->M; a.N = g->N; a.K = g->K; a.act = g->act;
     hipStream_t st = (hipStream_t)stream;
     const int N = g->N;
-    // <waves along n, n tiles per wave, m tiles per wave>: 256 x 256 | 192 x 256 | 128 x 512 | 96 x 512 output tiles
+    // <waves along n, n tiles per wave, m tiles per wave>: 256 x 256 | 192 x 256 | 128 x 512 | 96 x 512 output tiles, and 128 x 64
+    // for problems whose big-tile grid would leave most of the 256 CUs idle (the Code2Wav transformer / ConvNeXt at a few hundred
+    // frames, streaming chunks): there the K loop's latency is the cost, not MFMA throughput
+    {
+        const int big_n = N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : (N % 128 == 0 ? 128 : (N % 96 == 0 ? 96 : (N > 128 ? 256 : 128))));
+        const int big_m = big_n >= 192 ? 256 : 512;
+        const long long big_tiles = (long long)((N + big_n - 1) / big_n) * ((g->M + big_m - 1) / big_m);
+        const bool small = g->tile_hint == 2 || (g->tile_hint == 0 && big_tiles < 96 && g->N >= 64);
+        if (small) return gu8 ? launch_tile<4, 2, 2, true>(a, st) : launch_tile<4, 2, 2, false>(a, st);
+    }
     if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st) : launch_tile<1, 8, 4, true>(a, st);
     if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st);
     if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st);

@@ -267,7 +267,7 @@ def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
 
 def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bias=None, scale=None, act: int = L.TILE_ACT_NONE,
               resid=None, out=None, out_f32=None, out2=None, snake=None, taps: int = 1, dilation: int = 1,
-              row_off: int | None = None, want: str = "b"):
+              row_off: int | None = None, want: str = "b", tile_hint: int = 0):
     """omni_gemm_tile: y[M, N] = act(A . W^T + bias) * scale (+ resid) on the matrix cores, A = x for taps == 1, else the
     causal conv window A[m] = [x[m + row_off], x[m + row_off + dilation], ...] (taps rows of x.shape[1] channels; row_off
     defaults to -(taps - 1) * dilation; rows outside x read as zero).  x bf16 [rows, C] (row stride = x.stride(0)); w_frag bf16
@@ -307,6 +307,6 @@ def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bi
             res.append(out2)
         else:
             raise ValueError(want)
-    g.M, g.N, g.K = M, N, K
+    g.M, g.N, g.K, g.tile_hint = M, N, K, tile_hint
     L.check(L.load().omni_gemm_tile(C.byref(g), L.current_stream()), "omni_gemm_tile")
     return res[0] if len(res) == 1 else tuple(res)

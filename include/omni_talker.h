@@ -151,6 +151,7 @@ typedef struct omni_tile_gemm {
     void* out; int ldo;
     void* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;
+    int tile_hint;   /* 0: automatic; 1: the large output tiles (256 x 256 ...); 2: the 128 x 64 tile of small-M problems */
 } omni_tile_gemm;
 int omni_gemm_tile(const omni_tile_gemm* g, void* stream);
 

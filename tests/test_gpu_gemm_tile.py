@@ -29,14 +29,18 @@ def _close(got, ref, mag, what):
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 2048), (257, 192, 96), (513, 384, 672), (640, 128, 64),
                                    (1111, 96, 672), (255, 288, 96), (70, 48, 32), (900, 272, 160), (6400, 2048, 2048)])
 def test_plain_gemm_every_tile_configuration(M, N, K):
+    """tile_hint 1 = the large tiles (256 / 192 / 128 / 96 columns by N), 2 = the 128 x 64 small-M tile, 0 = the dispatch rule."""
     ops, L, frag_shuffle, _ = _ops()
     g = torch.Generator().manual_seed(M * 7 + N)
     x = torch.randn(M, K, generator=g).to(BF16)
     w = (torch.randn(N, K, generator=g) * 0.05).to(BF16)
-    out = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda())
     ref = x.double() @ w.double().T
     mag = x.double().abs() @ w.double().abs().T
-    _close(out, ref, mag, f"gemm {M}x{N}x{K}")
+    outs = []
+    for hint in (1, 2, 0):
+        outs.append(ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), tile_hint=hint))
+        _close(outs[-1], ref, mag, f"gemm {M}x{N}x{K} hint {hint}")
+    assert torch.equal(outs[0], outs[1])      # same k order per output element in both geometries: bit-identical
 
 
 @pytest.mark.parametrize("Cin,Cout,taps,dil,T", [(96, 96, 7, 1, 700), (96, 96, 7, 9, 531), (192, 192, 7, 3, 400), (512, 1024, 3, 1, 77),
@@ -50,7 +54,8 @@ def test_causal_dilated_conv1d_as_windowed_gemm(Cin, Cout, taps, dil, T):
     w = (torch.randn(Cout, Cin, taps, generator=g) * 0.05).to(BF16)
     b = torch.randn(Cout, generator=g)
     wk = w.permute(0, 2, 1).reshape(Cout, taps * Cin).contiguous()            # K index = tap * Cin + ci
-    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.cuda(), taps=taps, dilation=dil)
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.cuda(), taps=taps, dilation=dil, tile_hint=1)
+    assert torch.equal(out, ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.cuda(), taps=taps, dilation=dil, tile_hint=2))
     xp = torch.nn.functional.pad(x.double().T[None], ((taps - 1) * dil, 0))
     ref = torch.nn.functional.conv1d(xp, w.double(), b.double(), dilation=dil)[0].T
     mag = torch.nn.functional.conv1d(xp.abs(), w.double().abs(), b.double().abs(), dilation=dil)[0].T
@@ -69,7 +74,8 @@ def test_transposed_conv_stride_s_kernel_2s_as_one_gemm(Cin, Cout, s, T):
     b = torch.randn(Cout, generator=g)
     wk = torch.cat([w[:, :, s:], w[:, :, :s]], dim=0)                         # [2 Cin (x[i-1] | x[i]), Cout, s (phase r)]
     wk = wk.permute(2, 1, 0).reshape(s * Cout, 2 * Cin).contiguous()
-    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.repeat(s).cuda(), taps=2, dilation=1)
+    out = ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.repeat(s).cuda(), taps=2, dilation=1, tile_hint=1)
+    assert torch.equal(out, ops.gemm_tile(x.cuda(), frag_shuffle(wk).cuda(), bias=b.repeat(s).cuda(), taps=2, dilation=1, tile_hint=2))
     ref = torch.nn.functional.conv_transpose1d(x.double().T[None], w.double(), b.double(), stride=s)[0, :, : T * s].T
     mag = torch.nn.functional.conv_transpose1d(x.double().abs().T[None], w.double().abs(), b.double().abs(), stride=s)[0, :, : T * s].T
     _close(out.view(T * s, Cout), ref, mag, f"transconv s{s} {Cin}->{Cout}")
@@ -101,8 +107,12 @@ def test_epilogues_gelu_scale_fp32_residual_stream_and_snake_output():
     z = f.double().cpu()
     ref2 = z + ib.double() * torch.sin(z * al.double()) ** 2
     assert ((s2.double().cpu() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 1e-4 + 4e-6 * z.abs()).all()   # __sinf argument error
-    only = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()), want="s")
-    assert torch.equal(only, s2)
+    for hint in (1, 2):
+        only = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), resid=r.cuda(), snake=(al.cuda(), ib.cuda()),
+                             want="s", tile_hint=hint)
+        assert torch.equal(only, s2), hint
+        f2 = ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), bias=b.cuda(), scale=sc.cuda(), resid=r.cuda(), want="f", tile_hint=hint)
+        assert torch.equal(f2, f), hint
 
 
 @pytest.mark.parametrize("M,I,K", [(333, 3072, 1024), (6400, 6144, 2048), (100, 64, 64)])
@@ -113,8 +123,9 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     g = torch.Generator().manual_seed(I)
     x = torch.randn(M, K, generator=g).to(BF16)
     w = (torch.randn(2 * I, K, generator=g) * 0.03).to(BF16)
-    out = ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8)
+    out = ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=1)
     assert out.shape == (M, I)
+    assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=2))
     gu = (x.double() @ w.double().T)
     ga, up = gu[:, :I].float().to(BF16), gu[:, I:].float().to(BF16)
     ref = torch.nn.functional.silu(ga) * up                       # torch bf16 semantics: silu rounds, the product rounds
