@@ -73,9 +73,10 @@ def test_config2_0p6b_decode_bf16_kv_matches_oracle():
     lens = torch.randint(8, 70, (16,), generator=g).tolist()
     # the step's inputs are the previous step's outputs (hidden state, 16 summed code embeddings), so the single worst logit
     # of 16 x 3072 logits / 16 x 1024 hidden values widens with the step index: measured 2.9 (hipBLASLt prefill) and 5.2 (tile
-    # prefill: other rounding flips, same arithmetic) bf16 ulps at step 2 while the MEAN stays below 3e-3
-    rec = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=3e-3, max_ulps=8.0)
-    _check(rec, mean_tol=3e-3, max_ulps=8.0, weights=w)   # 16 rows x 15 greedy argmaxes per step: near-ties may flip (checked as such)
+    # prefill: other rounding flips, same arithmetic) bf16 ulps at step 2; the MEAN deviation of the step-2 hidden state measured
+    # 2.1e-3 / 3.06e-3 with the two prefills (8e-4 of its scale 3.7): bound 4e-3
+    rec = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
+    _check(rec, mean_tol=4e-3, max_ulps=8.0, weights=w)   # 16 rows x 15 greedy argmaxes per step: near-ties may flip (checked as such)
     assert rec["engine"].kv_caches[0].dtype == torch.bfloat16
 
 
