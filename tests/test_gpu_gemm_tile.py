@@ -137,6 +137,31 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     assert torch.equal(out, ops.silu_mul(plain))
 
 
+@pytest.mark.parametrize("M,N,K,taps,dil", [(6400, 2048, 2048, 1, 1), (3000, 96, 96, 7, 9), (5000, 192, 192, 7, 3), (700, 1024, 1024, 1, 1),
+                                              (2600, 768, 768, 7, 1)])
+def test_race_screen_repeated_launches_are_bit_identical(M, N, K, taps, dil):
+    """The ring's synchronisation (LDS-DMA retired by counted vmcnt + a barrier one phase before the read; buffers restaged only
+    after the barrier that follows their last read) screened the way a hand-scheduled pipeline has to be: 150 back-to-back
+    launches per shape and geometry, other kernels' traffic in between, every result bit-identical to the first and to the other
+    geometry (a read that overtakes its DMA shows up as a rare wrong tile, not as a failed reference check)."""
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(N + taps)
+    x = torch.randn(M, K, generator=g).to(BF16).cuda()
+    w = frag_shuffle((torch.randn(N, taps * K, generator=g) * 0.05).to(BF16)).cuda()
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    first = None
+    for hint in (1, 2):
+        outs = []
+        for it in range(150):
+            outs.append(ops.gemm_tile(x, w, taps=taps, dilation=dil, tile_hint=hint))
+            if it % 7 == 0:
+                noise.add_(1)                                  # evict / perturb between launches
+        ref = outs[0] if first is None else first
+        first = ref
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+        assert not bad, (hint, bad[:5])
+
+
 def test_rejects_bad_shapes():
     ops, L, frag_shuffle, _ = _ops()
     from ht_vllm_omni_amd._lib import OmniError
