@@ -49,6 +49,12 @@ class TileGemm(C.Structure):
 TILE_ACT_NONE, TILE_ACT_GELU, TILE_ACT_SILU_MUL_GU8 = 0, 1, 2
 
 
+class ResUnit(C.Structure):
+    """omni_res_unit (include/omni_codec.h): one fused residual unit of the Code2Wav decoder."""
+    _fields_ = [("s", vp), ("h", vp), ("s_next", vp), ("w1", vp), ("b1", vp), ("snake2_alpha", vp), ("snake2_inv_beta", vp),
+                ("w2", vp), ("b2", vp), ("next_alpha", vp), ("next_inv_beta", vp), ("T", i32), ("C", i32), ("dilation", i32)]
+
+
 class TalkerDesc(C.Structure):
     _fields_ = [
         ("hidden", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
@@ -108,6 +114,8 @@ SIGNATURES = {
     "omni_codec_window_attn": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "omni_codec_dwconv_ln": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     "omni_codec_out_conv": (i32, [vp, vp, f32, vp, i32, i32, i32, vp]),
+    "omni_codec_res_unit_supported": (i32, [i32, i32, i32]),
+    "omni_codec_res_unit": (i32, [C.POINTER(ResUnit), vp]),
     "omni_gemm_resid": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_xnorm": (i32, [vp, vp, i32, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,

@@ -20,6 +20,7 @@ There is no CPU path: the constructor needs the HIP library and a GPU.
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 import math
 from dataclasses import dataclass, fields
@@ -92,7 +93,7 @@ class _Conv:
 
 
 class Code2WavDecoder:
-    def __init__(self, cfg: Code2WavConfig | dict, state: dict[str, torch.Tensor], device: str = "cuda:0"):
+    def __init__(self, cfg: Code2WavConfig | dict, state: dict[str, torch.Tensor], device: str = "cuda:0", fused_units: bool = True):
         if not torch.cuda.is_available():
             raise L.OmniError("Code2WavDecoder needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -101,6 +102,8 @@ class Code2WavDecoder:
         self.device = torch.device(device)
         self.total_upsample = self.cfg.total_upsample
         self._graph = None
+        # residual units of the 96- / 192-channel blocks as one launch each (omni_codec_res_unit) instead of two omni_gemm_tile launches
+        self.fused_units = bool(fused_units)
         self._build(state)
 
     # ------------------------------------------------------------------ weights
@@ -266,10 +269,22 @@ class Code2WavDecoder:
             cout = blk["tc"].n // blk["r"]
             hstream, s = blk["tc"](s, snake=self._rep(units[0]["act1"], blk["r"]), want="fs")
             hstream, s = hstream.view(T, cout), s.view(T, cout)
+            s_alt = None
             for ui, un in enumerate(units):
-                t1 = un["conv1"](s, snake=un["act2"], want="s")
                 nxt = units[ui + 1]["act1"] if ui + 1 < len(units) else (self.blocks[bi + 1]["act"] if bi + 1 < nb else self.last_act)
-                _, s = un["conv2"](t1, resid=hstream, out_f32=hstream, snake=nxt, want="fs")
+                c1 = un["conv1"]
+                if self.fused_units and lib.omni_codec_res_unit_supported(cout, c1.taps, c1.dilation):
+                    s_alt = torch.empty_like(s) if s_alt is None else s_alt           # the unit reads a halo of s: no in-place s
+                    ru = L.ResUnit()
+                    ru.s, ru.h, ru.s_next = s.data_ptr(), hstream.data_ptr(), s_alt.data_ptr()
+                    ru.w1, ru.b1, ru.snake2_alpha, ru.snake2_inv_beta = c1.w.data_ptr(), c1.bias.data_ptr(), un["act2"][0].data_ptr(), un["act2"][1].data_ptr()
+                    ru.w2, ru.b2, ru.next_alpha, ru.next_inv_beta = un["conv2"].w.data_ptr(), un["conv2"].bias.data_ptr(), nxt[0].data_ptr(), nxt[1].data_ptr()
+                    ru.T, ru.C, ru.dilation = T, cout, c1.dilation
+                    self._check(lib.omni_codec_res_unit(C.byref(ru), st), "omni_codec_res_unit")
+                    s, s_alt = s_alt, s
+                else:
+                    t1 = c1(s, snake=un["act2"], want="s")
+                    _, s = un["conv2"](t1, resid=hstream, out_f32=hstream, snake=nxt, want="fs")
             tap(f"decoder{bi + 1}", hstream)
         tap(f"decoder{nb + 1}", s)
         wav = torch.empty(T, dtype=torch.float32, device=dev)

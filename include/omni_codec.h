@@ -45,6 +45,22 @@ int omni_codec_dwconv_ln(const float* x, int ldx, const float* w, const float* b
  * clamped to [-1, 1]: wav fp32 [T]. */
 int omni_codec_out_conv(const void* x, const float* w, float bias, float* wav, int T, int C, int taps, void* stream);
 
+/* One residual unit of a decoder block (…DecoderDecoderResidualUnit, …:726-742) in ONE launch, for the high-rate blocks:
+ *     h <- h + conv1x1(snake2(conv7_dilated(s))),   s_next = bf16(snake_next(h)),
+ * s = bf16(snake1(h)) (the previous launch's second output), h the fp32 residual stream (in place), all time-major [T, C].
+ * The x window of a row block sits in LDS once for all 7 taps and the 7-tap conv's output never leaves the chip.  C 96 | 192,
+ * 7 taps, dilation <= 9 (omni_codec_res_unit_supported); other shapes take two omni_gemm_tile launches.  s_next must not alias s.
+ *   w1 bf16 fragment-major [C, 7 C] (K index = tap * C + channel), b1 fp32 [C]; snake2_* fp32 [C] (exp(alpha), 1 / (exp(beta) + eps));
+ *   w2 bf16 fragment-major [C, C], b2 fp32 [C]; next_* = the SnakeBeta in front of the next consumer of h. */
+typedef struct omni_res_unit {
+    const void* s; float* h; void* s_next;
+    const void* w1; const float* b1; const float* snake2_alpha; const float* snake2_inv_beta;
+    const void* w2; const float* b2; const float* next_alpha; const float* next_inv_beta;
+    int T, C, dilation;
+} omni_res_unit;
+int omni_codec_res_unit_supported(int C, int taps, int dilation);
+int omni_codec_res_unit(const omni_res_unit* u, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

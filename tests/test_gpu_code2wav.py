@@ -118,6 +118,26 @@ def test_full_architecture_decoder_matches_the_oracle_in_fp32_torch_on_the_gpu()
     assert d.mean().item() <= 0.08 * sig and d.max().item() <= 0.2, (d.mean().item(), d.max().item(), sig)
 
 
+def test_fused_residual_units_are_bit_identical_to_the_two_launch_path():
+    """omni_codec_res_unit (x window in LDS once for the 7 taps, the 7-tap conv's output kept on chip for the 1x1 conv) keeps the k order
+    of the two omni_gemm_tile launches it replaces: the waveform and the residual streams of the 192- and 96-channel blocks of the
+    released architecture are bit-identical; ragged lengths (T * 640 and T * 1920 rows are no multiples of the 256 / 512-row blocks)."""
+    from ht_vllm_omni_amd import _lib as L
+    sd = make_codec_state(FULL_CODEC, 9, device="cuda")
+    a, b = _decoder(FULL_CODEC, sd), None
+    from ht_vllm_omni_amd.code2wav import Code2WavDecoder
+    b = Code2WavDecoder(FULL_CODEC, sd, fused_units=False)
+    assert L.load().omni_codec_res_unit_supported(96, 7, 9) and L.load().omni_codec_res_unit_supported(192, 7, 1)
+    assert not L.load().omni_codec_res_unit_supported(384, 7, 1) and not L.load().omni_codec_res_unit_supported(96, 7, 27)
+    for T in (1, 7, 33):
+        codes = torch.randint(0, 2048, (1, 16, T), generator=torch.Generator().manual_seed(T)).cuda()
+        ta, tb = {}, {}
+        wa, wb = a.forward(codes, ta), b.forward(codes, tb)
+        for k in ("decoder2", "decoder3", "decoder4", "decoder5"):
+            assert torch.equal(ta[k], tb[k]), (T, k, float((ta[k].float() - tb[k].float()).abs().max()))
+        assert torch.equal(wa, wb), T
+
+
 def test_window_attention_longer_than_the_window():
     """T = 200 > window 72 with two 64-key chunks per query: the transformer output against the oracle's."""
     sd = make_codec_state(MID_CODEC, 4)
