@@ -91,26 +91,26 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u) stage(u);
 
-    // ---- x window: rows m0 - halo .. m0 + BM - 1 of s -> LDS rows 0 .. halo + BM - 1 (16-byte chunks, zero outside [0, T))
+    // ---- x window: rows m0 - halo .. m0 + BM - 1 of s -> LDS rows 0 .. halo + BM - 1 (16-byte chunks, zero outside [0, T)); all of a
+    // thread's chunks (<= WCH) are in flight before the first LDS write: one memory latency, not one per batch
     {
         constexpr int CH = C / 8;                                                 // chunks per row
-        const int rows = halo + G::BM;
-        const int total = rows * CH;
-        for (int base = 0; base < total; base += RU_THREADS * 4) {
-            u32x4 v[4];
-            int lr[4], lc[4];
+        constexpr int WCH = (G::WIN_ROWS * CH + RU_THREADS - 1) / RU_THREADS;
+        const int total = (halo + G::BM) * CH;
+        u32x4 v[WCH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int id = base + k * RU_THREADS + (int)threadIdx.x;
-                lr[k] = id / CH;
-                lc[k] = id - lr[k] * CH;
-                const int g = m0 - halo + lr[k];
-                v[k] = u32x4{0u, 0u, 0u, 0u};
-                if (id < total && g >= 0 && g < a.T) v[k] = *reinterpret_cast<const u32x4*>(a.s + (size_t)g * C + lc[k] * 8);
-            }
+        for (int k = 0; k < WCH; ++k) {
+            const int id = k * RU_THREADS + (int)threadIdx.x;
+            const int lr = id / CH, lc = id - lr * CH;
+            const int g = m0 - halo + lr;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (id < total && g >= 0 && g < a.T) v[k] = *reinterpret_cast<const u32x4*>(a.s + (size_t)g * C + lc * 8);
+        }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (base + k * RU_THREADS + (int)threadIdx.x < total) *reinterpret_cast<u32x4*>(win + lr[k] * P + lc[k] * 16) = v[k];
+        for (int k = 0; k < WCH; ++k) {
+            const int id = k * RU_THREADS + (int)threadIdx.x;
+            const int lr = id / CH, lc = id - lr * CH;
+            if (id < total) *reinterpret_cast<u32x4*>(win + lr * P + lc * 16) = v[k];
         }
     }
     f32x4 acc[WN][WM];
@@ -174,12 +174,33 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    constexpr int IP = G::IPITCH;
+    constexpr int EIT = WM * 16 * 6 / 64;                  // row-side iterations per pass
+    uint8_t* img = lds + wave * (WM * 16 * IP);
+    const int mw0 = m0 + wm * WM * 16;
+    f32x4 hv[2][EIT][2];
+    auto load_h = [&](int half) {
+        const int nh0 = (wn * WN + half * 3) * 16;
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int row = idx / 6, ch = idx - row * 6;
+            const int m = mw0 + row;
+            hv[half][it][0] = hv[half][it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < a.T) {
+                const float* hp = a.h + (size_t)m * C + nh0 + ch * 8;
+                hv[half][it][0] = *reinterpret_cast<const f32x4*>(hp);
+                hv[half][it][1] = *reinterpret_cast<const f32x4*>(hp + 4);
+            }
+        }
+    };
     // ---- stage 2: the 1x1 conv: K = C; W2 fragments (tile (n16, ks) at (n16 * KS + ks) KB) straight from L2
     {
         const uint16_t* w2 = a.w2 + (size_t)(wn * WN) * KS * 512 + lane * 8;
         u32x4 wf[WN], wnx[WN];
 #pragma unroll
         for (int j = 0; j < WN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(w2 + (size_t)j * KS * 512);
+        load_h(0);                                         // lands behind the 1x1 conv's MFMAs
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
@@ -202,10 +223,8 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // all waves are done reading t: the image may overlay it
 
     // ---- epilogue: y = acc + b2 + h (fp32) -> h; bf16(snake_next(y)) -> s_next; transposed through a per-wave fp32 LDS image, 3 n-tiles
-    // per pass, 8 columns per lane on the row side
-    constexpr int IP = G::IPITCH;
-    uint8_t* img = lds + wave * (WM * 16 * IP);
-    const int mw0 = m0 + wm * WM * 16;
+    // per pass, 8 columns per lane on the row side.  A pass's 12 h loads per lane are issued before its image is written (and the
+    // second pass's before the first pass's stores): the epilogue is the unit's HBM phase, it must not be a chain of round trips
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int nh0 = (wn * WN + half * 3) * 16;
@@ -216,14 +235,17 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
             for (int i = 0; i < WM; ++i)
                 *reinterpret_cast<f32x4*>(img + (i * 16 + c) * IP + (jj * 16 + 4 * q) * 4) = acc[half * 3 + jj][i] + b;
         }
+        if (half == 0) load_h(1);
         __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < WM * 16 * 6; idx += 64) {
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int idx = lane + 64 * it;
             const int row = idx / 6, ch = idx - row * 6;
             const int m = mw0 + row, n = nh0 + ch * 8;
             if (m >= a.T) continue;
             float* hp = a.h + (size_t)m * C + n;
-            f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32) + *reinterpret_cast<const f32x4*>(hp);
-            f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32 + 16) + *reinterpret_cast<const f32x4*>(hp + 4);
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32) + hv[half][it][0];
+            const f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32 + 16) + hv[half][it][1];
             *reinterpret_cast<f32x4*>(hp) = y0;
             *reinterpret_cast<f32x4*>(hp + 4) = y1;
             const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.an + n), al1 = *reinterpret_cast<const f32x4*>(a.an + n + 4);

@@ -211,9 +211,27 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
     constexpr int IPITCH = HT * 64 + 16;                  // bytes per image row
     uint8_t* img = lds + wave * (WM * 16 * IPITCH);
     const int mw0 = m0 + wm * WM * 16;                    // first row of this wave
+    constexpr int RIT = GU8 ? 1 : WM * 16 * HT * 2 / 64;   // row-side iterations per pass (8 columns per lane each)
+    f32x4 rv[RIT][2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int nh0 = n0 + wn * WN * 16 + half * HT * 16;   // first column of this pass
+        if (!GU8 && a.resid) {
+            // the pass's residual loads go out before its image is written: the epilogue of a residual GEMM is an HBM phase and must
+            // not be a chain of load -> add -> store round trips
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / (HT * 2), ch = idx - row * (HT * 2);
+                const int m = mw0 + row, n = nh0 + ch * 8;
+                rv[it][0] = rv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < a.M && n < a.N) {
+                    const float* rp = a.resid + (size_t)m * a.ldr + n;
+                    rv[it][0] = *reinterpret_cast<const f32x4*>(rp);
+                    rv[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < HT; ++jj) {
             const int j = half * HT + jj;
@@ -256,16 +274,17 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
             }
         } else {
             constexpr int PER_ROW = HT * 2;               // 8-column pieces per image row
-            for (int idx = lane; idx < WM * 16 * PER_ROW; idx += 64) {
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
                 const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
                 const int m = mw0 + row, n = nh0 + ch * 8;
                 if (m >= a.M || n >= a.N) continue;
                 f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
                 f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
                 if (a.resid) {
-                    const float* rp = a.resid + (size_t)m * a.ldr + n;
-                    y0 += *reinterpret_cast<const f32x4*>(rp);
-                    y1 += *reinterpret_cast<const f32x4*>(rp + 4);
+                    y0 += rv[it][0];
+                    y1 += rv[it][1];
                 }
                 if (a.out_f32) {
                     float* op = a.out_f32 + (size_t)m * a.ldf + n;
