@@ -45,9 +45,9 @@ def build_engine(args, rank, world):
     w = make_weights(d, seed=1234, std=0.02, device="cuda" if args.device_weights else "cpu")
     log(f"[rank {rank}] weights generated in {time.time() - t0:.1f}s")
     ar = None
-    if world > 1 and args.parallel == "tp" and args.allreduce == "oneshot":
+    if (world > 1 or args.tp_force) and args.parallel == "tp" and args.allreduce == "oneshot":
         ar = setup_peer_allreduce(d, args, rank, world)
-    args.allreduce_used = "none" if world == 1 or args.parallel == "dp" else ("oneshot-xgmi (peer-mapped, fused with residual add)" if ar else "rccl")
+    args.allreduce_used = "none" if (world == 1 and not args.tp_force) or args.parallel == "dp" else ("oneshot-xgmi (peer-mapped, fused with residual add)" if ar else "rccl")
     eng = TalkerEngine(d, w, kv_dtype=args.kv, num_blocks=args.num_blocks, block_size=16, max_batch=args.batch,
                        device=f"cuda:{torch.cuda.current_device()}", tp_rank=0 if args.parallel == "dp" else rank,
                        tp_size=1 if args.parallel == "dp" else world, allow_eos=False,
