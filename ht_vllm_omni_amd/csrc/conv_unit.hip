@@ -38,27 +38,29 @@ __device__ __forceinline__ f32x4 ru_mfma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int C>
+template <int C, int WM_, int NBUF_>
 struct RuGeom {
-    static constexpr int NT = C / 16, KS = C / 32, WAVES_N = C / 96, WAVES_M = RU_WAVES / WAVES_N, WN = 6, WM = 4;
+    static constexpr int NT = C / 16, KS = C / 32, WAVES_N = C / 96, WAVES_M = RU_WAVES / WAVES_N, WN = 6, WM = WM_;
     static constexpr int BM = WAVES_M * WM * 16;
     static constexpr int PITCH = 2 * C + 16;                                      // window row pitch (bytes)
     static constexpr int WIN_ROWS = BM + RU_HALO_MAX;
     static constexpr int WIN_BYTES = (WIN_ROWS * PITCH + 1023) / 1024 * 1024;
     static constexpr int NSTEPS = RU_TAPS * KS;                                   // 32-deep k-steps of the 7-tap conv
     static constexpr int NLW = (NT + RU_WAVES - 1) / RU_WAVES;                    // W1 LDS-DMA pieces per wave and k-step
-    static constexpr int NBUF = C == 96 ? 4 : 3;
+    static constexpr int NBUF = NBUF_;
     static constexpr int RING_BYTES = NBUF * NT * 1024;
     static constexpr int TT_BYTES = BM * C * 2;                                   // stage-2 operand (overlays the window)
-    static constexpr int IPITCH = 3 * 64 + 16;                                    // epilogue image: 3 n-tiles x fp32 + pad
-    static constexpr int EPI_BYTES = RU_WAVES * WM * 16 * IPITCH;                 // overlays the window too
+    static constexpr int IPITCH = 6 * 64 + 16;                                    // epilogue image row: the wave's 96 columns x fp32 + pad
+    static constexpr int EPI_BYTES = RU_WAVES * 16 * IPITCH;                      // one m-tile (16 rows) per wave and pass; overlays the window
     static constexpr int LDS_BYTES = WIN_BYTES + RING_BYTES;
     static_assert(TT_BYTES <= WIN_BYTES && EPI_BYTES <= WIN_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int C>
-__global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs a) {
-    using G = RuGeom<C>;
+// <C, m tiles per wave, ring depth>: <96, 2, 2> = 256-row blocks in 76 KB of LDS and <= 128 registers: TWO workgroups per CU, so that one
+// block's HBM phases (window load, stream read / write) overlap the other's MFMA phase; <192, 4, 3> = 256-row blocks, one per CU
+template <int C, int WM_, int NBUF_>
+__global__ __launch_bounds__(RU_THREADS, (WM_ == 2 ? 4 : 2)) void res_unit_kernel(const ResUnitArgs a) {
+    using G = RuGeom<C, WM_, NBUF_>;
     constexpr int NT = G::NT, KS = G::KS, WN = G::WN, WM = G::WM, P = G::PITCH, NBUF = G::NBUF, NLW = G::NLW, NSTEPS = G::NSTEPS;
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     uint8_t* win = lds;
@@ -174,23 +176,25 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // epilogue geometry: one m-tile (16 rows) x the wave's 96 columns per pass: a row's 12 lanes cover 384 contiguous bytes of the fp32
+    // stream (whole 128-byte lines; passes over column halves wrote 192-byte pieces: 3.0 instead of 3.8 TB/s)
     constexpr int IP = G::IPITCH;
-    constexpr int EIT = WM * 16 * 6 / 64;                  // row-side iterations per pass
-    uint8_t* img = lds + wave * (WM * 16 * IP);
+    constexpr int EIT = 16 * 12 / 64;                      // row-side iterations per pass (8 columns per lane each)
+    uint8_t* img = lds + wave * (16 * IP);
     const int mw0 = m0 + wm * WM * 16;
-    f32x4 hv[2][EIT][2];
-    auto load_h = [&](int half) {
-        const int nh0 = (wn * WN + half * 3) * 16;
+    const int nw0 = wn * WN * 16;
+    f32x4 hv[2][EIT][2];                                   // the stream values of two passes in flight
+    auto load_h = [&](int pass) {
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
             const int idx = lane + 64 * it;
-            const int row = idx / 6, ch = idx - row * 6;
-            const int m = mw0 + row;
-            hv[half][it][0] = hv[half][it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = idx / 12, ch = idx - row * 12;
+            const int m = mw0 + pass * 16 + row;
+            hv[pass & 1][it][0] = hv[pass & 1][it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (m < a.T) {
-                const float* hp = a.h + (size_t)m * C + nh0 + ch * 8;
-                hv[half][it][0] = *reinterpret_cast<const f32x4*>(hp);
-                hv[half][it][1] = *reinterpret_cast<const f32x4*>(hp + 4);
+                const float* hp = a.h + (size_t)m * C + nw0 + ch * 8;
+                hv[pass & 1][it][0] = *reinterpret_cast<const f32x4*>(hp);
+                hv[pass & 1][it][1] = *reinterpret_cast<const f32x4*>(hp + 4);
             }
         }
     };
@@ -222,30 +226,26 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // all waves are done reading t: the image may overlay it
 
-    // ---- epilogue: y = acc + b2 + h (fp32) -> h; bf16(snake_next(y)) -> s_next; transposed through a per-wave fp32 LDS image, 3 n-tiles
-    // per pass, 8 columns per lane on the row side.  A pass's 12 h loads per lane are issued before its image is written (and the
-    // second pass's before the first pass's stores): the epilogue is the unit's HBM phase, it must not be a chain of round trips
+    // ---- epilogue: y = acc + b2 + h (fp32) -> h; bf16(snake_next(y)) -> s_next; one m-tile per pass through a per-wave fp32 LDS image
+    // [16 rows][96 columns]; pass p + 1's stream loads are issued before pass p's stores
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int nh0 = (wn * WN + half * 3) * 16;
+    for (int pass = 0; pass < WM; ++pass) {
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + nh0 + jj * 16 + 4 * q);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-                *reinterpret_cast<f32x4*>(img + (i * 16 + c) * IP + (jj * 16 + 4 * q) * 4) = acc[half * 3 + jj][i] + b;
+        for (int j = 0; j < WN; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + nw0 + j * 16 + 4 * q);
+            *reinterpret_cast<f32x4*>(img + c * IP + (j * 16 + 4 * q) * 4) = acc[j][pass] + b;
         }
-        if (half == 0) load_h(1);
+        if (pass + 1 < WM) load_h(pass + 1);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
             const int idx = lane + 64 * it;
-            const int row = idx / 6, ch = idx - row * 6;
-            const int m = mw0 + row, n = nh0 + ch * 8;
+            const int row = idx / 12, ch = idx - row * 12;
+            const int m = mw0 + pass * 16 + row, n = nw0 + ch * 8;
             if (m >= a.T) continue;
             float* hp = a.h + (size_t)m * C + n;
-            const f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32) + hv[half][it][0];
-            const f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32 + 16) + hv[half][it][1];
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32) + hv[pass & 1][it][0];
+            const f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IP + ch * 32 + 16) + hv[pass & 1][it][1];
             *reinterpret_cast<f32x4*>(hp) = y0;
             *reinterpret_cast<f32x4*>(hp + 4) = y1;
             const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.an + n), al1 = *reinterpret_cast<const f32x4*>(a.an + n + 4);
@@ -266,16 +266,16 @@ __global__ __launch_bounds__(RU_THREADS) void res_unit_kernel(const ResUnitArgs 
     }
 }
 
-template <int C>
+template <int C, int WM_, int NBUF_>
 static int launch_unit(const ResUnitArgs& a, hipStream_t st) {
-    using G = RuGeom<C>;
+    using G = RuGeom<C, WM_, NBUF_>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(res_unit_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(res_unit_kernel<C, WM_, NBUF_>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) { omni_set_error("omni_codec_res_unit: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(res_unit_kernel<C>, dim3((a.T + G::BM - 1) / G::BM), dim3(RU_THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((res_unit_kernel<C, WM_, NBUF_>), dim3((a.T + G::BM - 1) / G::BM), dim3(RU_THREADS), G::LDS_BYTES, st, a);
     OMNI_CHECK_LAUNCH("omni_codec_res_unit");
     return OMNI_OK;
 }
@@ -294,5 +294,5 @@ extern "C" int omni_codec_res_unit(const omni_res_unit* u, void* stream) {
     a.w1 = (const uint16_t*)u->w1; a.b1 = u->b1; a.a2 = u->snake2_alpha; a.ib2 = u->snake2_inv_beta;
     a.w2 = (const uint16_t*)u->w2; a.b2 = u->b2; a.an = u->next_alpha; a.ibn = u->next_inv_beta;
     a.T = u->T; a.dil = u->dilation;
-    return u->C == 96 ? launch_unit<96>(a, (hipStream_t)stream) : launch_unit<192>(a, (hipStream_t)stream);
+    return u->C == 96 ? launch_unit<96, 4, 4>(a, (hipStream_t)stream) : launch_unit<192, 4, 3>(a, (hipStream_t)stream);
 }
