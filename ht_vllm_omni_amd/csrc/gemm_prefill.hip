@@ -17,8 +17,8 @@
 // M tail) and k-steps past K are out of range of the buffer descriptor and read as zero.  Two LDS buffers; the loads of
 // slice t + 1 are issued before the MFMAs of slice t, one counted wait + barrier per slice.
 // MFMA v_mfma_f32_16x16x32_bf16 with W as the A operand: D[n][m], lane holds m = l & 15, n = 4 (l >> 4) + reg.
-// Epilogue: y = (acc + bias) -> GELU -> * scale (+ fp32 residual) in fp32, transposed through LDS so that global stores are whole
-// row pieces; on the way out SiLU(gate) * up for the interleaved gate_up layout, and up to three stores of y: fp32 (a residual
+// Epilogue: y = (acc + bias) -> GELU -> * scale (+ fp32 residual) in fp32, transposed through LDS (one m-tile per pass) so that global
+// stores are whole row pieces; on the way out SiLU(gate) * up for the interleaved gate_up layout, and up to three stores of y: fp32 (a residual
 // STREAM kept in fp32: snake's sin(alpha x) turns a bf16 ulp of x ~ 16 into a phase error of 0.1 rad), bf16 (the next GEMM's
 // operand) and bf16(snake(y)) = y + inv_beta * sin^2(alpha * y) -- the activation in front of the NEXT conv, so that no
 // stand-alone activation pass runs over the 24 kHz-rate tensors.
@@ -68,7 +68,7 @@ struct TileGeom {
     static constexpr bool X_RAGGED = MTILES % TG_WAVES != 0;                 // likewise for x (the 64-row tile of the small-M geometry)
     static constexpr bool RAGGED = W_RAGGED || X_RAGGED;
     static constexpr int NBUF = (TG_LDS_MAX - (RAGGED ? TG_WAVES * 1024 : 0)) / SLICE >= 4 ? 4 : 3;
-    static constexpr int EPI_BYTES = TG_WAVES * WM * 16 * ((WN / 2) * 64 + 16);   // fp32 image of half the wave's n tiles
+    static constexpr int EPI_BYTES = TG_WAVES * 16 * (WN * 64 + 16);           // fp32 image of one m-tile x the wave's columns
     static constexpr int RING_BYTES = NBUF * SLICE + (RAGGED ? TG_WAVES * 1024 : 0);
     static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
     static_assert(WN % 2 == 0 && LDS_BYTES <= TG_LDS_MAX, "geometry");
@@ -203,29 +203,40 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 #undef TG_SLICE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is dead: its tail loads (zeros) landed
 
-    // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image [m][n] in
-    // fp32, half of the wave's n tiles at a time (64 rows x 64 columns x 4 B + pad = 17 KB per wave).  Row side: 8 columns per
-    // lane (32 B of the image), + fp32 residual, then up to three stores of the SAME fp32 value: fp32 (the residual stream),
-    // bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand) -- each rounded once.
-    constexpr int HT = WN / 2;                            // n tiles per pass
-    constexpr int IPITCH = HT * 64 + 16;                  // bytes per image row
-    uint8_t* img = lds + wave * (WM * 16 * IPITCH);
+    // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image in fp32, ONE m-tile
+    // (16 rows x the wave's WN * 16 columns) per pass.  Row side: 8 columns per lane, a row's lanes cover WN * 64 contiguous bytes
+    // of an fp32 output (whole 128-byte lines); + fp32 residual (the pass's residual loads are issued before its image is written:
+    // the epilogue of a residual GEMM is an HBM phase, not a chain of load -> add -> store round trips), then up to three stores of
+    // the SAME fp32 value: fp32 (the residual stream), bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand).
+    constexpr int IPITCH = WN * 64 + 16;                  // bytes per image row
+    constexpr int PER_ROW = GU8 ? WN : WN * 2;            // lane items per image row: a [8 gate | 8 up] tile, or 8 columns
+    constexpr int RIT = (16 * PER_ROW + 63) / 64;         // row-side iterations per pass
+    uint8_t* img = lds + wave * (16 * IPITCH);
     const int mw0 = m0 + wm * WM * 16;                    // first row of this wave
-    constexpr int RIT = GU8 ? 1 : WM * 16 * HT * 2 / 64;   // row-side iterations per pass (8 columns per lane each)
+    const int nw0 = n0 + wn * WN * 16;                    // first column of this wave
+    f32x4 bq[WN], sq[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = nw0 + j * 16 + 4 * q;
+        bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sq[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (n < a.N) {
+            if (a.bias) bq[j] = *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.scale) sq[j] = *reinterpret_cast<const f32x4*>(a.scale + n);
+        }
+    }
     f32x4 rv[RIT][2];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int nh0 = n0 + wn * WN * 16 + half * HT * 16;   // first column of this pass
+    for (int pass = 0; pass < WM; ++pass) {
+        const int mp0 = mw0 + pass * 16;
         if (!GU8 && a.resid) {
-            // the pass's residual loads go out before its image is written: the epilogue of a residual GEMM is an HBM phase and must
-            // not be a chain of load -> add -> store round trips
 #pragma unroll
             for (int it = 0; it < RIT; ++it) {
                 const int idx = lane + 64 * it;
-                const int row = idx / (HT * 2), ch = idx - row * (HT * 2);
-                const int m = mw0 + row, n = nh0 + ch * 8;
+                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
+                const int m = mp0 + row, n = nw0 + ch * 8;
                 rv[it][0] = rv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m < a.M && n < a.N) {
+                if (idx < 16 * PER_ROW && m < a.M && n < a.N) {
                     const float* rp = a.resid + (size_t)m * a.ldr + n;
                     rv[it][0] = *reinterpret_cast<const f32x4*>(rp);
                     rv[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -233,35 +244,27 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < HT; ++jj) {
-            const int j = half * HT + jj;
-            const int n = nh0 + jj * 16 + 4 * q;
-            f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f}, sc = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (n < a.N) {
-                if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
-                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-            }
+        for (int j = 0; j < WN; ++j) {
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[j][i][e] + b[e];
-                    if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
-                    v[e] = t * sc[e];
-                }
-                *reinterpret_cast<f32x4*>(img + (i * 16 + c) * IPITCH + (jj * 16 + 4 * q) * 4) = v;
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[j][pass][e] + bq[j][e];
+                if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
+                v[e] = t * sq[j][e];
             }
+            *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
         }
         __builtin_amdgcn_wave_barrier();
         if (GU8) {
-            // tile jj of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
+            // tile j of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
             // torch's F.silu(g) * u on bf16 tensors (omni_silu_mul, oracle silu_mul)
-            for (int idx = lane; idx < WM * 16 * HT; idx += 64) {
-                const int row = idx / HT, jj = idx - row * HT;
-                const int m = mw0 + row, n = nh0 + jj * 16;
-                if (m >= a.M || n >= a.N) continue;
-                const float* gp = reinterpret_cast<const float*>(img + row * IPITCH + jj * 64);
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / PER_ROW, j = idx - row * PER_ROW;
+                const int m = mp0 + row, n = nw0 + j * 16;
+                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
+                const float* gp = reinterpret_cast<const float*>(img + row * IPITCH + j * 64);
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -273,13 +276,12 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
                 *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
             }
         } else {
-            constexpr int PER_ROW = HT * 2;               // 8-column pieces per image row
 #pragma unroll
             for (int it = 0; it < RIT; ++it) {
                 const int idx = lane + 64 * it;
                 const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
-                const int m = mw0 + row, n = nh0 + ch * 8;
-                if (m >= a.M || n >= a.N) continue;
+                const int m = mp0 + row, n = nw0 + ch * 8;
+                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
                 f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
                 f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
                 if (a.resid) {
