@@ -35,7 +35,8 @@ class MI355XOmniPlatform:
 
     @classmethod
     def get_omni_generation_worker_cls(cls) -> str:
-        # code2wav one-shot stage: out of scope for this path, served by the reference's own ROCm worker
+        # code2wav one-shot stage: the reference's own generation worker / runner host it; the decoder module it runs is
+        # code2wav.Code2WavDecoder (swapped in Qwen3TTSCode2Wav._ensure_speech_tokenizer_loaded)
         return "vllm_omni.worker.gpu_generation_worker.GPUGenerationWorker"
 
     @classmethod
