@@ -288,7 +288,7 @@ extern "C" int omni_codec_res_unit(const omni_res_unit* u, void* stream) {
     OMNI_CHECK_ARG(u && u->s && u->h && u->s_next && u->w1 && u->b1 && u->snake2_alpha && u->snake2_inv_beta && u->w2 && u->b2 &&
                    u->next_alpha && u->next_inv_beta, "omni_codec_res_unit: null argument");
     OMNI_CHECK_ARG(u->T > 0 && omni_codec_res_unit_supported(u->C, RU_TAPS, u->dilation), "omni_codec_res_unit: T=%d C=%d dilation=%d (C 96 | 192, dilation <= 9)", u->T, u->C, u->dilation);
-    OMNI_CHECK_ARG((int64_t)u->T * u->C * 4 < (int64_t)1 << 40, "omni_codec_res_unit: size");
+    OMNI_CHECK_ARG(u->s != u->s_next, "omni_codec_res_unit: s_next aliases s (neighbouring row blocks read a halo of s)");
     ResUnitArgs a;
     a.s = (const uint16_t*)u->s; a.h = u->h; a.s_next = (uint16_t*)u->s_next;
     a.w1 = (const uint16_t*)u->w1; a.b1 = u->b1; a.a2 = u->snake2_alpha; a.ib2 = u->snake2_inv_beta;
