@@ -14,8 +14,9 @@ import torch  # noqa: F401  (must precede the dlopen below: shares torch's HIP r
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libomni_talker.so")
 
-KV_BF16, KV_FP8, KV_INT8 = 0, 1, 2
-KV_CODES = {"bf16": KV_BF16, "auto": KV_BF16, "fp8": KV_FP8, "fp8_e4m3": KV_FP8, "int8": KV_INT8}
+KV_BF16, KV_FP8, KV_INT8, KV_FP16 = 0, 1, 2, 3
+KV_CODES = {"bf16": KV_BF16, "auto": KV_BF16, "fp8": KV_FP8, "fp8_e4m3": KV_FP8, "int8": KV_INT8, "fp16": KV_FP16, "float16": KV_FP16,
+            "half": KV_FP16}
 EPI_BF16, EPI_SILU_MUL, EPI_F32, EPI_F32_BF16RND = 0, 1, 2, 3
 EPI_RESID, EPI_SILU_MUL_GU8 = 4, 5
 SILU_EPIS = (EPI_SILU_MUL, EPI_SILU_MUL_GU8)

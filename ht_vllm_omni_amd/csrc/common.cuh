@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint3
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 
+// ---- IEEE half <-> f32 (OMNI_KV_FP16 storage)
+__device__ __forceinline__ float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float h_lo(uint32_t w) { return h2f((uint16_t)(w & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
+#define OMNI_KV_IS16(KV) ((KV) == OMNI_KV_BF16 || (KV) == OMNI_KV_FP16)
+
 // ---- lane exchanges inside a 16-lane row as DPP modifiers (~1 VALU op; hipcc lowers __shfl_xor to ds_bpermute_b32, an
 // LDS-pipe round trip of ~120 cycles that a one-wave-per-SIMD kernel cannot hide).  Full waves only (a disabled source
 // lane reads as 0).  For REDUCTIONS any pairing that merges disjoint groups works, so the 8- and 16-lane steps use the

@@ -45,14 +45,14 @@ struct KVRaw { u32x4 a, b; };   // b: bf16 only (second 8 elements)
 // element index (0..127) of the e-th value (0..15) held by a lane with sub = lane & 7
 template <int KV>
 __device__ __forceinline__ int elem_of(int sub, int e) {
-    if (KV == OMNI_KV_BF16) return (e < 8) ? (sub * 8 + e) : (64 + sub * 8 + (e - 8));
+    if (OMNI_KV_IS16(KV)) return (e < 8) ? (sub * 8 + e) : (64 + sub * 8 + (e - 8));
     return sub * 16 + e;
 }
 
 template <int KV>
 __device__ __forceinline__ KVRaw<KV> load_row(const void* base, size_t row, int sub) {
     KVRaw<KV> r;
-    if (KV == OMNI_KV_BF16) {
+    if (OMNI_KV_IS16(KV)) {
         const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + row * 128;
         r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + sub * 8));
         r.b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64 + sub * 8));
@@ -73,6 +73,14 @@ __device__ __forceinline__ void to_f32(const KVRaw<KV>& r, float* f) {
             f[2 * j + 1] = bf_hi(r.a[j]);
             f[8 + 2 * j] = bf_lo(r.b[j]);
             f[8 + 2 * j + 1] = bf_hi(r.b[j]);
+        }
+    } else if (KV == OMNI_KV_FP16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = h_lo(r.a[j]);
+            f[2 * j + 1] = h_hi(r.a[j]);
+            f[8 + 2 * j] = h_lo(r.b[j]);
+            f[8 + 2 * j + 1] = h_hi(r.b[j]);
         }
     } else if (KV == OMNI_KV_FP8) {
 #pragma unroll
@@ -207,6 +215,15 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
                     kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
                     vd[lane] = f2bf(vx0); vd[lane + 64] = f2bf(vx1);
                 }
+            } else if (KV == OMNI_KV_FP16) {
+                uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
+                uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
+                const uint16_t hk0 = f2h(kx0), hk1 = f2h(kx1), hv0 = f2h(vx0), hv1 = f2h(vx1);
+                if (kv_writer) {
+                    kd[lane] = hk0; kd[lane + 64] = hk1;
+                    vd[lane] = hv0; vd[lane + 64] = hv1;
+                }
+                kx0 = h2f(hk0); kx1 = h2f(hk1); vx0 = h2f(hv0); vx1 = h2f(hv1);     // what the cache now holds
             } else if (KV == OMNI_KV_FP8) {
                 const float ik = a.k_scale, iv = a.v_scale;
                 const uint32_t pk = pack_fp8x4(ik == 1.f ? kx0 : kx0 / ik, ik == 1.f ? kx1 : kx1 / ik, 0.f, 0.f);
@@ -799,6 +816,7 @@ static int pa_dispatch(PAArgs& a, int rows, int head_dim, int kv_dtype, bool fus
         case OMNI_KV_BF16: return GO(OMNI_KV_BF16);
         case OMNI_KV_FP8: return GO(OMNI_KV_FP8);
         case OMNI_KV_INT8: return GO(OMNI_KV_INT8);
+        case OMNI_KV_FP16: return GO(OMNI_KV_FP16);
         default: omni_set_error("omni_paged_attn: kv_dtype=%d", kv_dtype); return OMNI_EINVAL;
     }
 #undef GO

@@ -46,6 +46,13 @@ __device__ __forceinline__ void pf_stage(unsigned char* dst_row, const void* cac
     if (KV == OMNI_KV_BF16) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(cache) + row * 128 + ch * 8);
         *reinterpret_cast<u32x4*>(dst_row + ch * 16) = v;
+    } else if (KV == OMNI_KV_FP16) {
+        // half -> bf16: exact for the values a bf16 model writes (a bf16 number inside the half range keeps its 8 significant bits)
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(cache) + row * 128 + ch * 8);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = pack_bf2(h_lo(v[w]), h_hi(v[w]));
+        *reinterpret_cast<u32x4*>(dst_row + ch * 16) = o;
     } else {
         const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(cache) + row * 128 + ch * 16);
         uint32_t o[8];
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(64 * G) void paged_attn_prefill_mfma_kernel(const P
 
         for (int k0 = 0; k0 < nkeys; k0 += PF_BN) {
             __syncthreads();                             // the previous tile has been consumed by every wave
-            constexpr int CH = (KV == OMNI_KV_BF16) ? 16 : 8;     // 16-B chunks per cache row
+            constexpr int CH = OMNI_KV_IS16(KV) ? 16 : 8;          // 16-B chunks per cache row
             for (int it = threadIdx.x; it < PF_BN * CH; it += NT) {
                 const int kk = it / CH, ch = it - kk * CH;
                 const int key = min(k0 + kk, nkeys - 1);           // tail keys: valid address, masked below
@@ -251,6 +258,7 @@ int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, cons
         case OMNI_KV_BF16: return pf_launch_g<OMNI_KV_BF16>(a, G, st);
         case OMNI_KV_FP8: return pf_launch_g<OMNI_KV_FP8>(a, G, st);
         case OMNI_KV_INT8: return pf_launch_g<OMNI_KV_INT8>(a, G, st);
+        case OMNI_KV_FP16: return pf_launch_g<OMNI_KV_FP16>(a, G, st);
         default: omni_set_error("omni_paged_attn_prefill: kv_dtype %d", kv_dtype); return OMNI_EINVAL;
     }
 }

@@ -65,6 +65,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
         uint16_t* dst = reinterpret_cast<uint16_t*>(cache) + row * 128;
         *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]));
         *reinterpret_cast<uint2*>(dst + 64 + 4 * j) = make_uint2(pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]));
+    } else if (KV == OMNI_KV_FP16) {
+        // the model's bf16 K / V cast to half (RNE; exact inside the half range)
+        uint16_t* dst = reinterpret_cast<uint16_t*>(cache) + row * 128;
+        uint32_t h0[2], h1[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            h0[e] = (uint32_t)f2h(bfround(x0[2 * e])) | ((uint32_t)f2h(bfround(x0[2 * e + 1])) << 16);
+            h1[e] = (uint32_t)f2h(bfround(x1[2 * e])) | ((uint32_t)f2h(bfround(x1[2 * e + 1])) << 16);
+        }
+        *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(h0[0], h0[1]);
+        *reinterpret_cast<uint2*>(dst + 64 + 4 * j) = make_uint2(h1[0], h1[1]);
     } else if (KV == OMNI_KV_FP8) {
         const float inv = is_v ? inv_v_scale : inv_k_scale;
         const float sc = is_v ? v_scale : k_scale;
@@ -119,6 +130,7 @@ extern "C" int omni_qknorm_rope_kvwrite(const void* qkv, const void* qnorm_w, co
         case OMNI_KV_BF16: LAUNCH(OMNI_KV_BF16); break;
         case OMNI_KV_FP8: LAUNCH(OMNI_KV_FP8); break;
         case OMNI_KV_INT8: LAUNCH(OMNI_KV_INT8); break;
+        case OMNI_KV_FP16: LAUNCH(OMNI_KV_FP16); break;
         default: omni_set_error("omni_qknorm_rope_kvwrite: kv_dtype=%d", kv_dtype); return OMNI_EINVAL;
     }
 #undef LAUNCH

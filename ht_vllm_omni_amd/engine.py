@@ -271,7 +271,8 @@ class TalkerEngine:
                 setattr(self._cp_layers[i], n, lw[n].data_ptr())
 
         # ---- paged KV cache, one tensor per layer: [2, num_blocks, block_size, Hkv_local, D]
-        store = {"bf16": BF16, "auto": BF16, "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8}[kv_dtype]
+        store = {"bf16": BF16, "auto": BF16, "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8, "fp16": torch.float16,
+                 "float16": torch.float16, "half": torch.float16}[kv_dtype]
         shape = (2, num_blocks, block_size, self.hkv_l, d.head_dim)
         self.kv_caches = [torch.zeros(shape, dtype=store, device=dev) for _ in range(d.layers)]
         self.kv_scales = ([torch.zeros(shape[:-1], dtype=torch.float32, device=dev) for _ in range(d.layers)]
@@ -655,7 +656,7 @@ class TalkerEngine:
         from .weights import weight_bytes
         d = self.d
         wb = weight_bytes(d)
-        kvb = {"bf16": 2, "auto": 2}.get(self.kv_dtype, 1)
+        kvb = 2 if self.kv_code in (L.KV_BF16, L.KV_FP16) else 1
         per_tok = d.layers * 2 * self.hkv_l * d.head_dim * kvb
         if self.kv_code == L.KV_INT8:
             per_tok += d.layers * 2 * self.hkv_l * 4

@@ -13,7 +13,7 @@
  * process (V/worker error convention, SURVEY 8b "Error conventions").
  *
  * dtypes: bf16 = 16-bit brain float bit pattern; kv_dtype selects the KV-cache
- * storage: OMNI_KV_BF16 (vLLM cache_dtype "auto"), OMNI_KV_FP8 (OCP e4m3fn,
+ * storage: OMNI_KV_BF16 (vLLM cache_dtype "auto"), OMNI_KV_FP16, OMNI_KV_FP8 (OCP e4m3fn,
  * "fp8"), OMNI_KV_INT8 (build-defined, no reference semantics: SURVEY F3).
  *
  * KV cache layout (one allocation per layer), the stacked layout that
@@ -38,6 +38,8 @@ extern "C" {
 #define OMNI_KV_BF16 0
 #define OMNI_KV_FP8 1
 #define OMNI_KV_INT8 2
+#define OMNI_KV_FP16 3   /* IEEE half storage (BASELINE config #2's wording): a bf16 model's K / V are exactly representable unless
+                          * |x| > 65504 or < 2^-14; same results as OMNI_KV_BF16 for in-range values                            */
 
 /* GEMM epilogues */
 #define OMNI_EPI_BF16 0        /* out bf16 [M,N] = bf16(acc + bias)                         */

@@ -173,6 +173,8 @@ class PagedKV:
         shape = (2, num_blocks, block_size, n_kv, head_dim)
         if kv_dtype == "bf16":
             self.data = torch.zeros(shape, dtype=BF16)
+        elif kv_dtype == "fp16":            # BASELINE config #2's wording: a half cache under a bf16 model (torch's bf16 -> half cast)
+            self.data = torch.zeros(shape, dtype=torch.float16)
         elif kv_dtype == "fp8":
             self.data = torch.zeros(shape, dtype=torch.float8_e4m3fn)
         elif kv_dtype == "int8":
@@ -191,6 +193,9 @@ class PagedKV:
         if self.kv_dtype == "bf16":
             flat[0, s] = k.to(BF16)
             flat[1, s] = v.to(BF16)
+        elif self.kv_dtype == "fp16":
+            flat[0, s] = k.to(BF16).to(torch.float16)
+            flat[1, s] = v.to(BF16).to(torch.float16)
         elif self.kv_dtype == "fp8":
             flat[0, s] = fp8_quant(k, self.k_scale)
             flat[1, s] = fp8_quant(v, self.v_scale)
@@ -208,7 +213,7 @@ class PagedKV:
         ids = torch.as_tensor(np.asarray(block_row[:nblk]), dtype=torch.long)
         k = self.data[0, ids].flatten(0, 1)[:seq_len]
         v = self.data[1, ids].flatten(0, 1)[:seq_len]
-        if self.kv_dtype == "bf16":
+        if self.kv_dtype in ("bf16", "fp16"):
             return k.to(torch.float32), v.to(torch.float32)
         if self.kv_dtype == "fp8":
             return fp8_dequant(k, self.k_scale), fp8_dequant(v, self.v_scale)

@@ -80,6 +80,28 @@ def test_config2_0p6b_decode_bf16_kv_matches_oracle():
     assert rec["engine"].kv_caches[0].dtype == torch.bfloat16
 
 
+def test_config2_with_a_half_kv_cache_as_baseline_words_it():
+    """BASELINE config #2 says "bf16 weights / fp16 KV".  OMNI_KV_FP16 stores the model's bf16 K / V as IEEE half (exact inside the
+    half range): prefill (MFMA attention, half -> bf16 staging) + 3 decode steps (fused write, half -> fp32 reads) against the
+    oracle with a torch.float16 cache, and bit-identical to the bf16-cache engine on the same requests."""
+    d = get_dims("tts-0.6b").with_(layers=2, max_model_len=512)
+    w = make_weights(d, seed=77, std=0.02)
+    g = torch.Generator().manual_seed(2)
+    lens = torch.randint(8, 70, (16,), generator=g).tolist()
+    rec16 = _scenario(d, w, "fp16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
+    _check(rec16, mean_tol=4e-3, max_ulps=8.0, weights=w)
+    e16 = rec16["engine"]
+    assert e16.kv_caches[0].dtype == torch.float16
+    recbf = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
+    for a, b in zip(rec16["steps"], recbf["steps"]):
+        assert torch.equal(a["logits"][0], b["logits"][0]) and torch.equal(a["codes"][0], b["codes"][0]) and torch.equal(a["hidden"][0], b["hidden"][0])
+    for l in range(d.layers):
+        h, b = e16.kv_caches[l].float(), recbf["engine"].kv_caches[l].float()
+        normal = b.abs() >= 2.0 ** -14                               # half's normal range: the bf16 value is kept exactly
+        assert torch.equal(h[normal], b[normal]) and bool(normal.any())
+        assert float((h - b).abs().max()) <= 2.0 ** -25              # below it: rounded to the half subnormal grid
+
+
 # ------------------------------------------------------------------ G2 on the device kernels
 def _decode_chain(ops, d, wd, x_row, pos, kc, vc, bt, cos_sin):
     """One decode step of ONE layer on the per-op entry points (the kernels the engine's step launches):
