@@ -149,11 +149,13 @@ def setup_requests(d, eng, args):
     req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32)
     slots = torch.tensor([int(bt[int(req[t]), int(pos[t]) // bs]) * bs + int(pos[t]) % bs for t in range(len(pos))])
     pos, req, slots = pos.cuda(), req.cuda(), slots.cuda()
+    last = torch.tensor(np.cumsum(lens) - 1, dtype=torch.int32).cuda()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hid = eng.prefill(x, pos, req, slots)
-    last = torch.tensor(np.cumsum(lens) - 1).cuda()
-    hl = hid[last]
+    from ht_vllm_omni_amd import ops
+    hl = ops.embed(last, hid)        # row gather on the library's kernel (torch's first fancy-index launch loads a code object: 44 ms
+                                     # of process start-up that is no request latency, scripts/diag_b1_prefill.py)
     logits = eng.compute_logits(hl)
     from ht_vllm_omni_amd import ops
     s = eng.sampling

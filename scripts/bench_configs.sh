@@ -11,8 +11,9 @@ run W2-0.6b-bf16kv --model tts-0.6b --kv bf16 --steps 128
 run W2-0.6b-b16 --model tts-0.6b --kv bf16 --batch 16 --steps 128
 run W2-0.6b-b1 --model tts-0.6b --kv bf16 --batch 1 --steps 128 --ttfa-steps 2
 run W3-b1 --batch 1 --steps 128 --ttfa-steps 2
-run W3-ctx2048 --steps 64 --ctx-extra 1900 --num-blocks 12000
-run W3-ctx4000 --steps 32 --ctx-extra 3800 --num-blocks 20000
+run W3-fp16kv --kv fp16 --steps 128
+run W3-ctx2048 --steps 64 --ctx-extra 1900 --num-blocks 12000 --target-ctx 0
+run W3-ctx4000 --steps 32 --ctx-extra 3800 --num-blocks 20000 --target-ctx 0
 run omni-talker-int8 --model omni-talker --kv int8 --steps 128
 run W3-b128-2chains --batch 128 --sub-batches 2 --steps 64 --num-blocks 16384
 run W3-b256-4chains --batch 256 --sub-batches 4 --steps 64 --num-blocks 32768
