@@ -88,7 +88,7 @@ class MI355XARWorker:
 
     def kv_bytes_per_block(self) -> int:
         d = self.dims
-        per_elem = 2 if self.vllm_config.kv_cache_dtype in ("bf16", "auto") else 1
+        per_elem = 2 if self.vllm_config.kv_cache_dtype in ("bf16", "auto", "fp16", "float16", "half") else 1
         hkv = max(d.kv_heads // self.tp_size, 1)
         b = d.layers * 2 * self.vllm_config.block_size * hkv * d.head_dim * per_elem
         if self.vllm_config.kv_cache_dtype == "int8":
