@@ -226,6 +226,16 @@ def test_kv_quant_bytes_match_the_format_definitions(golden_dir):
     for half, qn, sn in ((0, "int8_k", "int8_scale_k"), (1, "int8_v", "int8_scale_v")):
         assert torch.equal(kv.data[half].reshape(-1, H, D)[slots], torch.from_numpy(z[qn]))
         assert torch.equal(kv.scales[half].reshape(-1, H)[slots], torch.from_numpy(z[sn]))
+    # IEEE-half cache (BASELINE config #2's wording): the same vectors against numpy's own float32 -> float16 conversion (RNE,
+    # overflow to inf, gradual underflow) -- bit patterns, with the exact-ties / 448-and-beyond / subnormal rows of the fixture
+    kv = O.PagedKV(max(bt) + 1, bs, H, D, "fp16")
+    kv.write(slots, k, v)
+    for half, src in ((0, k), (1, v)):
+        want = src.float().numpy().astype(np.float16).view(np.uint16)
+        got = kv.data[half].reshape(-1, H, D)[slots].view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(got, want)
+        inside = (src.float().abs() >= 2.0 ** -14) & (src.float().abs() <= 65504.0)
+        assert torch.equal(kv.data[half].reshape(-1, H, D)[slots].float()[inside], src.float()[inside])     # bf16 kept exactly in range
 
 
 # ------------------------------------------------------------------ Qwen3-TTS prompt-embedding builder
