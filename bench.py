@@ -56,76 +56,9 @@ def build_engine(args, rank, world):
 
 
 def setup_peer_allreduce(d, args, rank, world):
-    """Peer-mapped one-shot all-reduce for the tensor-parallel step, with a self-check against RCCL on random partials
-    before it is trusted: any failure (allocation, IPC mapping, a peer that does not arrive, a wrong sum on ANY rank) falls
-    back to RCCL all-reduces between the phase calls -- on every rank alike.  Every rank makes the same sequence of
-    collective calls whatever happens locally (local failures are recorded and agreed on by an all-reduce(MIN))."""
-    import torch.distributed as dist
-    from ht_vllm_omni_amd.engine import frag_shuffle
-    from ht_vllm_omni_amd.tp_comm import PeerAllReduce
-
-    def agree(ok: bool) -> bool:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return int(flag.item()) == 1
-
-    ar, ok = None, True
-    try:
-        ar = PeerAllReduce(rank, world, args.batch, d.hidden)
-    except Exception as e:   # noqa: BLE001
-        log(f"[rank {rank}] peer all-reduce buffers unavailable: {e!r}")
-        ok = False
-    if not agree(ok):
-        return _ar_fallback(rank, ar)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, ar.handles)
-    try:
-        ar.map_peers(gathered)
-    except Exception as e:   # noqa: BLE001
-        log(f"[rank {rank}] hipIpc mapping of the peers failed: {e!r}")
-        ok = False
-    if not agree(ok):
-        return _ar_fallback(rank, ar)
-    M = args.batch
-    g = torch.Generator().manual_seed(100 + rank)
-    for it in range(4):
-        part = torch.zeros(ar.rows16, d.hidden, dtype=torch.bfloat16)
-        part[:M] = torch.randn(M, d.hidden, generator=g).to(torch.bfloat16)
-        out = torch.zeros(M, d.hidden, dtype=torch.bfloat16, device="cuda")
-        ref = part[:M].float().cuda()
-        try:
-            ar.buffer(it & 1).copy_(frag_shuffle(part).cuda())
-            torch.cuda.synchronize()
-        except Exception as e:   # noqa: BLE001
-            log(f"[rank {rank}] self-check staging failed: {e!r}")
-            ok = False
-        dist.barrier()
-        try:
-            if ok:
-                ar.all_reduce(it & 1, out=out, M=M)
-        except Exception as e:   # noqa: BLE001
-            log(f"[rank {rank}] one-shot all-reduce launch failed: {e!r}")
-            ok = False
-        dist.all_reduce(ref)
-        torch.cuda.synchronize()
-        err = (out.float() - ref).abs().max().item()
-        if ok and (ar.error() != 0 or not err <= 2.0 ** -7 * max(ref.abs().max().item(), 1.0)):
-            log(f"[rank {rank}] one-shot all-reduce self-check failed (error word {ar.error()}, max diff {err})")
-            ok = False
-    if not agree(ok):
-        return _ar_fallback(rank, ar)
-    return ar
-
-
-def _ar_fallback(rank, ar):
-    if rank == 0:
-        log("falling back to RCCL all-reduces between the phase calls")
-    try:
-        if ar is not None:
-            ar.close()
-    except Exception:   # noqa: BLE001
-        pass
-    return None
+    """The checked set-up lives with the worker surface (ht_vllm_omni_amd/tp_comm.py); the bench uses the same function."""
+    from ht_vllm_omni_amd.tp_comm import setup_peer_allreduce as setup
+    return setup(d.hidden, args.batch, rank, world, log=log)
 
 
 def setup_requests(d, eng, args):

@@ -73,6 +73,7 @@ class TalkerDesc(C.Structure):
         ("scratch", vp), ("scratch_bytes", i64),
         ("ar_attn", C.POINTER(ArPeers)), ("ar_mlp", C.POINTER(ArPeers)),
         ("moe_e0", i32), ("moe_experts_local", i32), ("moe_w8", i32),
+        ("cp_chain", i32),
     ]
 
 
@@ -137,6 +138,7 @@ SIGNATURES = {
     "omni_talker_scratch_bytes": (i64, [C.POINTER(TalkerDesc)]),
     "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
     "omni_talker_destroy": (None, [vp]),
+    "omni_talker_chain_error": (i32, [vp, i32]),
     "omni_talker_mtp": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_layer_attn": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_layer_mlp": (i32, [vp, C.POINTER(StepIO), i32, vp]),

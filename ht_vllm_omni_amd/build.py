@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libomni_talker.so")
 LIB_DEBUG = os.path.join(HERE, "libomni_talker_debug.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm_prefill.hip", "norm.hip", "rope_kv.hip", "paged_attn.hip", "prefill_attn.hip", "moe.hip",
-           "sampler.hip", "allreduce.hip", "codec.hip", "conv_unit.hip"]
+           "sampler.hip", "cp_chain.hip", "allreduce.hip", "codec.hip", "conv_unit.hip"]
 DEBUG_ONLY = ["debug.hip"]
 # per-file extra flags
 EXTRA = {"debug.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
@@ -31,7 +31,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 def _headers() -> list[str]:
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".cuh", ".h"))]
-    hdrs.append(os.path.normpath(os.path.join(HERE, "..", "include", "omni_talker.h")))
+    inc = os.path.normpath(os.path.join(HERE, "..", "include"))      # every ABI header: a struct change in any of them is a new library
+    hdrs += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
     return hdrs
 
 

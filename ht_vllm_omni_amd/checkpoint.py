@@ -157,7 +157,9 @@ def dims_from_hf_config(cfg: str | dict, name: str = "checkpoint", max_model_len
     t = cfg.get("talker_config", cfg)
     c = t.get("code_predictor_config") or {}
     heads = int(t.get("num_attention_heads", 16))
-    hd = int(t.get("head_dim", 128))
+    # the talker config class has no head_dim field (configuration_qwen3_tts.py:376-409): the HF / vLLM Qwen3 convention is
+    # hidden_size // num_attention_heads when the key is absent; the code-predictor config class defaults it to 128 (:200)
+    hd = int(t.get("head_dim") or int(t.get("hidden_size", 1024)) // heads)
     return TalkerDims(
         name=name, hidden=int(t.get("hidden_size", 1024)), layers=int(t.get("num_hidden_layers", 20)), q_heads=heads,
         kv_heads=int(t.get("num_key_value_heads", 2)), head_dim=hd, inter=int(t.get("intermediate_size", 2048)),

@@ -18,7 +18,7 @@ void omni_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* omni_last_error(void) { return g_err; }
-extern "C" int omni_abi_version(void) { return 2; }
+extern "C" int omni_abi_version(void) { return 3; }
 
 #define TRY(expr)                    \
     do {                             \
@@ -111,6 +111,7 @@ struct omni_talker {
     int64_t* cp_slots;
     std::vector<uint16_t*> cp_k, cp_v;
     int32_t* pf_seq;   // prefill scratch
+    uint32_t* chain_flags;              // stage flags of the persistent code-predictor chain [256] + error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
 };
@@ -168,6 +169,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->cp_seq = c.take<int32_t>((Q + 1) * B);
     t->cp_slots = c.take<int64_t>((Q + 1) * B);
     t->pf_seq = c.take<int32_t>(8);
+    t->chain_flags = c.take<uint32_t>(512);
     if (d.moe_experts > 0) {
         const size_t k = d.moe_top_k, Im = d.moe_inter, Is = d.moe_shared_inter;
         t->normed_rm = c.take<uint16_t>(B * H);
@@ -288,6 +290,7 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
             slots[p * B + b] = (int64_t)b * t->cp_bs + p;
         }
     hipError_t e = hipMemcpy(t->cp_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(t->chain_flags, 0, 512 * 4);
     if (e == hipSuccess) e = hipMemcpy(t->cp_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->cp_seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->cp_slots, slots.data(), slots.size() * 8, hipMemcpyHostToDevice);
@@ -300,6 +303,19 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
 }
 
 extern "C" void omni_talker_destroy(omni_talker* t) { delete t; }
+
+// the sticky error word of the persistent code-predictor chain: 0 = every flag wait so far was satisfied; otherwise the
+// stage code (16 * layer + stage + 1) whose spin ran out first.  Synchronises the device; reset = 1 clears word and flags.
+extern "C" int omni_talker_chain_error(omni_talker* t, int reset) {
+    if (!t) return OMNI_EINVAL;
+    int32_t v = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, t->chain_flags + 320, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        omni_set_error("omni_talker_chain_error: device read failed");
+        return OMNI_EHIP;
+    }
+    if (reset && hipMemset(t->chain_flags, 0, 512 * 4) != hipSuccess) return OMNI_EHIP;
+    return v;
+}
 extern "C" void* omni_talker_attn_out(omni_talker* t) { return t ? t->attn_out : nullptr; }
 extern "C" void* omni_talker_mlp_out(omni_talker* t) { return t ? t->mlp_out : nullptr; }
 
@@ -523,7 +539,16 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         for (int g = 1; g < Q; ++g) {
             const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
-            if (!in_pair) TRY(cp_forward_fused(t, B, g, &np, st));
+            if (!in_pair) {
+                if (d.cp_chain && k_cp_chain_supported(d, g)) {
+                    // the whole layer stack of this pass as ONE persistent launch (cp_chain.hip): 25 stages behind flag hand-offs
+                    TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, np, t->cp_resid, t->cp_part, t->cp_qkv,
+                                   t->cp_attn, t->cp_act, t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), st));
+                    np = Hc / 16;
+                } else {
+                    TRY(cp_forward_fused(t, B, g, &np, st));
+                }
+            }
             TRY(k_gemm_xnorm(in_pair ? r1 : t->cp_resid, in_pair ? part1 : t->cp_part, np, d.cp_norm, d.eps, nullptr, head, t->cp_logits,
                              B, d.codebook, Hc, OMNI_EPI_F32_BF16RND, nullptr, 0, in_pair ? ps : 64, st));
             if (cp_logits_out) {

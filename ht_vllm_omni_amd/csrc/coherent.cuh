@@ -1,0 +1,93 @@
+// Cross-workgroup hand-offs INSIDE one launch (cp_chain.hip).  gfx950 has one L2 per XCD and a vector L1 per CU that other
+// CUs' stores never refresh, so bytes that another workgroup wrote during the same launch are moved "coherent by access"
+// (MI355X_MICROARCH, Workgroup dispatch / inter-workgroup visibility, first row of the sc1 table):
+//   producer  every store of the handed-off bytes carries sc1 (write-through, the line is dropped from the XCD's L2); every
+//             storing wave runs `s_waitcnt vmcnt(0)`; a workgroup barrier; then ONE lane publishes the workgroup's flag (sc1 store)
+//   consumer  one wave polls the flags with sc1 loads; the other waves pass a workgroup barrier behind it; every load of the
+//             handed-off bytes is an sc1 buffer load to registers (bypasses the L1; 4-, 8- or 16-byte accesses only)
+// No release / acquire fence anywhere: a fence writes back or invalidates whole caches (38-43 us per grid barrier measured in
+// round 2), an sc1 access costs what a plain one costs at 16 bytes.
+//
+// Buffer addressing: the resource descriptor is built from a wave-uniform base (SGPRs), lanes supply 32-bit byte offsets
+// (`buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen sc1`); hipcc counts these loads in vmcnt like any other.
+#pragma once
+#include "common.cuh"
+#include "gemm_frag.cuh"
+
+#define OMNI_AUX_SC1 16        // cache-policy bit of the raw buffer builtins: sc1 on gfx940+
+
+typedef __amdgpu_buffer_rsrc_t coh_rsrc_t;
+
+__device__ __forceinline__ coh_rsrc_t coh_rsrc(const void* base) {
+    // stride 0 (raw), num_records = max, flags: DATA_FORMAT = 32 (bits 12-18 of dword 3: 0x00020000)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 coh_ld16(coh_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, OMNI_AUX_SC1);
+}
+__device__ __forceinline__ u32x2 coh_ld8(coh_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, OMNI_AUX_SC1);
+}
+__device__ __forceinline__ uint32_t coh_ld4(coh_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, OMNI_AUX_SC1);
+}
+__device__ __forceinline__ float coh_ldf(coh_rsrc_t rs, uint32_t byte_off) { return __uint_as_float(coh_ld4(rs, byte_off)); }
+__device__ __forceinline__ void coh_st16(coh_rsrc_t rs, uint32_t byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, OMNI_AUX_SC1);
+}
+__device__ __forceinline__ void coh_st8(coh_rsrc_t rs, uint32_t byte_off, u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte_off, 0, OMNI_AUX_SC1);
+}
+__device__ __forceinline__ void coh_st4(coh_rsrc_t rs, uint32_t byte_off, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rs, byte_off, 0, OMNI_AUX_SC1);
+}
+
+// ---- grid-wide stage flags: flag[w] = number of stages workgroup w has completed since the engine was created (wraps).
+// A stage's dependent part starts once every flag has reached the epoch of the stage before it.  Spins are bounded: a
+// workgroup that never sees its peers (a grid that is not co-resident, a lost launch) sets *err and the launch runs to its
+// end without waiting -- a wrong step that the host sees in the error word, never a hung GPU.
+#define OMNI_CHAIN_WGS 256
+#define OMNI_CHAIN_SPIN_BOUND (1u << 21)
+
+struct ChainGate {
+    coh_rsrc_t frs;        // flag words [OMNI_CHAIN_WGS]
+    uint32_t epoch;        // stages this workgroup has completed
+    int32_t* err;
+    bool dead;             // a spin ran out (here or in an earlier launch): stop waiting
+};
+
+__device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, int32_t* err) {
+    g.frs = coh_rsrc(flags);
+    g.err = err;
+    g.epoch = __builtin_amdgcn_readfirstlane(coh_ld4(g.frs, blockIdx.x * 4));
+    g.dead = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+}
+
+// wait until every workgroup has completed the stage this workgroup completed last (g.epoch)
+__device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
+    if (threadIdx.x < 64 && !g.dead) {
+        const uint32_t off = threadIdx.x * 16;            // 64 lanes x 4 flags = all 256
+        unsigned spins = 0;
+        for (;;) {
+            const u32x4 f = coh_ld16(g.frs, off);
+            const bool behind = (int)(f[0] - g.epoch) < 0 || (int)(f[1] - g.epoch) < 0 || (int)(f[2] - g.epoch) < 0 ||
+                                (int)(f[3] - g.epoch) < 0;
+            if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > OMNI_CHAIN_SPIN_BOUND) {
+                if (threadIdx.x == 0) atomicCAS(g.err, 0, code);
+                g.dead = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// this workgroup's stores of the stage are out (every wave drains its own), then one lane publishes
+__device__ __forceinline__ void chain_gate_arrive(ChainGate& g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    g.epoch += 1;
+    if (threadIdx.x == 0) coh_st4(g.frs, blockIdx.x * 4, g.epoch);
+}

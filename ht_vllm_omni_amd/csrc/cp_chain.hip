@@ -1,0 +1,344 @@
+// The code predictor's layer stack as ONE persistent launch (reference: the 5-layer decoder that
+// qwen3_tts_code_predictor_vllm.py:480-561 re-runs for each of the 15 residual code groups of a talker step).
+//
+// Launch-per-op, a predictor pass is 25 dependent launches (5 layers x { qkv, attention, o_proj, gate_up, down_proj }) of
+// ~5.5 us each although a workgroup's share of a GEMM is 16-48 KB of weights and a few MFMAs: a dependent launch pays the
+// kernel boundary (1.65 us), a cold weight fetch, a cold activation fetch and a store drain, one after the other.
+// Here the 25 stages run inside one grid of 256 co-resident workgroups (one per CU):
+//   * a stage's WEIGHT slice does not depend on its predecessor: every wave loads its whole slice (4-12 k-steps, 32-64 VGPRs)
+//     before it looks at the stage flags, so the weight latency overlaps the predecessor's tail;
+//   * stages hand activations over "coherent by access" (coherent.cuh): sc1 write-through stores, one flag word per
+//     workgroup, sc1 loads behind the flag poll -- no cache write-back / invalidate, no kernel boundary;
+//   * what a stage may read BEFORE the flags (besides weights): bytes that were final two or more stages earlier -- the
+//     K / V history of the private cache, the old residual values of a residual epilogue.
+// Tiles, k-step ownership of the 8 waves, accumulation order, LDS combine order and every rounding point are those of
+// gemm_skinny_kernel / attn_tiny_dense_kernel: the chain is bit-identical to the launch-per-op path (tests/test_gpu_chain.py).
+// Bounded spins: a grid that is not co-resident times out into an error word (never a hang).
+#include "attn_common.cuh"
+#include "coherent.cuh"
+#include "common.cuh"
+#include "gemm_frag.cuh"
+#include "kernels.h"
+
+#define CH_WAVES 8
+#define CH_THREADS (CH_WAVES * 64)
+#define CH_MAX_LAYERS 8
+#define CH_LDS_FLOATS ((CH_WAVES * 6 * 4 * 64) + CH_WAVES * 64)      // combine slots of the widest stage (NT * MT = 6) + rstd area
+
+struct ChainLayer {
+    const uint16_t *ln1, *wqkv, *qnorm, *knorm, *wo, *ln2, *wgu, *wdown;
+    uint16_t *kc, *vc;                    // this layer's private K / V cache [B][bs][kv_heads][128] bf16
+};
+struct ChainArgs {
+    ChainLayer layer[CH_MAX_LAYERS];
+    int layers, B, pos, bs, np_in;
+    int q_heads, kv_heads;
+    float eps, sm_scale;
+    uint16_t* resid;                      // fragment-major residual stream [64][Hc]
+    float* part;                          // sum(r^2) slabs [np][64]
+    uint16_t *qkv, *attn, *act;           // stage outputs: row-major [B][4096], fragment-major [64][2048], fragment-major [64][3072]
+    const uint16_t* cos_sin;
+    uint32_t* flags;
+    int32_t* err;
+};
+
+// ---- one skinny GEMM stage.  K = NTW * 256 (every wave owns NTW k-steps: wave, wave + 8, ...), workgroup tile = NT 16-row
+// n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
+template <int MT, int NT, int NTW, int PRO, int EPI>
+__device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
+                                           const float* part_in, int np_in, uint16_t* out, float* part_out, int M, int N, float eps,
+                                           int bx, int by, float* lds, ChainGate& g, bool wait, int code) {
+    constexpr int K = NTW * CH_WAVES * 32;
+    constexpr int nsteps = K / 32;
+    constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
+    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || GU8, "chain_gemm: epilogue");
+    static_assert(EPI != OMNI_EPI_RESID || (NT == 1 && PRO == 0), "chain_gemm: residual epilogue = one n-tile, plain x");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4;
+    const int m_base = by * (MT * 16);
+    const int Mloc = min(M - m_base, MT * 16);
+    if (Mloc <= 0) {                      // no rows here (batch smaller than the grid's row range): keep the flag protocol only
+        if (wait) chain_gate_wait(g, code);
+        chain_gate_arrive(g);
+        return;
+    }
+    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out);
+
+    // ---- before the flags: everything that does not depend on the previous stage
+    u32x4 Wq[NTW][NT], NWq[NTW];
+#pragma unroll
+    for (int d = 0; d < NTW; ++d) {
+        const int ks = wave + d * CH_WAVES;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Wq[d][j] = ld16(W + ((size_t)(bx * NT + j) * nsteps + ks) * 512 + lane * 8);
+        if (PRO == 2) NWq[d] = ld16(norm_w + ks * 32 + 8 * q);
+    }
+    u32x2 r_old = (u32x2){0u, 0u};
+    if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
+        // the old residual values of this thread's epilogue item: last written two or more stages ago (o_proj: by the
+        // previous layer's down_proj; down_proj: by this layer's o_proj), final since the gate of the stage in between
+        const int ml = (threadIdx.x >> 6) * 16 + (lane & 15);
+        if (ml < Mloc) r_old = coh_ld8(ors, (uint32_t)frag_off(m_base + ml, bx * 16 + 4 * (lane >> 4), N) * 2);
+    }
+
+    if (wait) chain_gate_wait(g, code);
+
+    // ---- behind the flags: the slabs (first: they return first) and the activation fragments, all in one round trip
+    constexpr int XROWS = MT * 16, NCH = CH_THREADS / XROWS, PE = 128 / NCH;
+    float pv[PE];
+    if (PRO == 2) {
+        const coh_rsrc_t prs = coh_rsrc(part_in);
+        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+#pragma unroll
+        for (int e = 0; e < PE; ++e) {
+            const int p = ch + e * NCH;
+            pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * 64 + m_base + row) * 4);
+            if (p >= np_in) pv[e] = 0.f;
+        }
+    }
+    u32x4 Xq[NTW][MT];
+#pragma unroll
+    for (int d = 0; d < NTW; ++d)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            Xq[d][i] = coh_ld16(xrs, (uint32_t)((((m_base >> 4) + i) * nsteps + wave + d * CH_WAVES) * 512 + lane * 8) * 2);
+
+    float rstd[MT];
+    if (PRO == 2) {
+        // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
+        float s_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < PE; ++e) s_ += pv[e];
+        if (XROWS <= 32) s_ = xor32_sum(s_);
+        if (XROWS <= 16) s_ = xor16_sum(s_);
+        float* red = lds + CH_WAVES * NT * MT * 4 * 64;
+        red[wave * 64 + lane] = s_;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < CH_WAVES; ++w) t += red[w * 64 + lane];
+        const float rl = 1.0f / sqrtf(t / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rstd[i] = __shfl(rl, i * 16 + (lane & 15), 64);
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < NTW; ++d) {
+        if (PRO == 2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wq[d][j], Xq[d][i], acc[j][i]);
+    }
+
+    // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores
+    f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) lds4[(wave * (NT * MT) + j * MT + i) * 64 + lane] = acc[j][i];
+    __syncthreads();
+    constexpr int LN = GU8 ? 32 : 64;
+    constexpr int ITEMS = NT * MT * LN;
+    for (int it = threadIdx.x; it < ITEMS; it += CH_THREADS) {
+        const int l = it % LN;
+        const int t = it / LN;
+        const int i = t % MT, j = t / MT;
+        const int ml = i * 16 + (l & 15);
+        if (ml >= Mloc) continue;
+        const int m = m_base + ml;
+        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f}, sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < CH_WAVES; ++w) {
+            sum += lds4[(w * (NT * MT) + j * MT + i) * 64 + l];
+            if (GU8) sum2 += lds4[(w * (NT * MT) + j * MT + i) * 64 + l + 32];
+        }
+        if (GU8) {
+            const int n = (bx * NT + j) * 8 + 4 * (l >> 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu_mul_bf16(sum[e], sum2[e]);
+            coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])});
+        } else if (EPI == OMNI_EPI_RESID) {
+            const int n = bx * 16 + 4 * (l >> 4);
+            float rv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = bfround(sum[e]);
+            rv[0] = bfround(bf_lo(r_old[0]) + rv[0]); rv[1] = bfround(bf_hi(r_old[0]) + rv[1]);
+            rv[2] = bfround(bf_lo(r_old[1]) + rv[2]); rv[3] = bfround(bf_hi(r_old[1]) + rv[3]);
+            coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3])});
+            float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
+            ss = xor32_sum(xor16_sum(ss));
+            if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * 64 + m) * 4, __float_as_uint(ss));
+        } else {
+            const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
+            coh_st8(ors, (uint32_t)((size_t)m * N + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
+        }
+    }
+    chain_gate_arrive(g);
+}
+
+// ---- attention stage at buffer position pos <= 15 (dense private cache: row b owns block b): one wave per (row, q head),
+// the work layout of attn_tiny_dense_kernel (paged_attn.hip).  Waves 0-3 of workgroup w take pairs 4 w .. 4 w + 3.
+__device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs, pos = a.pos;
+    const int pair = blockIdx.x * 4 + wave;
+    const bool active = wave < 4 && pair < a.B * q_heads;
+    const int row = pair / q_heads, h = pair - row * q_heads;
+    const int ratio = q_heads / kv_heads, kvh = h / ratio;
+    const int nslots = q_heads + 2 * kv_heads;
+    const int t = lane >> 2, qd = lane & 3;
+    const coh_rsrc_t krs = coh_rsrc(L.kc), vrs = coh_rsrc(L.vc), qrs = coh_rsrc(a.qkv), ars = coh_rsrc(a.attn);
+    // ---- before the flags: the history rows (written by earlier passes; rows >= pos hold stale bytes and are masked)
+    u32x4 kq[4];
+    uint32_t vq[16];
+    if (active) {
+        const uint32_t hrow = ((uint32_t)(row * bs + t) * kv_heads + kvh) * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kq[j] = coh_ld16(krs, (hrow + qd * 32 + j * 8) * 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vq[u] = coh_ld4(vrs, (((uint32_t)(row * bs + u) * kv_heads + kvh) * 128 + 2 * lane) * 2);
+    }
+    chain_gate_wait(g, code);
+    if (active) {
+        // ---- behind the flags: this row's q / k / v heads out of the qkv GEMM's output, one dword per lane each; the
+        // (l, l + 64) pairing of the norm + RoPE is restored through LDS
+        const uint32_t qoff = ((uint32_t)row * nslots + h) * 128, koff = ((uint32_t)row * nslots + q_heads + kvh) * 128,
+                       voff = ((uint32_t)row * nslots + q_heads + kv_heads + kvh) * 128;
+        const uint32_t qw = coh_ld4(qrs, (qoff + 2 * lane) * 2), kw = coh_ld4(qrs, (koff + 2 * lane) * 2);
+        const uint32_t vnew = coh_ld4(qrs, (voff + 2 * lane) * 2);
+        float* sq = lds + wave * 256;                         // [0,128): q in the score layout; [128,256): raw q | k dwords
+        uint32_t* raw = reinterpret_cast<uint32_t*>(sq + 128);
+        raw[lane] = qw;
+        raw[64 + lane] = kw;
+        __builtin_amdgcn_wave_barrier();
+        const uint16_t* rq = reinterpret_cast<const uint16_t*>(raw);
+        const uint16_t* rk = rq + 128;
+        const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+        float q0, q1, k0, k1;
+        head_norm_rope_vals(bf2f(rq[lane]), bf2f(rq[lane + 64]), L.qnorm, cs, a.eps, lane, q0, q1);
+        head_norm_rope_vals(bf2f(rk[lane]), bf2f(rk[lane + 64]), L.knorm, cs, a.eps, lane, k0, k1);
+        if (h % ratio == 0) {
+            // the new token's K / V into the private cache: one dword per lane (even lanes elements l, l + 1 of the first
+            // half, odd lanes l + 63, l + 64 of the second), written through for the later passes
+            const uint32_t crow = ((uint32_t)(row * bs + pos) * kv_heads + kvh) * 128;
+            const uint32_t kb0 = f2bf(k0), kb1 = f2bf(k1);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kb0, OMNI_DPP_XOR1, 0xF, 0xF, true);
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kb1, OMNI_DPP_XOR1, 0xF, 0xF, true);
+            const bool odd = (lane & 1) != 0;
+            const uint32_t word = odd ? (n1 | (kb1 << 16)) : (kb0 | (n0 << 16));
+            const uint32_t elem = odd ? 64 + lane - 1 : lane;
+            coh_st4(krs, (crow + elem) * 2, word);
+            coh_st4(vrs, (crow + 2 * lane) * 2, vnew);
+        }
+        const float qs = a.sm_scale * LOG2E;
+        const float s_new = wave_sum(fmaf(q0 * qs, k0, (q1 * qs) * k1));
+        sq[lane] = q0 * qs;
+        sq[lane + 64] = q1 * qs;
+        __builtin_amdgcn_wave_barrier();
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 qa = *reinterpret_cast<const f32x4*>(&sq[qd * 32 + j * 8]);
+            const f32x4 qb = *reinterpret_cast<const f32x4*>(&sq[qd * 32 + j * 8 + 4]);
+            d = fmaf(qa[0], bf_lo(kq[j][0]), d); d = fmaf(qa[1], bf_hi(kq[j][0]), d);
+            d = fmaf(qa[2], bf_lo(kq[j][1]), d); d = fmaf(qa[3], bf_hi(kq[j][1]), d);
+            d = fmaf(qb[0], bf_lo(kq[j][2]), d); d = fmaf(qb[1], bf_hi(kq[j][2]), d);
+            d = fmaf(qb[2], bf_lo(kq[j][3]), d); d = fmaf(qb[3], bf_hi(kq[j][3]), d);
+        }
+        d += dpp_f<OMNI_DPP_XOR1>(d);
+        d += dpp_f<OMNI_DPP_XOR2>(d);
+        const float s = t < pos ? d : -INFINITY;
+        float m = fmaxf(s, dpp_f<OMNI_DPP_HALF_MIRROR>(s));
+        m = fmaxf(m, dpp_f<OMNI_DPP_MIRROR>(m));
+        m = xor32_max(xor16_max(m));
+        m = fmaxf(m, s_new);
+        const float p = exp2f(s - m);
+        const float p_new = exp2f(s_new - m);
+        float lsum = p + dpp_f<OMNI_DPP_HALF_MIRROR>(p);
+        lsum += dpp_f<OMNI_DPP_MIRROR>(lsum);
+        lsum = xor32_sum(xor16_sum(lsum));
+        const float inv = 1.0f / (lsum + p_new);
+        float o0 = p_new * bf_lo(vnew), o1 = p_new * bf_hi(vnew);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float pu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 4 * u));
+            o0 = fmaf(pu, bf_lo(vq[u]), o0);
+            o1 = fmaf(pu, bf_hi(vq[u]), o1);
+        }
+        coh_st4(ars, (uint32_t)frag_off(row, h * 128 + 2 * lane, q_heads * 128) * 2, pack_bf2(o0 * inv, o1 * inv));
+    }
+    chain_gate_arrive(g);
+}
+
+__global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
+    ChainGate g;
+    chain_gate_init(g, a.flags, a.err);
+    const int wg = blockIdx.x;
+    int np = a.np_in;
+    const int Hc = 1024, NQ = 4096, NI = 3072;
+    for (int l = 0; l < a.layers; ++l) {
+        const ChainLayer& L = a.layer[l];
+        // stage codes (error word): 16 * layer + stage + 1
+        chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
+                                              l > 0, 16 * l + 1);
+        chain_attn(a, L, lds, g, 16 * l + 2);
+        chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
+                                               true, 16 * l + 3);
+        np = Hc / 16;
+        chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7, lds,
+                                                      g, true, 16 * l + 4);
+        chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
+                                                true, 16 * l + 5);
+    }
+}
+
+// ---- host
+OMNI_KNOB g_cp_chain = 1;
+#ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on; }
+#endif
+
+bool k_cp_chain_supported(const omni_talker_desc& d, int pos) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
+    }
+    return g_cp_chain && cus >= OMNI_CHAIN_WGS && d.cp_fused_norm && d.frag_layout && d.cp_hidden == 1024 && d.cp_head_dim == 128 &&
+           d.cp_q_heads * 128 == 2048 && (d.cp_q_heads + 2 * d.cp_kv_heads) * 128 == 4096 && d.cp_inter == 3072 &&
+           d.cp_layers >= 1 && d.cp_layers <= CH_MAX_LAYERS && pos >= 1 && pos <= 15 && d.num_code_groups + 1 >= 16 &&
+           d.max_batch <= 64;
+}
+
+int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
+               int pos, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
+               int32_t* err, void* stream) {
+    ChainArgs a{};
+    for (int l = 0; l < d.cp_layers; ++l) {
+        const omni_layer_weights& w = layers[l];
+        a.layer[l] = ChainLayer{(const uint16_t*)w.ln1, (const uint16_t*)w.wqkv, (const uint16_t*)w.qnorm, (const uint16_t*)w.knorm,
+                                (const uint16_t*)w.wo, (const uint16_t*)w.ln2, (const uint16_t*)w.wgu, (const uint16_t*)w.wdown,
+                                k_cache[l], v_cache[l]};
+    }
+    a.layers = d.cp_layers; a.B = B; a.pos = pos; a.bs = d.num_code_groups + 1; a.np_in = np_in;
+    a.q_heads = d.cp_q_heads; a.kv_heads = d.cp_kv_heads;
+    a.eps = d.eps; a.sm_scale = 1.0f / sqrtf((float)d.cp_head_dim);
+    a.resid = resid; a.part = part; a.qkv = qkv; a.attn = attn; a.act = act;
+    a.cos_sin = (const uint16_t*)d.cp_cos_sin;
+    a.flags = flags; a.err = err;
+    hipLaunchKernelGGL(cp_chain_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+    OMNI_CHECK_LAUNCH("cp_chain");
+    return OMNI_OK;
+}

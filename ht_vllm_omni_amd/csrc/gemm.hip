@@ -25,19 +25,10 @@
 //              across grid.y instead: VALU per workgroup = rows_of_split x K x ~5 instructions.
 #include "common.cuh"
 #include "kernels.h"
+#include "gemm_frag.cuh"
 
 #define GEMM_WAVES 8
 #define GEMM_THREADS (GEMM_WAVES * 64)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u32x4 ld16(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ u32x4 ld16_nt(const uint16_t* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-}
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 struct GemmArgs {
     const uint16_t* x; int ldx;
@@ -55,18 +46,6 @@ struct GemmArgs {
     const int32_t* num_live;   // PRO_XNORM normed_out: rows >= *num_live are not written (NULL: all M rows)
     int dbg_stage;             // debug library only: leave the kernel after stage N (launch-cost attribution), 0 = run all
 };
-
-// PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
-// consumed: x = w * bf16(r * rstd), rstd from the producer's per-workgroup partial sums (talker_oracle.rms_norm)
-__device__ __forceinline__ u32x4 xnorm_frag(u32x4 v, u32x4 nw, float rstd) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd);
-        const float hi = bf_hi(nw[e]) * bfround(bf_hi(v[e]) * rstd);
-        v[e] = pack_bf2(lo, hi);
-    }
-    return v;
-}
 
 template <int MT, int NT, int PRO, int EPI, bool NTL>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArgs a) {

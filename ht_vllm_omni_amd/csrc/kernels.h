@@ -61,3 +61,9 @@ int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, cons
                    const int32_t* block_table, int bt_stride, const int32_t* req_of_tok, const int32_t* positions, void* out,
                    int T, int q_heads, int kv_heads, int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
                    int out_frag, void* stream);
+// the code predictor's layer stack at buffer position pos as one persistent launch (cp_chain.hip); supported = the released
+// predictor shape (1024 wide, 16 q / 8 kv heads, 3072 intermediate) on a GPU with >= 256 CUs
+bool k_cp_chain_supported(const omni_talker_desc& d, int pos);
+int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
+               int pos, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
+               int32_t* err, void* stream);

@@ -14,14 +14,13 @@
 // rounding to bf16); the fused prologue = oracle rms_norm / apply_rope / fp8_quant / int8_quant.
 #include "common.cuh"
 #include "kernels.h"
+#include "attn_common.cuh"
+#include "gemm_frag.cuh"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
 #define PA_U 4                 // 8-token groups per load batch per wave
-#define LOG2E 1.4426950408889634f
 #define PA_REC 130             // partial record: [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct PAArgs {
     const uint16_t* q;             // bf16 [rows, Hq*128]           (unfused)
@@ -95,19 +94,6 @@ __device__ __forceinline__ void to_f32(const KVRaw<KV>& r, float* f) {
             f[4 * j + 3] = (float)(w >> 24) - 128.0f;
         }
     }
-}
-
-// one wave: RMSNorm (optional) + RoPE (optional) of one 128-wide head; lane owns elements l, l+64
-__device__ __forceinline__ void head_norm_rope(const uint16_t* src, const uint16_t* nw, const uint16_t* cs, float eps,
-                                               int lane, float& y0, float& y1) {
-    float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
-    const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
-    const float n0 = bfround(bf2f(nw[lane]) * bfround(x0 * rstd));
-    const float n1 = bfround(bf2f(nw[lane + 64]) * bfround(x1 * rstd));
-    const float c = bf2f(cs[lane]), s = bf2f(cs[64 + lane]);
-    y0 = bfround(bfround(n0 * c) + bfround(-n1 * s));
-    y1 = bfround(bfround(n1 * c) + bfround(n0 * s));
 }
 
 template <int KV, int G, bool FUSED>

@@ -10,6 +10,7 @@ replicated; one all-reduce(sum) of [B,H] bf16 after o_proj and after down_proj (
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -300,6 +301,9 @@ class TalkerEngine:
         desc.moe_experts, desc.moe_top_k, desc.moe_inter = d.moe_experts, d.moe_top_k, self.moe_inter_l
         desc.moe_shared_inter, desc.moe_norm_topk = self.moe_shared_l, int(d.moe_norm_topk)
         desc.moe_e0, desc.moe_experts_local, desc.moe_w8 = self.moe_e0, self.moe_experts_l if d.moe_experts > 0 else 0, int(self.moe_fp8)
+        # the persistent code-predictor chain needs its 256-workgroup grid co-resident: not for engines whose steps run
+        # concurrently on one GPU (n_sub parallel graph branches)
+        desc.cp_chain = int(int(n_sub) <= 1 and os.environ.get("OMNI_CP_CHAIN", "1") != "0")
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
@@ -632,6 +636,13 @@ class TalkerEngine:
         """Sampler on arbitrary logits rows (first token after prefill); marks `seen`, increments `steps`."""
         return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, top_p=top_p, rep_penalty=rep_penalty, seen=seen,
                           seed=seed, steps=steps, inc_steps=steps is not None)
+
+    def chain_error(self, reset: bool = False) -> int:
+        """Sticky error word of the persistent code-predictor launches (0 = no flag wait ever timed out); synchronises."""
+        rc = self.lib.omni_talker_chain_error(self.handle, int(reset))
+        if rc < 0:
+            L.check(rc, "omni_talker_chain_error")
+        return rc
 
     def sample_rows(self, logits: torch.Tensor, rows: torch.Tensor, *, seen=None, steps=None) -> torch.Tensor:
         """First token after prefill for batch rows `rows` (int64 device indices), each with its own request's parameters."""

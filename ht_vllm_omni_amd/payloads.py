@@ -6,7 +6,7 @@ objects over unchanged (duck typing) -- see INTEGRATION.md.
 
   OmniNewRequestData / OmniCachedRequestData / OmniSchedulerOutput   V/core/sched/output.py:9-77
   OmniModelRunnerOutput                                              V/outputs.py:12-26
-  AdditionalInformationPayload (tensor entries as raw bytes)         V/engine/__init__.py:16-85
+  AdditionalInformationEntry / AdditionalInformationPayload         V/engine/__init__.py:29-57 (+ serialization.py:19-113)
 """
 from __future__ import annotations
 
@@ -42,7 +42,7 @@ class OmniNewRequestData:
     sampling_params: SamplingParams | None = None
     prompt_embeds: torch.Tensor | None = None
     external_req_id: str | None = None
-    additional_information: dict[str, Any] | None = None
+    additional_information: Any = None      # AdditionalInformationPayload (the reference's wire type) or a plain dict
 
 
 @dataclass
@@ -84,20 +84,108 @@ class OmniModelRunnerOutput:
 EMPTY_MODEL_RUNNER_OUTPUT = OmniModelRunnerOutput(req_ids=[], req_id_to_index={}, sampled_token_ids=[])
 
 
-# ---- additional_information wire format: tensors travel as {tensor_data bytes, shape, dtype}
-# (V/engine/serialization.py:73-113; decode helper V/worker/gpu_model_runner.py:883-936)
-def decode_additional_information(info: dict[str, Any] | None) -> dict[str, Any]:
-    out: dict[str, Any] = {}
-    for k, v in (info or {}).items():
-        if isinstance(v, dict) and "tensor_data" in v:
-            dt = getattr(torch, str(v["dtype"]).replace("torch.", ""))
-            raw = np.frombuffer(v["tensor_data"], dtype=np.uint8).copy()
-            out[k] = torch.from_numpy(raw).view(dt).reshape(tuple(v["shape"]))
+# ---- additional_information wire format (V/engine/__init__.py:29-57, V/engine/serialization.py:19-113; consumer
+# V/worker/gpu_model_runner.py:915-936).  The reference ships an AdditionalInformationPayload msgspec struct whose
+# `entries` maps each key to an AdditionalInformationEntry in exactly one of three forms:
+#   tensor  tensor_data (raw bytes, row-major) + tensor_shape + tensor_dtype (a numpy dtype name: dtype_to_name)
+#   list    list_data        scalar  scalar_data
+# msgspec is not a dependency of this package: the two structs are restated as dataclasses with the same field names, and
+# the decoder is duck-typed on those names, so it takes the reference's own objects unchanged.
+@dataclass
+class AdditionalInformationEntry:
+    tensor_data: bytes | None = None
+    tensor_shape: list[int] | None = None
+    tensor_dtype: str | None = None
+    list_data: list[Any] | None = None
+    scalar_data: Any | None = None
+
+
+@dataclass
+class AdditionalInformationPayload:
+    entries: dict[str, AdditionalInformationEntry] = field(default_factory=dict)
+
+
+_DTYPE_NAMES = {torch.float32: "float32", torch.float16: "float16", torch.bfloat16: "bfloat16", torch.float64: "float64",
+                torch.int64: "int64", torch.int32: "int32", torch.int16: "int16", torch.int8: "int8", torch.uint8: "uint8",
+                torch.bool: "bool"}
+
+
+def dtype_to_name(dtype: torch.dtype) -> str:
+    """serialization.py:19-39"""
+    return _DTYPE_NAMES.get(dtype, str(dtype).replace("torch.", ""))
+
+
+def _tensor_bytes(t: torch.Tensor) -> bytes:
+    t = t.detach().to("cpu").contiguous()
+    # numpy has no bfloat16 (the reference's `.numpy().tobytes()` raises on it): the bytes are taken through a uint8 view
+    return t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b""
+
+
+def _tensor_from_bytes(data: bytes, shape, dtype_name: str) -> torch.Tensor:
+    name = str(dtype_name).replace("torch.", "")
+    shape = tuple(shape) if shape is not None else ()
+    if name == "bfloat16":                       # extension: the reference's decoder goes through np.dtype and cannot
+        raw = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy())
+        return raw.view(torch.bfloat16).reshape(shape)
+    arr = np.frombuffer(data, dtype=np.dtype(name)).reshape(shape)
+    return torch.from_numpy(arr.copy())
+
+
+def serialize_additional_information(raw_info: dict[str, Any] | AdditionalInformationPayload | None
+                                     ) -> AdditionalInformationPayload | None:
+    """serialization.py:42-71: tensors -> byte entries, lists -> list_data, anything else -> scalar_data."""
+    if raw_info is None:
+        return None
+    if hasattr(raw_info, "entries"):
+        return raw_info
+    entries: dict[str, AdditionalInformationEntry] = {}
+    for key, value in raw_info.items():
+        if isinstance(value, torch.Tensor):
+            entries[key] = AdditionalInformationEntry(tensor_data=_tensor_bytes(value), tensor_shape=list(value.shape),
+                                                      tensor_dtype=dtype_to_name(value.dtype))
+        elif isinstance(value, list):
+            entries[key] = AdditionalInformationEntry(list_data=value)
         else:
-            out[k] = v
-    return out
+            entries[key] = AdditionalInformationEntry(scalar_data=value)
+    return AdditionalInformationPayload(entries=entries) if entries else None
+
+
+def deserialize_additional_information(payload: Any) -> dict[str, Any]:
+    """serialization.py:73-113: None -> {}; an object with an `.entries` dict (the reference's AdditionalInformationPayload
+    or the dataclass above) is decoded entry by entry; a plain dict is taken as it is, except that values in this package's
+    earlier {tensor_data, shape, dtype} dict form are decoded too.  A payload that cannot be decoded is an error HERE (the
+    reference logs and returns {}: a talker request without its prompt embeddings cannot run, so the runner refuses it)."""
+    if payload is None:
+        return {}
+    if isinstance(payload, dict):
+        out: dict[str, Any] = {}
+        for k, v in payload.items():
+            if isinstance(v, dict) and "tensor_data" in v:
+                out[k] = _tensor_from_bytes(v["tensor_data"], v.get("shape", v.get("tensor_shape")), v.get("dtype", v.get("tensor_dtype", "float32")))
+            elif hasattr(v, "tensor_data") or hasattr(v, "list_data") or hasattr(v, "scalar_data"):
+                out[k] = _decode_entry(v)
+            else:
+                out[k] = v
+        return out
+    entries = getattr(payload, "entries", None)
+    if not isinstance(entries, dict):
+        raise TypeError(f"additional_information: expected a dict or an object with an `entries` dict, got {type(payload).__name__}")
+    return {k: _decode_entry(e) for k, e in entries.items()}
+
+
+def _decode_entry(entry: Any) -> Any:
+    if getattr(entry, "tensor_data", None) is not None:
+        return _tensor_from_bytes(entry.tensor_data, getattr(entry, "tensor_shape", ()), getattr(entry, "tensor_dtype", None) or "float32")
+    if getattr(entry, "list_data", None) is not None:
+        return entry.list_data
+    if getattr(entry, "scalar_data", None) is not None:
+        return entry.scalar_data
+    return None
+
+
+decode_additional_information = deserialize_additional_information
 
 
 def encode_tensor(t: torch.Tensor) -> dict[str, Any]:
-    t = t.detach().cpu().contiguous()
-    return {"tensor_data": t.view(torch.uint8).numpy().tobytes(), "shape": list(t.shape), "dtype": str(t.dtype).replace("torch.", "")}
+    """One tensor in the plain-dict form (tests / scripts; the wire form is serialize_additional_information)."""
+    return {"tensor_data": _tensor_bytes(t), "shape": list(t.shape), "dtype": dtype_to_name(t.dtype)}

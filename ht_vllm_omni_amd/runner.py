@@ -119,6 +119,8 @@ class MI355XARModelRunner:
         e.input_ids[r] = 0
         e.steps[r] = 0
         e.seen[r].zero_()
+        # the previous occupant's sampling parameters must not outlive it: back to the stage default (greedy-safe values)
+        e.set_row_sampling(r, greedy=True, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seed=0)
 
     def _permute_rows(self, perm: list[int]) -> None:
         n = len(perm)
@@ -213,6 +215,7 @@ class MI355XARModelRunner:
             dev = e.input_ids.device
             if pad is None:
                 raise ValueError(f"request {nr.req_id}: missing tts_pad_embed (prefill must initialise it)")
+            row_sampling = self._row_sampling(nr.req_id, nr.sampling_params or self.default_sampling)   # validated BEFORE any state changes
             st = RequestState(req_id=nr.req_id, prompt_embeds=pe.to(BF16).cpu().contiguous(),
                               block_ids=list(nr.block_ids[0]), sampling=nr.sampling_params or self.default_sampling,
                               num_computed=int(nr.num_computed_tokens),
@@ -222,13 +225,7 @@ class MI355XARModelRunner:
             r = len(self.rows)
             self.rows.append(nr.req_id)
             self._reset_row(r)
-            sp = st.sampling
-            # vLLM: a seeded request owns a torch.Generator seeded with it, an unseeded one draws from the global stream
-            # (gpu_model_runner.py:315-319) -- here every request gets its own counter-RNG key: its seed, or one derived
-            # from the request id, so unseeded neighbours never share noise
-            seed = request_seed(nr.req_id, sp)
-            e.set_row_sampling(r, greedy=sp.greedy, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
-                               rep_penalty=sp.repetition_penalty, seed=seed)
+            e.set_row_sampling(r, **row_sampling)
             e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=dev)
         # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489); vLLM's own scheduler brings a
         # preempted request back HERE, flagged resumed_from_preemption, with its complete new block list (:470-489)
@@ -247,6 +244,24 @@ class MI355XARModelRunner:
                 dev = e.block_table.device
                 e.block_table[r, len(st.block_ids):len(st.block_ids) + len(new)] = torch.as_tensor(new, dtype=torch.int32, device=dev)
                 st.block_ids.extend(new)
+
+    @staticmethod
+    def _row_sampling(req_id: str, sp) -> dict:
+        """One request's SamplingParams as the engine's per-row arguments, checked before the runner touches its state (a bad
+        request is refused alone; its neighbours' step goes on).  vLLM: a seeded request owns a torch.Generator seeded with
+        it, an unseeded one draws from the global stream (gpu_model_runner.py:315-319) -- here every request gets its own
+        counter-RNG key: its seed, or one derived from the request id, so unseeded neighbours never share noise.  top_p < 1
+        with top_k disabled (a common vLLM setting) runs as top_k = 1024, the nucleus over the sampler's candidate capacity."""
+        greedy = bool(sp.greedy)
+        top_k, top_p = int(sp.top_k or 0), float(sp.top_p if sp.top_p is not None else 1.0)
+        if not greedy and not float(sp.temperature) > 0.0:
+            raise ValueError(f"request {req_id}: temperature must be > 0 when sampling")
+        if not float(sp.repetition_penalty) > 0.0:
+            raise ValueError(f"request {req_id}: repetition_penalty must be > 0")
+        if 0.0 < top_p < 1.0 and not 0 < top_k <= 1024:
+            top_k = 1024
+        return dict(greedy=greedy, temperature=float(sp.temperature), top_k=top_k, top_p=top_p,
+                    rep_penalty=float(sp.repetition_penalty), seed=request_seed(req_id, sp))
 
     # ------------------------------------------------------------------ recompute preemption
     def _rebuild_decode_inputs(self, st: RequestState, J: int) -> torch.Tensor:
@@ -273,6 +288,9 @@ class MI355XARModelRunner:
         decode row with input_ids = its last token, h = the hidden state of the last recomputed position, and its
         position, step counter (RNG key), repetition-penalty bitmap and text-queue cursor where they were."""
         e = self.engine
+        # the rows are about to change: the per-step text table is keyed by row (the cached-request route gets here without
+        # the flush at the top of _update_states: a resumed row would read a neighbour's text step otherwise)
+        self._tt_flush()
         st = self.preempted.pop(rid)
         if len(self.rows) >= self.max_num_seqs:
             raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
@@ -290,9 +308,7 @@ class MI355XARModelRunner:
         r = len(self.rows)
         self.rows.append(rid)
         self._reset_row(r)
-        sp = st.sampling
-        e.set_row_sampling(r, greedy=sp.greedy, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
-                           rep_penalty=sp.repetition_penalty, seed=request_seed(rid, sp))
+        e.set_row_sampling(r, **self._row_sampling(rid, st.sampling))
         e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=e.block_table.device)
 
     def _restore_decode_row(self, r: int, st: RequestState, hidden_last: torch.Tensor) -> None:
@@ -405,6 +421,8 @@ class MI355XARModelRunner:
             if self._tt is None:
                 self._tt_build()
             idx = self._tt_off[:nd] + np.minimum(self._tt_pos[:nd], self._tt_len[:nd])
+            if len(idx) != nd:
+                raise RuntimeError(f"text-step table covers {len(idx)} rows, the step has {nd} decode rows (stale table)")
             self._tt_pos[:nd] += 1
             torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
             self._run_decode(nd)

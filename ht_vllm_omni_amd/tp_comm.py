@@ -108,6 +108,78 @@ class PeerAllReduce:
         self._opened, self._own = [], []
 
 
+def setup_peer_allreduce(hidden: int, rows: int, rank: int, world: int, group=None, log=print):
+    """Peer-mapped one-shot all-reduce for the tensor-parallel step, with a self-check against RCCL on random partials
+    before it is trusted: any failure (allocation, IPC mapping, a peer that does not arrive, a wrong sum on ANY rank) makes
+    EVERY rank return None -- the engine then runs RCCL all-reduces between the phase calls.  Every rank makes the same
+    sequence of collective calls whatever happens locally (local failures are recorded and agreed on by an all-reduce(MIN)).
+    Called by MI355XARWorker.initialize_from_config (the reference's group: V/worker/gpu_ar_worker.py:69-75) and by bench.py."""
+    import torch.distributed as dist
+    from .engine import frag_shuffle
+
+    def agree(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    def fallback(ar):
+        if rank == 0:
+            log("peer all-reduce unavailable: falling back to RCCL all-reduces between the phase calls")
+        try:
+            if ar is not None:
+                ar.close()
+        except Exception:   # noqa: BLE001
+            pass
+        return None
+
+    ar, ok = None, True
+    try:
+        ar = PeerAllReduce(rank, world, rows, hidden)
+    except Exception as e:   # noqa: BLE001
+        log(f"[rank {rank}] peer all-reduce buffers unavailable: {e!r}")
+        ok = False
+    if not agree(ok):
+        return fallback(ar)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ar.handles, group=group)
+    try:
+        ar.map_peers(gathered)
+    except Exception as e:   # noqa: BLE001
+        log(f"[rank {rank}] hipIpc mapping of the peers failed: {e!r}")
+        ok = False
+    if not agree(ok):
+        return fallback(ar)
+    M = rows
+    g = torch.Generator().manual_seed(100 + rank)
+    for it in range(4):
+        part = torch.zeros(ar.rows16, hidden, dtype=torch.bfloat16)
+        part[:M] = torch.randn(M, hidden, generator=g).to(torch.bfloat16)
+        out = torch.zeros(M, hidden, dtype=torch.bfloat16, device="cuda")
+        ref = part[:M].float().cuda()
+        try:
+            ar.buffer(it & 1).copy_(frag_shuffle(part).cuda())
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            log(f"[rank {rank}] self-check staging failed: {e!r}")
+            ok = False
+        dist.barrier(group=group)
+        try:
+            if ok:
+                ar.all_reduce(it & 1, out=out, M=M)
+        except Exception as e:   # noqa: BLE001
+            log(f"[rank {rank}] one-shot all-reduce launch failed: {e!r}")
+            ok = False
+        dist.all_reduce(ref, group=group)
+        torch.cuda.synchronize()
+        err = (out.float() - ref).abs().max().item()
+        if ok and (ar.error() != 0 or not err <= 2.0 ** -7 * max(ref.abs().max().item(), 1.0)):
+            log(f"[rank {rank}] one-shot all-reduce self-check failed (error word {ar.error()}, max diff {err})")
+            ok = False
+    if not agree(ok):
+        return fallback(ar)
+    return ar
+
+
 def _device_tensor(ptr: int, n: int, dtype) -> torch.Tensor:
     """A torch view of device memory this module allocated through the C-ABI (no ownership: PeerAllReduce frees it)."""
     itemsize = torch.empty((), dtype=dtype).element_size()

@@ -5,8 +5,10 @@ minimal-backend template ``XPUARWorker`` (V/platforms/xpu/worker/xpu_ar_worker.p
   __init__(vllm_config, local_rank, rank, distributed_init_method, ...)  init_device()  load_model()
   determine_available_memory() -> bytes   initialize_from_config(kv_cache_config)   compile_or_warm_up_model()
   execute_model(scheduler_output)   sample_tokens(grammar_output)   profile(is_start, profile_prefix)
-``vllm_config`` is duck-typed: a namespace with the handful of fields the talker stage reads
-(model dims preset or TalkerDims, cache dtype / block size, max_num_seqs, tensor_parallel_size, gpu_memory_utilization).
+``vllm_config`` is either a real ``VllmConfig``-shaped object -- ``model_config.model``, ``cache_config.cache_dtype /
+block_size / gpu_memory_utilization / num_gpu_blocks_override``, ``parallel_config.tensor_parallel_size``,
+``scheduler_config.max_num_seqs`` (the fields GPUARWorker / GPUARModelRunner read: gpu_ar_worker.py:29-90,
+gpu_ar_model_runner.py:118-124) -- which ``config_from_vllm`` flattens, or the flat namespace ``make_config`` returns.
 """
 from __future__ import annotations
 
@@ -39,9 +41,75 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                            prompt_builder=prompt_builder, model_path=model_path)
 
 
+_PRESET_HINTS = (("omni", "omni-talker"), ("1.7b", "tts-1.7b"), ("0.6b", "tts-0.6b"))
+
+
+def _dims_from_model_config(mc) -> str | TalkerDims:
+    """What the talker stage is, from ``model_config``: a TalkerDims, a preset name, a checkpoint directory (its config.json
+    decides, as in the reference: configuration_qwen3_tts.py), an ``hf_config`` carrying ``talker_config``, else the size
+    tag in the model id ("Qwen/Qwen3-TTS-1.7B-Base")."""
+    from .config import PRESETS
+    model = getattr(mc, "model", None)
+    if isinstance(model, TalkerDims):
+        return model
+    if isinstance(model, str) and model in PRESETS:
+        return model
+    if isinstance(model, str) and os.path.exists(os.path.join(model, "config.json")):
+        from .checkpoint import dims_from_hf_config
+        return dims_from_hf_config(os.path.join(model, "config.json"), max_model_len=int(getattr(mc, "max_model_len", 4096) or 4096))
+    hf = getattr(mc, "hf_config", None)
+    if hf is not None:
+        as_dict = hf if isinstance(hf, dict) else (hf.to_dict() if hasattr(hf, "to_dict") else None)
+        if as_dict and ("talker_config" in as_dict or "code_predictor_config" in as_dict):
+            from .checkpoint import dims_from_hf_config
+            return dims_from_hf_config(as_dict, max_model_len=int(getattr(mc, "max_model_len", 4096) or 4096))
+    low = str(model).lower()
+    for tag, preset in _PRESET_HINTS:
+        if tag in low:
+            return preset
+    raise ValueError(f"MI355XARWorker: cannot tell the talker's dimensions from model_config.model={model!r} "
+                     "(pass a checkpoint directory with config.json, an hf_config with talker_config, or a preset name)")
+
+
+def config_from_vllm(vllm_config) -> SimpleNamespace:
+    """Flatten a VllmConfig-shaped object into the namespace this worker reads.  Field map (reference readers):
+      model_config.model / .hf_config / .seed / .enforce_eager / .max_model_len      gpu_ar_worker.py:63,78
+      cache_config.cache_dtype / .block_size / .gpu_memory_utilization / .num_gpu_blocks_override   gpu_ar_model_runner.py:118-124
+      parallel_config.tensor_parallel_size                                                        gpu_ar_worker.py:44-46
+      scheduler_config.max_num_seqs                                                               chunk_size_utils.py:5-33
+      additional_config: {connector, prompt_builder, default_sampling_params, weights}            (stage YAML engine_args)
+    A namespace that is already flat (make_config) is returned unchanged."""
+    if not hasattr(vllm_config, "model_config"):
+        return vllm_config
+    mc, cc = vllm_config.model_config, getattr(vllm_config, "cache_config", None)
+    pc, sc = getattr(vllm_config, "parallel_config", None), getattr(vllm_config, "scheduler_config", None)
+    extra = getattr(vllm_config, "additional_config", None) or {}
+    if not isinstance(extra, dict):
+        extra = dict(vars(extra))
+    model = _dims_from_model_config(mc)
+    path = mc.model if isinstance(getattr(mc, "model", None), str) and os.path.isdir(mc.model) else extra.get("model_path")
+    cache_dtype = str(getattr(cc, "cache_dtype", "auto") or "auto").replace("torch.", "")
+    if cache_dtype == "bfloat16":
+        cache_dtype = "bf16"
+    from . import _lib as L
+    if cache_dtype not in L.KV_CODES:
+        raise ValueError(f"MI355XARWorker: cache_config.cache_dtype={cache_dtype!r} is not one of {sorted(L.KV_CODES)}")
+    return SimpleNamespace(
+        model=model, kv_cache_dtype=cache_dtype, block_size=int(getattr(cc, "block_size", 16) or 16),
+        max_num_seqs=int(getattr(sc, "max_num_seqs", 64) or 64),
+        tensor_parallel_size=int(getattr(pc, "tensor_parallel_size", 1) or 1),
+        gpu_memory_utilization=float(getattr(cc, "gpu_memory_utilization", 0.9) or 0.9),
+        num_gpu_blocks_override=getattr(cc, "num_gpu_blocks_override", None), weights=extra.get("weights"),
+        seed=int(getattr(mc, "seed", 1234) or 0), connector=extra.get("connector"),
+        enforce_eager=bool(getattr(mc, "enforce_eager", False)), default_sampling_params=extra.get("default_sampling_params"),
+        prompt_builder=extra.get("prompt_builder"), model_path=path)
+
+
 class MI355XARWorker:
     def __init__(self, vllm_config, local_rank: int = 0, rank: int = 0, distributed_init_method: str | None = None,
                  is_driver_worker: bool = True, **_: Any):
+        self.raw_vllm_config = vllm_config
+        vllm_config = config_from_vllm(vllm_config)
         self.vllm_config = vllm_config
         self.local_rank, self.rank = local_rank, rank
         self.distributed_init_method = distributed_init_method
@@ -102,9 +170,17 @@ class MI355XARWorker:
         nb = getattr(kv_cache_config, "num_blocks", None) or cfg.num_gpu_blocks_override
         if nb is None:
             nb = max(self.determine_available_memory() // self.kv_bytes_per_block(), 2)
+        # tensor-parallel ranks: the all-reduce of the step is a kernel of the step (peer-mapped buffers over hipIpc, fused with
+        # the residual add: tp_comm.py) -- checked against RCCL on random data first, every rank falls back to RCCL
+        # all-reduces between the phase calls if any rank disagrees (the reference's group: gpu_ar_worker.py:69-75)
+        self.peer_allreduce = None
+        if self.tp_size > 1 and self.dims.moe_experts == 0:
+            from .tp_comm import setup_peer_allreduce
+            self.peer_allreduce = setup_peer_allreduce(self.dims.hidden, min(cfg.max_num_seqs, 64), self.rank, self.tp_size,
+                                                       log=logger.info)
         self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(nb),
                                    block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
-                                   tp_rank=self.rank, tp_size=self.tp_size)
+                                   tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce)
         embed_table = self._weights["embed"]
         self._weights = None
         conn = OmniConnectorFactory.create_connector(cfg.connector) if getattr(cfg, "connector", None) else None

@@ -373,6 +373,10 @@ typedef struct omni_talker_desc {
      * experts [moe_e0, moe_e0 + moe_experts_local) (0 local = all of them), each with moe_inter columns (already the shard);
      * moe_w8 != 0: fp8 expert weights + scales in omni_layer_weights */
     int moe_e0, moe_experts_local, moe_w8;
+    /* ABI v3: != 0 lets the code predictor's layer stack run as persistent launches (csrc/cp_chain.hip) where the shape is
+     * supported.  The grid of such a launch must be co-resident (256 workgroups, one per CU): leave it 0 for engines whose
+     * steps run CONCURRENTLY with another engine's on the same GPU (parallel graph branches). */
+    int cp_chain;
 } omni_talker_desc;
 
 typedef struct omni_talker omni_talker;
@@ -380,6 +384,13 @@ typedef struct omni_talker omni_talker;
 int64_t omni_talker_scratch_bytes(const omni_talker_desc* desc);
 omni_talker* omni_talker_create(const omni_talker_desc* desc);   /* copies the descriptor */
 void omni_talker_destroy(omni_talker* t);
+/* The code predictor's layer stack runs as persistent launches whose stages wait for each other on flag words with BOUNDED
+ * spins (csrc/cp_chain.hip; reference: the decoder loop of qwen3_tts_code_predictor_vllm.py:480-561).  A spin that runs out
+ * (grid not co-resident) is recorded in a sticky device word and the launch finishes without waiting: results of that step
+ * are wrong, the GPU never hangs.  Returns that word (0 = no wait ever timed out; else 16 * layer + stage + 1 of the first
+ * one) or a negative OMNI_E* code; synchronises the device (call it per output hand-over, not per launch).  reset != 0
+ * clears the word and the flags.                                                                                          */
+int omni_talker_chain_error(omni_talker* t, int reset);
 
 /* Per-step device buffers (persistent, graph-stable addresses).  Row r = batch slot r. */
 typedef struct omni_step_io {

@@ -12,6 +12,7 @@ void omni_debug_set(int nt, int generic_schedule, int wgs); /* nt & 1: non-tempo
 void omni_debug_tile(int nt, int mt);                       /* force the GEMM tile (0 = policy)                       */
 void omni_debug_int8_max_g(int g);                         /* int8-KV decode attention: q heads per workgroup (2 | 4) */
 void omni_debug_cp_pair01(int on);                         /* code predictor: positions 0 and 1 as one two-block pass */
+void omni_debug_cp_chain(int on);                          /* code predictor: the layer stack of a pass as one persistent launch */
 void omni_debug_gemm_stage(int stage);                      /* leave every GEMM kernel after stage 1..4 (timing attribution only) */
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
 void omni_debug_small_tiny(int on);                         /* code-predictor attention: the (token, quarter) / readlane kernel */

@@ -16,7 +16,7 @@ ap.add_argument("--ctx", type=int, default=352)
 ap.add_argument("settings", nargs="+")
 a = ap.parse_args()
 args = types.SimpleNamespace(allreduce="rccl", model=a.model, kv=a.kv, batch=64, num_blocks=8192, device_weights=True, parallel="tp", sub_batches=1,
-                             tp_force=False, warmup=0, steps=a.steps * a.rounds * len(a.settings) + 64, ttfa_steps=0, ctx_extra=0, target_ctx=a.ctx)
+                             tp_force=False, prefill_gemm="tile", warmup=0, steps=a.steps * a.rounds * len(a.settings) + 64, ttfa_steps=0, ctx_extra=0, target_ctx=a.ctx)
 torch.cuda.set_device(0)
 d, w, eng = bench.build_engine(args, 0, 1)
 lib = eng.lib

@@ -1,0 +1,100 @@
+"""The code predictor's layer stack as persistent launches (csrc/cp_chain.hip) against the launch-per-op path of the SAME
+library: the chain keeps tiles, k-step ownership, accumulation order and rounding points, so codes AND logits must be
+bit-identical; the flag waits must never time out (error word 0).  Reference function: the decoder loop of
+qwen3_tts_code_predictor_vllm.py:480-561 (parity of either schedule with the oracle: tests/test_gpu_engine.py)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from ht_vllm_omni_amd import _lib as L
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.weights import make_weights
+from oracle import talker_oracle as O
+from tests.util import BF16, assert_e2e_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d, w, **kw):
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    return TalkerEngine(d, w, **kw)
+
+
+def _inputs(d, w, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    code0 = torch.randint(1, d.codebook, (B,), generator=g)
+    return code0, w["embed"][code0], torch.randn(B, d.hidden, generator=g).to(BF16)
+
+
+@pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16)])
+def test_chain_is_bit_identical_to_the_launch_chain(model, B):
+    d = get_dims(model).with_(layers=1, max_model_len=256)          # the released predictor: 5 layers, 16 groups
+    w = make_weights(d, seed=33, std=0.02)
+    code0, e0, lh = _inputs(d, w, B, B)
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_cp_chain.argtypes = [C.c_int]; lib.omni_debug_cp_chain.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_cp_chain(on)
+                eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
+                for rep in range(3):                                 # flags / epochs carry over from call to call
+                    codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
+                    steps = torch.full((B,), 3 + rep, dtype=torch.int32)
+                    sampled = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=False, temperature=0.9,
+                                                 top_k=50, seed=7, steps=steps.cuda())
+                assert eng.chain_error() == 0
+                res[on] = (codes.cpu(), lg.cpu(), sampled.cpu())
+        finally:
+            lib.omni_debug_cp_chain(1)
+    assert torch.equal(res[1][0], res[0][0]), "greedy codes differ between the persistent chain and the launch chain"
+    assert torch.equal(res[1][1], res[0][1]), "logits differ between the persistent chain and the launch chain"
+    assert torch.equal(res[1][2], res[0][2]), "sampled codes differ between the persistent chain and the launch chain"
+
+
+def test_chain_matches_oracle_at_full_predictor_depth():
+    """Product library, chain on (the default): greedy codes / logits of the 5-layer, 16-group predictor vs the oracle."""
+    d = get_dims("tts-1.7b").with_(layers=1, max_model_len=256)
+    w = make_weights(d, seed=21, std=0.02)
+    B = 48
+    code0, e0, lh = _inputs(d, w, B, 5)
+    eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
+    codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
+    assert eng.chain_error() == 0
+    ref_codes, ref_lg = O.TalkerOracle(d, w).code_predictor(code0, e0, lh, do_sample=False, return_logits=True)
+    assert_e2e_close(lg.cpu()[:, 0], ref_lg[:, 0], mean_tol=6e-3, max_ulps=3, what="chain: code predictor logits, group 1 (5 layers)")
+    assert (codes.cpu()[:, 1] == ref_codes[:, 1]).float().mean().item() >= 0.9
+
+
+def test_chain_steps_replay_in_a_graph_and_stay_deterministic():
+    """Whole decode steps with the chain inside a captured hipGraph: two engines fed the same requests produce the same
+    codes step after step (flags and epochs advance on the device across replays), error word stays 0."""
+    d = get_dims("tts-1.7b").with_(layers=2, max_model_len=256)
+    w = make_weights(d, seed=4, std=0.02)
+    B = 64
+    outs = []
+    for _ in range(2):
+        eng = _engine(d, w, kv_dtype="fp8", num_blocks=256, max_batch=64)
+        g = torch.Generator().manual_seed(9)
+        eng.input_ids[:B] = torch.randint(1, d.codebook, (B,), generator=g).to(torch.int32).cuda()
+        eng.last_hidden[:B] = torch.randn(B, d.hidden, generator=g).to(BF16).cuda()
+        eng.text_step[:B] = (torch.randn(B, d.hidden, generator=g) * 0.02).to(BF16).cuda()
+        eng.positions[:B] = 17
+        eng.seq_lens[:B] = 18
+        for b in range(B):
+            eng.block_table[b, :2] = torch.tensor([1 + 2 * b, 2 + 2 * b], dtype=torch.int32)
+        eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+        eng.decode_step(B); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            eng.decode_step(B)
+        frames = []
+        for _ in range(6):
+            gr.replay()
+            frames.append(eng.audio_codes[:B].clone())
+        torch.cuda.synchronize()
+        assert eng.chain_error() == 0
+        outs.append(torch.stack(frames).cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0][1:] != outs[0][:-1]).any(), "steps did not advance"
