@@ -40,14 +40,31 @@ struct ChainArgs {
     const uint16_t* cos_sin;
     uint32_t* flags;
     int32_t* err;
+    int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
+    unsigned long long* stamps;           // debug library only: [stage][CH_NSTAMP][256] s_memrealtime ticks (100 MHz) of wave 0, or NULL
 };
+
+// ---- in-kernel timeline of a stage (libomni_talker_debug.so only; scripts/chain_timeline.py): wave 0 of every workgroup
+// stamps the constant 100 MHz counter at fixed points.  Product builds compile the macro away.
+#define CH_NSTAMP 8
+#ifdef OMNI_DEBUG_HOOKS
+#define CH_STAMP(buf, sidx, k)                                                                                          \
+    do {                                                                                                                \
+        if ((buf) != nullptr && threadIdx.x == 0)                                                                       \
+            (buf)[((size_t)(sidx) * CH_NSTAMP + (k)) * OMNI_CHAIN_WGS + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define CH_STAMP(buf, sidx, k) do { } while (0)
+#endif
 
 // ---- one skinny GEMM stage.  K = NTW * 256 (every wave owns NTW k-steps: wave, wave + 8, ...), workgroup tile = NT 16-row
 // n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
 template <int MT, int NT, int NTW, int PRO, int EPI>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, uint16_t* out, float* part_out, int M, int N, float eps,
-                                           int bx, int by, float* lds, ChainGate& g, bool wait, int code) {
+                                           int bx, int by, float* lds, ChainGate& g, bool wait, int code,
+                                           unsigned long long* stamps) {
+    const int sidx = (code >> 4) * 5 + (code & 15) - 1;
     constexpr int K = NTW * CH_WAVES * 32;
     constexpr int nsteps = K / 32;
     constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
@@ -63,6 +80,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         return;
     }
     const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out);
+    CH_STAMP(stamps, sidx, 0);                                           // 0: stage entered
 
     // ---- before the flags: everything that does not depend on the previous stage
     u32x4 Wq[NTW][NT], NWq[NTW];
@@ -71,7 +89,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         const int ks = wave + d * CH_WAVES;
 #pragma unroll
         for (int j = 0; j < NT; ++j) Wq[d][j] = ld16(W + ((size_t)(bx * NT + j) * nsteps + ks) * 512 + lane * 8);
-        if (PRO == 2) NWq[d] = ld16(norm_w + ks * 32 + 8 * q);
+        if (PRO == 2 && NT * NTW < 24) NWq[d] = ld16(norm_w + ks * 32 + 8 * q);
     }
     u32x2 r_old = (u32x2){0u, 0u};
     if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
@@ -81,7 +99,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         if (ml < Mloc) r_old = coh_ld8(ors, (uint32_t)frag_off(m_base + ml, bx * 16 + 4 * (lane >> 4), N) * 2);
     }
 
+    CH_STAMP(stamps, sidx, 1);                                           // 1: weight loads issued
     if (wait) chain_gate_wait(g, code);
+    CH_STAMP(stamps, sidx, 2);                                           // 2: flags seen, barrier passed
 
     // ---- behind the flags: the slabs (first: they return first) and the activation fragments, all in one round trip
     constexpr int XROWS = MT * 16, NCH = CH_THREADS / XROWS, PE = 128 / NCH;
@@ -95,6 +115,10 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * 64 + m_base + row) * 4);
             if (p >= np_in) pv[e] = 0.f;
         }
+    }
+    if (PRO == 2 && NT * NTW >= 24) {          // wide weight slices: the norm weights (2 KB, L2-hot) ride with the x fragments instead
+#pragma unroll
+        for (int d = 0; d < NTW; ++d) NWq[d] = ld16(norm_w + (wave + d * CH_WAVES) * 32 + 8 * q);
     }
     u32x4 Xq[NTW][MT];
 #pragma unroll
@@ -122,6 +146,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int i = 0; i < MT; ++i) rstd[i] = __shfl(rl, i * 16 + (lane & 15), 64);
     }
 
+    CH_STAMP(stamps, sidx, 3);                                           // 3: rstd known (slabs arrived, reduced)
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -145,7 +170,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i) lds4[(wave * (NT * MT) + j * MT + i) * 64 + lane] = acc[j][i];
+    CH_STAMP(stamps, sidx, 4);                                           // 4: operands arrived, MFMAs done, partials in LDS
     __syncthreads();
+    CH_STAMP(stamps, sidx, 5);                                           // 5: combine barrier passed
     constexpr int LN = GU8 ? 32 : 64;
     constexpr int ITEMS = NT * MT * LN;
     for (int it = threadIdx.x; it < ITEMS; it += CH_THREADS) {
@@ -183,12 +210,17 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             coh_st8(ors, (uint32_t)((size_t)m * N + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
         }
     }
+    CH_STAMP(stamps, sidx, 6);                                           // 6: epilogue stores issued
     chain_gate_arrive(g);
+    CH_STAMP(stamps, sidx, 7);                                           // 7: stores drained, barrier, flag published
 }
 
 // ---- attention stage at buffer position pos <= 15 (dense private cache: row b owns block b): one wave per (row, q head),
 // the work layout of attn_tiny_dense_kernel (paged_attn.hip).  Waves 0-3 of workgroup w take pairs 4 w .. 4 w + 3.
 __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code) {
+    const int sidx = (code >> 4) * 5 + (code & 15) - 1;
+    unsigned long long* stamps = a.stamps;
+    CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs, pos = a.pos;
     const int pair = blockIdx.x * 4 + wave;
@@ -208,7 +240,9 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
 #pragma unroll
         for (int u = 0; u < 16; ++u) vq[u] = coh_ld4(vrs, (((uint32_t)(row * bs + u) * kv_heads + kvh) * 128 + 2 * lane) * 2);
     }
+    CH_STAMP(stamps, sidx, 1);
     chain_gate_wait(g, code);
+    CH_STAMP(stamps, sidx, 2);
     if (active) {
         // ---- behind the flags: this row's q / k / v heads out of the qkv GEMM's output, one dword per lane each; the
         // (l, l + 64) pairing of the norm + RoPE is restored through LDS
@@ -277,13 +311,18 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
         }
         coh_st4(ars, (uint32_t)frag_off(row, h * 128 + 2 * lane, q_heads * 128) * 2, pack_bf2(o0 * inv, o1 * inv));
     }
+    CH_STAMP(stamps, sidx, 6);
     chain_gate_arrive(g);
+    CH_STAMP(stamps, sidx, 7);
 }
 
+template <bool GU_NARROW>
 __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
     ChainGate g;
     chain_gate_init(g, a.flags, a.err);
+    g.dom = a.dom;
+    g.nap = a.nap;
     const int wg = blockIdx.x;
     int np = a.np_in;
     const int Hc = 1024, NQ = 4096, NI = 3072;
@@ -291,22 +330,32 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
         const ChainLayer& L = a.layer[l];
         // stage codes (error word): 16 * layer + stage + 1
         chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
-                                              l > 0, 16 * l + 1);
+                                              l > 0, 16 * l + 1, a.stamps);
         chain_attn(a, L, lds, g, 16 * l + 2);
         chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                               true, 16 * l + 3);
+                                               true, 16 * l + 3, a.stamps);
         np = Hc / 16;
-        chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7, lds,
-                                                      g, true, 16 * l + 4);
+        // 16 rows x 48 act columns per workgroup (not the launch path's 32 x 24): the in-register RMSNorm costs VALU time per
+        // x fragment, and the weight slice -- twice as wide -- is prefetched off the critical path here
+        if (GU_NARROW)
+            chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7, lds,
+                                                          g, true, 16 * l + 4, a.stamps);
+        else
+        chain_gemm<1, 6, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6, lds,
+                                                      g, true, 16 * l + 4, a.stamps);
         chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                                true, 16 * l + 5);
+                                                true, 16 * l + 5, a.stamps);
     }
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1;
 #ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
+static unsigned long long* g_chain_stamps = nullptr;
 extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on; }
+// device buffer of CH_MAX_LAYERS * 5 * CH_NSTAMP * 256 uint64 that every following chain launch overwrites (NULL: off)
+extern "C" void omni_debug_chain_stamps(void* buf) { g_chain_stamps = (unsigned long long*)buf; }
 #endif
 
 bool k_cp_chain_supported(const omni_talker_desc& d, int pos) {
@@ -338,7 +387,15 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
     a.resid = resid; a.part = part; a.qkv = qkv; a.attn = attn; a.act = act;
     a.cos_sin = (const uint16_t*)d.cp_cos_sin;
     a.flags = flags; a.err = err;
-    hipLaunchKernelGGL(cp_chain_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+    a.dom = g_chain_dom < 6 ? 6 : (g_chain_dom > 8 ? 8 : g_chain_dom);
+    if (g_chain_gu_narrow && a.dom < 7) a.dom = 7;            // the 32-row tile ties two row groups together
+    a.gu_narrow = g_chain_gu_narrow;
+    a.nap = g_chain_nap;
+#ifdef OMNI_DEBUG_HOOKS
+    a.stamps = g_chain_stamps;
+#endif
+    if (a.gu_narrow) hipLaunchKernelGGL(cp_chain_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cp_chain_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     OMNI_CHECK_LAUNCH("cp_chain");
     return OMNI_OK;
 }

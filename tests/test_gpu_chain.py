@@ -27,17 +27,20 @@ def _inputs(d, w, B, seed):
     return code0, w["embed"][code0], torch.randn(B, d.hidden, generator=g).to(BF16)
 
 
+@pytest.mark.parametrize("mode", [(7, 1, 1), (8, 1, 1), (8, 1, 4)], ids=["default", "all-flags", "all-flags-nap4"])
 @pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16)])
-def test_chain_is_bit_identical_to_the_launch_chain(model, B):
+def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
     d = get_dims(model).with_(layers=1, max_model_len=256)          # the released predictor: 5 layers, 16 groups
     w = make_weights(d, seed=33, std=0.02)
     code0, e0, lh = _inputs(d, w, B, B)
     res = {}
     with L.debug_library() as lib:
         lib.omni_debug_cp_chain.argtypes = [C.c_int]; lib.omni_debug_cp_chain.restype = None
+        lib.omni_debug_chain_mode.argtypes = [C.c_int, C.c_int, C.c_int]; lib.omni_debug_chain_mode.restype = None
         try:
             for on in (0, 1):
                 lib.omni_debug_cp_chain(on)
+                lib.omni_debug_chain_mode(*mode)
                 eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
                 for rep in range(3):                                 # flags / epochs carry over from call to call
                     codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
@@ -48,7 +51,9 @@ def test_chain_is_bit_identical_to_the_launch_chain(model, B):
                 res[on] = (codes.cpu(), lg.cpu(), sampled.cpu())
         finally:
             lib.omni_debug_cp_chain(1)
-    assert torch.equal(res[1][0], res[0][0]), "greedy codes differ between the persistent chain and the launch chain"
+            lib.omni_debug_chain_mode(7, 1, 1)
+    bad = (res[1][0] != res[0][0]).any(dim=1).nonzero().flatten().tolist()
+    assert torch.equal(res[1][0], res[0][0]), f"greedy codes differ between the persistent chain and the launch chain in rows {bad}: first differing group per row {[int((res[1][0][b] != res[0][0][b]).nonzero()[0]) for b in bad]}"
     assert torch.equal(res[1][1], res[0][1]), "logits differ between the persistent chain and the launch chain"
     assert torch.equal(res[1][2], res[0][2]), "sampled codes differ between the persistent chain and the launch chain"
 
