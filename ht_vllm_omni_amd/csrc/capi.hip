@@ -536,14 +536,28 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 TRY(cp_project_fused(t, layer0_embed, B, &np, st));
             }
         }
+        uint32_t* cflags = t->chain_flags;
+        int32_t* cerr = reinterpret_cast<int32_t*>(t->chain_flags + 320);
         for (int g = 1; g < Q; ++g) {
             const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
+            if (!in_pair && d.cp_chain && k_cp_chain_all_supported(d, g, greedy, top_k, top_p)) {
+                // passes g .. Q - 1 -- layer stacks, head GEMMs, samplers, input gathers -- as ONE persistent launch
+                omni_chain_head hd{};
+                hd.logits = cp_logits_out ? cp_logits_out : t->cp_logits;
+                hd.logits_ld = cp_logits_out ? (Q - 1) * d.codebook : d.codebook;
+                hd.logits_pass = cp_logits_out ? d.codebook : 0;
+                hd.greedy = greedy; hd.top_k = top_k; hd.temperature = temperature; hd.top_p = top_p; hd.seed = seed;
+                hd.steps = steps; hd.row_seed = row_seed; hd.codes = t->codes;
+                TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, Q, np, t->cp_resid, t->cp_part, t->cp_qkv,
+                               t->cp_attn, t->cp_act, cflags, cerr, &hd, st));
+                break;
+            }
             if (!in_pair) {
                 if (d.cp_chain && k_cp_chain_supported(d, g)) {
-                    // the whole layer stack of this pass as ONE persistent launch (cp_chain.hip): 25 stages behind flag hand-offs
-                    TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, np, t->cp_resid, t->cp_part, t->cp_qkv,
-                                   t->cp_attn, t->cp_act, t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), st));
+                    // the layer stack of this pass as one persistent launch: 25 stages behind flag hand-offs
+                    TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, g + 1, np, t->cp_resid, t->cp_part, t->cp_qkv,
+                                   t->cp_attn, t->cp_act, cflags, cerr, nullptr, st));
                     np = Hc / 16;
                 } else {
                     TRY(cp_forward_fused(t, B, g, &np, st));

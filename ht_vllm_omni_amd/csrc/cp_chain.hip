@@ -19,6 +19,7 @@
 #include "common.cuh"
 #include "gemm_frag.cuh"
 #include "kernels.h"
+#include "sampler_body.cuh"
 
 #define CH_WAVES 8
 #define CH_THREADS (CH_WAVES * 64)
@@ -31,13 +32,22 @@ struct ChainLayer {
 };
 struct ChainArgs {
     ChainLayer layer[CH_MAX_LAYERS];
-    int layers, B, pos, bs, np_in;
+    int layers, B, bs, np_in;
+    int g0, g1;                           // passes = buffer positions g0 .. g1 - 1 (1 <= g0, g1 <= 16); with_head: each pass ends in
+    int with_head;                        // the group's head GEMM + sampler (+ gather of the next pass's input row)
     int q_heads, kv_heads;
     float eps, sm_scale;
     uint16_t* resid;                      // fragment-major residual stream [64][Hc]
     float* part;                          // sum(r^2) slabs [np][64]
     uint16_t *qkv, *attn, *act;           // stage outputs: row-major [B][4096], fragment-major [64][2048], fragment-major [64][3072]
     const uint16_t* cos_sin;
+    // head + sampler of pass g (group g): logits row b at logits + b * logits_ld + (g - 1) * logits_pass
+    const uint16_t *cp_norm, *lm_head;    // lm_head: [Q - 1][codebook][Hc] fragment-major per group
+    float* logits; int logits_ld, logits_pass;
+    int greedy, top_k, Q, codebook; float temperature, top_p; uint32_t seed;
+    const int32_t* steps; const uint32_t* row_seed;
+    int32_t* codes;                       // [B][Q]
+    const uint16_t* ptab;                 // folded projection tables [Q - 1][codebook][Hc]: pass g < Q - 1 gathers row `code` of table g - 1
     uint32_t* flags;
     int32_t* err;
     int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
@@ -61,16 +71,17 @@ struct ChainArgs {
 // n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
 template <int MT, int NT, int NTW, int PRO, int EPI>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
-                                           const float* part_in, int np_in, uint16_t* out, float* part_out, int M, int N, float eps,
+                                           const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
                                            unsigned long long* stamps) {
-    const int sidx = (code >> 4) * 5 + (code & 15) - 1;
+    const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int K = NTW * CH_WAVES * 32;
     constexpr int nsteps = K / 32;
     constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
-    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || GU8, "chain_gemm: epilogue");
+    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32_BF16RND || GU8, "chain_gemm: epilogue");
     static_assert(EPI != OMNI_EPI_RESID || (NT == 1 && PRO == 0), "chain_gemm: residual epilogue = one n-tile, plain x");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: address parts below stay in SGPRs
     const int q = lane >> 4;
     const int m_base = by * (MT * 16);
     const int Mloc = min(M - m_base, MT * 16);
@@ -79,7 +90,10 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         chain_gate_arrive(g);
         return;
     }
-    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out);
+    // every operand load is a buffer load: lane part (lane * 16 bytes) in ONE VGPR, tile / k-step part in an SGPR offset -- no
+    // 64-bit per-load address pairs (they cost the wide gate_up tile its last registers)
+    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out), wrs = coh_rsrc(W), nrs = coh_rsrc(PRO == 2 ? norm_w : W);
+    const uint32_t lane16 = lane * 16;
     CH_STAMP(stamps, sidx, 0);                                           // 0: stage entered
 
     // ---- before the flags: everything that does not depend on the previous stage
@@ -88,8 +102,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     for (int d = 0; d < NTW; ++d) {
         const int ks = wave + d * CH_WAVES;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Wq[d][j] = ld16(W + ((size_t)(bx * NT + j) * nsteps + ks) * 512 + lane * 8);
-        if (PRO == 2 && NT * NTW < 24) NWq[d] = ld16(norm_w + ks * 32 + 8 * q);
+        for (int j = 0; j < NT; ++j)
+            Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
+        if (PRO == 2 && NT * NTW < 24) NWq[d] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
     }
     u32x2 r_old = (u32x2){0u, 0u};
     if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
@@ -118,14 +133,15 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     }
     if (PRO == 2 && NT * NTW >= 24) {          // wide weight slices: the norm weights (2 KB, L2-hot) ride with the x fragments instead
 #pragma unroll
-        for (int d = 0; d < NTW; ++d) NWq[d] = ld16(norm_w + (wave + d * CH_WAVES) * 32 + 8 * q);
+        for (int d = 0; d < NTW; ++d) NWq[d] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
     }
     u32x4 Xq[NTW][MT];
 #pragma unroll
     for (int d = 0; d < NTW; ++d)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            Xq[d][i] = coh_ld16(xrs, (uint32_t)((((m_base >> 4) + i) * nsteps + wave + d * CH_WAVES) * 512 + lane * 8) * 2);
+            Xq[d][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane16, (uint32_t)((((m_base >> 4) + i) * nsteps + wave + d * CH_WAVES) * 1024),
+                                                             OMNI_AUX_SC1);
 
     float rstd[MT];
     if (PRO == 2) {
@@ -205,9 +221,15 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
             ss = xor32_sum(xor16_sum(ss));
             if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * 64 + m) * 4, __float_as_uint(ss));
+        } else if (EPI == OMNI_EPI_F32_BF16RND) {
+            // logits: fp32 cells holding bf16-rounded values (the reference's bf16 head output), row-major
+            const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
+            coh_st16(ors, (uint32_t)((size_t)m * ldo + n) * 4,
+                     (u32x4){__float_as_uint(bfround(sum[0])), __float_as_uint(bfround(sum[1])), __float_as_uint(bfround(sum[2])),
+                             __float_as_uint(bfround(sum[3]))});
         } else {
             const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
-            coh_st8(ors, (uint32_t)((size_t)m * N + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
+            coh_st8(ors, (uint32_t)((size_t)m * ldo + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
         }
     }
     CH_STAMP(stamps, sidx, 6);                                           // 6: epilogue stores issued
@@ -217,12 +239,12 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 
 // ---- attention stage at buffer position pos <= 15 (dense private cache: row b owns block b): one wave per (row, q head),
 // the work layout of attn_tiny_dense_kernel (paged_attn.hip).  Waves 0-3 of workgroup w take pairs 4 w .. 4 w + 3.
-__device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code) {
-    const int sidx = (code >> 4) * 5 + (code & 15) - 1;
+__device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, int pos, float* lds, ChainGate& g, int code) {
+    const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     unsigned long long* stamps = a.stamps;
     CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs, pos = a.pos;
+    const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
     const int pair = blockIdx.x * 4 + wave;
     const bool active = wave < 4 && pair < a.B * q_heads;
     const int row = pair / q_heads, h = pair - row * q_heads;
@@ -316,9 +338,78 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
     CH_STAMP(stamps, sidx, 7);
 }
 
+// ---- sampler stage of pass g: the workgroup that owns batch row b (inside b's flag domain) draws code g of row b from the
+// head GEMM's logits and, unless this was the last group, gathers the folded embedding -> projection row of the drawn code
+// into the residual stream as the next pass's input (slab 0 = its sum of squares).  sample_kernel's arithmetic (sampler_body.cuh):
+// waves 0-3 are the row's 256 threads, waves 4-7 only keep the barriers.
+__device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* lds, ChainGate& gate, int code) {
+    unsigned long long* stamps = a.stamps;
+    const int sidx = 26;
+    CH_STAMP(stamps, sidx, 0);
+    const int rows_per_dom = 16 << (gate.dom - 6);
+    const int wi = blockIdx.x & ((1 << gate.dom) - 1);
+    const int b = (blockIdx.x >> gate.dom) * rows_per_dom + wi;
+    const bool has_row = wi < rows_per_dom && b < a.B;              // workgroup-uniform
+    const bool live = threadIdx.x < SMP_THREADS;
+    const bool more = g < a.Q - 1 && a.ptab != nullptr;
+    CH_STAMP(stamps, sidx, 1);
+    chain_gate_wait(gate, code);
+    CH_STAMP(stamps, sidx, 2);
+    if (has_row) {
+        constexpr int NPT = 8;
+        const SmpLds S = smp_carve<NPT>(lds);
+        const coh_rsrc_t lrs = coh_rsrc(a.logits);
+        const int V = a.codebook;
+        const uint32_t base = (uint32_t)b * a.logits_ld + (uint32_t)(g - 1) * a.logits_pass;
+        float xr[NPT];
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            const int i = threadIdx.x + e * SMP_THREADS;
+            float x = -INFINITY;
+            if (live && i < V) {
+                x = coh_ldf(lrs, (base + i) * 4);
+                if (!a.greedy) x = x / a.temperature;
+            }
+            xr[e] = x;
+        }
+        const uint32_t seed = a.row_seed ? a.row_seed[b] : a.seed;
+        const uint32_t step = (uint32_t)(a.steps ? a.steps[b] * a.Q + g : g);
+        const int pick = smp_pick<NPT>(xr, V, a.greedy, a.top_k, a.top_p, seed, step, S, live);
+        CH_STAMP(stamps, sidx, 4);
+        if (more) {
+            const int Hc = 1024;
+            const uint16_t* tab = a.ptab + ((size_t)(g - 1) * a.codebook + pick) * Hc;
+            const coh_rsrc_t rrs = coh_rsrc(a.resid);
+            float ss = 0.f;
+            if (live) {
+                for (int v = threadIdx.x; v < Hc / 8; v += SMP_THREADS) {
+                    const u32x4 w4 = ld16(tab + v * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ss += bf_lo(w4[j]) * bf_lo(w4[j]) + bf_hi(w4[j]) * bf_hi(w4[j]);
+                    coh_st16(rrs, (uint32_t)frag_off(b, v * 8, Hc) * 2, w4);
+                }
+            }
+            ss = wave_sum(ss);
+            if ((threadIdx.x & 63) == 0) S.sval[threadIdx.x >> 6] = ss;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < SMP_WAVES; ++w) t += S.sval[w];
+                coh_st4(coh_rsrc(a.part), (uint32_t)b * 4, __float_as_uint(t));
+            }
+        }
+        if (threadIdx.x == 0) coh_st4(coh_rsrc(a.codes), ((uint32_t)b * a.Q + g) * 4, (uint32_t)pick);
+    }
+    CH_STAMP(stamps, sidx, 6);
+    chain_gate_arrive(gate);
+    CH_STAMP(stamps, sidx, 7);
+}
+
 template <bool GU_NARROW>
 __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
+    static_assert(CH_LDS_FLOATS * 4 >= SMP_LDS_BYTES(8), "sampler working set must fit the chain's LDS");
     ChainGate g;
     chain_gate_init(g, a.flags, a.err);
     g.dom = a.dom;
@@ -326,35 +417,43 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
     const int wg = blockIdx.x;
     int np = a.np_in;
     const int Hc = 1024, NQ = 4096, NI = 3072;
-    for (int l = 0; l < a.layers; ++l) {
-        const ChainLayer& L = a.layer[l];
-        // stage codes (error word): 16 * layer + stage + 1
-        chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
-                                              l > 0, 16 * l + 1, a.stamps);
-        chain_attn(a, L, lds, g, 16 * l + 2);
-        chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                               true, 16 * l + 3, a.stamps);
-        np = Hc / 16;
-        // 16 rows x 48 act columns per workgroup (not the launch path's 32 x 24): the in-register RMSNorm costs VALU time per
-        // x fragment, and the weight slice -- twice as wide -- is prefetched off the critical path here
-        if (GU_NARROW)
-            chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7, lds,
-                                                          g, true, 16 * l + 4, a.stamps);
-        else
-        chain_gemm<1, 6, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6, lds,
-                                                      g, true, 16 * l + 4, a.stamps);
-        chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                                true, 16 * l + 5, a.stamps);
+    for (int pass = a.g0; pass < a.g1; ++pass) {
+        const int pc = pass << 8;            // error-word stage codes: (pass << 8) | (16 * layer + stage + 1); head 0xF1, sampler 0xF2
+        for (int l = 0; l < a.layers; ++l) {
+            const ChainLayer& L = a.layer[l];
+            chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
+                                                  l > 0 || pass > a.g0, pc | (16 * l + 1), a.stamps);
+            chain_attn(a, L, pass, lds, g, pc | (16 * l + 2));
+            chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
+                                                   true, pc | (16 * l + 3), a.stamps);
+            np = Hc / 16;
+            if (GU_NARROW)
+                chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7,
+                                                              lds, g, true, pc | (16 * l + 4), a.stamps);
+            else   // 16 rows x 48 act columns: half the in-register RMSNorm per workgroup, a weight slice twice as wide (prefetched)
+                chain_gemm<1, 6, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6,
+                                                              lds, g, true, pc | (16 * l + 4), a.stamps);
+            chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
+                                                    true, pc | (16 * l + 5), a.stamps);
+        }
+        if (!a.with_head) continue;
+        // group `pass`: final norm folded into the head GEMM (2048 logits per row), then one workgroup per row samples
+        chain_gemm<1, 2, 4, 2, OMNI_EPI_F32_BF16RND>(a.lm_head + (size_t)(pass - 1) * a.codebook * Hc, a.cp_norm, a.resid, a.part, np,
+                                                     a.logits + (size_t)(pass - 1) * a.logits_pass, a.logits_ld, nullptr, a.B, a.codebook, a.eps,
+                                                     wg & 63, wg >> 6, lds, g, true, pc | 0x56, a.stamps);
+        chain_sample(a, pass, lds, g, pc | 0xF2);
+        np = 1;
     }
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
 static unsigned long long* g_chain_stamps = nullptr;
-extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on; }
-// device buffer of CH_MAX_LAYERS * 5 * CH_NSTAMP * 256 uint64 that every following chain launch overwrites (NULL: off)
+// 0: launch per op; 1: one persistent launch per pass (layer stack only); 2: one persistent launch for all passes incl. heads + samplers
+extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on != 0; g_chain_span = on; }
+// device buffer of 40 * CH_NSTAMP * 256 uint64 that every following chain launch overwrites (NULL: off)
 extern "C" void omni_debug_chain_stamps(void* buf) { g_chain_stamps = (unsigned long long*)buf; }
 #endif
 
@@ -370,10 +469,16 @@ bool k_cp_chain_supported(const omni_talker_desc& d, int pos) {
            d.cp_layers >= 1 && d.cp_layers <= CH_MAX_LAYERS && pos >= 1 && pos <= 15 && d.num_code_groups + 1 >= 16 &&
            d.max_batch <= 64;
 }
+// all passes g0 .. Q - 1 with their heads and samplers in ONE launch: additionally the 2048-entry codebook the in-chain sampler is
+// built for, the folded projection tables (the next pass's input is a gather) and top-k within the sampler's fast path
+bool k_cp_chain_all_supported(const omni_talker_desc& d, int g0, int greedy, int top_k, float top_p) {
+    return g_chain_span >= 2 && k_cp_chain_supported(d, g0) && d.codebook == 2048 && d.cp_proj_table != nullptr && d.cp_lm_head != nullptr &&
+           d.num_code_groups <= 16 && (greedy || !(top_p > 0.f && top_p < 1.f) || (top_k > 0 && top_k <= SMP_PCAP));
+}
 
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
-               int pos, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
-               int32_t* err, void* stream) {
+               int g0, int g1, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
+               int32_t* err, const omni_chain_head* head, void* stream) {
     ChainArgs a{};
     for (int l = 0; l < d.cp_layers; ++l) {
         const omni_layer_weights& w = layers[l];
@@ -381,15 +486,26 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
                                 (const uint16_t*)w.wo, (const uint16_t*)w.ln2, (const uint16_t*)w.wgu, (const uint16_t*)w.wdown,
                                 k_cache[l], v_cache[l]};
     }
-    a.layers = d.cp_layers; a.B = B; a.pos = pos; a.bs = d.num_code_groups + 1; a.np_in = np_in;
+    a.layers = d.cp_layers; a.B = B; a.g0 = g0; a.g1 = g1; a.bs = d.num_code_groups + 1; a.np_in = np_in;
     a.q_heads = d.cp_q_heads; a.kv_heads = d.cp_kv_heads;
     a.eps = d.eps; a.sm_scale = 1.0f / sqrtf((float)d.cp_head_dim);
     a.resid = resid; a.part = part; a.qkv = qkv; a.attn = attn; a.act = act;
     a.cos_sin = (const uint16_t*)d.cp_cos_sin;
     a.flags = flags; a.err = err;
+    if (head) {
+        a.with_head = 1;
+        a.cp_norm = (const uint16_t*)d.cp_norm; a.lm_head = (const uint16_t*)d.cp_lm_head;
+        a.logits = head->logits; a.logits_ld = head->logits_ld; a.logits_pass = head->logits_pass;
+        a.greedy = head->greedy; a.top_k = head->top_k; a.Q = d.num_code_groups; a.codebook = d.codebook;
+        a.temperature = head->temperature; a.top_p = head->top_p; a.seed = head->seed;
+        a.steps = head->steps; a.row_seed = head->row_seed; a.codes = head->codes;
+        a.ptab = (const uint16_t*)d.cp_proj_table;
+    }
     a.dom = g_chain_dom < 6 ? 6 : (g_chain_dom > 8 ? 8 : g_chain_dom);
-    if (g_chain_gu_narrow && a.dom < 7) a.dom = 7;            // the 32-row tile ties two row groups together
-    a.gu_narrow = g_chain_gu_narrow;
+    if (g_chain_gu_narrow && B > 32 && a.dom < 7) a.dom = 7;  // the 32-row tile ties two row groups together
+    // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: follow the launch path's tile
+    // policy (32-row tiles only above 32 rows) so that both schedules produce the same bits
+    a.gu_narrow = g_chain_gu_narrow && B > 32;
     a.nap = g_chain_nap;
 #ifdef OMNI_DEBUG_HOOKS
     a.stamps = g_chain_stamps;

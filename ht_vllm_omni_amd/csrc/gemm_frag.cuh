@@ -16,13 +16,22 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 
 // PRO_XNORM: the x operand is the fragment-major RESIDUAL stream r; the RMSNorm is applied to each fragment as it is
 // consumed: x = w * bf16(r * rstd), rstd from the producer's per-workgroup partial sums (talker_oracle.rms_norm)
+// Written on (lo, hi) PAIRS of one dword: v_pk_mul_f32 + v_cvt_pk_bf16_f32 produce the packed result in place -- the scalar
+// form made hipcc pair elements ACROSS dwords and re-interleave the halves afterwards (6 VALU per element; this: 4-5).  Same
+// operations on the same values: bit-identical.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t xnorm_pair(uint32_t v, f32x2 w2, f32x2 rstd2) {
+    f32x2 a = {bf_lo(v), bf_hi(v)};
+    a = a * rstd2;
+    const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t));      // bf16(r * rstd), both halves
+    f32x2 r = {bf_lo(p), bf_hi(p)};
+    r = r * w2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+}
 __device__ __forceinline__ u32x4 xnorm_frag(u32x4 v, u32x4 nw, float rstd) {
+    const f32x2 rstd2 = {rstd, rstd};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float lo = bf_lo(nw[e]) * bfround(bf_lo(v[e]) * rstd);
-        const float hi = bf_hi(nw[e]) * bfround(bf_hi(v[e]) * rstd);
-        v[e] = pack_bf2(lo, hi);
-    }
+    for (int e = 0; e < 4; ++e) v[e] = xnorm_pair(v[e], (f32x2){bf_lo(nw[e]), bf_hi(nw[e])}, rstd2);
     return v;
 }
 

@@ -61,9 +61,17 @@ int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, cons
                    const int32_t* block_table, int bt_stride, const int32_t* req_of_tok, const int32_t* positions, void* out,
                    int T, int q_heads, int kv_heads, int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
                    int out_frag, void* stream);
-// the code predictor's layer stack at buffer position pos as one persistent launch (cp_chain.hip); supported = the released
-// predictor shape (1024 wide, 16 q / 8 kv heads, 3072 intermediate) on a GPU with >= 256 CUs
+// the code predictor as persistent launches (cp_chain.hip): passes (buffer positions) g0 .. g1 - 1 of the layer stack, and with
+// `head` the head GEMM + sampler (+ gather of the next input row) of every pass too; supported = the released predictor shape
+// (1024 wide, 16 q / 8 kv heads, 3072 intermediate, 2048-entry codebooks) on a GPU with >= 256 CUs
+struct omni_chain_head {
+    float* logits; int logits_ld, logits_pass;     // row b of group g at logits + b * logits_ld + (g - 1) * logits_pass
+    int greedy, top_k; float temperature, top_p; uint32_t seed;
+    const int32_t* steps; const uint32_t* row_seed;
+    int32_t* codes;                                 // [B][Q]
+};
 bool k_cp_chain_supported(const omni_talker_desc& d, int pos);
+bool k_cp_chain_all_supported(const omni_talker_desc& d, int g0, int greedy, int top_k, float top_p);
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
-               int pos, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
-               int32_t* err, void* stream);
+               int g0, int g1, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
+               int32_t* err, const omni_chain_head* head, void* stream);

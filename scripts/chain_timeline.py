@@ -18,7 +18,8 @@ d = get_dims("tts-1.7b").with_(layers=1, max_model_len=256)
 w = make_weights(d, seed=1, std=0.02)
 eng = TalkerEngine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
 lib = eng.lib
-NS, NST, NW = 25, 8, 256
+NS, NST, NW = 27, 8, 256
+SLOT = list(range(25)) + [30, 26]            # stamp slots: 25 layer stages, head GEMM, sampler
 buf = torch.zeros(40 * NST * NW, dtype=torch.int64, device="cuda")
 lib.omni_debug_chain_stamps.argtypes = [C.c_void_p]; lib.omni_debug_chain_stamps.restype = None
 B = a.batch
@@ -34,12 +35,14 @@ acc = None
 for _ in range(a.reps):
     eng.code_predictor(code0, e0, lh, greedy=True)
     torch.cuda.synchronize()
-    t = buf[:NS * NST * NW].view(NS, NST, NW).cpu().double() * 0.01      # us
+    t = buf.view(40, NST, NW)[SLOT].cpu().double() * 0.01                 # us
     acc = t if acc is None else acc
     # keep the last repetition (every launch overwrites); medians over workgroups are stable
 lib.omni_debug_chain_stamps(None)
 t = acc
 names = ["qkv", "attn", "o", "gate_up", "down"]
+def nm(s):
+    return f"L{s // 5} {names[s % 5]:9s}" if s < 25 else ("head        " if s == 25 else "sampler     ")
 seg = ["W issue", "flag wait", "slabs->rstd", "x+MFMA", "barrier", "epilogue", "drain+flag"]
 print(f"B={B}; medians over 256 workgroups, us.  span = first workgroup entering -> last flag published; gap = this stage's median flag time -> next stage's median 'flags seen'")
 print(f"{'stage':12s} " + " ".join(f"{s:>11s}" for s in seg) + f" {'total':>8s} {'span':>8s} {'gap':>6s}")
@@ -49,6 +52,11 @@ for s in range(NS):
     d_ = [(x[k + 1] - x[k]).median().item() for k in range(7)]
     span = (x[7].max() - x[0].min()).item()
     gap = (t[s + 1][2].median() - x[7].median()).item() if s + 1 < NS else float("nan")
-    print(f"L{s // 5} {names[s % 5]:9s} " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {span:8.2f} {gap:6.2f}")
+    if s == 26:      # sampler: only the workgroups that own a row
+        own = (x[4] > 0)
+        x = x[:, own]
+        d_ = [(x[1] - x[0]).median().item(), (x[2] - x[1]).median().item(), 0.0, (x[4] - x[2]).median().item(), 0.0,
+              (x[6] - x[4]).median().item(), (x[7] - x[6]).median().item()]
+    print(nm(s) + " " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {span:8.2f} {gap:6.2f}")
     tot += sum(d_)
 print(f"whole pass: {(t[NS - 1][7].max() - t[0][0].min()).item():.1f} us for {NS} stages = {(t[NS - 1][7].max() - t[0][0].min()).item() / NS:.2f} us per stage")

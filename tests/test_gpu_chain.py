@@ -27,9 +27,13 @@ def _inputs(d, w, B, seed):
     return code0, w["embed"][code0], torch.randn(B, d.hidden, generator=g).to(BF16)
 
 
-@pytest.mark.parametrize("mode", [(7, 1, 1), (8, 1, 1), (8, 1, 4)], ids=["default", "all-flags", "all-flags-nap4"])
-@pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16)])
+@pytest.mark.parametrize("mode", [(2, 7, 1, 1), (1, 7, 1, 1), (2, 8, 1, 4), (2, 6, 0, 1)],
+                         ids=["all-passes", "per-pass", "all-passes-all-flags-nap4", "all-passes-wide-gate_up"])
+@pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16), ("tts-1.7b", 32)])
 def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
+    """mode = (span, flag domain, gate_up tile, poll pause): span 1 = one persistent launch per pass (layer stack only), 2 = ONE
+    launch for every pass with its head GEMM and sampler.  The 48-column gate_up tile sums the RMSNorm statistics in the
+    16-row order, which is the launch path's order only up to 32 rows: above that the comparison is on rounding distance."""
     d = get_dims(model).with_(layers=1, max_model_len=256)          # the released predictor: 5 layers, 16 groups
     w = make_weights(d, seed=33, std=0.02)
     code0, e0, lh = _inputs(d, w, B, B)
@@ -39,8 +43,8 @@ def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
         lib.omni_debug_chain_mode.argtypes = [C.c_int, C.c_int, C.c_int]; lib.omni_debug_chain_mode.restype = None
         try:
             for on in (0, 1):
-                lib.omni_debug_cp_chain(on)
-                lib.omni_debug_chain_mode(*mode)
+                lib.omni_debug_cp_chain(mode[0] if on else 0)
+                lib.omni_debug_chain_mode(*mode[1:])
                 eng = _engine(d, w, kv_dtype="bf16", num_blocks=8, max_batch=64)
                 for rep in range(3):                                 # flags / epochs carry over from call to call
                     codes, lg = eng.code_predictor(code0.to(torch.int32).cuda(), e0.cuda(), lh.cuda(), greedy=True, return_logits=True)
@@ -50,8 +54,12 @@ def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
                 assert eng.chain_error() == 0
                 res[on] = (codes.cpu(), lg.cpu(), sampled.cpu())
         finally:
-            lib.omni_debug_cp_chain(1)
+            lib.omni_debug_cp_chain(2)
             lib.omni_debug_chain_mode(7, 1, 1)
+    if mode[2] == 0 and B > 32:          # other summation order of the norm statistics: equal to rounding, not to the bit
+        assert_e2e_close(res[1][1], res[0][1], mean_tol=2e-3, max_ulps=3, what="wide gate_up tile vs launch chain")
+        assert (res[1][0] == res[0][0]).all(dim=1).float().mean().item() >= 0.8
+        return
     bad = (res[1][0] != res[0][0]).any(dim=1).nonzero().flatten().tolist()
     assert torch.equal(res[1][0], res[0][0]), f"greedy codes differ between the persistent chain and the launch chain in rows {bad}: first differing group per row {[int((res[1][0][b] != res[0][0][b]).nonzero()[0]) for b in bad]}"
     assert torch.equal(res[1][1], res[0][1]), "logits differ between the persistent chain and the launch chain"
