@@ -96,7 +96,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     const uint32_t lane16 = lane * 16;
     CH_STAMP(stamps, sidx, 0);                                           // 0: stage entered
 
-    // ---- before the flags: everything that does not depend on the previous stage
+    // ---- before the flags: everything that does not depend on the previous stage.  (The polling wave's first poll returns
+    // behind its own weight loads -- a wave's loads return in order -- but letting wave 0 fetch its share of the slice behind
+    // the flags instead measured WORSE: the predictor 1.80 -> 2.11 ms; its weights then arrive later than the activations.)
     u32x4 Wq[NTW][NT], NWq[NTW];
 #pragma unroll
     for (int d = 0; d < NTW; ++d) {
@@ -245,8 +247,8 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
     CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
-    const int pair = blockIdx.x * 4 + wave;
-    const bool active = wave < 4 && pair < a.B * q_heads;
+    const int pair = blockIdx.x * 4 + (wave & 3);               // waves 4-7 do the work: wave 0 polls the flags, and a wave's
+    const bool active = wave >= 4 && pair < a.B * q_heads;      // loads return in order -- history loads ahead of a poll delay it
     const int row = pair / q_heads, h = pair - row * q_heads;
     const int ratio = q_heads / kv_heads, kvh = h / ratio;
     const int nslots = q_heads + 2 * kv_heads;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
                        voff = ((uint32_t)row * nslots + q_heads + kv_heads + kvh) * 128;
         const uint32_t qw = coh_ld4(qrs, (qoff + 2 * lane) * 2), kw = coh_ld4(qrs, (koff + 2 * lane) * 2);
         const uint32_t vnew = coh_ld4(qrs, (voff + 2 * lane) * 2);
-        float* sq = lds + wave * 256;                         // [0,128): q in the score layout; [128,256): raw q | k dwords
+        float* sq = lds + (wave & 3) * 256;                   // [0,128): q in the score layout; [128,256): raw q | k dwords
         uint32_t* raw = reinterpret_cast<uint32_t*>(sq + 128);
         raw[lane] = qw;
         raw[64 + lane] = kw;
