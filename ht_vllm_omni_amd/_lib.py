@@ -144,6 +144,7 @@ SIGNATURES = {
     "omni_talker_layer_mlp": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_finish": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_decode_step": (i32, [vp, C.POINTER(StepIO), vp]),
+    "omni_talker_backbone_step": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_attn_out": (vp, [vp]),
     "omni_talker_mlp_out": (vp, [vp]),
     "omni_talker_prefill": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -808,8 +808,45 @@ __global__ void dbg_nop_kernel(int32_t* p) { if (threadIdx.x == 9999) p[0] = 0; 
 extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
 #endif
 
+// the backbone of one decode step (every layer; the residual stream in t->resid on entry, final residual on exit)
+static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
+    const omni_talker_desc& d = t->d;
+    if (k_bb_chain_supported(d, io->B, t->has_ar) && d.layers > 0) {
+        // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
+        const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
+        TRY(xnorm_gemm(t, t->resid, t->part, 1, t->layer[0].ln1, nullptr, t->layer[0].wqkv, t->qkv, B, (hq + 2 * hkv) * D, H, OMNI_EPI_BF16,
+                       nullptr, 0, stream));
+        for (int l = 0; l < d.layers; ++l) {
+            const omni_layer_weights& w = t->layer[l];
+            TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l], t->k_scales[l],
+                                    t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
+                                    t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
+                                    d.max_model_len, d.frag_layout, -1, stream, io->num_live));
+            TRY(k_bb_chain(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
+                           t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
+        }
+        return OMNI_OK;
+    }
+    for (int l = 0; l < d.layers; ++l) {
+        TRY(omni_talker_layer_attn(t, io, l, stream));
+        TRY(omni_talker_layer_mlp(t, io, l, stream));
+    }
+    return OMNI_OK;
+}
+
+// diagnostics / A-B timing: the backbone half of a step alone (layers + final norm + lm_head + sampler; no code predictor)
+extern "C" int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream) {
+    TRY(check_io(t, io));
+    TRY(run_backbone(t, io, stream));
+    return omni_talker_finish(t, io, stream);
+}
+
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(omni_talker_mtp(t, io, stream));
+    if (g_extra_trivial == 0) {
+        TRY(run_backbone(t, io, stream));
+        return omni_talker_finish(t, io, stream);
+    }
     for (int l = 0; l < t->d.layers; ++l) {
         TRY(omni_talker_layer_attn(t, io, l, stream));
         for (int k = 0; k < g_extra_trivial; ++k)

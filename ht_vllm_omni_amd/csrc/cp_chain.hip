@@ -18,11 +18,10 @@
 #include "coherent.cuh"
 #include "common.cuh"
 #include "gemm_frag.cuh"
+#include "chain_gemm.cuh"
 #include "kernels.h"
 #include "sampler_body.cuh"
 
-#define CH_WAVES 8
-#define CH_THREADS (CH_WAVES * 64)
 #define CH_MAX_LAYERS 8
 #define CH_LDS_FLOATS ((CH_WAVES * 6 * 4 * 64) + CH_WAVES * 64)      // combine slots of the widest stage (NT * MT = 6) + rstd area
 
@@ -53,191 +52,6 @@ struct ChainArgs {
     int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
     unsigned long long* stamps;           // debug library only: [stage][CH_NSTAMP][256] s_memrealtime ticks (100 MHz) of wave 0, or NULL
 };
-
-// ---- in-kernel timeline of a stage (libomni_talker_debug.so only; scripts/chain_timeline.py): wave 0 of every workgroup
-// stamps the constant 100 MHz counter at fixed points.  Product builds compile the macro away.
-#define CH_NSTAMP 8
-#ifdef OMNI_DEBUG_HOOKS
-#define CH_STAMP(buf, sidx, k)                                                                                          \
-    do {                                                                                                                \
-        if ((buf) != nullptr && threadIdx.x == 0)                                                                       \
-            (buf)[((size_t)(sidx) * CH_NSTAMP + (k)) * OMNI_CHAIN_WGS + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define CH_STAMP(buf, sidx, k) do { } while (0)
-#endif
-
-// ---- one skinny GEMM stage.  K = NTW * 256 (every wave owns NTW k-steps: wave, wave + 8, ...), workgroup tile = NT 16-row
-// n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
-template <int MT, int NT, int NTW, int PRO, int EPI>
-__device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
-                                           const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
-                                           int bx, int by, float* lds, ChainGate& g, bool wait, int code,
-                                           unsigned long long* stamps) {
-    const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
-    constexpr int K = NTW * CH_WAVES * 32;
-    constexpr int nsteps = K / 32;
-    constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
-    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32_BF16RND || GU8, "chain_gemm: epilogue");
-    static_assert(EPI != OMNI_EPI_RESID || (NT == 1 && PRO == 0), "chain_gemm: residual epilogue = one n-tile, plain x");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: address parts below stay in SGPRs
-    const int q = lane >> 4;
-    const int m_base = by * (MT * 16);
-    const int Mloc = min(M - m_base, MT * 16);
-    if (Mloc <= 0) {                      // no rows here (batch smaller than the grid's row range): keep the flag protocol only
-        if (wait) chain_gate_wait(g, code);
-        chain_gate_arrive(g);
-        return;
-    }
-    // every operand load is a buffer load: lane part (lane * 16 bytes) in ONE VGPR, tile / k-step part in an SGPR offset -- no
-    // 64-bit per-load address pairs (they cost the wide gate_up tile its last registers)
-    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out), wrs = coh_rsrc(W), nrs = coh_rsrc(PRO == 2 ? norm_w : W);
-    const uint32_t lane16 = lane * 16;
-    CH_STAMP(stamps, sidx, 0);                                           // 0: stage entered
-
-    // ---- before the flags: everything that does not depend on the previous stage.  (The polling wave's first poll returns
-    // behind its own weight loads -- a wave's loads return in order -- but letting wave 0 fetch its share of the slice behind
-    // the flags instead measured WORSE: the predictor 1.80 -> 2.11 ms; its weights then arrive later than the activations.)
-    u32x4 Wq[NTW][NT], NWq[NTW];
-#pragma unroll
-    for (int d = 0; d < NTW; ++d) {
-        const int ks = wave + d * CH_WAVES;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
-        if (PRO == 2 && NT * NTW < 24) NWq[d] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
-    }
-    u32x2 r_old = (u32x2){0u, 0u};
-    if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
-        // the old residual values of this thread's epilogue item: last written two or more stages ago (o_proj: by the
-        // previous layer's down_proj; down_proj: by this layer's o_proj), final since the gate of the stage in between
-        const int ml = (threadIdx.x >> 6) * 16 + (lane & 15);
-        if (ml < Mloc) r_old = coh_ld8(ors, (uint32_t)frag_off(m_base + ml, bx * 16 + 4 * (lane >> 4), N) * 2);
-    }
-
-    CH_STAMP(stamps, sidx, 1);                                           // 1: weight loads issued
-    if (wait) chain_gate_wait(g, code);
-    CH_STAMP(stamps, sidx, 2);                                           // 2: flags seen, barrier passed
-
-    // ---- behind the flags: the slabs (first: they return first) and the activation fragments, all in one round trip
-    constexpr int XROWS = MT * 16, NCH = CH_THREADS / XROWS, PE = 128 / NCH;
-    float pv[PE];
-    if (PRO == 2) {
-        const coh_rsrc_t prs = coh_rsrc(part_in);
-        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
-#pragma unroll
-        for (int e = 0; e < PE; ++e) {
-            const int p = ch + e * NCH;
-            pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * 64 + m_base + row) * 4);
-            if (p >= np_in) pv[e] = 0.f;
-        }
-    }
-    if (PRO == 2 && NT * NTW >= 24) {          // wide weight slices: the norm weights (2 KB, L2-hot) ride with the x fragments instead
-#pragma unroll
-        for (int d = 0; d < NTW; ++d) NWq[d] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
-    }
-    u32x4 Xq[NTW][MT];
-#pragma unroll
-    for (int d = 0; d < NTW; ++d)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-            Xq[d][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane16, (uint32_t)((((m_base >> 4) + i) * nsteps + wave + d * CH_WAVES) * 1024),
-                                                             OMNI_AUX_SC1);
-
-    float rstd[MT];
-    if (PRO == 2) {
-        // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
-        float s_ = 0.f;
-#pragma unroll
-        for (int e = 0; e < PE; ++e) s_ += pv[e];
-        if (XROWS <= 32) s_ = xor32_sum(s_);
-        if (XROWS <= 16) s_ = xor16_sum(s_);
-        float* red = lds + CH_WAVES * NT * MT * 4 * 64;
-        red[wave * 64 + lane] = s_;
-        __syncthreads();
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < CH_WAVES; ++w) t += red[w * 64 + lane];
-        const float rl = 1.0f / sqrtf(t / (float)K + eps);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) rstd[i] = __shfl(rl, i * 16 + (lane & 15), 64);
-    }
-
-    CH_STAMP(stamps, sidx, 3);                                           // 3: rstd known (slabs arrived, reduced)
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < NTW; ++d) {
-        if (PRO == 2) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wq[d][j], Xq[d][i], acc[j][i]);
-    }
-
-    // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores
-    f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) lds4[(wave * (NT * MT) + j * MT + i) * 64 + lane] = acc[j][i];
-    CH_STAMP(stamps, sidx, 4);                                           // 4: operands arrived, MFMAs done, partials in LDS
-    __syncthreads();
-    CH_STAMP(stamps, sidx, 5);                                           // 5: combine barrier passed
-    constexpr int LN = GU8 ? 32 : 64;
-    constexpr int ITEMS = NT * MT * LN;
-    for (int it = threadIdx.x; it < ITEMS; it += CH_THREADS) {
-        const int l = it % LN;
-        const int t = it / LN;
-        const int i = t % MT, j = t / MT;
-        const int ml = i * 16 + (l & 15);
-        if (ml >= Mloc) continue;
-        const int m = m_base + ml;
-        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f}, sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < CH_WAVES; ++w) {
-            sum += lds4[(w * (NT * MT) + j * MT + i) * 64 + l];
-            if (GU8) sum2 += lds4[(w * (NT * MT) + j * MT + i) * 64 + l + 32];
-        }
-        if (GU8) {
-            const int n = (bx * NT + j) * 8 + 4 * (l >> 4);
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = silu_mul_bf16(sum[e], sum2[e]);
-            coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])});
-        } else if (EPI == OMNI_EPI_RESID) {
-            const int n = bx * 16 + 4 * (l >> 4);
-            float rv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rv[e] = bfround(sum[e]);
-            rv[0] = bfround(bf_lo(r_old[0]) + rv[0]); rv[1] = bfround(bf_hi(r_old[0]) + rv[1]);
-            rv[2] = bfround(bf_lo(r_old[1]) + rv[2]); rv[3] = bfround(bf_hi(r_old[1]) + rv[3]);
-            coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3])});
-            float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
-            ss = xor32_sum(xor16_sum(ss));
-            if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * 64 + m) * 4, __float_as_uint(ss));
-        } else if (EPI == OMNI_EPI_F32_BF16RND) {
-            // logits: fp32 cells holding bf16-rounded values (the reference's bf16 head output), row-major
-            const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
-            coh_st16(ors, (uint32_t)((size_t)m * ldo + n) * 4,
-                     (u32x4){__float_as_uint(bfround(sum[0])), __float_as_uint(bfround(sum[1])), __float_as_uint(bfround(sum[2])),
-                             __float_as_uint(bfround(sum[3]))});
-        } else {
-            const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
-            coh_st8(ors, (uint32_t)((size_t)m * ldo + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
-        }
-    }
-    CH_STAMP(stamps, sidx, 6);                                           // 6: epilogue stores issued
-    chain_gate_arrive(g);
-    CH_STAMP(stamps, sidx, 7);                                           // 7: stores drained, barrier, flag published
-}
 
 // ---- attention stage at buffer position pos <= 15 (dense private cache: row b owns block b): one wave per (row, q head),
 // the work layout of attn_tiny_dense_kernel (paged_attn.hip).  Waves 0-3 of workgroup w take pairs 4 w .. 4 w + 3.

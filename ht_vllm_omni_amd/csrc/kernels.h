@@ -75,3 +75,8 @@ bool k_cp_chain_all_supported(const omni_talker_desc& d, int g0, int greedy, int
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
                int g0, int g1, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
                int32_t* err, const omni_chain_head* head, void* stream);
+// the backbone between two attention launches (o_proj -> gate_up -> down_proj -> next layer's qkv) as one persistent launch
+// (bb_chain.hip); supported = the 1.7B dense shape at 49-64 rows on a single rank
+bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
+int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
+               int B, float eps, uint32_t* flags, int32_t* err, void* stream);

@@ -496,11 +496,7 @@ class TalkerEngine:
         if self.tp_path:
             raise L.OmniError("backbone_step: single-rank diagnostic")
         io = self._io(B, False)
-        st = L.current_stream()
-        for l in range(self.d.layers):
-            L.check(self.lib.omni_talker_layer_attn(self.handle, C.byref(io), l, st), "omni_talker_layer_attn")
-            L.check(self.lib.omni_talker_layer_mlp(self.handle, C.byref(io), l, st), "omni_talker_layer_mlp")
-        L.check(self.lib.omni_talker_finish(self.handle, C.byref(io), st), "omni_talker_finish")
+        L.check(self.lib.omni_talker_backbone_step(self.handle, C.byref(io), L.current_stream()), "omni_talker_backbone_step")
 
     def prefill_wide(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
                      block_table: torch.Tensor | None = None, gemm: str | None = None) -> torch.Tensor:

@@ -436,6 +436,9 @@ int omni_talker_layer_attn(omni_talker* t, const omni_step_io* io, int layer, vo
 int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int layer, void* stream);
 int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* stream);
 int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream);
+/* every layer + finish, without the mtp phase: the backbone half of a step on whatever residual stream the last step left
+ * (timing attribution only: bench.py roofline.breakdown, scripts/ab_knobs.py)                                             */
+int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream);
 void* omni_talker_attn_out(omni_talker* t);   /* bf16 [max_batch,H] (TP all-reduce buffer)  */
 void* omni_talker_mlp_out(omni_talker* t);    /* bf16 [max_batch,H]                         */
 

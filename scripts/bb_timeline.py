@@ -1,0 +1,36 @@
+"""Stage timeline of the backbone segment launches (csrc/bb_chain.hip): o_proj -> gate_up -> down_proj -> next qkv, wave 0 of every
+workgroup stamps the 100 MHz counter at 8 points per stage (debug library).  Prints the LAST layer-launch of a W3 decode step.
+usage: OMNI_TALKER_DEBUG=1 python scripts/bb_timeline.py"""
+import ctypes as C, os, sys, types
+os.environ["OMNI_TALKER_DEBUG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+args = types.SimpleNamespace(allreduce="rccl", model="tts-1.7b", kv="fp8", batch=64, num_blocks=8192, device_weights=True, parallel="tp", sub_batches=1,
+                             tp_force=False, prefill_gemm="tile", warmup=0, steps=64, ttfa_steps=0, ctx_extra=0, target_ctx=352)
+torch.cuda.set_device(0)
+d, w, eng = bench.build_engine(args, 0, 1)
+lib = eng.lib
+eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+bench.setup_requests(d, eng, args)
+B = 64
+for _ in range(4):
+    eng.decode_step(B)
+torch.cuda.synchronize()
+NST, NW = 8, 256
+buf = torch.zeros(40 * NST * NW, dtype=torch.int64, device="cuda")
+lib.omni_debug_bb_stamps.argtypes = [C.c_void_p]; lib.omni_debug_bb_stamps.restype = None
+lib.omni_debug_bb_stamps(buf.data_ptr())
+eng.decode_step(B)
+torch.cuda.synchronize()
+lib.omni_debug_bb_stamps(None)
+t = buf.view(40, NST, NW)[:4].cpu().double() * 0.01
+names = ["o", "gate_up", "down", "qkv(next)"]
+seg = ["W issue", "flag wait", "slabs->rstd", "x+MFMA", "barrier", "epilogue", "drain+flag"]
+print("layer 26's segment launch (the last one with a qkv stage is layer 26; this is the step's final launch: 3 stages), us, medians over workgroups")
+print(f"{'stage':10s} " + " ".join(f"{s:>11s}" for s in seg) + f" {'total':>8s} {'span':>8s}")
+for s in range(3):
+    x = t[s]
+    d_ = [(x[k + 1] - x[k]).median().item() for k in range(7)]
+    print(f"{names[s]:10s} " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {(x[7].max() - x[0].min()).item():8.2f}")
+print(f"launch span {(t[2][7].max() - t[0][0].min()).item():.1f} us")

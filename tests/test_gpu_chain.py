@@ -80,6 +80,52 @@ def test_chain_matches_oracle_at_full_predictor_depth():
     assert (codes.cpu()[:, 1] == ref_codes[:, 1]).float().mean().item() >= 0.9
 
 
+def _decode_engine(d, w, B, kv="fp8"):
+    eng = _engine(d, w, kv_dtype=kv, num_blocks=256, max_batch=64)
+    g = torch.Generator().manual_seed(9)
+    eng.input_ids[:B] = torch.randint(1, d.codebook, (B,), generator=g).to(torch.int32).cuda()
+    eng.last_hidden[:B] = torch.randn(B, d.hidden, generator=g).to(BF16).cuda()
+    eng.text_step[:B] = (torch.randn(B, d.hidden, generator=g) * 0.02).to(BF16).cuda()
+    eng.positions[:B] = 17
+    eng.seq_lens[:B] = 18
+    for b in range(B):
+        eng.block_table[b, :3] = torch.tensor([1 + 3 * b, 2 + 3 * b, 3 + 3 * b], dtype=torch.int32)
+    for c in eng.kv_caches:        # a history to attend to (same bytes in every engine built from this seed)
+        c.view(torch.uint8).copy_(torch.randint(0, 120, c.view(torch.uint8).shape, generator=g, dtype=torch.uint8).cuda())
+    eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+    return eng
+
+
+@pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16")])
+def test_backbone_segment_chain_is_bit_identical_to_the_launch_path(B, kv):
+    """o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer (csrc/bb_chain.hip) against the
+    launch-per-op backbone of the same library at the 1.7B shape: logits, hidden state, sampled ids, codes and every KV byte
+    of three decode steps are identical; no flag wait times out."""
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
+    w = make_weights(d, seed=8, std=0.02)
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_bb_chain.argtypes = [C.c_int]; lib.omni_debug_bb_chain.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_bb_chain(on)
+                eng = _decode_engine(d, w, B, kv)
+                outs = []
+                for _ in range(3):
+                    eng.decode_step(B)
+                    outs.append((eng.logits[:B].clone(), eng.last_hidden[:B].clone(), eng.input_ids[:B].clone(), eng.audio_codes[:B].clone()))
+                torch.cuda.synchronize()
+                assert eng.chain_error() == 0
+                res[on] = (outs, [c.view(torch.uint8).clone() for c in eng.kv_caches])
+        finally:
+            lib.omni_debug_bb_chain(1)
+    for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        for name, x, y in zip(("logits", "hidden", "ids", "codes"), a, b):
+            assert torch.equal(x, y), f"step {s}: {name} differ between the backbone chain and the launch path"
+    for l, (x, y) in enumerate(zip(res[1][1], res[0][1])):
+        assert torch.equal(x, y), f"KV cache of layer {l} differs"
+
+
 def test_chain_steps_replay_in_a_graph_and_stay_deterministic():
     """Whole decode steps with the chain inside a captured hipGraph: two engines fed the same requests produce the same
     codes step after step (flags and epochs advance on the device across replays), error word stays 0."""
