@@ -27,7 +27,9 @@
 // n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
 // XG = k-steps of x (and norm weights) in flight per wave behind the flags: 0 = the wave's whole share at once (small K), else
 // a ring refilled as the MFMAs retire steps (fully unrolled: every load unconditional, hipcc counts vmcnt).
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0>
+// WRING: the weight fragments ride in the same ring instead of being fetched whole ahead of the flags (wide slices under a
+// tight register budget; the segment kernel's prefetch wave has them in L2 by then).
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, bool WRING = false>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -59,14 +61,17 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     // ---- before the flags: everything that does not depend on the previous stage.  (The polling wave's first poll returns
     // behind its own weight loads -- a wave's loads return in order -- but letting wave 0 fetch its share of the slice behind
     // the flags instead measured WORSE: the predictor 1.80 -> 2.11 ms; its weights then arrive later than the activations.)
-    u32x4 Wq[NTW][NT], NWq[G];
+    constexpr int WS = WRING ? G : NTW;                                   // weight slots held at a time
+    u32x4 Wq[WS][NT], NWq[G];
+    if (!WRING) {
 #pragma unroll
-    for (int d = 0; d < NTW; ++d) {
-        const int ks = wave + d * CH_WAVES;
+        for (int d = 0; d < NTW; ++d) {
+            const int ks = wave + d * CH_WAVES;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
-        if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
+            for (int j = 0; j < NT; ++j)
+                Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
+            if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
+        }
     }
     u32x2 r_old = (u32x2){0u, 0u};
     if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
@@ -95,6 +100,11 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     }
     u32x4 Xq[G][MT];
     auto load_x = [&](int d) {           // k-step d of this wave's share into ring slot d % G
+        if (WRING) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                Wq[d % G][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + wave + d * CH_WAVES) * 1024), 0);
+        }
         if (PRO == 2 && !NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -131,14 +141,16 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < NTW; ++d) {
-        u32x4 Xn[MT];
+        u32x4 Xn[MT], Wn[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) Xn[i] = PRO == 2 ? xnorm_frag(Xq[d % G][i], NWq[d % G], rstd[i]) : Xq[d % G][i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Wn[j] = Wq[WRING ? d % G : d][j];
         if (d + G < NTW) load_x(d + G);                                   // refill the slot just consumed
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wq[d][j], Xn[i], acc[j][i]);
+            for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wn[j], Xn[i], acc[j][i]);
     }
 
     // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores
