@@ -263,7 +263,7 @@ def main():
                          cp_top_k=50)
     setup_requests(d, eng, args)                 # untimed: hipBLASLt handle / heuristics, code objects
     lens, prefill_ms = setup_requests(d, eng, args)
-    log(f"[rank {rank}] prefill of {sum(lens)} prompt tokens: {prefill_ms:.1f} ms (hipBLASLt GEMMs + native norm/rope/attention)")
+    log(f"[rank {rank}] prefill of {sum(lens)} prompt tokens: {prefill_ms:.1f} ms ({'omni_gemm_tile (hand-written MFMA)' if args.prefill_gemm == 'tile' else 'hipBLASLt'} GEMMs + native norm/rope/attention)")
 
     # ---- capture the whole decode step as one hipGraph
     graph, use_graph = None, not args.no_graph
@@ -322,6 +322,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ev_ms = e0.elapsed_time(e1) / args.steps
+    # a timed-out flag wait (peer all-reduce, persistent chains) makes the remaining steps wrong AND faster: void the run
+    # on every rank when any rank saw one
+    dev_err = int(eng.chain_error() != 0) + 2 * int(eng.ar is not None and eng.ar.error() != 0)
+    if dist is not None:
+        emax = torch.tensor([dev_err], dtype=torch.int32, device="cuda")
+        dist.all_reduce(emax, op=dist.ReduceOp.MAX)
+        dev_err = int(emax.item())
+    if dev_err:
+        log(f"[rank {rank}] in-kernel hand-off timed out during the timed region (code {dev_err}: 1 = chain flags, 2 = peer all-reduce): result void")
+        sys.exit(3)
 
     # ---- diagnostics (after the timed region): the backbone half of the step alone, as its own graph
     bb_ms = None

@@ -26,7 +26,7 @@
 #include "kernels.h"
 
 #define AR_MAX_WORLD 8
-#define AR_SPIN_BOUND (1u << 22)        // x ~64-cycle sleeps: some 0.1 s at 2.4 GHz
+#define AR_SPIN_BOUND (1u << 27)        // x ~64-cycle sleeps: several seconds at 2.4 GHz (a rank may be late by a graph upload, a GC pause)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

@@ -640,6 +640,17 @@ class TalkerEngine:
             L.check(rc, "omni_talker_chain_error")
         return rc
 
+    def check_device_errors(self) -> None:
+        """The bounded spins of the in-kernel hand-offs (peer all-reduce flags across ranks, stage flags of the persistent
+        chains) record a time-out in a sticky device word and carry on with wrong data: whoever consumes step outputs must
+        look at those words.  Raises RuntimeError -- the reference's convention for a dead stage (engine core
+        sees the exception) -- instead of handing wrong audio on."""
+        err = self.chain_error()
+        if err:
+            raise RuntimeError(f"persistent-chain flag wait timed out (stage code {err:#x}): the step's outputs are invalid")
+        if self.ar is not None and self.ar.error() != 0:
+            raise RuntimeError(f"peer all-reduce: a rank did not arrive in time (error word {self.ar.error()}): the step's outputs are invalid")
+
     def sample_rows(self, logits: torch.Tensor, rows: torch.Tensor, *, seen=None, steps=None) -> torch.Tensor:
         """First token after prefill for batch rows `rows` (int64 device indices), each with its own request's parameters."""
         par = {k: getattr(self, "row_" + k).index_select(0, rows) for k in self.ROW_KEYS}

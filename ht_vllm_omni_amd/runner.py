@@ -17,6 +17,7 @@ are inert.
 from __future__ import annotations
 
 import logging
+import os
 import zlib
 from dataclasses import dataclass, field
 from typing import Any
@@ -72,6 +73,33 @@ class _StepState:
     prefill_spans: dict[int, tuple[int, int, torch.Tensor]]  # row -> (start, n, hidden[n,H])
 
 
+class _Range:
+    """Profiler range with the reference's phase names (gpu_ar_model_runner.py:138 preprocess, :293 forward, :314 postprocess,
+    :454 sample, :514 bookkeep): a torch.profiler record_function AND a roctx range (torch.cuda.nvtx is roctx on ROCm, so the
+    names show up in `rocprofv3 --marker-trace` too).  Off unless the worker's profile() -- or OMNI_PROFILE_RANGES=1 -- turned
+    ranges on: two Python context managers per phase are not free at 4 ms per step."""
+    enabled = os.environ.get("OMNI_PROFILE_RANGES") == "1"
+
+    def __init__(self, name: str):
+        self.name, self.rf, self.pushed = name, None, False
+
+    def __enter__(self):
+        if _Range.enabled:
+            self.rf = torch.profiler.record_function(self.name)
+            self.rf.__enter__()
+            if torch.cuda.is_available():
+                torch.cuda.nvtx.range_push(self.name)
+                self.pushed = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.pushed:
+            torch.cuda.nvtx.range_pop()
+        if self.rf is not None:
+            self.rf.__exit__(*exc)
+        return False
+
+
 def request_seed(req_id: str, sp: SamplingParams) -> int:
     """RNG key of a request: its own seed, else one derived from the request id (distinct noise per unseeded request)."""
     return int(sp.seed) & 0xFFFFFFFF if sp.seed is not None else (zlib.crc32(req_id.encode()) ^ 0x9E3779B9) & 0xFFFFFFFF
@@ -94,6 +122,8 @@ class MI355XARModelRunner:
         self.kv_caches = engine.kv_caches               # runner-owned list, one [2,nb,bs,h,d] tensor per layer
         self.kv_transfer_manager = kv_transfer or OmniKVTransferManager(None)
         self.requests: dict[str, RequestState] = {}
+        self.model_intermediate_buffer: dict[str, dict[str, Any]] = {}      # gpu_model_runner.py:60
+        self.gpu_resident_buffer_keys: set[str] = set()                      # model hook (gpu_model_runner.py:1337-1339)
         self.rows: list[str] = []                       # input_batch.req_ids (row order)
         self.preempted: dict[str, RequestState] = {}    # state of preempted requests (vLLM keeps self.requests across preemption)
         self.execute_model_state: _StepState | None = None
@@ -186,6 +216,8 @@ class MI355XARModelRunner:
             self.rows.pop()
             self._reset_row(last)
             del self.requests[rid]
+            if rid not in self.preempted:
+                self.model_intermediate_buffer.pop(rid, None)                # gpu_model_runner.py:259
         # new requests (a preempted request re-enters here with fresh blocks and num_computed_tokens = 0)
         for nr in so.scheduled_new_reqs:
             if len(self.rows) >= self.max_num_seqs:
@@ -202,7 +234,7 @@ class MI355XARModelRunner:
                     raise ValueError(f"request {nr.req_id}: thinker outputs given but the runner has no prompt_builder")
                 prompt, upd = self.prompt_builder.from_info(info)     # qwen3_omni.py:678-809
                 pe, tail, pad = prompt.embeds, upd.get("trailing_text_hidden"), prompt.tts_pad
-                info.update(upd)
+                info.update(upd)      # (merged into model_intermediate_buffer below, once the request is admitted)
             elif pe is None and getattr(self.prompt_builder, "from_info", None) is not None and (info.get("text") or info.get("input_ids") is not None):
                 # Qwen3-TTS request (text / task_type / speaker / voice_clone_prompt): _build_prompt_embeds on the device
                 # (prompt_builder_tts.TTSTalkerPromptBuilder = qwen3_tts_talker.py:1211-1567)
@@ -222,6 +254,8 @@ class MI355XARModelRunner:
                               tail=None if tail is None else tail.to(device=dev, dtype=BF16).reshape(-1, self.d.hidden),
                               tts_pad=pad.to(device=dev, dtype=BF16).reshape(-1), info=info)
             self.requests[nr.req_id] = st
+            # per-request model state the stage hooks read and extend (gpu_model_runner.py:60,371,935): same dict as st.info
+            self.model_intermediate_buffer[nr.req_id] = st.info
             r = len(self.rows)
             self.rows.append(nr.req_id)
             self._reset_row(r)
@@ -244,6 +278,27 @@ class MI355XARModelRunner:
                 dev = e.block_table.device
                 e.block_table[r, len(st.block_ids):len(st.block_ids) + len(new)] = torch.as_tensor(new, dtype=torch.int32, device=dev)
                 st.block_ids.extend(new)
+
+    def _update_intermediate_buffer(self, req_id: str, upd: dict) -> None:
+        """Merge a per-request update into ``model_intermediate_buffer`` (V/worker/gpu_model_runner.py:1330-1353, known answers
+        T/worker/test_omni_gpu_model_runner.py:172-227): tensors go to the host unless the key is declared GPU-resident, tensors
+        inside lists likewise, successive updates accumulate, an empty update or an unknown request is a no-op, and the same
+        dict stays reachable as the request state's ``additional_information_cpu`` (here ``info``)."""
+        if not isinstance(upd, dict) or not upd:
+            return
+        st = self.requests.get(req_id)
+        if st is None:
+            return
+        existing = self.model_intermediate_buffer.setdefault(req_id, {})
+        for k, v in upd.items():
+            if isinstance(v, torch.Tensor):
+                existing[k] = v.detach().clone() if k in self.gpu_resident_buffer_keys else v.detach().to("cpu").contiguous()
+            elif isinstance(v, list):
+                existing[k] = [(i.detach().to("cpu").contiguous() if isinstance(i, torch.Tensor) else i) for i in v]
+            else:
+                existing[k] = v
+        st.info = existing
+        st.additional_information_cpu = existing
 
     @staticmethod
     def _row_sampling(req_id: str, sp) -> dict:
@@ -329,12 +384,13 @@ class MI355XARModelRunner:
         if self.execute_model_state is not None:
             raise RuntimeError("State error: sample_tokens() must be called after execute_model() returns None.")
         e = self.engine
-        # [Omni] KV transfer BEFORE updating states (which removes finished requests)
-        self.kv_extracted_req_ids = self.kv_transfer_manager.handle_finished_requests_kv_transfer(
-            finished_reqs=scheduler_output.finished_requests_needing_kv_transfer, kv_caches=self.kv_caches,
-            block_size=e.block_size, cache_dtype=str(e.kv_dtype), kv_scales=getattr(e, "kv_scales", None),
-            tp_rank=getattr(e, "tp_rank", 0), tp_size=getattr(e, "tp_size", 1)) or None
-        self._update_states(scheduler_output)
+        with _Range("gpu_model_runner: preprocess"):
+            # [Omni] KV transfer BEFORE updating states (which removes finished requests)
+            self.kv_extracted_req_ids = self.kv_transfer_manager.handle_finished_requests_kv_transfer(
+                finished_reqs=scheduler_output.finished_requests_needing_kv_transfer, kv_caches=self.kv_caches,
+                block_size=e.block_size, cache_dtype=str(e.kv_dtype), kv_scales=getattr(e, "kv_scales", None),
+                tp_rank=getattr(e, "tp_rank", 0), tp_size=getattr(e, "tp_size", 1)) or None
+            self._update_states(scheduler_output)
         if not scheduler_output.total_num_scheduled_tokens:
             if self.kv_extracted_req_ids:
                 # nothing to run but a KV extraction happened: ack it now (the reference returns the bare empty output,
@@ -425,7 +481,8 @@ class MI355XARModelRunner:
                 raise RuntimeError(f"text-step table covers {len(idx)} rows, the step has {nd} decode rows (stale table)")
             self._tt_pos[:nd] += 1
             torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
-            self._run_decode(nd)
+            with _Range("gpu_model_runner: forward"):      # the native step: talker_mtp, backbone, compute_logits AND the sampler
+                self._run_decode(nd)
         self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans)
         return None
 
@@ -485,14 +542,25 @@ class MI355XARModelRunner:
         e = self.engine
         nd = len(stt.decode_rows)
         Q = self.d.num_code_groups
-        # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550)
-        ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
-        hid_cpu = e.last_hidden[:len(self.rows)].cpu()
-        codes_cpu = e.audio_codes[:nd].cpu() if nd else None
-        codes_list = codes_cpu.tolist() if nd else []
+        # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550).  The sampler itself ran inside the
+        # native step; the "sample" range is the wait for it plus the copy of the ids
+        with _Range("gpu_model_runner: sample"):
+            ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
+        # the copy above synchronised the step: every 16th step (and whenever a request leaves) look at the sticky error words
+        # of the in-kernel hand-offs (a timed-out flag wait produces wrong data, not a hang)
+        self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
+        if (self._steps_since_check >= 16 or stt.scheduler_output.finished_req_ids) and hasattr(e, "check_device_errors"):
+            self._steps_since_check = 0
+            e.check_device_errors()
+        with _Range("gpu_model_runner: postprocess"):
+            hid_cpu = e.last_hidden[:len(self.rows)].cpu()
+            codes_cpu = e.audio_codes[:nd].cpu() if nd else None
+            codes_list = codes_cpu.tolist() if nd else []
         # (pinned staging + one sync was tried: the CPU then reads uncached pinned memory -- 37 ms per step)
         sched = stt.scheduler_output.num_scheduled_tokens
         req_ids, sampled, pooler = [], [], []
+        bookkeep = _Range("gpu_model_runner: bookkeep")
+        bookkeep.__enter__()
         for r, rid in enumerate(self.rows):
             if rid not in sched or sched[rid] <= 0:
                 continue
@@ -518,6 +586,7 @@ class MI355XARModelRunner:
                     sampled.append([])
             req_ids.append(rid)
             pooler.append(payload)
+        bookkeep.__exit__(None, None, None)
         return OmniModelRunnerOutput(
             req_ids=req_ids, req_id_to_index={rid: i for i, rid in enumerate(req_ids)}, sampled_token_ids=sampled,
             pooler_output=pooler if self.engine_output_type != "text" else None, kv_extracted_req_ids=kv_extracted,

@@ -117,8 +117,10 @@ def setup_peer_allreduce(hidden: int, rows: int, rank: int, world: int, group=No
     import torch.distributed as dist
     from .engine import frag_shuffle
 
+    dev = "cuda" if torch.cuda.is_available() else "cpu"      # cpu: the gloo tests of the fall-back agreement
+
     def agree(ok: bool) -> bool:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         return int(flag.item()) == 1
 

@@ -130,8 +130,11 @@ class MI355XARWorker:
         torch.cuda.set_device(self.device)
         if self.tp_size > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.distributed.init_process_group("nccl", init_method=self.distributed_init_method or "env://",
-                                                 rank=self.rank, world_size=self.tp_size, device_id=self.device)
+            # "nccl" IS RCCL on ROCm; OMNI_DIST_BACKEND=gloo only for tests that put two ranks on ONE GPU (RCCL refuses that)
+            backend = os.environ.get("OMNI_DIST_BACKEND", "nccl")
+            kw = {"device_id": self.device} if backend == "nccl" else {}
+            torch.distributed.init_process_group(backend, init_method=self.distributed_init_method or "env://",
+                                                 rank=self.rank, world_size=self.tp_size, **kw)
         torch.cuda.empty_cache()
         self.init_free, self.init_total = torch.cuda.mem_get_info(self.device)
 
@@ -211,6 +214,8 @@ class MI355XARWorker:
 
     # ---- profiling (base.py:49-76; range names of gpu_ar_model_runner.py:138,293,314,454,514 via torch.profiler)
     def profile(self, is_start: bool = True, profile_prefix: str | None = None):
+        from .runner import _Range
+        _Range.enabled = bool(is_start) or os.environ.get("OMNI_PROFILE_RANGES") == "1"      # the reference's five phase names as ranges
         if is_start:
             self._profiler = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU,
                                                                 torch.profiler.ProfilerActivity.CUDA])

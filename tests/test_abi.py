@@ -105,3 +105,20 @@ def test_stale_library_is_refused(tmp_path, monkeypatch):
     finally:
         open(stamp, "w").write(good)
     _lib._open(_lib.LIB_PATH, False)
+
+
+def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
+    """SURVEY 8b / north_star: the per-op entry points as PyTorch custom ops (`TORCH_LIBRARY(mi355x_omni)` in the survey's
+    words; registered through torch.library over the same C symbols).  On a host without a GPU the ops exist, and a CPU
+    tensor fails loudly -- there is no CPU kernel to fall back to."""
+    import pytest
+    import torch
+    from ht_vllm_omni_amd import torch_ops as T
+    for n in ("rmsnorm_residual_", "qknorm_rope_kvwrite_", "paged_attn_decode", "paged_attn_prefill", "silu_mul", "skinny_gemm",
+              "lmhead_mask", "topk_sample", "allreduce_oneshot_"):
+        assert n in T.OPS and hasattr(torch.ops.mi355x_omni, n), n
+    assert "Tensor(b!) out" in str(torch.ops.mi355x_omni.rmsnorm_residual_.default._schema)      # caller-allocated output: graph-safe
+    with pytest.raises(NotImplementedError):
+        torch.ops.mi355x_omni.silu_mul(torch.zeros(2, 8, dtype=torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        torch.ops.mi355x_omni.topk_sample(torch.zeros(2, 8), None, None, True, 1.0, 0, 1.0, 1.0, 0, 1, 0, False)

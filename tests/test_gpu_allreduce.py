@@ -227,3 +227,65 @@ def test_two_processes_exchange_ipc_handles_and_allreduce():
         p.join(60)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}, res
+
+
+def _tp_worker_proc(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMNI_DIST_BACKEND="gloo")
+    from ht_vllm_omni_amd.payloads import (OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams,
+                                           serialize_additional_information)
+    from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
+    d = get_dims("tts-1.7b").with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
+    w = make_weights(d, seed=17, std=0.02)
+    sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
+    cfg = make_config(d, kv_cache_dtype="fp8", max_num_seqs=4, tensor_parallel_size=world, num_gpu_blocks_override=32, weights=w,
+                      default_sampling_params=sp)
+    wk = MI355XARWorker(cfg, local_rank=0, rank=rank, distributed_init_method=f"tcp://127.0.0.1:{port}")   # both ranks on the box's one GPU
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    wired = wk.peer_allreduce is not None and wk.engine.ar is wk.peer_allreduce and wk.engine.tp_path
+    wk.engine.set_sampling(cp_greedy=1)
+    wk.compile_or_warm_up_model()
+    g = torch.Generator().manual_seed(3)
+    spec = {"a": 5, "b": 21}
+    blocks = {"a": [1, 2], "b": [3, 4, 5]}
+    reqs = []
+    for k, n in spec.items():
+        info = serialize_additional_information({"talker_prompt_embeds": torch.randn(n, d.hidden, generator=g),
+                                                 "tts_pad_embed": torch.randn(d.hidden, generator=g)})      # the reference's wire type
+        reqs.append(OmniNewRequestData(req_id=k, prompt_token_ids=[d.codec_pad_id] * n, block_ids=(blocks[k],), sampling_params=sp,
+                                       additional_information=info))
+    wk.execute_model(OmniSchedulerOutput(scheduled_new_reqs=reqs, num_scheduled_tokens=dict(spec), total_num_scheduled_tokens=sum(spec.values())))
+    out = wk.sample_tokens(None)
+    ids, codes = [out.sampled_token_ids], []
+    for _ in range(3):
+        wk.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a", "b"], new_block_ids=[None, None]),
+                                             num_scheduled_tokens={"a": 1, "b": 1}, total_num_scheduled_tokens=2))
+        out = wk.sample_tokens(None)
+        ids.append(out.sampled_token_ids)
+        codes.append([p["audio_codes"].tolist() for p in out.pooler_output])
+    torch.cuda.synchronize()
+    q.put((rank, wired, wk.peer_allreduce.error() if wk.peer_allreduce else -1, ids, codes))
+    torch.distributed.barrier()
+    wk.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_two_worker_processes_run_the_tp_step_on_the_peer_allreduce():
+    """the worker surface vLLM's executor drives (init_device -> load_model -> initialize_from_config ->
+    compile_or_warm_up_model -> execute_model / sample_tokens), one PROCESS per tensor-parallel rank, wires the checked
+    peer-mapped all-reduce into the engine by itself; both ranks decode the same ids and codes, no peer wait timed out.
+    (Both ranks share this box's one GPU, so the group is gloo here; on a multi-GPU node the same code runs over RCCL.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_tp_worker_proc, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True], "the worker did not wire the peer all-reduce into its engine"
+    assert [r[2] for r in res] == [0, 0], "a peer wait timed out"
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4], "the ranks decoded different ids / codes"
+    assert all(len(step[0]) == 1 and len(step[1]) == 1 for step in res[0][3]), res[0][3]

@@ -740,3 +740,55 @@ def test_moe_experts_expert_parallel_and_fp8_weights(ops, H, E, K, I, Is, T, ep)
     ref_o = _moe_oracle_with_routing(x.cpu(), w8, idx.cpu().long(), wts.cpu())
     assert_e2e_close(got8.cpu(), ref_o, mean_tol=5e-4 * max(1.0, float(ref_o.float().abs().max())), max_ulps=2, what="fp8-weight experts vs oracle")
     assert float((got8.float() - full.float()).abs().mean()) > 0          # the quantisation is really in effect
+
+
+def test_torch_library_ops_run_the_same_kernels_as_the_ctypes_wrappers():
+    """torch.ops.mi355x_omni.* (torch_ops.py) against ops.* on the same inputs: bit-identical (same C entry points)."""
+    import ht_vllm_omni_amd.torch_ops  # noqa: F401  (registers the ops)
+    from ht_vllm_omni_amd import _lib as LL, ops as OP
+    t = torch.ops.mi355x_omni
+    g = torch.Generator().manual_seed(0)
+    M, H, I = 24, 512, 768
+    x = torch.randn(M, H, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(H, generator=g) * 0.1 + 1).to(torch.bfloat16).cuda()
+    res = torch.randn(M, H, generator=g).to(torch.bfloat16).cuda()
+    # rmsnorm_residual_: out-variant, residual updated in place
+    r1, r2 = res.clone(), res.clone()
+    out = torch.empty_like(x)
+    t.rmsnorm_residual_(None, x, r1, w, out, 1e-6)
+    ref = OP.rmsnorm(None, w, 1e-6, delta=x, residual=r2)
+    assert torch.equal(out, ref) and torch.equal(r1, r2)
+    # skinny_gemm / lmhead_mask / silu_mul
+    W = (torch.randn(2 * I, H, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    y = t.skinny_gemm(x, W, None, None, LL.EPI_BF16, 0)
+    assert torch.equal(y, OP.gemm(x, W))
+    assert torch.equal(t.silu_mul(y), OP.silu_mul(y))
+    mask = (torch.arange(2 * I) % 3 != 0).to(torch.uint8).cuda()
+    lg = t.lmhead_mask(x, W, mask, True)
+    assert torch.equal(lg, OP.gemm(x, W, epilogue=LL.EPI_F32_BF16RND, mask=mask)) and torch.isinf(lg[:, 0]).all()
+    # topk_sample
+    steps = torch.full((M,), 3, dtype=torch.int32).cuda()
+    a = t.topk_sample(lg, None, steps.clone(), False, 0.9, 50, 1.0, 1.0, 42, 1, 0, False)
+    b = OP.sample(lg, greedy=False, temperature=0.9, top_k=50, seed=42, steps=steps.clone())
+    assert torch.equal(a, b)
+    # qknorm_rope_kvwrite_ + paged_attn_decode over a small fp8 cache
+    hq, hkv, D, bs, nb = 4, 2, 128, 16, 8
+    T_ = 20
+    qkv = torch.randn(T_, (hq + 2 * hkv) * D, generator=g).to(torch.bfloat16).cuda()
+    qn = torch.ones(D, dtype=torch.bfloat16).cuda(); kn = torch.ones(D, dtype=torch.bfloat16).cuda()
+    pos = torch.arange(T_, dtype=torch.int32).cuda()
+    cs = OP.rope_table(64, D, 1e6).cuda()
+    slots = (torch.arange(T_) + bs).to(torch.int64).cuda()
+    caches = [[torch.zeros(nb, bs, hkv, D, dtype=torch.uint8).cuda() for _ in range(2)] for _ in range(2)]
+    q1 = torch.empty(T_, hq * D, dtype=torch.bfloat16).cuda()
+    t.qknorm_rope_kvwrite_(qkv, qn, kn, pos, cs, slots, q1, caches[0][0], caches[0][1], None, None, hq, hkv, D, 1e-6, LL.KV_FP8, 1.0, 1.0)
+    q2 = OP.qknorm_rope_kvwrite(qkv, qn, kn, pos, cs, slots, caches[1][0], caches[1][1], q_heads=hq, kv_heads=hkv, head_dim=D, eps=1e-6,
+                                kv_dtype=LL.KV_FP8)
+    assert torch.equal(q1, q2) and torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1], caches[1][1])
+    bt = torch.tensor([[1, 2, 0, 0]], dtype=torch.int32).cuda()
+    sl = torch.tensor([T_], dtype=torch.int32).cuda()
+    qd = q1[-1:].contiguous()
+    o1 = t.paged_attn_decode(qd, caches[0][0], caches[0][1], bt, sl, None, None, hq, hkv, D, bs, LL.KV_FP8, 1.0, 1.0, 64)
+    o2 = OP.paged_attn_decode(qd, caches[0][0], caches[0][1], bt, sl, q_heads=hq, kv_heads=hkv, head_dim=D, block_size=bs, kv_dtype=LL.KV_FP8,
+                              max_seq_len=64)
+    assert torch.equal(o1, o2)

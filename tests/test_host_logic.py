@@ -258,10 +258,14 @@ def test_runner_per_request_sampling_rows_follow_their_request():
                                           num_scheduled_tokens={"a": 1, "c": 1, "d": 1}, total_num_scheduled_tokens=3))
     run.sample_tokens(None)
     assert sorted(run.rows) == ["a", "c", "d"] and row("a")[0] == 1 and row("c")[1] == 1.3
+    # top_p < 1 with top_k disabled (a common vLLM setting) is served as top_k = 1024; a non-positive temperature
+    # with sampling is refused BEFORE the request touches the runner's state
     bad = _new_req(d, "z", 3, [9])
-    bad.sampling_params = SamplingParams(temperature=0.8, top_k=0, top_p=0.5)
-    with pytest.raises(ValueError, match="top_p"):
+    bad.sampling_params = SamplingParams(temperature=-1.0, top_k=0, top_p=0.5)
+    rows_before = list(run.rows)
+    with pytest.raises(ValueError, match="temperature"):
         run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[bad], num_scheduled_tokens={"z": 3}, total_num_scheduled_tokens=3))
+    assert run.rows == rows_before and "z" not in run.requests
 
 
 def test_runner_rejects_missing_prompt_embeds_and_overflow():
