@@ -822,6 +822,10 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
                                     t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
                                     t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
                                     d.max_model_len, d.frag_layout, -1, stream, io->num_live));
+            if (k_bb_engine_enabled())
+                TRY(k_bb_engine(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
+                                t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
+            else
             TRY(k_bb_chain(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
         }

@@ -27,9 +27,10 @@
 // n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
 // XG = k-steps of x (and norm weights) in flight per wave behind the flags: 0 = the wave's whole share at once (small K), else
 // a ring refilled as the MFMAs retire steps (fully unrolled: every load unconditional, hipcc counts vmcnt).
-// WRING: the weight fragments ride in the same ring instead of being fetched whole ahead of the flags (wide slices under a
-// tight register budget; the segment kernel's prefetch wave has them in L2 by then).
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, bool WRING = false>
+// WSRC: where the weight fragments come from -- 0: fetched whole into registers ahead of the flags; 1: they ride in the x ring
+// (wide slices under a tight register budget); 2: the workgroup's LDS FIFO that loader waves fill by LDS-DMA (bb_engine.hip):
+// round d = the k-steps 8 d .. 8 d + 7 of every n-tile = 8 NT pieces in the order [tile][k-step], wave w reads piece (j, w).
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -40,6 +41,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     constexpr int K = NTW * CH_WAVES * 32;
     constexpr int nsteps = K / 32;
     constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
+    constexpr bool WRING = WSRC == 1, WFIFO = WSRC == 2;
     static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32_BF16RND || GU8, "chain_gemm: epilogue");
     static_assert(EPI != OMNI_EPI_RESID || (NT == 1 && PRO == 0), "chain_gemm: residual epilogue = one n-tile, plain x");
     const int lane = threadIdx.x & 63;
@@ -61,17 +63,17 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     // ---- before the flags: everything that does not depend on the previous stage.  (The polling wave's first poll returns
     // behind its own weight loads -- a wave's loads return in order -- but letting wave 0 fetch its share of the slice behind
     // the flags instead measured WORSE: the predictor 1.80 -> 2.11 ms; its weights then arrive later than the activations.)
-    constexpr int WS = WRING ? G : NTW;                                   // weight slots held at a time
+    constexpr int WS = WFIFO ? 1 : (WRING ? G : NTW);                     // weight slots held at a time
     u32x4 Wq[WS][NT], NWq[G];
-    if (!WRING) {
 #pragma unroll
-        for (int d = 0; d < NTW; ++d) {
-            const int ks = wave + d * CH_WAVES;
+    for (int d = 0; d < NTW; ++d) {
+        const int ks = wave + d * CH_WAVES;
+        if (WSRC == 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
-            if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
         }
+        if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
     }
     u32x2 r_old = (u32x2){0u, 0u};
     if (EPI == OMNI_EPI_RESID && threadIdx.x < MT * 64) {
@@ -122,9 +124,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int e = 0; e < PE; ++e) s_ += pv[e];
         if (XROWS <= 32) s_ = xor32_sum(s_);
         if (XROWS <= 16) s_ = xor16_sum(s_);
-        float* red = lds + CH_WAVES * NT * MT * 4 * 64;
+        float* red = lds + CH_WAVES * (NT * MT > 6 ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
         red[wave * 64 + lane] = s_;
-        __syncthreads();
+        chain_barrier(g);
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < CH_WAVES; ++w) t += red[w * 64 + lane];
@@ -144,29 +146,45 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         u32x4 Xn[MT], Wn[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) Xn[i] = PRO == 2 ? xnorm_frag(Xq[d % G][i], NWq[d % G], rstd[i]) : Xq[d % G][i];
+        if (WFIFO) {
+            const unsigned first = g.piece_base + (unsigned)d * (8 * NT);
+            eng_wait_ready(g, first + (NT - 1) * 8 + wave + 1);               // this wave's last piece of the round (pieces land in order)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Wn[j] = Wq[WRING ? d % G : d][j];
+            for (int j = 0; j < NT; ++j)
+                Wn[j] = *reinterpret_cast<const u32x4*>(g.fifo + (size_t)((first + j * 8 + wave) % ENG_FIFO_PIECES) * 1024 + lane16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Wn[j] = Wq[WRING ? d % G : d][j];
+        }
         if (d + G < NTW) load_x(d + G);                                   // refill the slot just consumed
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(Wn[j], Xn[i], acc[j][i]);
+        if (WFIFO) eng_release(g, wave, g.piece_base + (unsigned)(d + 1) * (8 * NT));      // the MFMAs above hold the fragments: the pieces are free
     }
 
-    // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores
+    // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores.  More than 6 tiles (the
+    // backbone's gate_up: 12) go through the combine area in two passes of NT * MT / 2 tiles, so that it stays at 48 KB
+    constexpr int PASSES = NT * MT > 6 ? 2 : 1, TP = NT * MT / PASSES;
+    static_assert(NT * MT % PASSES == 0, "chain_gemm: tiles per combine pass");
     f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
+    constexpr int LN = GU8 ? 32 : 64;
+    constexpr int ITEMS = TP * LN;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+    if (pass > 0) chain_barrier(g);                                      // the previous pass's readers are done with the slots
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) lds4[(wave * (NT * MT) + j * MT + i) * 64 + lane] = acc[j][i];
-    CH_STAMP(stamps, sidx, 4);                                           // 4: operands arrived, MFMAs done, partials in LDS
-    __syncthreads();
-    CH_STAMP(stamps, sidx, 5);                                           // 5: combine barrier passed
-    constexpr int LN = GU8 ? 32 : 64;
-    constexpr int ITEMS = NT * MT * LN;
+        for (int i = 0; i < MT; ++i)
+            if ((j * MT + i) / TP == pass) lds4[(wave * TP + (j * MT + i) % TP) * 64 + lane] = acc[j][i];
+    if (pass == 0) CH_STAMP(stamps, sidx, 4);                            // 4: operands arrived, MFMAs done, partials in LDS
+    chain_barrier(g);
+    if (pass == 0) CH_STAMP(stamps, sidx, 5);                            // 5: combine barrier passed
     for (int it = threadIdx.x; it < ITEMS; it += CH_THREADS) {
         const int l = it % LN;
-        const int t = it / LN;
+        const int tl = it / LN, t = pass * TP + tl;                       // tile index j * MT + i
         const int i = t % MT, j = t / MT;
         const int ml = i * 16 + (l & 15);
         if (ml >= Mloc) continue;
@@ -174,8 +192,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f}, sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < CH_WAVES; ++w) {
-            sum += lds4[(w * (NT * MT) + j * MT + i) * 64 + l];
-            if (GU8) sum2 += lds4[(w * (NT * MT) + j * MT + i) * 64 + l + 32];
+            sum += lds4[(w * TP + tl) * 64 + l];
+            if (GU8) sum2 += lds4[(w * TP + tl) * 64 + l + 32];
         }
         if (GU8) {
             const int n = (bx * NT + j) * 8 + 4 * (l >> 4);
@@ -205,6 +223,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             coh_st8(ors, (uint32_t)((size_t)m * ldo + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});
         }
     }
+    }   // combine pass
     CH_STAMP(stamps, sidx, 6);                                           // 6: epilogue stores issued
     chain_gate_arrive(g);
     CH_STAMP(stamps, sidx, 7);                                           // 7: stores drained, barrier, flag published

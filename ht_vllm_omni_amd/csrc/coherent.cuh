@@ -49,6 +49,18 @@ __device__ __forceinline__ void coh_st4(coh_rsrc_t rs, uint32_t byte_off, uint32
 #define OMNI_CHAIN_WGS 256
 #define OMNI_CHAIN_SPIN_BOUND (1u << 21)
 
+// ---- loader / consumer engine (bb_engine.hip): waves 0-7 of a workgroup compute, waves 8-11 stream weights into an LDS FIFO
+// by LDS-DMA.  All intra-workgroup synchronisation is through these LDS words (s_barrier would stop the loader waves too):
+// monotonic counters, relaxed polls, every wait bounded.
+#define ENG_FIFO_PIECES 96           // 1 KB pieces (one MFMA operand fragment of one wave each) in the FIFO: 96 KB
+#define ENG_SPIN_BOUND (1u << 24)
+struct EngSync {
+    unsigned loaded[4];              // per loader wave: its pieces that have landed in LDS
+    unsigned consumed[8];            // per compute wave: every piece below this global index has been read by it
+    unsigned bar;                    // compute-wave barrier: arrivals
+    unsigned dead;                   // a bounded wait ran out (results invalid; the launch runs to its end)
+};
+
 struct ChainGate {
     coh_rsrc_t frs;        // flag words [OMNI_CHAIN_WGS]
     uint32_t epoch;        // stages this workgroup has completed
@@ -56,7 +68,59 @@ struct ChainGate {
     bool dead;             // a spin ran out (here or in an earlier launch): stop waiting
     int dom;               // log2 of the flag domain: 6 = the row group's 64 workgroups, 7 = a pair of groups, 8 = all 256
     int nap;               // s_sleep units (64 clocks) between two polls: 0, 1, 2, 4, 8
+    // engine mode (NULL / unused in the plain chains): barriers among the 8 compute waves only, weights from the LDS FIFO
+    EngSync* es;
+    unsigned bgen;         // compute-wave barriers this wave has passed
+    const uint8_t* fifo;   // LDS FIFO base
+    unsigned piece_base;   // global index of the current stage's first piece
+    unsigned ready;        // pieces known to have landed (cache of 4 * min(loaded[]))
 };
+
+// workgroup barrier of the chain code: s_barrier, or -- engine mode -- arrivals of the 8 compute waves on an LDS counter
+__device__ __forceinline__ void chain_barrier(ChainGate& g) {
+    if (g.es == nullptr) {
+        __syncthreads();
+        return;
+    }
+    // LDS operations of a wave execute in order and the words below are relaxed atomics: what is needed is that the COMPILER
+    // keeps the order (a workgroup-scope fence would also drain the wave's outstanding global loads: vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g.bgen += 1;
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&g.es->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned target = g.bgen * 8u;
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(&g.es->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > ENG_SPIN_BOUND) {
+            __hip_atomic_store(&g.es->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// engine mode: wait until every FIFO piece below `upto` has landed; publish that this wave has read everything below `upto`
+__device__ __forceinline__ void eng_wait_ready(ChainGate& g, unsigned upto) {
+    unsigned spins = 0;
+    while ((int)(g.ready - upto) < 0) {
+        unsigned m = __hip_atomic_load(&g.es->loaded[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) m = min(m, __hip_atomic_load(&g.es->loaded[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        g.ready = 4u * m;             // loader wave q owns pieces q, q + 4, ...: everything below 4 * min is in LDS
+        if ((int)(g.ready - upto) < 0) __builtin_amdgcn_s_sleep(1);
+        if (++spins > ENG_SPIN_BOUND) {
+            __hip_atomic_store(&g.es->dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+// the FIFO reads of this wave were issued before this store and LDS executes a wave's operations in order: a relaxed store
+// behind a compiler barrier is enough (a release store would wait for the wave's global loads in flight too)
+__device__ __forceinline__ void eng_release(ChainGate& g, int wave, unsigned upto) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g.es->consumed[wave], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, int32_t* err) {
     g.frs = coh_rsrc(flags);
@@ -65,6 +129,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
     g.dead = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
     g.dom = 8;
     g.nap = 1;
+    g.es = nullptr; g.bgen = 0; g.fifo = nullptr; g.piece_base = 0; g.ready = 0;
 }
 
 // wait until every workgroup of this workgroup's flag DOMAIN has completed the stage this workgroup completed last (g.epoch).
@@ -96,13 +161,13 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
             }
         }
     }
-    __syncthreads();
+    chain_barrier(g);
 }
 
 // this workgroup's stores of the stage are out (every wave drains its own), then one lane publishes
 __device__ __forceinline__ void chain_gate_arrive(ChainGate& g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    chain_barrier(g);
     g.epoch += 1;
     if (threadIdx.x == 0) coh_st4(g.frs, blockIdx.x * 4, g.epoch);
 }

@@ -19,11 +19,11 @@ for _ in range(4):
 torch.cuda.synchronize()
 NST, NW = 8, 256
 buf = torch.zeros(40 * NST * NW, dtype=torch.int64, device="cuda")
-lib.omni_debug_bb_stamps.argtypes = [C.c_void_p]; lib.omni_debug_bb_stamps.restype = None
-lib.omni_debug_bb_stamps(buf.data_ptr())
+STAMPS = getattr(lib, "omni_debug_" + os.environ.get("BB_STAMPS", "eng") + "_stamps"); STAMPS.argtypes = [C.c_void_p]; STAMPS.restype = None
+STAMPS(buf.data_ptr())
 eng.decode_step(B)
 torch.cuda.synchronize()
-lib.omni_debug_bb_stamps(None)
+STAMPS(None)
 t = buf.view(40, NST, NW)[:4].cpu().double() * 0.01
 names = ["o", "gate_up", "down", "qkv(next)"]
 seg = ["W issue", "flag wait", "slabs->rstd", "x+MFMA", "barrier", "epilogue", "drain+flag"]
@@ -34,3 +34,11 @@ for s in range(3):
     d_ = [(x[k + 1] - x[k]).median().item() for k in range(7)]
     print(f"{names[s]:10s} " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {(x[7].max() - x[0].min()).item():8.2f}")
 print(f"launch span {(t[2][7].max() - t[0][0].min()).item():.1f} us")
+
+if os.environ.get("BB_STAMPS", "eng") == "eng":
+    L_ = buf.view(40, NST, NW)[32].cpu().double()
+    ts = L_[:5] * 0.01
+    print("loader wave 8 (medians, us): issue o %.2f | gate_up %.2f | down %.2f | (qkv %.2f); polls spent waiting for FIFO space: median %d, max %d" % (
+        (ts[1] - ts[0]).median(), (ts[2] - ts[1]).median(), (ts[3] - ts[2]).median(), (ts[4] - ts[3]).median(), int(L_[5].median()), int(L_[5].max())))
+    print("loader start -> compute-wave o-stage entry (us): %.2f; loader end vs down-stage end: %.2f" % (
+        (t[0][0] - ts[0]).median(), (t[2][7] - ts[3]).median()))

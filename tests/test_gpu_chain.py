@@ -96,8 +96,9 @@ def _decode_engine(d, w, B, kv="fp8"):
     return eng
 
 
+@pytest.mark.parametrize("engine", [1, 0], ids=["engine", "plain-chain"])
 @pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16")])
-def test_backbone_segment_chain_is_bit_identical_to_the_launch_path(B, kv):
+def test_backbone_segment_chain_is_bit_identical_to_the_launch_path(B, kv, engine):
     """o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer (csrc/bb_chain.hip) against the
     launch-per-op backbone of the same library at the 1.7B shape: logits, hidden state, sampled ids, codes and every KV byte
     of three decode steps are identical; no flag wait times out."""
@@ -106,9 +107,11 @@ def test_backbone_segment_chain_is_bit_identical_to_the_launch_path(B, kv):
     res = {}
     with L.debug_library() as lib:
         lib.omni_debug_bb_chain.argtypes = [C.c_int]; lib.omni_debug_bb_chain.restype = None
+        lib.omni_debug_bb_engine.argtypes = [C.c_int]; lib.omni_debug_bb_engine.restype = None
         try:
             for on in (0, 1):
                 lib.omni_debug_bb_chain(on)
+                lib.omni_debug_bb_engine(engine)
                 eng = _decode_engine(d, w, B, kv)
                 outs = []
                 for _ in range(3):
@@ -119,6 +122,7 @@ def test_backbone_segment_chain_is_bit_identical_to_the_launch_path(B, kv):
                 res[on] = (outs, [c.view(torch.uint8).clone() for c in eng.kv_caches])
         finally:
             lib.omni_debug_bb_chain(1)
+            lib.omni_debug_bb_engine(0)
     for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
         for name, x, y in zip(("logits", "hidden", "ids", "codes"), a, b):
             assert torch.equal(x, y), f"step {s}: {name} differ between the backbone chain and the launch path"
