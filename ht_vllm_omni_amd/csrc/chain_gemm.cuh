@@ -30,11 +30,23 @@
 // WSRC: where the weight fragments come from -- 0: fetched whole into registers ahead of the flags; 1: they ride in the x ring
 // (wide slices under a tight register budget); 2: the workgroup's LDS FIFO that loader waves fill by LDS-DMA (bb_engine.hip):
 // round d = the k-steps 8 d .. 8 d + 7 of every n-tile = 8 NT pieces in the order [tile][k-step], wave w reads piece (j, w).
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0>
+//        3: registers the PREVIOUS stage filled (Wpre): a stage calls `prefetch()` -- PF::LOADS loads of the next stage's slice
+//        per wave -- behind its epilogue stores and then drains only down to vmcnt(PF::LOADS): the stores are out, the weight
+//        loads stay in flight through the barrier, the flag and the next hand-off.  (Issued earlier -- behind the last
+//        activation load -- they sit in front of the stores in the wave's in-order queue and the flag waits for the whole
+//        slice: measured +0.2 ms per step.)
+struct ChainNoPrefetch { static constexpr int LOADS = 0; __device__ __forceinline__ void operator()() const {} };
+template <int N, class F>
+struct ChainPrefetch {           // N = loads per wave that F issues
+    F& f;
+    static constexpr int LOADS = N;
+    __device__ __forceinline__ void operator()() const { f(); }
+};
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
-                                           unsigned long long* stamps) {
+                                           unsigned long long* stamps, const u32x4 (*Wpre)[NT] = nullptr, PF prefetch = PF()) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int G = (XG == 0 || XG > NTW) ? NTW : XG;
     constexpr bool NW_EARLY = PRO == 2 && G == NTW && NT * NTW < 24;      // norm weights ahead of the flags (registers permitting)
@@ -63,7 +75,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     // ---- before the flags: everything that does not depend on the previous stage.  (The polling wave's first poll returns
     // behind its own weight loads -- a wave's loads return in order -- but letting wave 0 fetch its share of the slice behind
     // the flags instead measured WORSE: the predictor 1.80 -> 2.11 ms; its weights then arrive later than the activations.)
-    constexpr int WS = WFIFO ? 1 : (WRING ? G : NTW);                     // weight slots held at a time
+    constexpr int WS = (WFIFO || WSRC == 3) ? 1 : (WRING ? G : NTW);      // weight slots held at a time
     u32x4 Wq[WS][NT], NWq[G];
 #pragma unroll
     for (int d = 0; d < NTW; ++d) {
@@ -152,6 +164,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 Wn[j] = *reinterpret_cast<const u32x4*>(g.fifo + (size_t)((first + j * 8 + wave) % ENG_FIFO_PIECES) * 1024 + lane16);
+        } else if (WSRC == 3) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Wn[j] = Wpre[d][j];
         } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) Wn[j] = Wq[WRING ? d % G : d][j];
@@ -225,7 +240,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     }
     }   // combine pass
     CH_STAMP(stamps, sidx, 6);                                           // 6: epilogue stores issued
-    chain_gate_arrive(g);
+    prefetch();
+    chain_gate_arrive<PF::LOADS>(g);
     CH_STAMP(stamps, sidx, 7);                                           // 7: stores drained, barrier, flag published
 }
 

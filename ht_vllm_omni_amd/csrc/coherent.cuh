@@ -164,10 +164,22 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
     chain_barrier(g);
 }
 
-// this workgroup's stores of the stage are out (every wave drains its own), then one lane publishes
+// this workgroup's stores of the stage are out (every wave drains its own), then one lane publishes.  KEEP = loads the wave
+// issued BEHIND its stores (the next stage's weight prefetch) that may stay in flight: the queue is in order, so vmcnt(KEEP)
+// covers exactly the stores
+template <int KEEP = 0>
 __device__ __forceinline__ void chain_gate_arrive(ChainGate& g) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    chain_barrier(g);
+    static_assert(KEEP >= 0 && KEEP <= 48, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(KEEP) : "memory");
+    if (KEEP > 0 && g.es == nullptr) {
+        // bare s_barrier: __syncthreads() carries workgroup-scope fences, and the release fence would wait for the KEEP loads
+        // this wave wants to keep in flight.  Nothing of this stage crosses the barrier through memory any more: every wave has
+        // just waited for its own stores, and the waves exchange nothing through LDS here.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        chain_barrier(g);
+    }
     g.epoch += 1;
     if (threadIdx.x == 0) coh_st4(g.frs, blockIdx.x * 4, g.epoch);
 }
