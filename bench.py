@@ -372,6 +372,9 @@ def main():
                    "parallelism": f"{args.parallel}{world}", "allreduce": getattr(args, "allreduce_used", "none"),
                    "prefill_gemm": "omni_gemm_tile (hand-written MFMA)" if args.prefill_gemm == "tile" else "hipBLASLt",
                    "hipgraph": graph is not None, "sub_batches": args.sub_batches,
+                   "decode_launches": ("persistent chains: code-predictor passes 2..15 (layer stacks, heads, samplers) = 1 launch; backbone = "
+                                       "1 attention + 1 segment launch (o_proj, gate_up, down_proj, next qkv) per layer"
+                                       if getattr(eng, "persistent_chains", False) else "one launch per op"),
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
                    "target_ctx": args.target_ctx, "untimed_advance_steps": advance,
                    **({"ctx_extra": args.ctx_extra} if args.ctx_extra else {})},

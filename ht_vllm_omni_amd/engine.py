@@ -304,6 +304,7 @@ class TalkerEngine:
         # the persistent code-predictor chain needs its 256-workgroup grid co-resident: not for engines whose steps run
         # concurrently on one GPU (n_sub parallel graph branches)
         desc.cp_chain = int(int(n_sub) <= 1 and os.environ.get("OMNI_CP_CHAIN", "1") != "0")
+        self.persistent_chains = bool(desc.cp_chain)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
             self._cp_lm_head_f = up(frag_shuffle(self.cp_lm_head))
