@@ -236,3 +236,152 @@ def test_resume_restores_row_state_and_rebuilds_inputs():
         want = (acc.to(BF16).float() + xs[j].float()).to(BF16)
         assert torch.equal(rebuilt[j], want), j
     assert int(eng.positions[0]) == state[0] + 1 and int(eng.steps[0]) == state[2] + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Known answers read off the reference (its update_from_output needs vLLM and cannot be imported here):
+# each case scripts the runner's output by hand and states the reference lines whose behaviour it pins.
+# (tests/core/sched/test_generation_scheduler_restore.py, the only file under the reference's tests/core/sched, pins the
+# try/finally queue restore of OmniGenerationScheduler's chunk adapter -- the generation stage, not this AR path: no counterpart.)
+def _scripted(sched, tokens, acks=()):
+    """One engine-core step with a hand-written runner output: `tokens` = {req_id: [sampled ids]} for the rows that sampled."""
+    from ht_vllm_omni_amd.payloads import OmniModelRunnerOutput
+    so = sched.schedule()
+    ids = list(so.num_scheduled_tokens)
+    out = OmniModelRunnerOutput(req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
+                                sampled_token_ids=[list(tokens.get(r, [])) for r in ids], kv_extracted_req_ids=list(acks) or None)
+    return so, sched.update_from_output(so, out)
+
+
+def _plain_request(rid, n_prompt, *, max_tokens=8, stop=()):
+    return Request(request_id=rid, num_prompt_tokens=n_prompt, prompt_token_ids=list(range(1, n_prompt + 1)),
+                   sampling_params=SamplingParams(temperature=0.0, max_tokens=max_tokens, stop_token_ids=tuple(stop)))
+
+
+def test_ref_pin_prefill_finished_marks_once_with_truncated_blocks():
+    """omni_ar_scheduler.py:104-112 (prefill_finished: mark with num_computed_tokens, do not stop), :97-99 (once),
+    :549-588 (_mark_request_for_kv_transfer: block ids cut to ceil(seq_len / block_size), no second marking)."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_num_batched_tokens=24, max_model_len=512,
+                          kv_transfer_criteria={"type": "prefill_finished"})
+    s.add_request(_plain_request("a", 40))
+    _scripted(s, {})                                      # chunk 1 of the prompt (24 of 40): nothing computed past the prompt yet
+    assert "a" not in s.transfer_triggered_requests and not s.requests_needing_kv_transfer
+    _, outs = _scripted(s, {"a": [7]})                    # chunk 2 ends the prompt and samples
+    assert s.requests["a"].num_computed_tokens == 40 and not s.requests["a"].is_finished()
+    assert s.requests_needing_kv_transfer == {"a": {"seq_len": 40, "block_ids": s.pool.block_ids("a")[:3]}}   # ceil(40 / 16)
+    assert outs[0].kv_transfer_params is None             # a non-stop trigger hands nothing to the client (:293-294 returns False)
+    first = dict(s.requests_needing_kv_transfer["a"])
+    _scripted(s, {"a": [8]})                              # delivered to the runner in this step's scheduler output, not re-marked
+    assert not s.requests_needing_kv_transfer and s.active_kv_transfers == {"a": first} or "a" in s.active_kv_transfers
+    _scripted(s, {"a": [9]})
+    assert not s.requests_needing_kv_transfer             # once semantics: later steps never mark again
+
+
+def test_ref_pin_special_token_snapshot_length_excludes_tokens_after_the_sentinel():
+    """omni_ar_scheduler.py:114-133: snapshot_len = num_computed_tokens - (len(new_token_ids) - (idx + 1)), first occurrence."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512,
+                          kv_transfer_criteria={"type": "special_token", "token_id": 99})
+    s.add_request(_plain_request("a", 20, max_tokens=16))
+    _scripted(s, {"a": [5]})
+    assert not s.requests_needing_kv_transfer             # no sentinel yet
+    req = s.requests["a"]
+    _scripted(s, {"a": [6]})
+    computed_before = req.num_computed_tokens
+    # a multi-token step (spec-decode shaped): sentinel second of four, and again fourth -> the FIRST one counts
+    so = s.schedule()
+    from ht_vllm_omni_amd.payloads import OmniModelRunnerOutput
+    out = OmniModelRunnerOutput(req_ids=["a"], req_id_to_index={"a": 0}, sampled_token_ids=[[11, 99, 12, 99]])
+    s.update_from_output(so, out)
+    assert req.num_computed_tokens == computed_before + 1
+    assert s.requests_needing_kv_transfer["a"]["seq_len"] == req.num_computed_tokens - (4 - (1 + 1))
+    assert "a" in s.transfer_triggered_requests and not req.is_finished()
+
+
+def test_ref_pin_finish_after_trigger_waits_for_the_ack_then_frees():
+    """omni_ar_scheduler.py:497-506 (finished while its earlier-triggered transfer is still active: hold the blocks, no
+    second marking, no kv_transfer_params), :455-479 (kv_extracted_req_ids ack: leave active set; if waiting, free now)."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512,
+                          kv_transfer_criteria={"type": "prefill_finished"})
+    s.add_request(_plain_request("a", 18, max_tokens=2))
+    _scripted(s, {"a": [5]})                              # prefill done: triggered + marked
+    so, outs = _scripted(s, {"a": [6]})                   # marked set handed over in this schedule(); max_tokens reached -> finished
+    assert "a" in so.finished_requests_needing_kv_transfer and "a" in s.active_kv_transfers
+    assert outs[0].finish_reason is not None and outs[0].kv_transfer_params is None
+    assert "a" in s.waiting_for_transfer_free and "a" in s.requests and s.pool.num_free == 16 - 1 - 2   # blocks held (block 0 reserved)
+    assert not s.requests_needing_kv_transfer             # not marked a second time
+    _scripted(s, {}, acks=["a"])                          # the runner reports the extraction
+    assert "a" not in s.active_kv_transfers and "a" not in s.waiting_for_transfer_free
+    assert "a" not in s.requests and "a" not in s.transfer_triggered_requests and s.pool.num_free == 15
+
+
+def test_ref_pin_finish_after_acked_trigger_frees_immediately():
+    """omni_ar_scheduler.py:507-511: triggered earlier and already extracted -> the stop frees at once, nothing to send."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512,
+                          kv_transfer_criteria={"type": "prefill_finished"})
+    s.add_request(_plain_request("a", 18, max_tokens=3))
+    _scripted(s, {"a": [5]})
+    _scripted(s, {"a": [6]}, acks=["a"])                  # handed over and acked in the same step
+    assert not s.active_kv_transfers and "a" in s.transfer_triggered_requests
+    _, outs = _scripted(s, {"a": [7]})                    # third token = max_tokens
+    assert outs[0].finish_reason is not None and outs[0].kv_transfer_params is None
+    assert "a" not in s.requests and not s.waiting_for_transfer_free and s.pool.num_free == 15
+
+
+def test_ref_pin_finish_without_trigger_marks_and_returns_kv_transfer_params():
+    """omni_ar_scheduler.py:512-543: an untriggered finished request is marked with num_computed_tokens, waits for the ack, and
+    the client gets {"past_key_values": block_ids, "kv_metadata": {"seq_len", "block_ids"}}; :397-401 a request that is waiting
+    keeps its trigger bookkeeping until the ack."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512, need_send_cache=True)     # no criteria
+    s.add_request(_plain_request("a", 30, max_tokens=3))
+    _scripted(s, {"a": [5]}); _scripted(s, {"a": [6]})
+    _, outs = _scripted(s, {"a": [7]})
+    seq_len = s.requests["a"].num_computed_tokens         # 30 prompt + 2 decoded-and-computed; the last sample was never run
+    assert seq_len == 32
+    blocks = s.pool.block_ids("a")[:2]                    # ceil(32 / 16)
+    assert outs[0].kv_transfer_params == {"past_key_values": blocks, "kv_metadata": {"seq_len": 32, "block_ids": blocks}}
+    assert "a" in s.waiting_for_transfer_free and s.requests_needing_kv_transfer["a"]["seq_len"] == 32
+    so, _ = _scripted(s, {})                              # delivered once
+    assert so.finished_requests_needing_kv_transfer == {"a": {"seq_len": 32, "block_ids": blocks}}
+    so, _ = _scripted(s, {}, acks=["a"])
+    assert not so.finished_requests_needing_kv_transfer and "a" not in s.requests and s.pool.num_free == 15
+
+
+def test_ref_pin_waiting_request_is_not_retriggered():
+    """omni_ar_scheduler.py:93-95: a request already waiting for its transfer to finish is skipped by the trigger."""
+    s = MI355XARScheduler(num_blocks=16, block_size=16, max_num_seqs=4, max_model_len=512,
+                          kv_transfer_criteria={"type": "special_token", "token_id": 99})
+    s.add_request(_plain_request("a", 18, max_tokens=8))
+    _scripted(s, {"a": [5]})
+    req = s.requests["a"]
+    s.waiting_for_transfer_free.add("a")
+    assert s._process_kv_transfer_trigger(req, [99]) is False and not s.requests_needing_kv_transfer
+    s.waiting_for_transfer_free.discard("a")
+    assert s._process_kv_transfer_trigger(req, [99]) is False and "a" in s.requests_needing_kv_transfer   # never stops (:133)
+
+
+def test_ref_pin_mtp_rows_land_on_their_requests():
+    """tests/worker/test_omni_gpu_model_runner.py:119-152 (reference): talker_mtp output row b belongs to request b of the
+    batch -- embeds back at the request's first flattened position, codes row b into that request's info under
+    `code_predictor_codes`.  Here the batch is row-major on the device; the same statement is that decode row r's codes reach
+    request r's pooler payload and history, whatever the admission order and however rows are recycled."""
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    runner = MI355XARModelRunner(eng, use_graphs=False)
+    sched = MI355XARScheduler(num_blocks=32, block_size=16, max_num_seqs=4, max_model_len=512)
+    core = TalkerStageEngine(_Worker(runner), sched)
+    for i, n in enumerate((9, 14, 11)):
+        core.add_request(_request(d, f"r{i}", n, max_tokens=5, seed=i))
+    rows_seen, last_tok = {}, {}
+    for _ in range(12):
+        for o in core.step():
+            if o.pooling_output is not None and o.new_token_ids and o.pooling_output["audio_codes"].shape[0] == 1:
+                st = runner.requests.get(o.request_id)
+                frame = o.pooling_output["audio_codes"][0].tolist()
+                if st is not None and o.request_id in runner.rows and frame[0] != 0:
+                    row = runner.rows.index(o.request_id)
+                    assert frame == eng.audio_codes[row].tolist() == st.codes_hist[-1]       # row r -> request r, and its history
+                    assert frame[0] == last_tok[o.request_id]      # layer-0 code = the token this step consumed (the previous sample)
+                    rows_seen.setdefault(o.request_id, set()).add(row)
+            if o.new_token_ids:
+                last_tok[o.request_id] = o.new_token_ids[-1]
+    assert len(rows_seen) == 3 and len({next(iter(v)) for v in rows_seen.values()}) == 3          # three requests, three rows
