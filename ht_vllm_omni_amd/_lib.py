@@ -44,7 +44,8 @@ class TileGemm(C.Structure):
     """omni_tile_gemm: one large-M MFMA GEMM / conv-as-GEMM launch (include/omni_talker.h)."""
     _fields_ = [("x", vp), ("x_rows", i64), ("ldx", i32), ("seg_len", i32), ("seg_rows", i32), ("row_off", i32),
                 ("w", vp), ("bias", vp), ("scale", vp), ("act", i32), ("resid", vp), ("ldr", i32), ("out_f32", vp), ("ldf", i32), ("out", vp), ("ldo", i32),
-                ("out2", vp), ("ldo2", i32), ("snake_alpha", vp), ("snake_inv_beta", vp), ("M", i32), ("N", i32), ("K", i32), ("tile_hint", i32)]
+                ("out2", vp), ("ldo2", i32), ("snake_alpha", vp), ("snake_inv_beta", vp), ("M", i32), ("N", i32), ("K", i32), ("tile_hint", i32),
+                ("groups", i32), ("x_group_rows", i64), ("w_group_elems", i64), ("out_group_rows", i64), ("group_rows", vp)]
 
 
 TILE_ACT_NONE, TILE_ACT_GELU, TILE_ACT_SILU_MUL_GU8 = 0, 1, 2

@@ -46,6 +46,11 @@ struct TileArgs {
     int M, N, K;
     int act;                         // OMNI_TILE_ACT_*
     int mblocks, nblocks, band;
+    // grouped (batched) launch: blockIdx.y = group; group g reads x rows [g * gx_rows, + its row count), the matrix
+    // W + g * gw_elems, and writes output rows from g * gout_rows.  group_rows (device, optional) = live rows per group:
+    // tiles past it leave at once, rows past it read as zero and are not stored
+    long long gx_rows, gw_elems, gout_rows;
+    const int32_t* group_rows;
 };
 
 __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
@@ -75,8 +80,22 @@ struct TileGeom {
 };
 
 template <int WAVES_N, int WN, int WM, bool GU8>
-__global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a) {
+__global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a_in) {
     using G = TileGeom<WAVES_N, WN, WM>;
+    TileArgs a = a_in;
+    long long x_lo = 0, x_hi = a.x_rows;                                      // rows of x this launch may read
+    if (gridDim.y > 1 || a.group_rows) {
+        const int grp = blockIdx.y;
+        if (a.group_rows) a.M = min(a.M, a.group_rows[grp]);
+        x_lo = grp * a.gx_rows;
+        x_hi = min(x_lo + a.M, a.x_rows);
+        a.W += (size_t)grp * a.gw_elems;
+        const size_t orow = (size_t)grp * a.gout_rows;
+        if (a.out) a.out += orow * a.ldo;
+        if (a.out2) a.out2 += orow * a.ldo2;
+        if (a.out_f32) a.out_f32 += orow * a.ldf;
+        if (a.resid) a.resid += orow * a.ldr;
+    }
     constexpr int NTILES = G::NTILES, SLICE = G::SLICE, NLW = G::NLW, NLX = G::NLX, NBUF = G::NBUF;
     constexpr int INFLIGHT = NBUF - 2;                                        // slices still landing when slice t + 1 is awaited
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         m_blk = b * a.band + (r - n_blk * h);
     }
     const int m0 = m_blk * G::BM, n0 = n_blk * G::BN;
+    if (m0 >= a.M) return;                                                    // a group with fewer rows than the launch's M (uniform)
     const int nsteps = a.K >> 5;                                              // 32-deep slices
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
         const int g = wave + TG_WAVES * i;
-        xrow[i] = m0 + g * 16 + c + a.row_off;
+        xrow[i] = (int)x_lo + m0 + g * 16 + c + a.row_off;
         xbyte[i] = (xrow[i] * a.ldx + 8 * q) * 2;        // wraps out of the descriptor for rows < 0 (never used then)
     }
     int seg = 0, cs = 0;                                  // segment walk of the NEXT slice to stage: k = seg * seg_len + cs
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
         for (int i = 0; i < NLX; ++i) {
             const bool mine = !G::X_RAGGED || wave + TG_WAVES * i < G::MTILES;
             const int r = xrow[i] + shift;
-            const unsigned off = (live && mine && r >= 0 && r < (int)a.x_rows) ? (unsigned)(xbyte[i] + add) : TG_OOB;
+            const unsigned off = (live && mine && r >= (int)x_lo && r < (int)x_hi) ? (unsigned)(xbyte[i] + add) : TG_OOB;
             uint8_t* dst = mine ? base + (NTILES + i * TG_WAVES) * 1024 : lds + NBUF * SLICE + wave * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)dst, 16, off, 0, 0, 0);
         }
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a)
 }
 
 template <int WAVES_N, int WN, int WM, bool GU8>
-static int launch_tile(TileArgs a, hipStream_t st) {
+static int launch_tile(TileArgs a, hipStream_t st, int groups = 1) {
     using G = TileGeom<WAVES_N, WN, WM>;
     a.mblocks = (a.M + G::BM - 1) / G::BM;
     a.nblocks = (a.N + G::BN - 1) / G::BN;
@@ -338,7 +358,7 @@ static int launch_tile(TileArgs a, hipStream_t st) {
         if (e != hipSuccess) { omni_set_error("omni_gemm_tile: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<WAVES_N, WN, WM, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_tile_kernel<WAVES_N, WN, WM, GU8>), dim3(a.mblocks * a.nblocks, groups), dim3(TG_THREADS), G::LDS_BYTES, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_tile");
     return OMNI_OK;
 }
@@ -369,6 +389,13 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     a.out = (uint16_t*)g->out; a.ldo = g->ldo;
     a.out2 = (uint16_t*)g->out2; a.ldo2 = g->ldo2; a.snake_alpha = g->snake_alpha; a.snake_inv_beta = g->snake_inv_beta;
     a.M = g->M; a.N = g->N; a.K = g->K; a.act = g->act;
+    const int groups = g->groups > 1 ? g->groups : 1;
+    OMNI_CHECK_ARG(groups <= 65535, "omni_gemm_tile: groups=%d", g->groups);
+    OMNI_CHECK_ARG(groups == 1 || (seg_len == g->K && g->row_off == 0 && g->x_group_rows >= 0 && g->w_group_elems >= 0 && g->out_group_rows >= 0),
+                   "omni_gemm_tile: a grouped launch is a plain GEMM per group (no conv window) with non-negative group strides");
+    OMNI_CHECK_ARG(groups == 1 || (int64_t)groups * g->w_group_elems * 2 + (int64_t)g->N * g->K * 2 < ((int64_t)1 << 40), "omni_gemm_tile: W groups");
+    a.gx_rows = groups > 1 ? g->x_group_rows : 0; a.gw_elems = groups > 1 ? g->w_group_elems : 0; a.gout_rows = groups > 1 ? g->out_group_rows : 0;
+    a.group_rows = g->group_rows;
     hipStream_t st = (hipStream_t)stream;
     const int N = g->N;
     // <waves along n, n tiles per wave, m tiles per wave>: 256 x 256 | 192 x 256 | 128 x 512 | 96 x 512 output tiles, and 128 x 64
@@ -377,14 +404,14 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     {
         const int big_n = N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : (N % 128 == 0 ? 128 : (N % 96 == 0 ? 96 : (N > 128 ? 256 : 128))));
         const int big_m = big_n >= 192 ? 256 : 512;
-        const long long big_tiles = (long long)((N + big_n - 1) / big_n) * ((g->M + big_m - 1) / big_m);
+        const long long big_tiles = (long long)((N + big_n - 1) / big_n) * ((g->M + big_m - 1) / big_m) * groups;
         const bool small = g->tile_hint == 2 || (g->tile_hint == 0 && big_tiles < 96 && g->N >= 64);
-        if (small) return gu8 ? launch_tile<4, 2, 2, true>(a, st) : launch_tile<4, 2, 2, false>(a, st);
+        if (small) return gu8 ? launch_tile<4, 2, 2, true>(a, st, groups) : launch_tile<4, 2, 2, false>(a, st, groups);
     }
-    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st) : launch_tile<1, 8, 4, true>(a, st);
-    if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st);
-    if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st);
-    if (N % 128 == 0) return launch_tile<1, 8, 4, false>(a, st);
-    if (N % 96 == 0) return launch_tile<1, 6, 4, false>(a, st);
-    return N > 128 ? launch_tile<2, 8, 4, false>(a, st) : launch_tile<1, 8, 4, false>(a, st);
+    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st, groups) : launch_tile<1, 8, 4, true>(a, st, groups);
+    if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st, groups);
+    if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st, groups);
+    if (N % 128 == 0) return launch_tile<1, 8, 4, false>(a, st, groups);
+    if (N % 96 == 0) return launch_tile<1, 6, 4, false>(a, st, groups);
+    return N > 128 ? launch_tile<2, 8, 4, false>(a, st, groups) : launch_tile<1, 8, 4, false>(a, st, groups);
 }

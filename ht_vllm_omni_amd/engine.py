@@ -224,6 +224,7 @@ class TalkerEngine:
         bb_names = names[:6] + MOE_NAMES if d.moe_experts > 0 else names
         frag_names = ("wqkv", "wo", "wgu", "wdown", "moe_gate_up", "moe_down", "moe_shared_gate_up", "moe_shared_down")
         self._layers = (L.LayerWeights * d.layers)()
+        self._frag_keep: dict = {}
         self.layer_w: list[dict] = []
         for i in range(d.layers):
             sh = shard_layer(d, weights, f"l{i}.", tp_rank, tp_size)
@@ -251,15 +252,33 @@ class TalkerEngine:
                         del src
                     if n in dense:
                         lw[n + "_f"] = t_
+                    elif not (self.moe_fp8 and n in ("moe_gate_up", "moe_down")):
+                        self._frag_keep[(i, n)] = t_
                 else:
                     t_ = lw[n]
                 setattr(self._layers[i], n, t_.data_ptr())
-            if d.moe_experts > 0:
-                # the batched hipBLASLt prefill wants [E, K, N] operands stored that way: torch.bmm on the transposed VIEW of
-                # [E, N, K] faults on this ROCm build at the talker's shapes (scripts/diag_bmm.py); they replace the row-major
-                # expert copies, which nothing else reads
+            if d.moe_experts > 0 and self.prefill_gemm in ("tile", "both"):
+                # the prefill's grouped omni_gemm_tile reads the decode step's fragment-major expert matrices (bf16 experts: the
+                # very same tensors; fp8 experts: one dequantised fragment-major copy -- the tile kernel's LDS-DMA path moves
+                # bf16 fragments); router / shared-expert gate as fragment-major too (the gate's single row padded to one tile)
                 for n in ("moe_gate_up", "moe_down"):
-                    lw[n + "_t"] = lw.pop(n).transpose(1, 2).contiguous()
+                    lw[n + "_f"] = up(frag_shuffle(lw[n])) if self.moe_fp8 else self._frag_keep[(i, n)]
+                lw["moe_router_f"] = up(frag_shuffle(lw["moe_router"]))
+                if self.moe_shared_l > 0:
+                    for n in ("moe_shared_gate_up", "moe_shared_down"):
+                        lw[n + "_f"] = self._frag_keep[(i, n)]
+                    g16 = torch.zeros(16, d.hidden, dtype=BF16, device=dev)
+                    g16[:1] = lw["moe_shared_gate"].reshape(1, -1)
+                    lw["moe_shared_gate_f"] = frag_shuffle(g16)
+            if d.moe_experts > 0:
+                # the batched hipBLASLt prefill (prefill_gemm="blas", kept for A/B) wants [E, K, N] operands stored that way:
+                # torch.bmm on the transposed VIEW of [E, N, K] faults on this ROCm build at the talker's shapes
+                # (scripts/diag_bmm.py); they replace the row-major expert copies, which nothing else reads
+                for n in ("moe_gate_up", "moe_down"):
+                    rm = lw.pop(n)
+                    if self.prefill_gemm in ("blas", "both"):
+                        lw[n + "_t"] = rm.transpose(1, 2).contiguous()
+                    del rm
         self._cp_layers = (L.LayerWeights * d.cp_layers)()
         self.cp_layer_w: list[dict] = []
         for i in range(d.cp_layers):
@@ -535,7 +554,7 @@ class TalkerEngine:
                 torch.distributed.all_reduce(o, group=self.tp_group)
             a = ops.rmsnorm(None, w["ln2"], d.eps, delta=o, residual=resid)
             if d.moe_experts > 0:
-                delta = self._moe_mlp_blas(a, w)
+                delta = self._moe_mlp_tile(a, w) if tile else self._moe_mlp_blas(a, w)
             elif tile:
                 delta = ops.gemm_tile(ops.gemm_tile(a, w["wgu_f"], act=L.TILE_ACT_SILU_MUL_GU8), w["wdown_f"])
             else:
@@ -547,18 +566,11 @@ class TalkerEngine:
     def prefill_blas(self, x, positions, req_of_tok, slot_mapping, block_table=None):
         return self.prefill_wide(x, positions, req_of_tok, slot_mapping, block_table, gemm="blas")
 
-    def _moe_mlp_blas(self, a: torch.Tensor, w: dict) -> torch.Tensor:
-        """Sparse-MoE MLP over T prompt rows (a = normalised rows, bf16 [T, H]) with the expert GEMMs as TWO batched hipBLASLt
-        calls: the (token, expert) slots are grouped by expert into a padded [E, cap, H] batch (cap = the busiest expert's
-        token count, one host read per layer), gate_up -> SiLU*up (omni_silu_mul) -> down run for all experts at once, and
-        the weighted results are added back per token in ascending expert order in bf16 -- the accumulation order and the
-        rounding points of HF's expert loop (oracle.moe_block); routing on the HIP kernel.  The native per-expert kernels
-        stay the decode path (<= 64 rows); re-running them per 64-row prompt chunk streamed every hit expert 100 times."""
-        import torch.nn.functional as F
-        d = self.d
-        T, H = a.shape
-        E, k, I = self.moe_experts_l, d.moe_top_k, self.moe_inter_l
-        idx, wts = ops.moe_route(F.linear(a, w["moe_router"]), k, d.moe_norm_topk)       # int32 [T, k], bf16 [T, k]
+    def _moe_group_slots(self, idx: torch.Tensor, wts: torch.Tensor, T: int):
+        """(token, expert) slots grouped by expert into a padded [E, cap, .] batch: returns (order, dst, wts_s, counts, cap) with
+        slot order[s] (= t * k + j of the token's j-th expert in ascending expert order) stored at batch row dst[s]; cap = the
+        busiest expert's token count rounded to 64 (one host read per layer)."""
+        E, k = self.moe_experts_l, self.d.moe_top_k
         if self.moe_mode == "ep":       # slots of experts another rank holds: weight 0 here (their share arrives by all-reduce)
             local = (idx >= self.moe_e0) & (idx < self.moe_e0 + E)
             wts = torch.where(local, wts, torch.zeros_like(wts))
@@ -568,21 +580,62 @@ class TalkerEngine:
         flat_e = idx_s.reshape(-1)                                      # expert of slot (t, j), slot = t * k + j
         order = torch.argsort(flat_e, stable=True)                      # slots grouped by expert
         counts = torch.bincount(flat_e, minlength=E)
-        cap = (max(int(counts.max().item()), 1) + 63) // 64 * 64        # padded rows are zero; whole 64-row tiles per expert
+        cap = (max(int(counts.max().item()), 1) + 63) // 64 * 64
         e_sorted = flat_e[order]
-        rank = torch.arange(T * k, device=a.device) - (torch.cumsum(counts, 0) - counts)[e_sorted]
-        dst = e_sorted * cap + rank                                     # row of the slot in the padded batch
+        rank = torch.arange(T * k, device=idx.device) - (torch.cumsum(counts, 0) - counts)[e_sorted]
+        return order, e_sorted * cap + rank, wts_s, counts, cap
+
+    def _moe_combine(self, y: torch.Tensor, order, dst, wts_s, T: int) -> torch.Tensor:
+        """Weighted expert outputs added back per token in ascending expert order in bf16 -- the accumulation order and the
+        rounding points of HF's expert loop (oracle.moe_block)."""
+        k, H = self.d.moe_top_k, y.shape[1]
+        ys = torch.empty(T * k, H, dtype=BF16, device=y.device)
+        ys[order] = y[dst]
+        ys = ys.view(T, k, H) * wts_s[:, :, None]
+        out = torch.zeros(T, H, dtype=BF16, device=y.device)
+        for j in range(k):
+            out += ys[:, j]
+        return out
+
+    def _moe_mlp_tile(self, a: torch.Tensor, w: dict) -> torch.Tensor:
+        """Sparse-MoE MLP over T prompt rows on the hand-written MFMA kernel: router, both expert GEMMs (ONE grouped
+        omni_gemm_tile launch each over the expert-sorted [E, cap, H] batch, reading the decode step's fragment-major expert
+        matrices; tiles past an expert's live rows leave at once) and the shared expert -- no library GEMM on the path.
+        Same grouping, rounding points and accumulation order as _moe_mlp_blas (reference: vLLM FusedMoE under
+        V/model_executor/models/qwen3_omni/qwen3_moe.py:8,152-161; arithmetic = HF's expert loop, oracle.moe_block)."""
+        d = self.d
+        T, H = a.shape
+        E, k, I = self.moe_experts_l, d.moe_top_k, self.moe_inter_l
+        idx, wts = ops.moe_route(ops.gemm_tile(a, w["moe_router_f"]), k, d.moe_norm_topk)      # int32 [T, k], bf16 [T, k]
+        order, dst, wts_s, counts, cap = self._moe_group_slots(idx, wts, T)
+        rows = counts.to(torch.int32)
+        xb = torch.empty(E * cap, H, dtype=BF16, device=a.device)       # rows past an expert's count are never read
+        xb[dst] = a[order // k]
+        gu = ops.gemm_tile(xb, w["moe_gate_up_f"], groups=E, group_rows=rows)                   # [E * cap, 2I]
+        act = ops.silu_mul(gu)
+        y = ops.gemm_tile(act, w["moe_down_f"], groups=E, group_rows=rows)                      # [E * cap, H]
+        out = self._moe_combine(y, order, dst, wts_s, T)
+        if self.moe_shared_l > 0:
+            sh = ops.gemm_tile(ops.silu_mul(ops.gemm_tile(a, w["moe_shared_gate_up_f"])), w["moe_shared_down_f"])
+            gate = ops.gemm_tile(a, w["moe_shared_gate_f"])[:, :1]
+            out = out + torch.sigmoid(gate) * sh
+        return out
+
+    def _moe_mlp_blas(self, a: torch.Tensor, w: dict) -> torch.Tensor:
+        """The same block with the expert GEMMs as TWO batched hipBLASLt calls on [E, K, N] copies (prefill_gemm="blas": the
+        A/B arm of _moe_mlp_tile; padded rows are zero)."""
+        import torch.nn.functional as F
+        d = self.d
+        T, H = a.shape
+        E, k, I = self.moe_experts_l, d.moe_top_k, self.moe_inter_l
+        idx, wts = ops.moe_route(F.linear(a, w["moe_router"]), k, d.moe_norm_topk)       # int32 [T, k], bf16 [T, k]
+        order, dst, wts_s, counts, cap = self._moe_group_slots(idx, wts, T)
         xb = torch.zeros(E * cap, H, dtype=BF16, device=a.device)
         xb[dst] = a[order // k]
         gu = torch.bmm(xb.view(E, cap, H), w["moe_gate_up_t"])                            # [E, cap, 2I]
         act = ops.silu_mul(gu.view(E * cap, 2 * I))
         y = torch.bmm(act.view(E, cap, I), w["moe_down_t"]).view(E * cap, H)
-        ys = torch.empty(T * k, H, dtype=BF16, device=a.device)
-        ys[order] = y[dst]
-        ys = ys.view(T, k, H) * wts_s[:, :, None]
-        out = torch.zeros(T, H, dtype=BF16, device=a.device)
-        for j in range(k):
-            out += ys[:, j]
+        out = self._moe_combine(y, order, dst, wts_s, T)
         if self.moe_shared_l > 0:
             sh = F.linear(ops.silu_mul(F.linear(a, w["moe_shared_gate_up"])), w["moe_shared_down"])
             out = out + torch.sigmoid(F.linear(a, w["moe_shared_gate"])) * sh

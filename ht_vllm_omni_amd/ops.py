@@ -267,17 +267,24 @@ def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
 
 def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bias=None, scale=None, act: int = L.TILE_ACT_NONE,
               resid=None, out=None, out_f32=None, out2=None, snake=None, taps: int = 1, dilation: int = 1,
-              row_off: int | None = None, want: str = "b", tile_hint: int = 0):
+              row_off: int | None = None, want: str = "b", tile_hint: int = 0, groups: int = 1, group_rows=None):
     """omni_gemm_tile: y[M, N] = act(A . W^T + bias) * scale (+ resid) on the matrix cores, A = x for taps == 1, else the
     causal conv window A[m] = [x[m + row_off], x[m + row_off + dilation], ...] (taps rows of x.shape[1] channels; row_off
     defaults to -(taps - 1) * dilation; rows outside x read as zero).  x bf16 [rows, C] (row stride = x.stride(0)); w_frag bf16
     [N, taps * C] fragment-major (engine.frag_shuffle); bias / scale fp32 [N]; resid fp32 [M, N].
     `want` names the outputs: "f" = fp32 y, "b" = bf16(y), "s" = bf16(snake(y)) with snake = (alpha, inv_beta) fp32 [N];
     given buffers (out_f32 / out / out2) are used, missing ones allocated.  Returns them in the order of `want` (a single
-    tensor when one is wanted)."""
+    tensor when one is wanted).
+    groups > 1: the batched form -- x [groups * cap, C] (cap rows per group), w_frag [groups, N, K] (each matrix fragment-major),
+    outputs [groups * cap, N]; group_rows int32 [groups] (device) = live rows per group (the rest is neither computed nor written)."""
     assert x.dtype == BF16 and w_frag.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
     rows, Cin = x.shape
-    N, K = w_frag.shape
+    if groups > 1:
+        assert w_frag.dim() == 3 and w_frag.shape[0] == groups and w_frag.is_contiguous() and taps == 1 and rows % groups == 0
+        N, K = w_frag.shape[1:]
+        cap = rows // groups
+    else:
+        N, K = w_frag.shape
     assert K == taps * Cin, (K, taps, Cin)
     M = rows if M is None else M
     gu8 = act == L.TILE_ACT_SILU_MUL_GU8
@@ -308,5 +315,11 @@ def gemm_tile(x: torch.Tensor, w_frag: torch.Tensor, *, M: int | None = None, bi
         else:
             raise ValueError(want)
     g.M, g.N, g.K, g.tile_hint = M, N, K, tile_hint
+    if groups > 1:
+        assert M == rows, "a grouped launch covers every group's cap rows"
+        g.M, g.groups, g.x_group_rows, g.w_group_elems, g.out_group_rows = cap, groups, cap, N * K, cap
+        if group_rows is not None:
+            assert group_rows.dtype == torch.int32 and group_rows.numel() == groups and group_rows.is_contiguous()
+            g.group_rows = group_rows.data_ptr()
     L.check(L.load().omni_gemm_tile(C.byref(g), L.current_stream()), "omni_gemm_tile")
     return res[0] if len(res) == 1 else tuple(res)

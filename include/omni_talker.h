@@ -154,6 +154,12 @@ typedef struct omni_tile_gemm {
     void* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;
     int tile_hint;   /* 0: automatic; 1: the large output tiles (256 x 256 ...); 2: the 128 x 64 tile of small-M problems */
+    /* grouped (batched) launch, groups > 1: group g computes out rows [g * out_group_rows, + M) from x rows [g * x_group_rows, + M)
+     * and the matrix w + g * w_group_elems (elements) -- the expert-sorted [E, cap, H] batch of the MoE prefill against the
+     * decode step's per-expert fragment-major weights (replaces the batched GEMMs vLLM's FusedMoE issues under
+     * V/model_executor/models/qwen3_omni/qwen3_moe.py:8,152-161).  group_rows (device int32 [groups], or NULL = M each) is the
+     * live row count per group: rows past it read as zero and are not written, whole tiles past it are skipped. */
+    int groups; int64_t x_group_rows, w_group_elems, out_group_rows; const int32_t* group_rows;
 } omni_tile_gemm;
 int omni_gemm_tile(const omni_tile_gemm* g, void* stream);
 

@@ -406,6 +406,53 @@ def test_prefill_wide_paths_match_chunked_native_and_oracle():
         e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=True, gemm="blas")
 
 
+@pytest.mark.parametrize("fp8w", [False, True])
+def test_moe_prefill_grouped_tile_matches_batched_blas_and_oracle(fp8w):
+    """The Omni talker's MoE prefill at its real expert shapes (128 experts top-8 of width 384, shared 768; 2 layers): router,
+    grouped expert GEMMs and shared expert on omni_gemm_tile (fragment-major decode weights) == the batched hipBLASLt arm ==
+    oracle at the last prompt rows; bf16 and fp8 expert weights (the latter: everyone sees bf16(fp8 * scale))."""
+    from ht_vllm_omni_amd.engine import fp8_quant_rows, fp8_dequant_rows
+    d = get_dims("omni-talker").with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=1024)
+    w = make_weights(d, seed=23, std=0.02)
+    ow = w
+    if fp8w:
+        ow = dict(w)
+        for li in range(d.layers):
+            for n in ("moe_gate_up", "moe_down"):
+                q8, sc = fp8_quant_rows(w[f"l{li}.{n}"])
+                ow[f"l{li}.{n}"] = fp8_dequant_rows(q8, sc)
+    bs, nb = 16, 80
+    lens = [300, 257, 140, 9]
+    engs = [_engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=8, moe_fp8=fp8w, prefill_gemm="both") for _ in range(2)]
+    orc = O.TalkerOracle(d, ow, kv_dtype="bf16", num_blocks=nb, block_size=bs)
+    pool = BlockPool(nb, bs)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in lens]
+    for r, n in enumerate(lens):
+        pool.allocate(f"r{r}", n)
+    bts = [pool.block_ids(f"r{r}") for r in range(len(lens))]
+    states = [O.OracleState() for _ in lens]
+    _, _, o_h = orc.prefill(states, prompts, bts)
+    x = torch.cat(prompts).cuda()
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32).cuda()
+    req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32).cuda()
+    outs = []
+    for e, gemm in zip(engs, ("tile", "blas")):
+        for r in range(len(lens)):
+            e.block_table[r, :len(bts[r])] = torch.tensor(bts[r], dtype=torch.int32)
+        outs.append(e.prefill(x, pos, req, orc.last_slots.cuda(), use_blas=True, gemm=gemm))
+    last = torch.tensor(np.cumsum(lens) - 1)
+    # a routing near-tie may send a token to a different 8th expert in either arm: compare the bulk, bound the outliers
+    diff = (outs[0].float() - outs[1].float()).abs().mean(-1) / outs[1].float().abs().mean(-1)
+    assert (diff > 0.02).float().mean().item() < 0.02, f"{int((diff > 0.02).sum())} of {diff.numel()} rows differ between the arms"
+    for h in outs:
+        dr = (h[last.cuda()].float().cpu() - o_h.float()).abs().mean(-1) / o_h.float().abs().mean(-1)
+        assert dr.median().item() < 8e-3 and (dr < 0.03).sum().item() >= len(lens) - 1, dr
+    # the tile arm holds no [E, K, N] copies unless asked for both
+    e = _engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=8, moe_fp8=fp8w)
+    assert "moe_gate_up_t" not in e.layer_w[0] and "moe_gate_up_f" in e.layer_w[0] and "moe_gate_up" not in e.layer_w[0]
+
+
 def test_tp_collective_path_captured_in_hipgraph():
     """The tensor-parallel step (phase calls + RCCL all-reduce after o_proj and down_proj) on a 1-rank nccl group:
     eager and hipGraph replay reproduce the single-call step bit for bit.  (N > 1 needs the driver's 8-GPU node.)"""

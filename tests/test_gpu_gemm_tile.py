@@ -170,3 +170,39 @@ def test_rejects_bad_shapes():
         ops.gemm_tile(x, torch.zeros(32, 48, dtype=BF16, device="cuda"))            # K % 32
     with pytest.raises(OmniError):
         ops.gemm_tile(torch.zeros(64, 64, dtype=BF16, device="cuda"), torch.zeros(24, 64, dtype=BF16, device="cuda"))   # N % 16
+
+
+@pytest.mark.parametrize("E,cap,N,K", [(16, 128, 128, 256), (128, 448, 768, 1024), (128, 448, 1024, 384), (5, 320, 192, 96)])
+def test_grouped_launch_over_an_expert_sorted_batch(E, cap, N, K):
+    """groups > 1: group g multiplies its rows [g cap, g cap + rows[g]) by ITS matrix; rows past the live count are neither read
+    nor written (the output buffer keeps its sentinel there), empty groups cost nothing -- the MoE prefill's [E, cap, H] batch
+    (engine._moe_mlp_tile).  The same rows through E separate plain launches give the same bits."""
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(E * 31 + N)
+    x = torch.randn(E * cap, K, generator=g).to(BF16)
+    w = (torch.randn(E, N, K, generator=g) * 0.05).to(BF16)
+    rows = torch.randint(0, cap + 1, (E,), generator=g).to(torch.int32)
+    rows[0], rows[-1] = cap, 0                                               # a full group and an empty one
+    if E > 2:
+        rows[1] = 1
+    wf = frag_shuffle(w).cuda()
+    out = torch.full((E * cap, N), 7.0, dtype=BF16, device="cuda")
+    # poison the dead rows of x: they must read as zero, i.e. not leak into live rows (they cannot: rows are independent) nor fault
+    xp = x.clone()
+    for e in range(E):
+        xp[e * cap + int(rows[e]): (e + 1) * cap] = float("nan")
+    ops.gemm_tile(xp.cuda(), wf, out=out, groups=E, group_rows=rows.cuda())
+    out = out.cpu()
+    for e in range(E):
+        r = int(rows[e])
+        live, dead = out[e * cap: e * cap + r], out[e * cap + r: (e + 1) * cap]
+        assert torch.equal(dead, torch.full_like(dead, 7.0)), f"group {e}: rows past the live count were written"
+        if r:
+            xe = x[e * cap: e * cap + r]
+            _close(live, xe.double() @ w[e].double().T, xe.double().abs() @ w[e].double().abs().T, f"group {e}")
+            if e < 3:
+                assert torch.equal(live, ops.gemm_tile(xe.cuda(), wf[e].contiguous()).cpu())
+    # without group_rows: every group computes its cap rows
+    full = ops.gemm_tile(x.cuda(), wf, groups=E).cpu()
+    assert torch.equal(full[:cap], ops.gemm_tile(x[:cap].cuda(), wf[0].contiguous()).cpu())
+    assert torch.equal(full[-cap:], ops.gemm_tile(x[-cap:].cuda(), wf[-1].contiguous()).cpu())
