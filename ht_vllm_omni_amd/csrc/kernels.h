@@ -80,6 +80,11 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
                int B, float eps, uint32_t* flags, int32_t* err, void* stream);
+// the same segment with its stages dealt to two alternating 4-wave groups of a workgroup (bb_pp.hip): one group's weight stream
+// covers the other group's hand-off
+bool k_bb_pp_enabled();
+int k_bb_pp(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
+            int B, float eps, uint32_t* flags, int32_t* err, void* stream);
 // the same segment as a loader / consumer engine (bb_engine.hip): 4 extra waves stream the weights into an LDS FIFO by LDS-DMA
 bool k_bb_engine_enabled();
 int k_bb_engine(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,

@@ -16,6 +16,8 @@ void omni_debug_cp_chain(int on);                          /* code predictor: th
 void omni_debug_chain_mode(int dom, int gu_narrow, int nap); /* chain A/B: log2 flag domain (6 | 7 | 8); gate_up on the 32 x 24 tile; s_sleep units between polls */
 void omni_debug_chain_stamps(void* buf);                   /* device uint64 [40][8][256]: per-stage timeline stamps of every chain launch (NULL: off) */
 void omni_debug_bb_chain(int on);                          /* backbone: o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer */
+void omni_debug_bb_pp(int on);                             /* backbone segment on two alternating wave groups (bb_pp.hip); 0 = the plain chain */
+void omni_debug_pp_stamps(void* buf);                      /* int64 [4][8][256] timeline stamps of the two-group chain (scripts/bb_timeline.py) */
 void omni_debug_bb_engine(int on);                         /* backbone segment as the loader / consumer engine (bb_engine.hip) instead of the plain chain */
 void omni_debug_eng_stamps(void* buf);                     /* stage stamps of the engine's compute wave 0 */
 void omni_debug_bb_stamps(void* buf);                      /* as omni_debug_chain_stamps for the backbone segment launches */

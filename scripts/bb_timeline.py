@@ -35,6 +35,13 @@ for s in range(3):
     print(f"{names[s]:10s} " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {(x[7].max() - x[0].min()).item():8.2f}")
 print(f"launch span {(t[2][7].max() - t[0][0].min()).item():.1f} us")
 
+if os.environ.get("BB_STAMPS", "eng") == "pp":
+    t0 = t[0][0].min()
+    print("absolute times since the first workgroup entered (us), median over workgroups [max]:")
+    lab = ["entry", "W issued", "flags seen", "rstd", "MFMA done", "combine bar", "stores issued", "flag out"]
+    print(f"{'stage':10s} " + " ".join(f"{s:>15s}" for s in lab))
+    for s in range(3):
+        print(f"{names[s]:10s} " + " ".join(f"{(t[s][k] - t0).median().item():8.2f}[{(t[s][k] - t0).max().item():5.1f}]" for k in range(8)))
 if os.environ.get("BB_STAMPS", "eng") == "eng":
     L_ = buf.view(40, NST, NW)[32].cpu().double()
     ts = L_[:5] * 0.01
