@@ -91,7 +91,7 @@ class StepIO(C.Structure):
         ("greedy", i32), ("temperature", f32), ("top_k", i32), ("rep_penalty", f32), ("seed", u32),
         ("cp_greedy", i32), ("cp_temperature", f32), ("cp_top_k", i32),
         ("advance", i32), ("top_p", f32), ("cp_top_p", f32),
-        ("num_live", vp), ("rows", RowSampling),
+        ("num_live", vp), ("rows", RowSampling), ("rope_delta", vp),
     ]
 
 
@@ -124,6 +124,7 @@ SIGNATURES = {
     "omni_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                      f32, f32, f32, i32, vp]),
     "omni_qknorm_rope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),
+    "omni_qknorm_mrope_kvwrite": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, f32, vp]),
     "omni_slot_mapping": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
     "omni_paged_attn_decode": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, vp]),
     "omni_paged_attn_workspace_bytes": (i64, [i32, i32, i32, i32]),

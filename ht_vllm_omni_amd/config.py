@@ -42,6 +42,10 @@ class TalkerDims:
     moe_inter: int = 0
     moe_shared_inter: int = 0
     moe_norm_topk: bool = False
+    # M-RoPE (HF rope_scaling {"mrope_section", "interleaved"}): None = plain RoPE.  The talker's prompt ids normally have three
+    # identical rows (positions.py); differing rows and a non-zero mrope_position_delta are honoured when a request carries them
+    mrope_section: tuple | None = None
+    mrope_interleaved: bool = False
 
     @property
     def qkv_out(self) -> int:
@@ -87,6 +91,7 @@ PRESETS: dict[str, TalkerDims] = {
         cp_hidden=256, cp_layers=2, cp_q_heads=2, cp_kv_heads=1, cp_head_dim=128, cp_inter=256,
         cp_rope_theta=10_000.0, max_model_len=512,
         moe_experts=16, moe_top_k=4, moe_inter=64, moe_shared_inter=64,
+        mrope_section=(24, 20, 20), mrope_interleaved=True,
     ),
     # Qwen3-Omni talker (BASELINE configs #4 / #5): HF Qwen3OmniMoeTalkerTextConfig defaults (hidden 1024, 20 layers, 16 q /
     # 2 kv heads, 128 experts top-8 of width 384) + shared expert 768 and head_dim 128 as in the released checkpoint
@@ -98,6 +103,7 @@ PRESETS: dict[str, TalkerDims] = {
         cp_hidden=1024, cp_layers=5, cp_q_heads=16, cp_kv_heads=8, cp_head_dim=128, cp_inter=3072,
         cp_rope_theta=10_000.0,
         moe_experts=128, moe_top_k=8, moe_inter=384, moe_shared_inter=768,
+        mrope_section=(24, 20, 20), mrope_interleaved=True,
     ),
     "tts-0.6b": _tts("tts-0.6b", 1024, 3072),   # BASELINE config #2
     "tts-1.7b": _tts("tts-1.7b", 2048, 6144),   # BASELINE config #3 (headline)

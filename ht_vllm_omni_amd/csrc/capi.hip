@@ -667,7 +667,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
-                            io->num_live));
+                            io->num_live, io->rope_delta));
     if (d.fused_norm && t->has_ar) {
         // tensor-parallel rank on the norm-free stream: partial o_proj -> this rank's peer-mapped buffer (fragment-major),
         // then ONE launch sums the ranks' partials, adds into r and writes the sum(r^2) slabs
@@ -821,7 +821,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
             TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l], t->k_scales[l],
                                     t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
                                     t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
-                                    d.max_model_len, d.frag_layout, -1, stream, io->num_live));
+                                    d.max_model_len, d.frag_layout, -1, stream, io->num_live, io->rope_delta));
             if (k_bb_engine_enabled())
                 TRY(k_bb_engine(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                                 t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));

@@ -50,7 +50,8 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag,
                         int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream,
-                        const int32_t* num_live = nullptr /* device: rows >= *num_live write no KV / slot */);
+                        const int32_t* num_live = nullptr /* device: rows >= *num_live write no KV / slot */,
+                        const int32_t* rope_delta = nullptr /* device [B]: rotary position = positions[b] + rope_delta[b] */);
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,

@@ -25,7 +25,7 @@
 struct PAArgs {
     const uint16_t* q;             // bf16 [rows, Hq*128]           (unfused)
     const uint16_t* qkv;           // bf16 [rows, (Hq+2Hkv)*128]    (fused)
-    const uint16_t* qnorm_w; const uint16_t* knorm_w; const int32_t* positions; const uint16_t* cos_sin;
+    const uint16_t* qnorm_w; const uint16_t* knorm_w; const int32_t* positions; const int32_t* rope_delta; const uint16_t* cos_sin;
     int64_t* slot_out; float eps;
     void* k_cache; void* v_cache; float* k_scales; float* v_scales;
     const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
     float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
     if (FUSED) {
         const int pos = a.positions[row];
-        const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+        const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float y0, y1;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_decode_kernel(const PAA
         const int sp_cur = cur / per;
         if (wave == 0 && sp == sp_cur) {
             const int pos = a.positions[row];
-            const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+            const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
             const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
             // rows of a padded graph bucket past the live count may be live PREFILL rows of the persistent batch: they
             // compute (results discarded) but leave the cache and the slot record alone
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
     const int cur = DENSE ? a.dense_pos : a.seq_lens[row] - 1;
     const int pos = DENSE ? a.dense_pos : a.positions[row];
-    const uint16_t* cs = a.cos_sin + (size_t)pos * 128;
+    const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
     float* wq = sm[wave];
     float* kvs = sm[wave] + G * 128;
     const float qs = a.sm_scale * LOG2E;
@@ -834,8 +834,9 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, int dense_pos,
-                        void* stream, const int32_t* num_live) {
+                        void* stream, const int32_t* num_live, const int32_t* rope_delta) {
     PAArgs a{};
+    a.rope_delta = rope_delta;
     a.out_frag = out_frag;
     a.dense_pos = dense_pos;
     a.num_live = num_live;

@@ -11,10 +11,14 @@ __device__ __forceinline__ float sum16(float v) { return row16_sum(v); }
 __device__ __forceinline__ float max16(float v) { return row16_max(v); }
 __device__ __forceinline__ void unpack4(uint2 w, float* f) { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
 
-template <int KV>
+// MROPE: `positions` is [3, T] (temporal / height / width ids, vLLM MRotaryEmbedding) and rotary pair p of a head takes the id of
+// axis mrope_axis[p] (the section layout, chunked or interleaved, as a 64-entry table): cos / sin are gathered per pair from the
+// row of THAT id -- with three identical rows this is the plain kernel bit for bit.
+template <int KV, bool MROPE = false>
 __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
-    const int32_t* __restrict__ positions, const uint16_t* __restrict__ cos_sin, const int64_t* __restrict__ slot_mapping,
+    const int32_t* __restrict__ positions, const uint8_t* __restrict__ mrope_axis, int T,
+    const uint16_t* __restrict__ cos_sin, const int64_t* __restrict__ slot_mapping,
     uint16_t* __restrict__ q_out, void* __restrict__ k_cache, void* __restrict__ v_cache,
     float* __restrict__ k_scales, float* __restrict__ v_scales, int q_heads, int kv_heads, float eps, float inv_k_scale,
     float inv_v_scale, float k_scale, float v_scale) {
@@ -34,9 +38,19 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
         float w0[4], w1[4], c[4], sn[4];
         unpack4(*reinterpret_cast<const uint2*>(nw + 4 * j), w0);
         unpack4(*reinterpret_cast<const uint2*>(nw + 64 + 4 * j), w1);
-        const int pos = positions[t];
-        unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 4 * j), c);
-        unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 64 + 4 * j), sn);
+        if (MROPE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p = 4 * j + e;
+                const uint16_t* row = cos_sin + (size_t)positions[(size_t)mrope_axis[p] * T + t] * 128;
+                c[e] = bf2f(row[p]);
+                sn[e] = bf2f(row[64 + p]);
+            }
+        } else {
+            const int pos = positions[t];
+            unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 4 * j), c);
+            unpack4(*reinterpret_cast<const uint2*>(cos_sin + (size_t)pos * 128 + 64 + 4 * j), sn);
+        }
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
@@ -107,35 +121,54 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(
     }
 }
 
+static int qknorm_rope_launch(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions,
+                              const uint8_t* mrope_axis, const void* cos_sin, const int64_t* slot_mapping, void* q_out, void* k_cache,
+                              void* v_cache, float* k_scales, float* v_scales, int T, int q_heads, int kv_heads, int head_dim, float eps,
+                              int kv_dtype, float k_scale, float v_scale, void* stream, const char* who) {
+    OMNI_CHECK_ARG(qkv && qnorm_w && knorm_w && positions && cos_sin && slot_mapping && q_out && k_cache && v_cache, "%s: null pointer", who);
+    OMNI_CHECK_ARG(head_dim == 128, "%s: head_dim=%d (only 128)", who, head_dim);
+    OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (k_scales && v_scales), "%s: int8 needs scale arrays", who);
+    OMNI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f, "%s: scales must be > 0", who);
+    if (T <= 0) return OMNI_OK;
+    const int nslots = q_heads + 2 * kv_heads;
+    dim3 grid((nslots + 15) / 16, T), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(KVT, MR)                                                                                                  \
+    hipLaunchKernelGGL((qknorm_rope_kvwrite_kernel<KVT, MR>), grid, block, 0, st, (const uint16_t*)qkv,                  \
+                       (const uint16_t*)qnorm_w, (const uint16_t*)knorm_w, positions, mrope_axis, T, (const uint16_t*)cos_sin, \
+                       slot_mapping, (uint16_t*)q_out, k_cache, v_cache, k_scales, v_scales, q_heads, kv_heads,          \
+                       eps, 1.0f / k_scale, 1.0f / v_scale, k_scale, v_scale)
+#define LAUNCH2(KVT) do { if (mrope_axis) LAUNCH(KVT, true); else LAUNCH(KVT, false); } while (0)
+    switch (kv_dtype) {
+        case OMNI_KV_BF16: LAUNCH2(OMNI_KV_BF16); break;
+        case OMNI_KV_FP8: LAUNCH2(OMNI_KV_FP8); break;
+        case OMNI_KV_INT8: LAUNCH2(OMNI_KV_INT8); break;
+        case OMNI_KV_FP16: LAUNCH2(OMNI_KV_FP16); break;
+        default: omni_set_error("%s: kv_dtype=%d", who, kv_dtype); return OMNI_EINVAL;
+    }
+#undef LAUNCH2
+#undef LAUNCH
+    OMNI_CHECK_LAUNCH(who);
+    return OMNI_OK;
+}
+
 extern "C" int omni_qknorm_rope_kvwrite(const void* qkv, const void* qnorm_w, const void* knorm_w,
                                         const int32_t* positions, const void* cos_sin, const int64_t* slot_mapping,
                                         void* q_out, void* k_cache, void* v_cache, float* k_scales, float* v_scales,
                                         int T, int q_heads, int kv_heads, int head_dim, float eps, int kv_dtype,
                                         float k_scale, float v_scale, void* stream) {
-    OMNI_CHECK_ARG(qkv && qnorm_w && knorm_w && positions && cos_sin && slot_mapping && q_out && k_cache && v_cache,
-                   "omni_qknorm_rope_kvwrite: null pointer");
-    OMNI_CHECK_ARG(head_dim == 128, "omni_qknorm_rope_kvwrite: head_dim=%d (only 128)", head_dim);
-    OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (k_scales && v_scales), "omni_qknorm_rope_kvwrite: int8 needs scale arrays");
-    OMNI_CHECK_ARG(k_scale > 0.f && v_scale > 0.f, "omni_qknorm_rope_kvwrite: scales must be > 0");
-    if (T <= 0) return OMNI_OK;
-    const int nslots = q_heads + 2 * kv_heads;
-    dim3 grid((nslots + 15) / 16, T), block(256);
-    hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(KVT)                                                                                              \
-    hipLaunchKernelGGL(qknorm_rope_kvwrite_kernel<KVT>, grid, block, 0, st, (const uint16_t*)qkv,               \
-                       (const uint16_t*)qnorm_w, (const uint16_t*)knorm_w, positions, (const uint16_t*)cos_sin, \
-                       slot_mapping, (uint16_t*)q_out, k_cache, v_cache, k_scales, v_scales, q_heads, kv_heads,  \
-                       eps, 1.0f / k_scale, 1.0f / v_scale, k_scale, v_scale)
-    switch (kv_dtype) {
-        case OMNI_KV_BF16: LAUNCH(OMNI_KV_BF16); break;
-        case OMNI_KV_FP8: LAUNCH(OMNI_KV_FP8); break;
-        case OMNI_KV_INT8: LAUNCH(OMNI_KV_INT8); break;
-        case OMNI_KV_FP16: LAUNCH(OMNI_KV_FP16); break;
-        default: omni_set_error("omni_qknorm_rope_kvwrite: kv_dtype=%d", kv_dtype); return OMNI_EINVAL;
-    }
-#undef LAUNCH
-    OMNI_CHECK_LAUNCH("omni_qknorm_rope_kvwrite");
-    return OMNI_OK;
+    return qknorm_rope_launch(qkv, qnorm_w, knorm_w, positions, nullptr, cos_sin, slot_mapping, q_out, k_cache, v_cache, k_scales, v_scales,
+                              T, q_heads, kv_heads, head_dim, eps, kv_dtype, k_scale, v_scale, stream, "omni_qknorm_rope_kvwrite");
+}
+
+extern "C" int omni_qknorm_mrope_kvwrite(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions3,
+                                         const uint8_t* mrope_axis, const void* cos_sin, const int64_t* slot_mapping, void* q_out,
+                                         void* k_cache, void* v_cache, float* k_scales, float* v_scales, int T, int q_heads,
+                                         int kv_heads, int head_dim, float eps, int kv_dtype, float k_scale, float v_scale,
+                                         void* stream) {
+    OMNI_CHECK_ARG(mrope_axis != nullptr, "omni_qknorm_mrope_kvwrite: null axis table");
+    return qknorm_rope_launch(qkv, qnorm_w, knorm_w, positions3, mrope_axis, cos_sin, slot_mapping, q_out, k_cache, v_cache, k_scales,
+                              v_scales, T, q_heads, kv_heads, head_dim, eps, kv_dtype, k_scale, v_scale, stream, "omni_qknorm_mrope_kvwrite");
 }
 
 __global__ void slot_mapping_kernel(const int32_t* __restrict__ bt, int bt_stride, const int32_t* __restrict__ positions,

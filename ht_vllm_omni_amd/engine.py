@@ -403,6 +403,10 @@ class TalkerEngine:
         self.row_seed = z(Bm, dt=torch.int32)               # uint32 bit patterns
         # live decode rows of the step: rows [num_live, B) of a padded graph bucket are inert (no KV write / sample / advance)
         self.num_live = torch.full((1,), Bm, dtype=torch.int32, device=dev)
+        # M-RoPE models: the axis table of the prefill kernel and every row's rotary offset for the decode steps (a request's
+        # mrope_position_delta; 0 for the talker's usual three identical id rows)
+        self.mrope_axis = ops.mrope_axis_table(d.mrope_section, d.mrope_interleaved).to(dev) if d.mrope_section else None
+        self.rope_delta = torch.zeros(Bm, dtype=torch.int32, device=dev) if d.mrope_section else None
         # launch-wide scalars: the code predictor's model-level parameters (qwen3_tts_talker.py:1620-1627); the layer-0
         # entries mirror what set_sampling last broadcast into the row arrays
         self.sampling = dict(greedy=1, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seed=0, cp_greedy=1,
@@ -471,6 +475,7 @@ class TalkerEngine:
             setattr(io.rows, k, getattr(self, "row_" + k)[row0:].data_ptr())
         # sub-batch branches see their own row range: their live count is the bucket (only the runner path pads buckets)
         io.num_live = self.num_live.data_ptr() if row0 == 0 and self.n_sub == 1 else None
+        io.rope_delta = self.rope_delta[row0:].data_ptr() if self.rope_delta is not None else None
         return io
 
     def decode_step(self, B: int, advance: bool = True) -> None:
@@ -519,7 +524,7 @@ class TalkerEngine:
         L.check(self.lib.omni_talker_backbone_step(self.handle, C.byref(io), L.current_stream()), "omni_talker_backbone_step")
 
     def prefill_wide(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
-                     block_table: torch.Tensor | None = None, gemm: str | None = None) -> torch.Tensor:
+                     block_table: torch.Tensor | None = None, gemm: str | None = None, rope_positions: torch.Tensor | None = None) -> torch.Tensor:
         """Prefill of all T prompt tokens in one pass per layer (instead of max_batch-row chunks that each re-stream the
         weights): norm, q/k-norm + RoPE + KV write, causal paged attention on the native kernels; the four per-layer GEMMs
         either on omni_gemm_tile (gemm = "tile": the decode step's fragment-major weights, SiLU(gate) * up fused into the
@@ -535,16 +540,24 @@ class TalkerEngine:
         D, hq, hkv = d.head_dim, self.hq_l, self.hkv_l
         resid = x.clone()
         delta = None
+        # rope_positions int32 [3, T]: M-RoPE ids (positions.get_input_positions_tensor) that may differ between rows and from the
+        # cache positions; `positions` stays the token's index in its sequence (cache slot order, causal mask)
+        rope_pos, axis = positions, None
+        if rope_positions is not None:
+            if self.mrope_axis is None:
+                raise L.OmniError("rope_positions given but the model has no mrope_section")
+            rope_pos, axis = rope_positions.to(torch.int32).contiguous(), self.mrope_axis
         for l in range(d.layers):
             w = self.layer_w[l]
             a = ops.rmsnorm(None, w["ln1"], d.eps, delta=delta, residual=resid)
             qkv = ops.gemm_tile(a, w["wqkv_f"]) if tile else F.linear(a, w["wqkv"])
             kc, vc = self.kv_caches[l][0], self.kv_caches[l][1]
             ks = self.kv_scales[l] if self.kv_scales is not None else None
-            q = ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], positions, self.cos_sin, slot_mapping, kc, vc,
+            q = ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], rope_pos, self.cos_sin, slot_mapping, kc, vc,
                                         q_heads=hq, kv_heads=hkv, head_dim=D, eps=d.eps, kv_dtype=self.kv_code,
                                         k_scale=self._desc.k_scale, v_scale=self._desc.v_scale,
-                                        k_scales=None if ks is None else ks[0], v_scales=None if ks is None else ks[1])
+                                        k_scales=None if ks is None else ks[0], v_scales=None if ks is None else ks[1],
+                                        mrope_axis=axis)
             o = ops.paged_attn_prefill(q, kc, vc, bt, req_of_tok, positions, q_heads=hq, kv_heads=hkv, head_dim=D,
                                        block_size=self.block_size, kv_dtype=self.kv_code, k_scale=self._desc.k_scale,
                                        v_scale=self._desc.v_scale, k_scales=None if ks is None else ks[0],
@@ -642,16 +655,18 @@ class TalkerEngine:
         return out
 
     def prefill(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
-                block_table: torch.Tensor | None = None, use_blas: bool | None = None, gemm: str | None = None) -> torch.Tensor:
+                block_table: torch.Tensor | None = None, use_blas: bool | None = None, gemm: str | None = None,
+                rope_positions: torch.Tensor | None = None) -> torch.Tensor:
         """Backbone over T prompt tokens (x bf16 [T,H]) -> final-normed hidden [T,H].  use_blas (historic name) selects the
         all-tokens-per-layer pass (prefill_wide; its GEMMs per `gemm` / the engine's prefill_gemm) over max_batch-row chunks
-        on the decode kernels; default: wide when T > max_batch."""
+        on the decode kernels; default: wide when T > max_batch.  rope_positions int32 [3, T]: M-RoPE ids with differing rows
+        (always the all-tokens pass; the decode rows then need engine.rope_delta[row] = the request's mrope_position_delta)."""
         bt = self.block_table if block_table is None else block_table
         T = x.shape[0]
         if use_blas is None:
             use_blas = T > self.max_batch
-        if use_blas:
-            return self.prefill_wide(x, positions, req_of_tok, slot_mapping, bt, gemm=gemm)
+        if use_blas or rope_positions is not None:
+            return self.prefill_wide(x, positions, req_of_tok, slot_mapping, bt, gemm=gemm, rope_positions=rope_positions)
         out = torch.empty_like(x)
         st = L.current_stream()
         if not self.tp_path:

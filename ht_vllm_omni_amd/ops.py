@@ -182,11 +182,36 @@ def slot_mapping(block_table, positions, block_size, B_padded=None):
     return out
 
 
+def mrope_axis_table(mrope_section, interleaved: bool) -> torch.Tensor:
+    """uint8 [64]: the position-id axis (0 temporal, 1 height, 2 width) rotary pair p of a 128-wide head uses -- vLLM
+    MRotaryEmbedding.forward: chunked sections (cos split by `mrope_section`, chunk i from row i) or `apply_interleaved_rope`
+    (row 1 at p = 1, 4, ... < 3 * section[1], row 2 at p = 2, 5, ... < 3 * section[2], row 0 elsewhere; Qwen3-Omni)."""
+    t, h, w = (int(v) for v in mrope_section)
+    assert t + h + w == 64, mrope_section
+    ax = torch.zeros(64, dtype=torch.uint8)
+    if interleaved:
+        ax[1:3 * h:3] = 1
+        ax[2:3 * w:3] = 2
+    else:
+        ax[t:t + h] = 1
+        ax[t + h:] = 2
+    return ax
+
+
 def qknorm_rope_kvwrite(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cache, v_cache, *, q_heads, kv_heads,
-                        head_dim, eps, kv_dtype, k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None):
-    _chk_dev(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cache, v_cache, k_scales, v_scales)
+                        head_dim, eps, kv_dtype, k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None, mrope_axis=None):
+    """positions int32 [T]; or, with mrope_axis (uint8 [64] on the device, `mrope_axis_table`), int32 [3, T] M-RoPE ids."""
+    _chk_dev(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cache, v_cache, k_scales, v_scales, mrope_axis)
     T = qkv.shape[0]
     q = torch.empty(T, q_heads * head_dim, dtype=BF16, device=qkv.device)
+    if mrope_axis is not None:
+        assert positions.shape == (3, T) and positions.dtype == torch.int32 and positions.is_contiguous(), positions.shape
+        assert mrope_axis.dtype == torch.uint8 and mrope_axis.numel() == 64
+        L.check(L.load().omni_qknorm_mrope_kvwrite(
+            L.ptr(qkv), L.ptr(qnorm_w), L.ptr(knorm_w), L.ptr(positions), L.ptr(mrope_axis), L.ptr(cos_sin), L.ptr(slots), L.ptr(q),
+            L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), T, q_heads, kv_heads, head_dim, float(eps),
+            kv_dtype, float(k_scale), float(v_scale), L.current_stream()), "omni_qknorm_mrope_kvwrite")
+        return q
     L.check(L.load().omni_qknorm_rope_kvwrite(
         L.ptr(qkv), L.ptr(qnorm_w), L.ptr(knorm_w), L.ptr(positions), L.ptr(cos_sin), L.ptr(slots), L.ptr(q),
         L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), T, q_heads, kv_heads, head_dim, float(eps),

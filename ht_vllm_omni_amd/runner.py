@@ -48,6 +48,21 @@ class RequestState:
     codes_hist: list[list[int]] = field(default_factory=list)   # audio codes of every decode step taken (recompute after preemption)
     recompute: int = 0                     # resumed after preemption: decode inputs appended to the prompt for the KV recompute
     n_prompt: int = 0                      # prompt rows proper (prompt_embeds may carry `recompute` rebuilt rows behind them)
+    # M-RoPE ids of the prompt with differing rows and the resulting offset of every later position (vLLM CachedRequestState
+    # .mrope_positions / .mrope_position_delta, set by _init_mrope_positions, V/worker/gpu_model_runner.py:121-180); None / 0 for
+    # the talker's usual text-only prompt (three identical rows == plain RoPE)
+    mrope_positions: torch.Tensor | None = None     # int64 [3, prompt_len]
+    mrope_delta: int = 0
+
+    def rope_ids(self, s0: int, n: int):
+        """[3, n] rotary ids of sequence indices [s0, s0 + n): the prompt's own ids, then index + delta."""
+        idx = torch.arange(s0, s0 + n, dtype=torch.int64)
+        out = (idx + self.mrope_delta).expand(3, -1).clone()
+        if self.mrope_positions is not None:
+            k = max(0, min(n, self.mrope_positions.shape[1] - s0))
+            if k > 0:
+                out[:, :k] = self.mrope_positions[:, s0:s0 + k]
+        return out
 
     @property
     def prompt_len(self) -> int:
@@ -149,6 +164,8 @@ class MI355XARModelRunner:
         e.input_ids[r] = 0
         e.steps[r] = 0
         e.seen[r].zero_()
+        if getattr(e, "rope_delta", None) is not None:
+            e.rope_delta[r] = 0
         # the previous occupant's sampling parameters must not outlive it: back to the stage default (greedy-safe values)
         e.set_row_sampling(r, greedy=True, temperature=1.0, top_k=0, top_p=1.0, rep_penalty=1.0, seed=0)
 
@@ -158,8 +175,10 @@ class MI355XARModelRunner:
             return
         self._tt_flush()
         idx = torch.as_tensor(perm, device=self.engine.input_ids.device)
-        for name in _ROW_BUFFERS:
-            buf = getattr(self.engine, name)
+        for name in _ROW_BUFFERS + ("rope_delta",):
+            buf = getattr(self.engine, name, None)
+            if buf is None:
+                continue
             buf[:n] = buf[:n].index_select(0, idx)
         self.rows = [self.rows[i] for i in perm]
 
@@ -253,6 +272,20 @@ class MI355XARModelRunner:
                               num_computed=int(nr.num_computed_tokens),
                               tail=None if tail is None else tail.to(device=dev, dtype=BF16).reshape(-1, self.d.hidden),
                               tts_pad=pad.to(device=dev, dtype=BF16).reshape(-1), info=info)
+            mp = getattr(nr, "mrope_positions", None)
+            mp = info.get("mrope_positions") if mp is None else mp
+            if mp is not None:
+                mp = torch.as_tensor(mp, dtype=torch.int64).reshape(3, -1)
+                md = getattr(nr, "mrope_position_delta", None)
+                md = info.get("mrope_position_delta", 0) if md is None else md
+                md = int(md.item() if isinstance(md, torch.Tensor) else md)
+                if mp.shape[1] != st.prompt_len:
+                    raise ValueError(f"request {nr.req_id}: mrope_positions cover {mp.shape[1]} tokens, the prompt has {st.prompt_len}")
+                if getattr(e, "rope_delta", None) is None and not (torch.equal(mp[0], mp[1]) and torch.equal(mp[0], mp[2]) and md == 0
+                                                                   and torch.equal(mp[0], torch.arange(mp.shape[1]))):
+                    raise ValueError(f"request {nr.req_id}: M-RoPE ids with differing rows, but the model has no mrope_section")
+                if getattr(e, "rope_delta", None) is not None:
+                    st.mrope_positions, st.mrope_delta = mp, md
             self.requests[nr.req_id] = st
             # per-request model state the stage hooks read and extend (gpu_model_runner.py:60,371,935): same dict as st.info
             self.model_intermediate_buffer[nr.req_id] = st.info
@@ -373,6 +406,8 @@ class MI355XARModelRunner:
         e.last_hidden[r] = hidden_last
         e.positions[r] = st.prefill_len
         e.seq_lens[r] = st.prefill_len + 1
+        if getattr(e, "rope_delta", None) is not None:
+            e.rope_delta[r] = st.mrope_delta
         e.steps[r] = L
         e.seen[r].zero_()
         ids = [d.codec_pad_id] + [t for t in st.output_ids if 0 <= t < d.vocab]
@@ -424,7 +459,8 @@ class MI355XARModelRunner:
         # ---- prefill spans (chunked prefill: a span is any slice of the prompt)
         prefill_done: dict[int, torch.Tensor] = {}
         spans: dict[int, tuple[int, int, torch.Tensor]] = {}
-        xs, pos, req, slots, meta = [], [], [], [], []
+        xs, pos, req, slots, meta, rope = [], [], [], [], [], []
+        any_mrope = False
         bs = e.block_size
         for r in range(len(self.rows)):
             rid = self.rows[r]
@@ -442,13 +478,16 @@ class MI355XARModelRunner:
             req.append(np.full(n, r))
             slots.append(np.asarray(st.block_ids)[p // bs] * bs + p % bs)
             meta.append((r, s0, n))
+            rope.append(st.rope_ids(s0, n))
+            any_mrope = any_mrope or st.mrope_positions is not None or st.mrope_delta != 0
         sampled = None
         if xs:
             dev = e.input_ids.device
             x = torch.cat(xs, 0).to(dev)
             hid = e.prefill(x, torch.as_tensor(np.concatenate(pos), dtype=torch.int32, device=dev),
                             torch.as_tensor(np.concatenate(req), dtype=torch.int32, device=dev),
-                            torch.as_tensor(np.concatenate(slots), dtype=torch.int64, device=dev))
+                            torch.as_tensor(np.concatenate(slots), dtype=torch.int64, device=dev),
+                            **({"rope_positions": torch.cat(rope, 1).to(device=dev, dtype=torch.int32)} if any_mrope else {}))
             o = 0
             for r, s0, n in meta:
                 st = self.requests[self.rows[r]]
@@ -470,6 +509,8 @@ class MI355XARModelRunner:
                     e.last_hidden[r] = hl[j]
                     e.positions[r] = st.prompt_len
                     e.seq_lens[r] = st.prompt_len + 1
+                    if getattr(e, "rope_delta", None) is not None:
+                        e.rope_delta[r] = st.mrope_delta
                 e.input_ids[torch.as_tensor(rows_done, device=dev)] = sampled
 
         # ---- decode rows: text-step queue pop (talker.py:618-629), then the native step

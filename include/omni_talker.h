@@ -200,6 +200,16 @@ int omni_qknorm_rope_kvwrite(const void* qkv, const void* qnorm_w, const void* k
                              int T, int q_heads, int kv_heads, int head_dim, float eps,
                              int kv_dtype, float k_scale, float v_scale, void* stream);
 
+/* The same with M-RoPE position ids (vLLM MRotaryEmbedding.forward with `mrope_section`; ids from
+ * OmniMRotaryEmbedding.get_input_positions_tensor, V/model_executor/layers/rotary_embedding/mrope.py:64-109): positions3 int32
+ * [3, T] = temporal / height / width id of every token, mrope_axis uint8 [64] (device) = the axis whose id rotary pair p uses
+ * (chunked sections [24, 20, 20]: 0 x 24, 1 x 20, 2 x 20; interleaved (Qwen3-Omni): p % 3 for p < 60 (axes h, w need
+ * p < 3 * section), else 0).  Three identical rows give omni_qknorm_rope_kvwrite's result bit for bit. */
+int omni_qknorm_mrope_kvwrite(const void* qkv, const void* qnorm_w, const void* knorm_w, const int32_t* positions3,
+                              const uint8_t* mrope_axis, const void* cos_sin, const int64_t* slot_mapping, void* q_out,
+                              void* k_cache, void* v_cache, float* k_scales, float* v_scales, int T, int q_heads, int kv_heads,
+                              int head_dim, float eps, int kv_dtype, float k_scale, float v_scale, void* stream);
+
 /* Slot mapping for a uniform decode batch, computed on device (vLLM BlockTable.compute_slot_mapping,
  * reached from gpu_ar_model_runner.py:239-244):  slot[r] = bt[r][pos/bs]*bs + pos%bs, -1 when r >= B. */
 int omni_slot_mapping(const int32_t* block_table, int bt_stride, const int32_t* positions,
@@ -425,6 +435,11 @@ typedef struct omni_step_io {
                                      no KV-cache write, no slot_mapping / last_hidden / input_ids / seen / steps / positions /
                                      seq_lens update (they may hold live prefill rows of the persistent batch)            */
     omni_row_sampling rows;       /* layer-0 sampler parameters per row; rows.seed also keys the code predictor's noise    */
+    /* ABI v3 */
+    const int32_t* rope_delta;    /* device int32 [B] or NULL: the backbone's rotary position of row b is positions[b] +
+                                     rope_delta[b] (the request's mrope_position_delta: after a prompt whose M-RoPE ids ran
+                                     ahead of / behind its token count, vLLM get_next_input_positions); cache slots and the
+                                     attention context still follow positions[] / seq_lens[] */
 } omni_step_io;
 
 /* The four phases of one decode step.  With TP > 1 the host

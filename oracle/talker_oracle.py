@@ -113,6 +113,29 @@ def rope_cos_sin(positions: torch.Tensor, head_dim: int, theta: float) -> tuple[
     return emb.cos().to(BF16), emb.sin().to(BF16)
 
 
+def mrope_cos_sin(positions3: torch.Tensor, head_dim: int, theta: float, section, interleaved: bool):
+    """M-RoPE cos / sin [T, head_dim] from ids [3, T] (temporal / height / width).  The reference runs vLLM's MRotaryEmbedding
+    (third party, vllm == 0.18.0, absent: `vllm/model_executor/layers/rotary_embedding/mrope.py` forward_native +
+    `apply_interleaved_rope`); its published algorithm restated: cos_sin = cache[positions] per axis; chunked layout = the
+    half-dim split by `mrope_section`, chunk i taken from axis i; interleaved layout (Qwen3-Omni) = axis 0 everywhere except
+    pairs 1, 4, ... < 3 * section[1] (axis 1) and 2, 5, ... < 3 * section[2] (axis 2); the half is then duplicated (neox)."""
+    half = head_dim // 2
+    cs = [rope_cos_sin(positions3[i], head_dim, theta) for i in range(3)]
+    cos3 = torch.stack([c[0][:, :half] for c in cs])
+    sin3 = torch.stack([c[1][:, :half] for c in cs])
+    if interleaved:
+        cos, sin = cos3[0].clone(), sin3[0].clone()
+        for ax in (1, 2):
+            sl = slice(ax, int(section[ax]) * 3, 3)
+            cos[:, sl] = cos3[ax][:, sl]
+            sin[:, sl] = sin3[ax][:, sl]
+    else:
+        sec = [int(s) for s in section]
+        cos = torch.cat([m[i] for i, m in enumerate(cos3.split(sec, dim=-1))], dim=-1)
+        sin = torch.cat([m[i] for i, m in enumerate(sin3.split(sec, dim=-1))], dim=-1)
+    return torch.cat((cos, cos), dim=-1), torch.cat((sin, sin), dim=-1)
+
+
 def rotate_half(x: torch.Tensor) -> torch.Tensor:
     h = x.shape[-1] // 2
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
@@ -330,6 +353,7 @@ class OracleState:
     tts_pad: torch.Tensor | None = None            # bf16 [H]
     out_ids: list = field(default_factory=list)
     prompt_len: int = 0
+    rope_delta: int = 0                            # mrope_position_delta of the prompt: decode rotary position = index + delta
 
 
 class TalkerOracle:
@@ -356,7 +380,7 @@ class TalkerOracle:
 
     # ---- backbone: tokens of several requests in one flat batch
     def backbone(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: list[int],
-                 block_tables: list, seq_lens_after: list[int]) -> torch.Tensor:
+                 block_tables: list, seq_lens_after: list[int], rope_positions: torch.Tensor | None = None) -> torch.Tensor:
         """x [T, H] bf16 input embeddings; positions [T]; req_of_tok[t] = request row;
         block_tables[r] = block ids; seq_lens_after[r] = context length incl. this step.
         Writes K/V of every token at its slot, then attends through the cache.
@@ -366,7 +390,13 @@ class TalkerOracle:
         slots = torch.tensor([slot_of(block_tables[req_of_tok[t]], int(positions[t]), self.block_size)
                               for t in range(T)], dtype=torch.long)
         self.last_slots = slots
-        cos, sin = rope_cos_sin(positions, d.head_dim, d.rope_theta)
+        # rope_positions: [T] (rotary position differs from the cache index by a delta) or [3, T] M-RoPE ids; default = positions
+        if rope_positions is None:
+            cos, sin = rope_cos_sin(positions, d.head_dim, d.rope_theta)
+        elif rope_positions.ndim == 1:
+            cos, sin = rope_cos_sin(rope_positions, d.head_dim, d.rope_theta)
+        else:
+            cos, sin = mrope_cos_sin(rope_positions, d.head_dim, d.rope_theta, d.mrope_section, d.mrope_interleaved)
         hq, hkv, D = d.q_heads, d.kv_heads, d.head_dim
         h = x
         for li in range(d.layers):
@@ -512,7 +542,9 @@ class TalkerOracle:
         x, codes = self.talker_mtp(ids, e0, last_h, text, **cp_kw)
         positions = torch.tensor([s.seq_len for s in states], dtype=torch.long)
         seq_after = [s.seq_len + 1 for s in states]
-        hidden = self.backbone(x, positions, list(range(B)), block_tables, seq_after)
+        deltas = torch.tensor([s.rope_delta for s in states], dtype=torch.long)
+        hidden = self.backbone(x, positions, list(range(B)), block_tables, seq_after,
+                               rope_positions=positions + deltas if bool(deltas.any()) else None)
         logits = self.compute_logits(hidden)
         sampled = []
         for b, s in enumerate(states):
@@ -532,8 +564,9 @@ class TalkerOracle:
         return logits, torch.tensor(sampled), hidden, codes, self.last_slots
 
     def prefill(self, states: list[OracleState], prompt_embeds: list[torch.Tensor], block_tables: list,
-                *, greedy: bool = True, sampling: dict | None = None):
-        """Whole-prompt prefill of each request (one chunk)."""
+                *, greedy: bool = True, sampling: dict | None = None, rope_positions: torch.Tensor | None = None):
+        """Whole-prompt prefill of each request (one chunk).  rope_positions [3, T]: M-RoPE ids of the flat token batch (the
+        requests' get_input_positions_tensor outputs side by side); the states' rope_delta carry into the decode steps."""
         d = self.d
         xs, pos, req = [], [], []
         for r, pe in enumerate(prompt_embeds):
@@ -543,7 +576,7 @@ class TalkerOracle:
             req += [r] * n
         x = torch.cat(xs, 0)
         seq_after = [pe.shape[0] for pe in prompt_embeds]
-        hidden = self.backbone(x, torch.tensor(pos), req, block_tables, seq_after)
+        hidden = self.backbone(x, torch.tensor(pos), req, block_tables, seq_after, rope_positions=rope_positions)
         last_idx = np.cumsum(seq_after) - 1
         hl = hidden[torch.as_tensor(last_idx)]
         logits = self.compute_logits(hl)

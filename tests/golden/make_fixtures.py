@@ -514,6 +514,56 @@ def mint_graph_decoder():
     print("graph_decoder.json", os.path.getsize(path), "bytes;", len(sizes), "size tables,", len(chunked), "chunked decodes")
 
 
+def mint_mrope_positions():
+    """M-RoPE position ids with DIFFERING rows from the reference's own OmniMRotaryEmbedding.get_input_positions_tensor
+    (V/model_executor/layers/rotary_embedding/mrope.py:64-109 -> the Omni arm 311-478): text, audio, image, video, and audio
+    interleaved with video, plus context_len / seq_len slicing.  Inputs and outputs only -> tests/golden/mrope_positions.json."""
+    import json
+    install_vllm_stubs()
+    _stub("vllm.model_executor.layers")
+    _stub("vllm.model_executor.layers.rotary_embedding")
+    _stub("vllm.model_executor.layers.rotary_embedding.mrope", MRotaryEmbedding=type("MRotaryEmbedding", (), {}))
+    _stub("vllm.transformers_utils")
+    _stub("vllm.transformers_utils.config", thinker_uses_mrope=lambda cfg: hasattr(cfg, "thinker_config"))
+    mod = load_by_path("ref_mrope", os.path.join(REF, "vllm_omni/model_executor/layers/rotary_embedding/mrope.py"))
+    R = mod.OmniMRotaryEmbedding
+    ids = dict(audio_token_index=901, image_token_index=902, video_token_index=903, audio_start_token_id=904, audio_end_token_id=905,
+               vision_start_token_id=906, vision_end_token_id=907, seconds_per_chunk=2)
+    vis = dict(spatial_merge_size=2, tokens_per_second=25)
+    cfg = types.SimpleNamespace(thinker_config=types.SimpleNamespace(vision_config=types.SimpleNamespace(**vis), **ids))
+    A, I, V, AS, AE, VS, VE = 901, 902, 903, 904, 905, 906, 907
+    txt = lambda n, base=10: list(range(base, base + n))
+    naud = lambda L: ((L - 1) // 2 + 1 - 2) // 2 + 1
+    cases = []
+
+    def case(name, tokens, **kw):
+        call = dict(image_grid_thw=[], video_grid_thw=[], second_per_grid_ts=[], audio_feature_lengths=None, use_audio_in_video=False,
+                    context_len=0, seq_len=None)
+        call.update(kw)
+        afl = call["audio_feature_lengths"]
+        pos, delta = R.get_input_positions_tensor(tokens, cfg, call["image_grid_thw"], call["video_grid_thw"], call["second_per_grid_ts"],
+                                                  context_len=call["context_len"], seq_len=call["seq_len"],
+                                                  audio_feature_lengths=None if afl is None else torch.tensor(afl),
+                                                  use_audio_in_video=call["use_audio_in_video"])
+        cases.append(dict(name=name, tokens=tokens, positions=pos.tolist(), delta=int(delta), **call))
+
+    case("text_only", txt(20))
+    case("text_only_sliced", txt(20), context_len=5, seq_len=17)
+    case("audio", txt(3) + [AS] + [A] * naud(101) + [AE] + txt(4), audio_feature_lengths=[101])
+    case("image", txt(2) + [VS] + [I] * 24 + [VE] + txt(5), image_grid_thw=[[1, 8, 12]])
+    case("two_images_and_audio", txt(2) + [VS] + [I] * 6 + [VE] + txt(1) + [VS] + [I] * 16 + [VE] + [AS] + [A] * naud(57) + [AE] + txt(3),
+         image_grid_thw=[[1, 4, 6], [1, 8, 8]], audio_feature_lengths=[57])
+    case("video", txt(2) + [VS] + [V] * 16 + [VE] + txt(3), video_grid_thw=[[4, 4, 4]], second_per_grid_ts=[0.5])
+    case("video_sliced", txt(2) + [VS] + [V] * 16 + [VE] + txt(3), video_grid_thw=[[4, 4, 4]], second_per_grid_ts=[0.5], context_len=4, seq_len=20)
+    for L, tag in ((401, "audio_shorter"), (801, "audio_longer")):
+        n = naud(L)
+        case("audio_in_video_" + tag, txt(2) + [VS, AS] + [V] * (24 + n) + [AE, VE] + txt(3), video_grid_thw=[[6, 4, 4]], second_per_grid_ts=[1.0],
+             audio_feature_lengths=[L], use_audio_in_video=True)
+    out = dict(config=dict(ids, **vis), cases=cases)
+    json.dump(out, open(os.path.join(HERE, "mrope_positions.json"), "w"))
+    print("mrope_positions.json:", [(c["name"], len(c["positions"][0]), c["delta"]) for c in cases])
+
+
 def install_auto_stubs():
     """qwen3_omni.py imports ~20 vllm / vllm_omni symbols at module level (registries, interfaces, thinker classes) that its
     prompt-embedding methods never touch: every such name resolves to an empty placeholder class so that the module
@@ -981,7 +1031,7 @@ def mint_code2wav():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "tp", "g2", "g3", "c2w"]
+    which = sys.argv[1:] or ["cp", "bb", "kv", "cw", "os", "sb", "moe", "gd", "op", "tp", "g2", "g3", "c2w", "mr"]
     if "cp" in which:
         mint_code_predictor()
     if "bb" in which:
@@ -1008,3 +1058,5 @@ if __name__ == "__main__":
         mint_kv_quant()
     if "c2w" in which:
         mint_code2wav()
+    if "mr" in which:
+        mint_mrope_positions()

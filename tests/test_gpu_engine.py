@@ -527,6 +527,66 @@ def test_moe_backbone_decode_steps_match_oracle():
     assert bad_rows <= 2, f"{bad_rows} rows diverged"
 
 
+def test_mrope_prompt_with_differing_rows_and_decode_offset_match_oracle():
+    """A prompt whose M-RoPE ids differ between rows (an image block in the middle: ids from positions.omni_input_positions,
+    pinned to the reference by tests/golden/mrope_positions.json) through prefill and three decode steps: the prefill kernel
+    rotates every pair by its axis' id, the decode steps by index + mrope_position_delta (engine.rope_delta, read inside the
+    captured step), cache slots and attention context by the plain index.  Against the oracle's restatement of vLLM's
+    MRotaryEmbedding; a second request in the same batch keeps plain ids (delta 0)."""
+    import types
+    from ht_vllm_omni_amd import positions as P
+    d = get_dims("omni-moe-tiny")
+    assert d.mrope_section == (24, 20, 20) and d.mrope_interleaved
+    w = make_weights(d, seed=31, std=0.06, norm_noise=0.1)
+    bs, nb, n_steps = 16, 32, 3
+    ids = dict(audio_token_index=901, image_token_index=902, video_token_index=903, audio_start_token_id=904, audio_end_token_id=905,
+               vision_start_token_id=906, vision_end_token_id=907, seconds_per_chunk=2)
+    cfg = types.SimpleNamespace(thinker_config=types.SimpleNamespace(vision_config=types.SimpleNamespace(spatial_merge_size=2, tokens_per_second=25), **ids))
+    toks = [11, 12, 906] + [902] * 24 + [907, 13, 14, 15]
+    mp, delta = P.get_input_positions_tensor(toks, cfg, [[1, 8, 12]], [], [])
+    assert delta == -18 and not torch.equal(mp[1], mp[2])
+    lens = [len(toks), 9]
+    rope = torch.cat([mp, torch.arange(lens[1]).expand(3, -1)], 1)
+    deltas = [delta, 0]
+    eng = _engine(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs, max_batch=4)
+    orc = O.TalkerOracle(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs)
+    pool = BlockPool(nb, bs)
+    g = torch.Generator().manual_seed(2)
+    prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in lens]
+    pads = [torch.randn(d.hidden, generator=g).to(BF16) for _ in lens]
+    for r, n in enumerate(lens):
+        pool.allocate(f"r{r}", n + n_steps + 1)
+    bts = [pool.block_ids(f"r{r}") for r in range(2)]
+    states = [O.OracleState(tts_pad=pads[r], rope_delta=deltas[r]) for r in range(2)]
+    o_logits, o_ids, o_h = orc.prefill(states, prompts, bts, rope_positions=rope)
+    plain_h = O.TalkerOracle(d, w, kv_dtype="bf16", num_blocks=nb, block_size=bs).prefill([O.OracleState(tts_pad=pads[r]) for r in range(2)], prompts, bts)[2]
+    assert (plain_h[0].float() - o_h[0].float()).abs().mean() > 10 * (plain_h[1].float() - o_h[1].float()).abs().mean() + 1e-3   # the ids matter
+    for r in range(2):
+        eng.block_table[r, :len(bts[r])] = torch.tensor(bts[r], dtype=torch.int32)
+    x = torch.cat(prompts).cuda()
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32).cuda()
+    req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32).cuda()
+    hid = eng.prefill(x, pos, req, orc.last_slots.cuda(), rope_positions=rope.to(torch.int32).cuda())
+    last = torch.tensor(np.cumsum(lens) - 1)
+    assert_e2e_close(hid[last.cuda()], o_h, mean_tol=8e-3, max_ulps=3, what="M-RoPE prefill hidden")
+    eng.input_ids[:2] = o_ids.to(torch.int32).cuda()
+    eng.last_hidden[:2] = o_h.cuda()
+    eng.positions[:2] = torch.tensor(lens, dtype=torch.int32).cuda()
+    eng.seq_lens[:2] = (torch.tensor(lens, dtype=torch.int32) + 1).cuda()
+    eng.rope_delta[:2] = torch.tensor(deltas, dtype=torch.int32).cuda()
+    eng.steps[:2] = 1
+    for s in range(n_steps):
+        eng.text_step[:2] = torch.stack(pads).cuda()
+        eng.decode_step(2)
+        lg, ids_o, h_o, codes_o, slots_o = orc.decode_step(states, bts)
+        assert torch.equal(eng.slot_mapping[:2].cpu(), slots_o), "cache slots follow the plain index, not the rotary id"
+        assert_e2e_close(eng.last_hidden[:2].cpu(), h_o, mean_tol=8e-3, max_ulps=3, what=f"M-RoPE decode step {s} hidden")
+        eng.input_ids[:2] = ids_o.to(torch.int32).cuda()        # keep both on the oracle's token (a routing near-tie may flip one)
+        eng.last_hidden[:2] = h_o.cuda()
+    # the offset matters: the same step without it lands elsewhere
+    assert eng.rope_delta[:2].tolist() == deltas
+
+
 def test_omni_finite_suppression_value():
     """The Omni talker's compute_logits writes -1e9 for suppressed tokens instead of -inf (qwen3_omni.py:1143-1149): same
     picks, finite logits; desc.masked_logit carries the value into the lm_head epilogue of the step and of omni_talker_logits."""

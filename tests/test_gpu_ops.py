@@ -283,6 +283,57 @@ def test_qknorm_rope_kvwrite(ops, kv, hq, hkv):
     assert got[:, 0].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("interleaved", [True, False])
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_qknorm_mrope_kvwrite_with_differing_rows(ops, kv, interleaved):
+    """M-RoPE ids whose three rows differ (image / video tokens; tests/golden/mrope_positions.json holds real ones): the kernel
+    gathers cos / sin per rotary pair from the row of the pair's axis -- against the oracle's restatement of vLLM's
+    MRotaryEmbedding.forward (chunked sections and apply_interleaved_rope); identical rows reproduce the plain kernel bit for bit."""
+    from ht_vllm_omni_amd import _lib as L
+    D, T, nb, bs, hq, hkv = 128, 13, 6, 16, 4, 2
+    sec = (24, 20, 20)
+    g = torch.Generator().manual_seed(5 + int(interleaved))
+    qkv = _rand(g, T, (hq + 2 * hkv) * D, scale=2.0)
+    qn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    kn = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16)
+    base = torch.tensor([0, 1, 2, 3, 3, 3, 3, 9, 10, 40, 41, 95, 96])
+    pos3 = torch.stack([base, base + torch.tensor([0, 0, 0, 0, 1, 0, 1, 0, 0, 2, 3, 0, 7]), base + torch.tensor([0, 0, 0, 1, 0, 2, 1, 0, 0, 5, 1, 0, 11])])
+    slots = torch.arange(16, 16 + T, dtype=torch.int64)
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    cos_sin = ops.rope_table(128, D, 1e6)
+    axis = ops.mrope_axis_table(sec, interleaved).cuda()
+    store = {"bf16": BF16, "fp8": torch.uint8}[kv]
+
+    def run(positions, ax):
+        cache = torch.zeros(2, nb, bs, hkv, D, dtype=store, device="cuda")
+        q = ops.qknorm_rope_kvwrite(qkv.cuda(), qn.cuda(), kn.cuda(), positions.to(torch.int32).cuda().contiguous(), cos_sin.cuda(), slots.cuda(),
+                                    cache[0], cache[1], q_heads=hq, kv_heads=hkv, head_dim=D, eps=1e-6, kv_dtype=L.KV_CODES[kv],
+                                    k_scale=k_scale, v_scale=v_scale, mrope_axis=ax)
+        return q.cpu(), cache.cpu()
+
+    q, cache = run(pos3, axis)
+    cos, sin = O.mrope_cos_sin(pos3, D, 1e6, sec, interleaved)
+    qq = qkv[:, : hq * D].reshape(T, hq, D)
+    kk = qkv[:, hq * D:(hq + hkv) * D].reshape(T, hkv, D)
+    vv = qkv[:, (hq + hkv) * D:].reshape(T, hkv, D)
+    q_ref = O.apply_rope(O.rms_norm(qq, qn, 1e-6), cos, sin)
+    k_ref = O.apply_rope(O.rms_norm(kk, kn, 1e-6), cos, sin)
+    assert_bf16_close(q.view(T, hq, D), q_ref, what="q norm + M-RoPE")
+    pk = O.PagedKV(nb, bs, hkv, D, kv, k_scale, v_scale)
+    pk.write(slots, k_ref, vv)
+    if kv == "bf16":
+        assert_bf16_close(cache[0], pk.data[0], what="K cache, M-RoPE")
+    else:
+        assert (cache[0] != pk.data.view(torch.uint8)[0]).float().mean().item() < 0.01
+    # the rows really matter: the plain kernel on row 0 gives something else ...
+    q_plain, _ = run(pos3[0], None)
+    assert not torch.equal(q, q_plain)
+    # ... and three identical rows give the plain kernel's bits
+    q_same, c_same = run(pos3[0].expand(3, -1), axis)
+    q_p0, c_p0 = run(pos3[0], None)
+    assert torch.equal(q_same, q_p0) and torch.equal(c_same.view(torch.uint8), c_p0.view(torch.uint8))
+
+
 def _fill_cache(kv, nb, bs, hkv, D, gen, k_scale, v_scale):
     pk = O.PagedKV(nb, bs, hkv, D, kv, k_scale, v_scale)
     slots = torch.arange(nb * bs)

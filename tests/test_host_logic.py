@@ -321,6 +321,56 @@ def test_shard_layer_partitions_weights():
     assert torch.equal(parts[0]["wqkv"][D:2 * D], parts[1]["wqkv"][D:2 * D]) and not torch.equal(parts[0]["wqkv"][D:2 * D], parts[2]["wqkv"][D:2 * D])
 
 
+def test_mrope_positions_with_differing_rows_match_the_reference(golden_dir):
+    """Row a14 beyond text: audio runs, image / video (t, h, w) blocks, audio interleaved with video, context slicing -- every
+    case of tests/golden/mrope_positions.json, minted from the reference's own OmniMRotaryEmbedding.get_input_positions_tensor
+    (mrope.py:64-109 -> 311-478; make_fixtures.py `mr`): ids and delta exact."""
+    import json
+    import os
+    import types
+    import pytest
+    import torch
+    from ht_vllm_omni_amd import positions as P
+    z = json.load(open(os.path.join(golden_dir, "mrope_positions.json")))
+    c = dict(z["config"])
+    vis = types.SimpleNamespace(spatial_merge_size=c.pop("spatial_merge_size"), tokens_per_second=c.pop("tokens_per_second"))
+    cfg = types.SimpleNamespace(thinker_config=types.SimpleNamespace(vision_config=vis, **c))
+    assert len(z["cases"]) >= 9
+    differing = 0
+    for cs in z["cases"]:
+        pos, delta = P.get_input_positions_tensor(cs["tokens"], cfg, cs["image_grid_thw"], cs["video_grid_thw"], cs["second_per_grid_ts"],
+                                                  context_len=cs["context_len"], seq_len=cs["seq_len"],
+                                                  audio_feature_lengths=cs["audio_feature_lengths"], use_audio_in_video=cs["use_audio_in_video"])
+        assert pos.dtype == torch.int64 and pos.tolist() == cs["positions"], cs["name"]
+        assert delta == cs["delta"], cs["name"]
+        differing += int(not (torch.equal(pos[0], pos[1]) and torch.equal(pos[0], pos[2])))
+        lists, d2 = P.get_input_positions(cs["tokens"], cfg, cs["image_grid_thw"], cs["video_grid_thw"], cs["second_per_grid_ts"],
+                                          context_len=cs["context_len"], seq_len=cs["seq_len"],
+                                          audio_feature_lengths=cs["audio_feature_lengths"], use_audio_in_video=cs["use_audio_in_video"])
+        assert lists == cs["positions"] and d2 == cs["delta"]
+    assert differing >= 5                       # the fixture really exercises rows that differ
+    with pytest.raises(NotImplementedError):    # the Qwen2-VL / GLM-4V arms are not talker paths
+        P.get_input_positions_tensor([1, 2, 3], types.SimpleNamespace(model_type="qwen2_vl"), [[1, 4, 4]], [], [])
+
+
+def test_mrope_axis_table_and_request_rope_ids():
+    """The section layouts as a 64-entry axis table (vLLM MRotaryEmbedding.forward: chunked sections, apply_interleaved_rope) and
+    the runner's per-request ids: the prompt's own [3, n] ids, then index + delta for everything after it."""
+    import torch
+    from ht_vllm_omni_amd import ops
+    from ht_vllm_omni_amd.runner import RequestState
+    ax = ops.mrope_axis_table((24, 20, 20), False).tolist()
+    assert ax == [0] * 24 + [1] * 20 + [2] * 20
+    ai = ops.mrope_axis_table((24, 20, 20), True).tolist()
+    assert ai[:6] == [0, 1, 2, 0, 1, 2] and ai[57:60] == [0, 1, 2] and ai[60:] == [0, 0, 0, 0] and ai.count(1) == 20 and ai.count(2) == 20
+    mp = torch.tensor([[0, 1, 2, 2, 2, 3], [0, 1, 2, 2, 3, 3], [0, 1, 2, 3, 2, 3]])
+    st = RequestState(req_id="a", prompt_embeds=torch.zeros(6, 4), block_ids=[1], sampling=None, mrope_positions=mp, mrope_delta=-2)
+    assert st.rope_ids(0, 6).tolist() == mp.tolist()
+    assert st.rope_ids(4, 4).tolist() == [[2, 3, 4, 5], [3, 3, 4, 5], [2, 3, 4, 5]]       # two prompt ids, then 6 - 2, 7 - 2
+    plain = RequestState(req_id="b", prompt_embeds=torch.zeros(6, 4), block_ids=[1], sampling=None)
+    assert plain.rope_ids(3, 2).tolist() == [[3, 4]] * 3
+
+
 def test_mrope_positions_text_only_and_collapse():
     """Row a14: text-only M-RoPE ids = three identical aranges, delta 0 (mrope.py:196-203), sliced by context_len / seq_len."""
     import pytest
