@@ -81,19 +81,37 @@ class Code2WavConfig:
             raise ValueError("Code2Wav on MI355X: head_dim 64 | 128, latent_dim <= 1024, q heads a multiple of kv heads")
 
 
-class _Conv:
-    """One omni_gemm_tile launch: weights fragment-major bf16 [N, taps * C_in], fp32 bias / scale."""
-    __slots__ = ("w", "bias", "scale", "taps", "dilation", "n")
+def _split(a: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """fp32 -> (hi, lo) bf16 with hi + lo = a to 2^-17 relative: the two operands of a split-bf16 product."""
+    hi = a.to(BF16)
+    return hi, (a - hi.float()).to(BF16)
 
-    def __init__(self, w, bias, taps=1, dilation=1, scale=None):
-        self.w, self.bias, self.scale, self.taps, self.dilation, self.n = w, bias, scale, taps, dilation, w.shape[0]
+
+class _Conv:
+    """One omni_gemm_tile launch: weights fragment-major bf16 [N, taps * C_in], fp32 bias / scale.  With `w_lo` (the bf16 residue
+    of the fp32 weights, operand_precision="fp32") `f32()` computes the product on fp32-precision operands as three launches:
+    hi.hi + hi.lo + lo.hi accumulated in fp32 (the lo.lo term is 2^-34 of the product)."""
+    __slots__ = ("w", "w_lo", "bias", "scale", "taps", "dilation", "n")
+
+    def __init__(self, w, bias, taps=1, dilation=1, scale=None, w_lo=None):
+        self.w, self.bias, self.scale, self.taps, self.dilation, self.n, self.w_lo = w, bias, scale, taps, dilation, w.shape[0], w_lo
 
     def __call__(self, x, **kw):
         return ops.gemm_tile(x, self.w, bias=self.bias, scale=self.scale, taps=self.taps, dilation=self.dilation, **kw)
 
+    def f32(self, x: torch.Tensor, resid: torch.Tensor | None = None) -> torch.Tensor:
+        """x fp32 [rows, C_in] -> fp32 (x . W^T + bias) * scale (+ resid), operands at fp32 precision (split-bf16 on the MFMA tile kernel)."""
+        hi, lo = _split(x)
+        kw = dict(scale=self.scale, taps=self.taps, dilation=self.dilation, want="f")
+        y = ops.gemm_tile(hi, self.w, bias=self.bias, resid=resid, **kw)
+        ops.gemm_tile(hi, self.w_lo, resid=y, out_f32=y, **kw)
+        ops.gemm_tile(lo, self.w, resid=y, out_f32=y, **kw)
+        return y
+
 
 class Code2WavDecoder:
-    def __init__(self, cfg: Code2WavConfig | dict, state: dict[str, torch.Tensor], device: str = "cuda:0", fused_units: bool = True):
+    def __init__(self, cfg: Code2WavConfig | dict, state: dict[str, torch.Tensor], device: str = "cuda:0", fused_units: bool = True,
+                 operand_precision: str = "bf16"):
         if not torch.cuda.is_available():
             raise L.OmniError("Code2WavDecoder needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -104,6 +122,12 @@ class Code2WavDecoder:
         self._graph = None
         # residual units of the 96- / 192-channel blocks as one launch each (omni_codec_res_unit) instead of two omni_gemm_tile launches
         self.fused_units = bool(fused_units)
+        # "bf16" (default): GEMM operands bf16, fp32 accumulate and fp32 residual streams -- the fast path.  "fp32": the
+        # reference's arithmetic (it loads the decoder in fp32, qwen3_tts_code2wav.py:71-75): every GEMM on fp32-precision
+        # operands (split-bf16, three MFMA launches), every activation between them kept in fp32 (forward_fp32)
+        if operand_precision not in ("bf16", "fp32"):
+            raise ValueError(f"operand_precision={operand_precision!r}")
+        self.operand_precision = operand_precision
         self._build(state)
 
     # ------------------------------------------------------------------ weights
@@ -113,16 +137,25 @@ class Code2WavDecoder:
         def f32(name):
             return sd[name].detach().to(dev, torch.float32).contiguous()
 
+        fp32_mode = self.operand_precision == "fp32"
+
         def frag(w2d):                      # [N, K] fp32 -> bf16 fragment-major on the device
             return frag_shuffle(w2d.to(dev, torch.float32).to(BF16).contiguous())
 
+        def frag_lo(w2d, shuffle=frag_shuffle):     # the bf16 residue of the fp32 weights, same layout (fp32 mode only)
+            if not fp32_mode:
+                return None
+            w32 = w2d.to(dev, torch.float32)
+            return shuffle((w32 - w32.to(BF16).float()).to(BF16).contiguous())
+
         def linear(name, bias=True, scale=None):
-            return _Conv(frag(sd[name + ".weight"]), f32(name + ".bias") if bias else None, scale=scale)
+            return _Conv(frag(sd[name + ".weight"]), f32(name + ".bias") if bias else None, scale=scale, w_lo=frag_lo(sd[name + ".weight"]))
 
         def conv(name, dilation=1):         # Conv1d weight [Cout, Cin, k] -> K index = tap * Cin + ci
             w = sd[name + ".conv.weight"].detach().float()
             co, ci, k = w.shape
-            return _Conv(frag(w.permute(0, 2, 1).reshape(co, k * ci)), f32(name + ".conv.bias"), taps=k, dilation=dilation)
+            wk = w.permute(0, 2, 1).reshape(co, k * ci)
+            return _Conv(frag(wk), f32(name + ".conv.bias"), taps=k, dilation=dilation, w_lo=frag_lo(wk))
 
         def tconv(name, stride):            # ConvTranspose1d weight [Cin, Cout, k], k = stride | 2 * stride -> rows n = r * Cout + co
             w = sd[name + ".conv.weight"].detach().float()
@@ -134,7 +167,7 @@ class Code2WavDecoder:
             else:
                 raise ValueError(f"{name}: transposed conv kernel {k} with stride {stride} (k = s or 2 s)")
             wk = wk.permute(2, 1, 0).reshape(stride * co, taps * ci)
-            return _Conv(frag(wk), f32(name + ".conv.bias").repeat(stride), taps=taps)
+            return _Conv(frag(wk), f32(name + ".conv.bias").repeat(stride), taps=taps, w_lo=frag_lo(wk))
 
         def snake(name):
             a, b = sd[name + ".alpha"].detach().float(), sd[name + ".beta"].detach().float()
@@ -160,10 +193,12 @@ class Code2WavDecoder:
             gu = torch.cat([sd[p + "mlp.gate_proj.weight"].detach().float(), sd[p + "mlp.up_proj.weight"].detach().float()], 0)
             self.layers.append(dict(
                 ln1=f32(p + "input_layernorm.weight"), ln2=f32(p + "post_attention_layernorm.weight"),
-                qkv=_Conv(frag(qkv), None),
-                o=_Conv(frag(sd[p + "self_attn.o_proj.weight"]), None, scale=f32(p + "self_attn_layer_scale.scale")),
-                gu=_Conv(gu8_shuffle(gu.to(dev).to(BF16)), None),
-                down=_Conv(frag(sd[p + "mlp.down_proj.weight"]), None, scale=f32(p + "mlp_layer_scale.scale"))))
+                qkv=_Conv(frag(qkv), None, w_lo=frag_lo(qkv)),
+                o=_Conv(frag(sd[p + "self_attn.o_proj.weight"]), None, scale=f32(p + "self_attn_layer_scale.scale"),
+                        w_lo=frag_lo(sd[p + "self_attn.o_proj.weight"])),
+                gu=_Conv(gu8_shuffle(gu.to(dev).to(BF16)), None, w_lo=frag_lo(gu, gu8_shuffle)),
+                down=_Conv(frag(sd[p + "mlp.down_proj.weight"]), None, scale=f32(p + "mlp_layer_scale.scale"),
+                           w_lo=frag_lo(sd[p + "mlp.down_proj.weight"]))))
         # upsample stages: transposed conv (k = s) + ConvNeXt
         self.ups = []
         for i, f in enumerate(c.upsampling_ratios):
@@ -185,6 +220,9 @@ class Code2WavDecoder:
         self.last_act = snake(f"decoder.{n + 1}")
         wl = sd[f"decoder.{n + 2}.conv.weight"].detach().float()                              # [1, C, taps]
         self.out_w = wl[0].T.to(dev).contiguous()                                             # [taps, C]
+        if fp32_mode:       # the depthwise conv of the ConvNeXt blocks as torch weights for forward_fp32
+            for i, u in enumerate(self.ups):
+                u["dw_w3"] = sd[f"upsample.{i}.1.dwconv.conv.weight"].detach().to(dev, torch.float32).contiguous()
         self.out_taps, self.out_c = wl.shape[2], wl.shape[1]
         self.out_b = float(sd[f"decoder.{n + 2}.conv.bias"].detach().float().reshape(-1)[0])
 
@@ -208,8 +246,10 @@ class Code2WavDecoder:
         c, lib, st = self.cfg, self.lib, L.current_stream()
         if codes.dim() == 3:
             if codes.shape[0] != 1:
-                return torch.cat([self.forward(codes[b:b + 1]) for b in range(codes.shape[0])], 0)
+                return torch.cat([self.forward(codes[b:b + 1], taps) for b in range(codes.shape[0])], 0)
             codes = codes[0]
+        if self.operand_precision == "fp32":
+            return self.forward_fp32(codes, taps)
         if codes.shape[0] != c.num_quantizers:
             raise ValueError(f"Expected {c.num_quantizers} layer of codes, got {codes.shape[0]}")
         codes = codes.to(self.device, torch.long)
@@ -291,6 +331,91 @@ class Code2WavDecoder:
         self._check(lib.omni_codec_out_conv(s.data_ptr(), self.out_w.data_ptr(), self.out_b, wav.data_ptr(), T, self.out_c, self.out_taps, st),
                     "omni_codec_out_conv")
         return wav.view(1, 1, T)
+
+    def forward_fp32(self, codes: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
+        """The decoder in the reference's arithmetic (fp32 module, qwen3_tts_code2wav.py:71-75): every conv / linear through
+        `_Conv.f32` (fp32-precision operands on the MFMA tile kernel, fp32 accumulate), everything between them -- RVQ sum,
+        RMSNorm, RoPE, sliding-window attention, depthwise conv + LayerNorm, GELU / SiLU, SnakeBeta, the final conv -- as fp32
+        elementwise / reduction work on the device.  Several times slower than the bf16-operand path; selected by
+        operand_precision="fp32" when a stage must match the reference to fp32 rounding.  codes long [Q, T]."""
+        import torch.nn.functional as F
+        c, dev = self.cfg, self.device
+        if codes.shape[0] != c.num_quantizers:
+            raise ValueError(f"Expected {c.num_quantizers} layer of codes, got {codes.shape[0]}")
+        codes = codes.to(dev, torch.long)
+        T = codes.shape[1]
+
+        def tap(k, v):
+            if taps is not None:
+                taps[k] = v
+
+        def snake(y, sn):
+            return y + sn[1] * torch.sin(y * sn[0]) ** 2
+
+        def rms(h, w_):
+            return h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + c.rms_norm_eps) * w_
+
+        q = self.rvq_table[torch.arange(c.num_quantizers, device=dev)[:, None], codes].sum(0)        # [T, cd] fp32
+        tap("quantized", q)
+        x = self.pre_conv.f32(q)
+        tap("pre_conv", x)
+        # ---- transformer
+        H, nh, nkv, hd = c.hidden_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        h = self.in_proj.f32(x)
+        pos = torch.arange(T, device=dev, dtype=torch.float32)
+        inv = 1.0 / (float(c.rope_theta) ** (torch.arange(0, hd, 2, device=dev, dtype=torch.float32) / hd))
+        ang = pos[:, None] * inv[None, :]
+        cos, sin = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :], torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+        rot = lambda v: torch.cat([-v[..., hd // 2:], v[..., :hd // 2]], -1)
+        ti = torch.arange(T, device=dev)
+        keep = (ti[None, :] <= ti[:, None]) & (ti[:, None] - ti[None, :] < c.sliding_window)         # causal, `sliding_window` keys
+        for lw in self.layers:
+            qkv = lw["qkv"].f32(rms(h, lw["ln1"]))
+            qh = qkv[:, :nh * hd].view(T, nh, hd)
+            kh = qkv[:, nh * hd:(nh + nkv) * hd].view(T, nkv, hd)
+            vh = qkv[:, (nh + nkv) * hd:].view(T, nkv, hd)
+            qh, kh = qh * cos + rot(qh) * sin, kh * cos + rot(kh) * sin
+            rep = nh // nkv
+            kh, vh = kh.repeat_interleave(rep, 1), vh.repeat_interleave(rep, 1)
+            sc = torch.einsum("thd,shd->hts", qh, kh) * hd ** -0.5
+            sc = sc.masked_fill(~keep[None], float("-inf")).softmax(-1)
+            attn = torch.einsum("hts,shd->thd", sc, vh).reshape(T, nh * hd)
+            h = lw["o"].f32(attn, resid=h)
+            gu = lw["gu"].f32(rms(h, lw["ln2"]))                         # rows interleaved [8 gate | 8 up] (gu8 layout)
+            gu = gu.view(T, -1, 2, 8)
+            h = lw["down"].f32((F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(T, -1), resid=h)
+        x = self.out_proj.f32(rms(h, self.final_norm))
+        tap("pre_transformer", x)
+        # ---- upsample stages
+        Lt = c.latent_dim
+        for u in self.ups:
+            T = T * u["f"]
+            xs = u["tc"].f32(x).view(T, Lt)
+            k = u["dw_taps"]
+            xp = F.pad(xs, (0, 0, k - 1, 0))                                                        # causal depthwise conv: k shifted
+            y = sum(xp[j:j + T] * u["dw_w3"][:, 0, j] for j in range(k)) + u["dw_b"]                # elementwise multiply-adds
+            y = F.layer_norm(y, (Lt,), u["ln_w"], u["ln_b"], 1e-6)
+            y = F.gelu(u["pw1"].f32(y))
+            x = u["pw2"].f32(y, resid=xs)
+        tap("upsampled", x)
+        # ---- decoder
+        f = self.dec0.f32(x)
+        tap("decoder0", f)
+        nb = len(self.blocks)
+        for bi, blk in enumerate(self.blocks):
+            T = T * blk["r"]
+            cout = blk["tc"].n // blk["r"]
+            hs = blk["tc"].f32(snake(f, blk["act"])).view(T, cout)
+            for un in blk["units"]:
+                t1 = un["conv1"].f32(snake(hs, un["act1"]))
+                hs = un["conv2"].f32(snake(t1, un["act2"]), resid=hs)
+            tap(f"decoder{bi + 1}", hs)
+            f = hs
+        s = snake(f, self.last_act)
+        tap(f"decoder{nb + 1}", s)
+        sp = F.pad(s, (0, 0, self.out_taps - 1, 0))                                                # causal left padding in time
+        wav = sum((sp[j:j + T] * self.out_w[j]).sum(-1) for j in range(self.out_taps)) + self.out_b
+        return wav.clamp(-1.0, 1.0).view(1, 1, T)
 
     def _rep(self, sn, r: int):
         """Snake parameters of a [T, r * C] transposed-conv output: channel n = phase * C + c."""

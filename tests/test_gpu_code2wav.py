@@ -92,6 +92,50 @@ def test_mid_size_decoder_matches_the_oracle(T):
     assert d32.mean().item() <= 2.0 * dor.mean().item() + 1e-4, "the HIP path is no further from fp32 than bf16 operands make it"
 
 
+@pytest.mark.parametrize("T", [13, 50])
+def test_fp32_operand_mode_matches_the_fp32_oracle(T):
+    """operand_precision="fp32": the reference's arithmetic (it loads the decoder in fp32, qwen3_tts_code2wav.py:71-75) -- every
+    GEMM on fp32-precision operands (split-bf16: hi.hi + hi.lo + lo.hi on the MFMA tile kernel), fp32 between them.  At the mid
+    configuration (real depth, quarter widths) the waveform is then within 2e-4 of the fp32 oracle where the bf16-operand path is
+    5e-3 away, and every stage boundary agrees to 1e-3 of its scale."""
+    from ht_vllm_omni_amd.code2wav import Code2WavDecoder
+    sd = make_codec_state(MID_CODEC, 3)
+    g = torch.Generator().manual_seed(T)
+    codes = torch.randint(0, MID_CODEC["codebook_size"], (1, MID_CODEC["num_quantizers"], T), generator=g)
+    ref = Code2WavOracle(MID_CODEC, sd)(codes)
+    dec32 = Code2WavDecoder(MID_CODEC, sd, operand_precision="fp32")
+    taps = {}
+    wav32 = dec32.forward(codes.cuda(), taps).cpu()
+    wav16 = _decoder(MID_CODEC, sd)(codes.cuda()).cpu()
+    assert wav32.shape == ref.shape == (1, 1, T * 1920) and wav32.dtype == torch.float32
+    d32, d16 = (wav32 - ref).abs(), (wav16 - ref).abs()
+    assert d32.max().item() <= 2e-4 and d32.mean().item() <= 2e-5, (d32.mean().item(), d32.max().item())
+    assert d16.mean().item() > 20 * d32.mean().item(), "the mode must actually be closer to fp32 than the bf16-operand path"
+    assert all(v.dtype == torch.float32 for v in taps.values())
+    with pytest.raises(ValueError):
+        Code2WavDecoder(MID_CODEC, sd, operand_precision="fp16")
+
+
+def test_fp32_operand_mode_against_the_reference_module_outputs(golden_dir):
+    """The same mode against the reference's own decoder outputs (tests/golden/code2wav_tiny.npz, fp32 torch module): waveform
+    and every stage boundary -- 1e-4 where the bf16-operand path is allowed 5e-3."""
+    from ht_vllm_omni_amd.code2wav import Code2WavDecoder
+    z = np.load(os.path.join(golden_dir, "code2wav_tiny.npz"))
+    sd = make_codec_state(TINY_CODEC, int(z["seed"]))
+    dec = Code2WavDecoder(TINY_CODEC, sd, operand_precision="fp32")
+    for i in range(3):
+        taps = {}
+        wav = dec.forward(torch.from_numpy(z[f"codes{i}"]).cuda(), taps).cpu()
+        d = (wav - torch.from_numpy(z[f"wav{i}"])).abs()
+        assert d.max().item() <= 1e-4, (i, d.mean().item(), d.max().item())
+    for k in ("quantized", "pre_conv", "pre_transformer", "upsampled", "decoder0", "decoder1", "decoder2", "decoder3"):
+        ref = torch.from_numpy(z["tap_" + k])[0]
+        got = taps[k].float().cpu()
+        got = got if got.shape == ref.shape else got.T
+        assert got.shape == ref.shape, k
+        assert (got - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1.0), k
+
+
 def test_full_architecture_decoder_matches_the_oracle_in_fp32_torch_on_the_gpu():
     """The released architecture's sizes (latent 1024, 8 x 1024-wide layers with 16 heads, codebooks of 2048 x 16, decoder
     1536 -> 768 -> 384 -> 192 -> 96 channels: every tile configuration of omni_gemm_tile at its real shape, the 1024-channel
