@@ -108,6 +108,7 @@ SIGNATURES = {
     "omni_moe_route": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "omni_moe_experts": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "omni_moe_experts_ex": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "omni_moe_experts_resid": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "omni_snake_beta": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "omni_gemm_tile": (i32, [C.POINTER(TileGemm), vp]),
     # include/omni_codec.h

@@ -233,10 +233,10 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
         omni_set_error("omni_talker_create: fused_norm / cp_fused_norm need frag_layout");
         return nullptr;
     }
-    if (desc->moe_experts > 0 && (desc->fused_norm || !desc->frag_layout || desc->moe_top_k < 1 || desc->moe_top_k > 8 ||
+    if (desc->moe_experts > 0 && (!desc->frag_layout || desc->moe_top_k < 1 || desc->moe_top_k > 8 ||
                                   desc->moe_experts % 16 || desc->moe_experts > 256 || desc->moe_inter % 32 ||
                                   desc->moe_shared_inter % 32 || desc->hidden % 64 || desc->moe_shared_inter > desc->inter)) {
-        omni_set_error("omni_talker_create: MoE backbone needs frag_layout, fused_norm = 0, top_k <= 8, experts %% 16 == 0 (<= 256), "
+        omni_set_error("omni_talker_create: MoE backbone needs frag_layout, top_k <= 8, experts %% 16 == 0 (<= 256), "
                        "moe / shared intermediate %% 32 == 0, hidden %% 64 == 0, shared intermediate <= inter (scratch)");
         return nullptr;
     }
@@ -264,9 +264,9 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
     if (t->has_ar) {
         t->ar_attn = *desc->ar_attn;
         t->ar_mlp = *desc->ar_mlp;
-        if (!desc->fused_norm || desc->moe_experts > 0 || t->ar_attn.world != t->ar_mlp.world || t->ar_attn.rank != t->ar_mlp.rank ||
+        if (!desc->fused_norm || t->ar_attn.world != t->ar_mlp.world || t->ar_attn.rank != t->ar_mlp.rank ||
             t->ar_attn.world < 1 || t->ar_attn.world > 8 || !t->ar_attn.data[t->ar_attn.rank] || !t->ar_mlp.data[t->ar_mlp.rank]) {
-            omni_set_error("omni_talker_create: peer-mapped all-reduce needs fused_norm, a dense backbone and consistent peer tables");
+            omni_set_error("omni_talker_create: peer-mapped all-reduce needs fused_norm and consistent peer tables");
             delete t;
             return nullptr;
         }
@@ -706,7 +706,9 @@ static int layer_mlp_rows(omni_talker* t, int l, int rows, void* st) {
         const int H = d.hidden, E = d.moe_experts, Is = d.moe_shared_inter;
         const int lay = OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG;
         TRY(k_rmsnorm(nullptr, t->attn_out, t->resid_b, t->resid, w.ln2, t->normed_rm, t->normed, rows, H, d.eps, st));
-        TRY(omni_gemm_bf16_ex(t->normed, H, w.moe_router, nullptr, t->moe_logits, rows, E, H, OMNI_EPI_BF16, nullptr, OMNI_LAYOUT_X_FRAG, st));
+        // (the router matrix is fragment-major on fused_norm engines: their decode steps give it the fused-norm prologue)
+        TRY(omni_gemm_bf16_ex(t->normed, H, w.moe_router, nullptr, t->moe_logits, rows, E, H, OMNI_EPI_BF16, nullptr,
+                              OMNI_LAYOUT_X_FRAG | (d.fused_norm ? OMNI_LAYOUT_W_FRAG : 0), st));
         TRY(omni_moe_route(t->moe_logits, rows, E, d.moe_top_k, d.moe_norm_topk, t->moe_idx, t->moe_w, st));
         const void* shared = nullptr;
         if (Is > 0) {
@@ -753,6 +755,29 @@ extern "C" int omni_talker_layer_mlp(omni_talker* t, const omni_step_io* io, int
     TRY(check_io(t, io));
     OMNI_CHECK_ARG(layer >= 0 && layer < t->d.layers, "omni_talker_layer_mlp: layer=%d", layer);
     const omni_talker_desc& d = t->d;
+    if (d.fused_norm && d.moe_experts > 0) {
+        // sparse-MoE MLP on the norm-free stream: the router GEMM takes the fused-norm prologue and leaves the normalised rows
+        // (row-major) for the expert kernels; the combine adds into r and writes the slabs -- or, on a tensor- / expert-parallel
+        // rank, leaves the partial in the peer-mapped buffer for the one-shot all-reduce
+        const omni_layer_weights& w = t->layer[layer];
+        const int H = d.hidden, E = d.moe_experts, Is = d.moe_shared_inter, B = io->B;
+        const int lay = OMNI_LAYOUT_W_FRAG | OMNI_LAYOUT_X_FRAG;
+        TRY(xnorm_gemm(t, t->resid, t->part, H / 16, w.ln2, t->normed_rm, w.moe_router, t->moe_logits, B, E, H, OMNI_EPI_BF16, nullptr, 0, stream));
+        TRY(omni_moe_route(t->moe_logits, B, E, d.moe_top_k, d.moe_norm_topk, t->moe_idx, t->moe_w, stream));
+        const void* shared = nullptr;
+        if (Is > 0) {
+            TRY(xnorm_gemm(t, t->resid, t->part, H / 16, w.ln2, nullptr, w.moe_shared_gate_up, t->act, B, Is, H, OMNI_EPI_SILU_MUL, nullptr, 1, stream));
+            TRY(omni_gemm_bf16_ex(t->act, Is, w.moe_shared_down, nullptr, t->moe_shared, B, H, Is, OMNI_EPI_BF16, nullptr, lay, stream));
+            shared = t->moe_shared;
+        }
+        const int El = d.moe_experts_local > 0 ? d.moe_experts_local : E;
+        void* mine = t->has_ar ? const_cast<void*>(t->ar_mlp.data[t->ar_mlp.rank]) : nullptr;
+        TRY(omni_moe_experts_resid(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, d.moe_w8 ? w.moe_gate_up_scale : nullptr, w.moe_down,
+                                   d.moe_w8 ? w.moe_down_scale : nullptr, shared, w.moe_shared_gate, t->moe_act, t->moe_y, t->resid, t->part,
+                                   mine, B, H, d.moe_inter, El, d.moe_e0, d.moe_top_k, stream));
+        if (t->has_ar) return omni_allreduce_resid(&t->ar_mlp, t->resid, 1, t->part, 64, nullptr, B, H, stream);
+        return OMNI_OK;
+    }
     if (d.fused_norm) {
         const omni_layer_weights& w = t->layer[layer];
         TRY(xnorm_gemm(t, t->resid, t->part, d.hidden / 16, w.ln2, nullptr, w.wgu, t->act, io->B, d.inter, d.hidden,

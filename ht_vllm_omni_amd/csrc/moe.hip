@@ -224,10 +224,15 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_expert_kernel(const MoeArgs a
 // ---------------------------------------------------------------- combine: one workgroup per token
 // out = bf16( sum over the token's experts in ascending expert index of y[slot] (bf16 accumulate)
 //             + bf16(sigmoid(bf16(x . w_shared_gate)) * shared) )
+// OUT 0: out bf16 [T, H] row-major (the separate-norm path's mlp_out).  OUT 1: the same values fragment-major (a tensor- /
+// expert-parallel rank's partial, handed to omni_allreduce_resid).  OUT 2: the norm-free stream -- out IS the fragment-major
+// residual r: r = bf16(r + delta) in place, and part[c][t] = sum of r^2 over the 16 columns of slab c (what gemm.hip's
+// EPI_RESID leaves: the next RMSNorm is folded into the GEMMs that read r).
+template <int OUT>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ y, const int32_t* __restrict__ topk_idx,
                                                           const uint16_t* __restrict__ x, const uint16_t* __restrict__ w_sg,
                                                           const uint16_t* __restrict__ shared, uint16_t* __restrict__ out,
-                                                          int top_k, int H, int e_lo, int e_hi) {
+                                                          float* __restrict__ part, int top_k, int H, int e_lo, int e_hi) {
     const int t = blockIdx.x;
     __shared__ int order[MOE_MAXK];
     __shared__ float red[4];
@@ -278,7 +283,21 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
             a0 = bfround(a0 + bfround(gate * bf_lo(sv)));
             a1 = bfround(a1 + bfround(gate * bf_hi(sv)));
         }
-        *reinterpret_cast<uint32_t*>(out + (size_t)t * H + h) = pack_bf2(a0, a1);
+        if (OUT == 0) {
+            *reinterpret_cast<uint32_t*>(out + (size_t)t * H + h) = pack_bf2(a0, a1);
+        } else if (OUT == 1) {
+            *reinterpret_cast<uint32_t*>(out + frag_off(t, h, H)) = pack_bf2(a0, a1);
+        } else {
+            uint32_t* rp = reinterpret_cast<uint32_t*>(out + frag_off(t, h, H));
+            const uint32_t ro = *rp;
+            const float r0 = bfround(bf_lo(ro) + a0), r1 = bfround(bf_hi(ro) + a1);
+            *rp = pack_bf2(r0, r1);
+            float ss = r0 * r0 + r1 * r1;                  // 8 adjacent threads hold the 16 columns of one slab
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            if ((threadIdx.x & 7) == 0) part[(size_t)(h >> 4) * 64 + t] = ss;
+        }
     }
 }
 
@@ -298,7 +317,8 @@ extern "C" int omni_moe_route(const void* logits, int T, int E, int top_k, int n
 // E = experts held here (the router's ids [e0, e0 + E)); scales != NULL: fp8 e4m3fn weights + per-row fp32 scales
 static int moe_experts_impl(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up,
                             const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
-                            void* y_ws, void* out, int T, int H, int I, int E, int e0, int top_k, void* stream) {
+                            void* y_ws, void* out, int T, int H, int I, int E, int e0, int top_k, void* stream, int out_mode = 0,
+                            float* part = nullptr) {
     OMNI_CHECK_ARG(x && topk_idx && topk_w && w_gate_up && w_down && act_ws && y_ws && out, "omni_moe_experts: null pointer");
     OMNI_CHECK_ARG(T >= 1 && T <= MOE_MAXT && top_k >= 1 && top_k <= MOE_MAXK && T * top_k <= MOE_THREADS,
                    "omni_moe_experts: T=%d top_k=%d (T <= %d, T * top_k <= %d)", T, top_k, MOE_MAXT, MOE_THREADS);
@@ -319,8 +339,13 @@ static int moe_experts_impl(const void* x, const int32_t* topk_idx, const void* 
     if (w8) hipLaunchKernelGGL((moe_expert_kernel<2, 4, true>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
     else hipLaunchKernelGGL((moe_expert_kernel<2, 4, false>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
     OMNI_CHECK_LAUNCH("omni_moe_experts(down)");
-    hipLaunchKernelGGL(moe_combine_kernel, dim3(T), dim3(256), 0, st, (const uint16_t*)y_ws, topk_idx, (const uint16_t*)x,
-                       (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, top_k, H, e0, e0 + E);
+#define COMBINE(M_)                                                                                                        \
+    hipLaunchKernelGGL(moe_combine_kernel<M_>, dim3(T), dim3(256), 0, st, (const uint16_t*)y_ws, topk_idx, (const uint16_t*)x, \
+                       (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, part, top_k, H, e0, e0 + E)
+    if (out_mode == 0) COMBINE(0);
+    else if (out_mode == 1) COMBINE(1);
+    else COMBINE(2);
+#undef COMBINE
     OMNI_CHECK_LAUNCH("omni_moe_experts(combine)");
     return OMNI_OK;
 }
@@ -338,4 +363,14 @@ extern "C" int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const
                                    int E_local, int e0, int top_k, void* stream) {
     return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, s_gate_up, w_down, s_down, shared, w_shared_gate, act_ws, y_ws, out, T, H, I,
                             E_local, e0, top_k, stream);
+}
+
+extern "C" int omni_moe_experts_resid(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,
+                                      const float* s_gate_up, const void* w_down, const float* s_down, const void* shared,
+                                      const void* w_shared_gate, void* act_ws, void* y_ws, void* resid_frag, float* part,
+                                      void* partial_frag, int T, int H, int I, int E_local, int e0, int top_k, void* stream) {
+    OMNI_CHECK_ARG(partial_frag || (resid_frag && part), "omni_moe_experts_resid: a partial buffer, or the residual stream and its slabs");
+    OMNI_CHECK_ARG(H % 32 == 0 && T <= 64, "omni_moe_experts_resid: fragment-major output needs H %% 32 == 0 and T <= 64 (slab stride)");
+    return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, s_gate_up, w_down, s_down, shared, w_shared_gate, act_ws, y_ws,
+                            partial_frag ? partial_frag : resid_frag, T, H, I, E_local, e0, top_k, stream, partial_frag ? 1 : 2, part);
 }

@@ -162,12 +162,13 @@ class TalkerEngine:
         if prefill_gemm not in ("tile", "blas", "both"):
             raise ValueError(f"prefill_gemm={prefill_gemm!r}")
         self.prefill_gemm = prefill_gemm if self.frag_layout else "blas"
-        # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm): single-rank decode only -- the tensor-parallel
-        # step must all-reduce the o_proj / down_proj outputs BEFORE the residual add, so it keeps the separate norms
-        self.fused_norm = (self.frag_layout and (not self.tp_path or self.ar is not None) and dims.moe_experts == 0) \
+        # norm-free residual stream (omni_gemm_resid / omni_gemm_xnorm; MoE layers: omni_moe_experts_resid): single rank, or
+        # tensor- / expert-parallel ranks with the peer-mapped all-reduce (it sums the partials BEFORE the residual add);
+        # ranks that all-reduce through RCCL between the phase calls keep the separate norms
+        self.fused_norm = (self.frag_layout and (not self.tp_path or self.ar is not None)) \
             if fused_norm is None else bool(fused_norm)
-        if dims.moe_experts > 0 and (self.fused_norm or not self.frag_layout):
-            raise ValueError("the sparse-MoE backbone runs the separate-norm, fragment-major path")
+        if dims.moe_experts > 0 and not self.frag_layout:
+            raise ValueError("the sparse-MoE backbone needs the fragment-major layout")
         self.moe_fp8 = bool(moe_fp8) and dims.moe_experts > 0
         self.moe_mode = moe_parallel_mode(dims, tp_size) if dims.moe_experts > 0 else "none"
         if self.fused_norm and ((self.tp_path and self.ar is None) or not self.frag_layout):
@@ -223,6 +224,8 @@ class TalkerEngine:
         names = ("ln1", "wqkv", "qnorm", "knorm", "wo", "ln2", "wgu", "wdown")
         bb_names = names[:6] + MOE_NAMES if d.moe_experts > 0 else names
         frag_names = ("wqkv", "wo", "wgu", "wdown", "moe_gate_up", "moe_down", "moe_shared_gate_up", "moe_shared_down")
+        if self.fused_norm:
+            frag_names += ("moe_router",)      # takes the fused-norm prologue on the norm-free stream (omni_gemm_xnorm: W fragment-major)
         self._layers = (L.LayerWeights * d.layers)()
         self._frag_keep: dict = {}
         self.layer_w: list[dict] = []

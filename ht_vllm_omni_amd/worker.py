@@ -177,7 +177,7 @@ class MI355XARWorker:
         # the residual add: tp_comm.py) -- checked against RCCL on random data first, every rank falls back to RCCL
         # all-reduces between the phase calls if any rank disagrees (the reference's group: gpu_ar_worker.py:69-75)
         self.peer_allreduce = None
-        if self.tp_size > 1 and self.dims.moe_experts == 0:
+        if self.tp_size > 1:       # dense and sparse-MoE backbones alike (MoE: omni_moe_experts_resid leaves the rank's partial)
             from .tp_comm import setup_peer_allreduce
             self.peer_allreduce = setup_peer_allreduce(self.dims.hidden, min(cfg.max_num_seqs, 64), self.rank, self.tp_size,
                                                        log=logger.info)

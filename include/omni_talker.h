@@ -124,6 +124,17 @@ int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const void* topk
                         const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
                         void* y_ws, void* out, int T, int H, int I, int E_local, int e0, int top_k, void* stream);
 
+/* The same block on the norm-free residual stream (OMNI_EPI_RESID's conventions): instead of `out`,
+ *   partial_frag == NULL: resid_frag (bf16 [T, H] fragment-major) += the block's output in place (bf16 add) and part
+ *                         (fp32 [H / 16][64]) receives the per-slab sums of squares of the new residual -- the next RMSNorm is
+ *                         folded into the GEMMs that read it (omni_gemm_xnorm);
+ *   partial_frag != NULL: a tensor- / expert-parallel rank's partial output, fragment-major, for omni_allreduce_resid
+ *                         (which adds the ranks' partials into the residual and writes the slabs). */
+int omni_moe_experts_resid(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up,
+                           const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
+                           void* y_ws, void* resid_frag, float* part, void* partial_frag, int T, int H, int I, int E_local, int e0,
+                           int top_k, void* stream);
+
 /* Large-M bf16 GEMM on the matrix cores (csrc/gemm_prefill.hip): out[M, N] = epilogue(x[M, K] . W[N, K]^T), fp32 accumulate.
  * The prefill GEMMs of the talker (replaces the F.linear calls vLLM's Qwen3 layers make under
  * vllm_omni/worker/gpu_model_runner.py:1305-1328 for prompt tokens) and every convolution of the Code2Wav decoder
@@ -341,7 +352,8 @@ typedef struct omni_talker_desc {
     int cp_hidden, cp_layers, cp_q_heads, cp_kv_heads, cp_head_dim, cp_inter;
     int has_cp_projection;
     int frag_layout;   /* != 0: every GEMM weight below is fragment-major (OMNI_LAYOUT_W_FRAG); activations follow */
-    /* backbone MLP = sparse MoE when moe_experts > 0 (omni_moe_route / omni_moe_experts; needs fused_norm == 0) */
+    /* backbone MLP = sparse MoE when moe_experts > 0 (omni_moe_route / omni_moe_experts).  With fused_norm the router weight
+       must be fragment-major too (it takes the fused-norm prologue and leaves the normalised rows for the expert kernels) */
     int moe_experts, moe_top_k, moe_inter, moe_shared_inter, moe_norm_topk;
     int fused_norm;    /* != 0 (needs frag_layout, the folded tables, single rank): the decode step keeps the residual
                           stream fragment-major and folds every RMSNorm into its neighbouring GEMMs (omni_gemm_resid /

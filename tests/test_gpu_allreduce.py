@@ -96,16 +96,19 @@ def test_missing_peer_times_out_instead_of_hanging():
         a.close()
 
 
+@pytest.mark.parametrize("model", ["tts-1.7b", "omni-moe-tiny"])
 @pytest.mark.parametrize("tp", [2])      # (one process: HIP maps streams onto 4 hardware queues; beyond ~3 "ranks" two of them
-def test_tp_engines_on_peer_allreduce_match_oracle(tp):      # share a queue and the waiting one blocks the other until it times out)
+def test_tp_engines_on_peer_allreduce_match_oracle(tp, model):      # share a queue and the waiting one blocks the other until it times out)
     """Tensor parallel with the all-reduces INSIDE the native step (VERDICT r1 #4b): every rank engine of the group (one
     process, one GPU, one stream per rank) runs omni_talker_decode_step -- sharded GEMMs, this rank's KV heads, the
     one-shot all-reduce fused with the residual add and the sum(r^2) slabs, i.e. the norm-free stream kept under TP -- as
-    ONE captured hipGraph per rank; codes / slots bit-exact vs the unsharded oracle, ranks bit-identical to each other."""
+    ONE captured hipGraph per rank; codes / slots bit-exact vs the unsharded oracle, ranks bit-identical to each other.
+    Sparse-MoE backbone (round 3): the same, its expert intermediate dimension split over the ranks, each rank's combine leaving
+    its partial in the peer-mapped buffer (omni_moe_experts_resid) -- a routing near-tie may flip a code, so most rows must agree."""
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
-    d = get_dims("tts-1.7b").with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
-    w = make_weights(d, seed=17, std=0.02)
+    d = get_dims(model).with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
+    w = make_weights(d, seed=17, std=0.02 if model == "tts-1.7b" else 0.06)
     bs, nb, n_steps = 16, 32, 3
     prompt_lens = [5, 17, 33, 9]
     B = len(prompt_lens)
@@ -167,10 +170,15 @@ def test_tp_engines_on_peer_allreduce_match_oracle(tp):      # share a queue and
         for r, e in enumerate(engs):
             assert ars[r].error() == 0, f"step {s} rank {r}: a peer did not arrive"
             assert torch.equal(e.slot_mapping[:B].cpu(), osl), f"step {s} rank {r}: slots"
-            assert torch.equal(e.audio_codes[:B].cpu(), oc), f"step {s} rank {r}: codes"
+            tol = 6e-3 if model == "tts-1.7b" else 1e-2
+            same = (e.audio_codes[:B].cpu() == oc).all(-1)
+            if model == "tts-1.7b":
+                assert same.all(), f"step {s} rank {r}: codes"
+            else:
+                assert same.float().mean().item() >= 0.75, f"step {s} rank {r}: codes"
             # same bounds as the RCCL-path lockstep test: sharded partial sums are rounded per rank before they are added
-            assert_e2e_close(e.logits[:B].cpu(), ol, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} logits")
-            assert_e2e_close(e.last_hidden[:B].cpu(), oh, mean_tol=6e-3, max_ulps=3, what=f"step {s} rank {r} hidden")
+            assert_e2e_close(e.logits[:B].cpu()[same], ol[same], mean_tol=tol, max_ulps=3, what=f"step {s} rank {r} logits")
+            assert_e2e_close(e.last_hidden[:B].cpu()[same], oh[same], mean_tol=tol, max_ulps=3, what=f"step {s} rank {r} hidden")
             assert torch.equal(e.logits[:B], engs[0].logits[:B]), "ranks must agree bit for bit"
         for e in engs:
             e.input_ids[:B] = oi.to(torch.int32).cuda()
@@ -229,13 +237,13 @@ def test_two_processes_exchange_ipc_handles_and_allreduce():
     assert res == {0: True, 1: True}, res
 
 
-def _tp_worker_proc(rank, world, port, q):
+def _tp_worker_proc(rank, world, port, q, model="tts-1.7b"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMNI_DIST_BACKEND="gloo")
     from ht_vllm_omni_amd.payloads import (OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams,
                                            serialize_additional_information)
     from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
-    d = get_dims("tts-1.7b").with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
-    w = make_weights(d, seed=17, std=0.02)
+    d = get_dims(model).with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
+    w = make_weights(d, seed=17, std=0.02 if model == "tts-1.7b" else 0.06)
     sp = SamplingParams(temperature=0.0, top_k=0, repetition_penalty=1.0)
     cfg = make_config(d, kv_cache_dtype="fp8", max_num_seqs=4, tensor_parallel_size=world, num_gpu_blocks_override=32, weights=w,
                       default_sampling_params=sp)
@@ -269,16 +277,19 @@ def _tp_worker_proc(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_worker_processes_run_the_tp_step_on_the_peer_allreduce():
+@pytest.mark.parametrize("model", ["tts-1.7b", "omni-moe-tiny"])
+def test_two_worker_processes_run_the_tp_step_on_the_peer_allreduce(model):
     """the worker surface vLLM's executor drives (init_device -> load_model -> initialize_from_config ->
     compile_or_warm_up_model -> execute_model / sample_tokens), one PROCESS per tensor-parallel rank, wires the checked
     peer-mapped all-reduce into the engine by itself; both ranks decode the same ids and codes, no peer wait timed out.
+    Dense backbone, and (round 3) the sparse-MoE backbone: its layers run on the norm-free stream, the
+    combine leaves each rank's partial in the peer-mapped buffer and omni_allreduce_resid adds the ranks into the residual.
     (Both ranks share this box's one GPU, so the group is gloo here; on a multi-GPU node the same code runs over RCCL.)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = [ctx.Process(target=_tp_worker_proc, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker_proc, args=(r, 2, port, q, model)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=500) for _ in range(2))

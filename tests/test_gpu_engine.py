@@ -505,15 +505,18 @@ def test_tp_collective_path_captured_in_hipgraph():
             dist.destroy_process_group()
 
 
-def test_moe_backbone_decode_steps_match_oracle():
+@pytest.mark.parametrize("fused", [True, False], ids=["norm-free-stream", "separate-norms"])
+def test_moe_backbone_decode_steps_match_oracle(fused):
     """Row a11 end to end: the talker with a sparse-MoE MLP in every backbone layer (Omni talker in miniature: 16 experts,
     top-4, gated shared expert, no code-predictor projection) -- prefill + decode steps through the native engine against
-    the oracle whose MoE block is pinned to HF's module."""
+    the oracle whose MoE block is pinned to HF's module.  Default (round 3): the MoE layers on the norm-free residual stream --
+    router and shared expert with the fused-norm prologue, the combine adding into the fragment-major residual and writing the
+    sum-of-squares slabs (omni_moe_experts_resid); the separate-norm path stays for RCCL-reduced tensor-parallel ranks."""
     d = get_dims("omni-moe-tiny")
     assert d.moe_experts == 16 and not d.has_cp_projection
     w = make_weights(d, seed=15, std=0.06, norm_noise=0.1)
-    rec = _scenario(d, w, "fp8", prompt_lens=[5, 17, 33, 16, 9], n_steps=4, mean_tol=8e-3)
-    assert rec["engine"].fused_norm is False
+    rec = _scenario(d, w, "fp8", prompt_lens=[5, 17, 33, 16, 9], n_steps=4, mean_tol=8e-3, engine_kw=None if fused else dict(fused_norm=False))
+    assert rec["engine"].fused_norm is fused
     lg, ol = rec["prefill_logits"]
     assert_e2e_close(lg, ol, mean_tol=8e-3, max_ulps=3, what="MoE prefill logits")
     bad_rows = 0
