@@ -142,6 +142,24 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
         // (1 << dom) / 4 lanes x 4 flags each (the other lanes read copies)
         const uint32_t off = ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
         unsigned spins = 0;
+        if (g.nap >= 16) {
+            // two polls in flight, half a round trip apart: the flags are sampled twice as often as one load's latency allows
+            u32x4 fa = coh_ld16(g.frs, off);
+            for (;;) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_sleep(4);
+                const u32x4 fb = coh_ld16(g.frs, off);
+                const bool behind = (int)(fa[0] - g.epoch) < 0 || (int)(fa[1] - g.epoch) < 0 || (int)(fa[2] - g.epoch) < 0 ||
+                                    (int)(fa[3] - g.epoch) < 0;
+                if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+                fa = fb;
+                if (++spins > OMNI_CHAIN_SPIN_BOUND) {
+                    if (threadIdx.x == 0) atomicCAS(g.err, 0, code);
+                    g.dead = true;
+                    break;
+                }
+            }
+        } else
         for (;;) {
             asm volatile("" ::: "memory");                // the buffer load is a plain read to the compiler: keep it inside the loop
             const u32x4 f = coh_ld16(g.frs, off);
