@@ -28,6 +28,9 @@ struct BbArgs {
 // (Round 3 also tried a ninth wave that warms the XCD's L2 with the next stage's slice -- one dword per 64 bytes, nothing
 // depending on it: +0.10 ms per step, removed; and the loader / consumer split of bb_engine.hip.  What is kept is below:
 // the NEXT stage's weight loads issued by the compute waves themselves, behind their last activation load.)
+// GU_G / DN_G / QK_G: activation-ring depth (k-steps per wave in flight behind the flags) of gate_up (its weights ride in the same
+// ring) / down_proj / the next qkv; PF: the cross-stage weight prefetch arm
+template <int GU_G, int DN_G, int QK_G, bool PF>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     ChainPrefetch<24, decltype(pf_g_)> pf_g{pf_g_};
     ChainPrefetch<24, decltype(pf_d_)> pf_d{pf_d_};
     ChainPrefetch<16, decltype(pf_k_)> pf_k{pf_k_};
-    if (a.pf) {
+    if constexpr (PF) {
         chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                      false, 0x1001, a.stamps, nullptr, pf_g);
         chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, 2, 3>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
@@ -81,20 +84,21 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     }
     chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                               false, 0x1001, a.stamps);
-    chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, 2, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
-                                                        true, 0x1002, a.stamps);
-    chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, 4>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
-                                               true, 0x1003, a.stamps);
+    chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, GU_G, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
+                                                           true, 0x1002, a.stamps);
+    chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, DN_G>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
+                                                  true, 0x1003, a.stamps);
     if (a.wqkv_next)
-        chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 4>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127,
-                                                 wg >> 7, lds, g, true, 0x1004, a.stamps);
+        chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, QK_G>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127,
+                                                    wg >> 7, lds, g, true, 0x1004, a.stamps);
 }
 
-OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0;      // cross-stage prefetch: measured +0.4 ms per step, off
+OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
 extern "C" void omni_debug_bb_chain(int on) { g_bb_chain = on != 0; g_bb_prefetch = on == 2; }      // 2: with the cross-stage weight prefetch
 extern "C" void omni_debug_bb_stamps(void* buf) { g_bb_stamps = (unsigned long long*)buf; }
+extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }                                  // deeper activation / weight rings
 #endif
 
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
@@ -113,7 +117,11 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
                int B, float eps, uint32_t* flags, int32_t* err, void* stream) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<4, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<3, 6, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         attr = true;
     }
     BbArgs a{};
@@ -126,7 +134,13 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
 #ifdef OMNI_DEBUG_HOOKS
     a.stamps = g_bb_stamps;
 #endif
-    hipLaunchKernelGGL(bb_chain_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a);
+#define BB_LAUNCH(...) hipLaunchKernelGGL((bb_chain_kernel<__VA_ARGS__>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a)
+    if (a.pf) BB_LAUNCH(2, 4, 4, true);
+    else if (g_bb_deep == 1) BB_LAUNCH(4, 8, 8, false);
+    else if (g_bb_deep == 2) BB_LAUNCH(3, 6, 8, false);
+    else if (g_bb_deep == 3) BB_LAUNCH(2, 8, 8, false);
+    else BB_LAUNCH(2, 4, 4, false);
+#undef BB_LAUNCH
     OMNI_CHECK_LAUNCH("bb_chain");
     return OMNI_OK;
 }

@@ -228,3 +228,74 @@ extern "C" int omni_debug_grid_barrier_chain(int mode, float* a, float* b, unsig
     OMNI_CHECK_LAUNCH("omni_debug_grid_barrier_chain");
     return OMNI_OK;
 }
+
+// ---------------------------------------------------------------- operand-stream probe (scripts/probe_stream_mix.py)
+// What bounds the backbone chain's streaming phases?  256 workgroups x 8 waves, one per CU.  Every wave keeps DEPTH 1-KB loads in
+// flight (buffer_load_dwordx4, the chains' access) and walks
+//   W: a private slice of a large buffer (unique bytes: HBM), and / or
+//   X: one small buffer that EVERY workgroup reads again and again (L2 hits after the first touch; plain or sc1 loads).
+// mode 0: W only.  1: X only.  2: every wave alternates W and X in ONE queue (the plain chain).  3: waves 0-3 stream W, waves 4-7
+// stream X (two queues per SIMD pair).  Per-wave counts are given in 1-KB loads; the result word keeps the loads alive.
+template <int DEPTH>
+__global__ __launch_bounds__(512) void dbg_stream_mix_kernel(const uint8_t* __restrict__ W, size_t w_wg_bytes, const uint8_t* __restrict__ X,
+                                                             unsigned x_bytes, int nw, int nx, int mode, int sc1, unsigned* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)blockIdx.x * w_wg_bytes), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0x7fffffff, 0x00020000);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 ring[DEPTH];
+    unsigned acc = 0;
+    const bool w_wave = mode == 0 || mode == 2 || (mode == 3 && wave < 4);
+    const bool x_wave = mode == 1 || mode == 2 || (mode == 3 && wave >= 4);
+    const int per = (mode == 3) ? 4 : 8;                  // waves sharing a stream
+    const int wi = (mode == 3) ? (wave & 3) : wave;
+    // total loads of this wave: W loads nw, X loads nx; in mode 2 they alternate 1 : (nx / nw) as the counts dictate
+    const int total = (w_wave ? nw : 0) + (x_wave ? nx : 0);
+    // loads are issued in order k = 0, 1, ...: running counters instead of divisions; mixed waves issue one W then R = nx / nw X loads
+    const int R = (w_wave && x_wave) ? max(nx / max(nw, 1), 1) : 0;
+    // sc1 bit 1 (value 2 added): stagger -- every workgroup starts its walk over X at a different place (no chip-wide same-line rush)
+    const bool stagger = (sc1 & 2) != 0;
+    sc1 &= 1;
+    int wn = 0, xn = stagger ? (int)((blockIdx.x * 29u) & 0xffu) : 0, phase = 0;
+    auto issue = [&](int) -> u4 {
+        bool is_w = w_wave;
+        if (w_wave && x_wave) {
+            is_w = phase == 0;
+            phase = phase == R ? 0 : phase + 1;
+        }
+        if (is_w) {
+            const unsigned off = (unsigned)((((size_t)wn * per + wi) * 1024) & (w_wg_bytes - 1)) + lane * 16;     // sizes are powers of two
+            ++wn;
+            return __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0);
+        }
+        const unsigned off = (unsigned)((((size_t)xn * per + wi) * 1024) & (x_bytes - 1)) + lane * 16;
+        ++xn;
+        return sc1 ? __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 1);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ring[d] = d < total ? issue(d) : (u4){0, 0, 0, 0};
+    for (int k0 = 0; k0 < total; k0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int k = k0 + d;
+            if (k < total) {
+                acc ^= ring[d][0] ^ ring[d][3];
+                if (k + DEPTH < total) ring[d] = issue(k + DEPTH);
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;
+}
+
+extern "C" int omni_debug_stream_mix(const void* W, size_t w_wg_bytes, const void* X, unsigned x_bytes, int nw, int nx, int mode, int sc1,
+                                     int depth, unsigned* out, int reps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < reps; ++r) {
+        if (depth == 4) hipLaunchKernelGGL(dbg_stream_mix_kernel<4>, dim3(256), dim3(512), 0, st, (const uint8_t*)W, w_wg_bytes, (const uint8_t*)X, x_bytes, nw, nx, mode, sc1, out);
+        else if (depth == 8) hipLaunchKernelGGL(dbg_stream_mix_kernel<8>, dim3(256), dim3(512), 0, st, (const uint8_t*)W, w_wg_bytes, (const uint8_t*)X, x_bytes, nw, nx, mode, sc1, out);
+        else if (depth == 16) hipLaunchKernelGGL(dbg_stream_mix_kernel<16>, dim3(256), dim3(512), 0, st, (const uint8_t*)W, w_wg_bytes, (const uint8_t*)X, x_bytes, nw, nx, mode, sc1, out);
+        else hipLaunchKernelGGL(dbg_stream_mix_kernel<32>, dim3(256), dim3(512), 0, st, (const uint8_t*)W, w_wg_bytes, (const uint8_t*)X, x_bytes, nw, nx, mode, sc1, out);
+    }
+    OMNI_CHECK_LAUNCH("omni_debug_stream_mix");
+    return OMNI_OK;
+}

@@ -16,6 +16,8 @@ void omni_debug_cp_chain(int on);                          /* code predictor: th
 void omni_debug_chain_mode(int dom, int gu_narrow, int nap); /* chain A/B: log2 flag domain (6 | 7 | 8); gate_up on the 32 x 24 tile; s_sleep units between polls */
 void omni_debug_chain_stamps(void* buf);                   /* device uint64 [40][8][256]: per-stage timeline stamps of every chain launch (NULL: off) */
 void omni_debug_bb_chain(int on);                          /* backbone: o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer */
+void omni_debug_bb_xw(int on);                             /* backbone segment with weights and activations on different waves (bb_xw.hip) */
+void omni_debug_bb_deep(int mode);                         /* backbone chain: deeper rings (1: gate_up 4 / down 8 / qkv 8 k-steps; 2: 3 / 6 / 8; 3: 2 / 8 / 8) */
 void omni_debug_bb_pp(int on);                             /* backbone segment on two alternating wave groups (bb_pp.hip); 0 = the plain chain */
 void omni_debug_pp_stamps(void* buf);                      /* int64 [4][8][256] timeline stamps of the two-group chain (scripts/bb_timeline.py) */
 void omni_debug_bb_engine(int on);                         /* backbone segment as the loader / consumer engine (bb_engine.hip) instead of the plain chain */
@@ -34,6 +36,8 @@ int omni_debug_chain(int mode, float* a, float* b, int blocks, int reps, void* s
 /* One persistent launch of `blocks` (<= 256, multiple of 8) co-resident workgroups running `iters` steps of { cross-workgroup hand-off;
  * grid barrier } -- the in-kernel alternative to a kernel boundary (mode 0: one counter; 1: + s_sleep between polls; 2: per-XCD
  * counters feeding the global one).  counters: >= 576 zeroable bytes; err: int32 set when a spin ran out (bounded: no hang). */
+int omni_debug_stream_mix(const void* W, size_t w_wg_bytes, const void* X, unsigned x_bytes, int nw, int nx, int mode, int sc1, int depth,
+                          unsigned* out, int reps, void* stream);   /* operand-stream probe (scripts/probe_stream_mix.py) */
 int omni_debug_grid_barrier_chain(int mode, float* a, float* b, unsigned* counters, int* err, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus

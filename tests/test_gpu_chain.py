@@ -96,7 +96,7 @@ def _decode_engine(d, w, B, kv="fp8"):
     return eng
 
 
-@pytest.mark.parametrize("mode", ["engine", "plain-chain", "ping-pong"])
+@pytest.mark.parametrize("mode", ["engine", "plain-chain", "ping-pong", "split-roles", "deep-rings"])
 @pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16")])
 def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
     """o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer against the launch-per-op backbone of the
@@ -109,13 +109,15 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
     w = make_weights(d, seed=8, std=0.02)
     res = {}
     with L.debug_library() as lib:
-        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_engine, lib.omni_debug_bb_pp):
+        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_engine, lib.omni_debug_bb_pp, lib.omni_debug_bb_xw, lib.omni_debug_bb_deep):
             fn.argtypes = [C.c_int]; fn.restype = None
         try:
             for on in (0, 1):
                 lib.omni_debug_bb_chain(on)
                 lib.omni_debug_bb_engine(int(mode == "engine"))
                 lib.omni_debug_bb_pp(int(mode == "ping-pong"))
+                lib.omni_debug_bb_xw(int(mode == "split-roles"))
+                lib.omni_debug_bb_deep(int(mode == "deep-rings"))
                 eng = _decode_engine(d, w, B, kv)
                 outs = []
                 for _ in range(3):
@@ -128,6 +130,8 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
             lib.omni_debug_bb_chain(1)
             lib.omni_debug_bb_engine(0)
             lib.omni_debug_bb_pp(0)
+            lib.omni_debug_bb_xw(0)
+            lib.omni_debug_bb_deep(0)
     if mode == "ping-pong":
         (lg1, h1, ids1, _), (lg0, h0, ids0, _) = res[1][0][0], res[0][0][0]
         assert_e2e_close(h1.cpu(), h0.cpu(), mean_tol=3e-3, max_ulps=3, what="two-group chain vs launch path: hidden, step 0")
