@@ -81,6 +81,12 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     for (int d = 0; d < NTW; ++d) {
         const int ks = wave + d * CH_WAVES;
         if (WSRC == 0) {
+#ifdef OMNI_DEBUG_HOOKS
+            if (g.skip == 1 && d >= (NTW + 1) / 2) {       // ingest experiment: the second half of the slice is not fetched
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Wq[d][j] = (u32x4){0u, 0u, 0u, 0u};
+            } else
+#endif
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
@@ -120,6 +126,13 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
                 Wq[d % G][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + wave + d * CH_WAVES) * 1024), 0);
         }
         if (PRO == 2 && !NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
+#ifdef OMNI_DEBUG_HOOKS
+        if (g.skip == 2 && d >= (NTW + 1) / 2) {           // ingest experiment: half of the activation fragments are not fetched
+#pragma unroll
+            for (int i = 0; i < MT; ++i) Xq[d % G][i] = (u32x4){0u, 0u, 0u, 0u};
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i)
             Xq[d % G][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane16, (uint32_t)((((m_base >> 4) + i) * nsteps + wave + d * CH_WAVES) * 1024),

@@ -68,6 +68,7 @@ struct ChainGate {
     bool dead;             // a spin ran out (here or in an earlier launch): stop waiting
     int dom;               // log2 of the flag domain: 6 = the row group's 64 workgroups, 7 = a pair of groups, 8 = all 256
     int nap;               // s_sleep units (64 clocks) between two polls: 0, 1, 2, 4, 8
+    int skip;              // debug library only (timing experiments, results garbage): 1 = fetch half of every weight slice, 2 = half of the activations
     // engine mode (NULL / unused in the plain chains): barriers among the 8 compute waves only, weights from the LDS FIFO
     EngSync* es;
     unsigned bgen;         // compute-wave barriers this wave has passed
@@ -129,6 +130,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
     g.dead = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
     g.dom = 8;
     g.nap = 1;
+    g.skip = 0;
     g.es = nullptr; g.bgen = 0; g.fifo = nullptr; g.piece_base = 0; g.ready = 0;
 }
 

@@ -49,6 +49,7 @@ struct ChainArgs {
     const uint16_t* ptab;                 // folded projection tables [Q - 1][codebook][Hc]: pass g < Q - 1 gathers row `code` of table g - 1
     uint32_t* flags;
     int32_t* err;
+    int skip;                             // debug library: ingest experiment (coherent.cuh ChainGate::skip)
     int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
     unsigned long long* stamps;           // debug library only: [stage][CH_NSTAMP][256] s_memrealtime ticks (100 MHz) of wave 0, or NULL
 };
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
     chain_gate_init(g, a.flags, a.err);
     g.dom = a.dom;
     g.nap = a.nap;
+    g.skip = a.skip;
     const int wg = blockIdx.x;
     int np = a.np_in;
     const int Hc = 1024, NQ = 4096, NI = 3072;
@@ -263,9 +265,10 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
+extern "C" void omni_debug_chain_skip(int mode) { g_chain_skip = mode; }      // timing experiment: 1 = half the weight bytes, 2 = half the activation bytes (results garbage)
 static unsigned long long* g_chain_stamps = nullptr;
 // 0: launch per op; 1: one persistent launch per pass (layer stack only); 2: one persistent launch for all passes incl. heads + samplers
 extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on != 0; g_chain_span = on; }
@@ -319,6 +322,7 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
     }
     a.dom = g_chain_dom < 6 ? 6 : (g_chain_dom > 8 ? 8 : g_chain_dom);
     if (g_chain_gu_narrow && B > 32 && a.dom < 7) a.dom = 7;  // the 32-row tile ties two row groups together
+    a.skip = g_chain_skip;
     // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: follow the launch path's tile
     // policy (32-row tiles only above 32 rows) so that both schedules produce the same bits
     a.gu_narrow = g_chain_gu_narrow && B > 32;
