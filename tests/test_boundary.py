@@ -246,3 +246,68 @@ def test_update_intermediate_buffer_known_answers_of_the_reference_tests():
     assert "unknown_req" not in run.model_intermediate_buffer
     run.execute_model(OmniSchedulerOutput(finished_req_ids={"r1"}))                  # :259: the buffer goes with the request
     assert "r1" not in run.model_intermediate_buffer
+
+
+def test_runner_carries_a_requests_mrope_ids_into_prefill_and_decode():
+    """A request that arrives with M-RoPE ids whose rows differ (vLLM CachedRequestState.mrope_positions / .mrope_position_delta,
+    V/worker/gpu_model_runner.py:121-180): the runner hands the engine [3, T] rotary ids for the prefill tokens -- the request's own
+    ids, plain index ids for its batch mates -- and sets the row's rotary offset for the decode steps; rows are re-packed and
+    freed rows reset with that offset.  An engine without an mrope_section refuses such a request."""
+    import pytest
+    import torch
+    from ht_vllm_omni_amd.config import get_dims
+    from ht_vllm_omni_amd.payloads import OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams, encode_tensor
+    from ht_vllm_omni_amd.runner import MI355XARModelRunner
+    from tests.fakes import FakeEngine
+
+    class _MRopeEngine(FakeEngine):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.rope_delta = torch.zeros(self.max_batch, dtype=torch.int32)
+            self.rope_seen = []
+
+        def prefill(self, x, positions, req_of_tok, slot_mapping, block_table=None, rope_positions=None):
+            self.rope_seen.append(None if rope_positions is None else rope_positions.clone())
+            return super().prefill(x, positions, req_of_tok, slot_mapping, block_table)
+
+    d = get_dims("tiny")
+    sp = SamplingParams(temperature=0.0, max_tokens=8)
+    g = torch.Generator().manual_seed(0)
+
+    def req(rid, n, blocks, **extra):
+        info = {"talker_prompt_embeds": encode_tensor(torch.randn(n, d.hidden, generator=g).to(torch.bfloat16)),
+                "tts_pad_embed": encode_tensor(torch.zeros(d.hidden).to(torch.bfloat16))}
+        info.update(extra)
+        return OmniNewRequestData(req_id=rid, prompt_token_ids=[d.codec_pad_id] * n, block_ids=(blocks,), sampling_params=sp, additional_information=info)
+
+    mp = torch.tensor([[0, 1, 2, 2, 2, 3], [0, 1, 2, 2, 3, 3], [0, 1, 2, 3, 2, 3]])
+    eng = _MRopeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    so = OmniSchedulerOutput(scheduled_new_reqs=[req("plain", 4, [1]), req("mm", 6, [2], mrope_positions=mp, mrope_position_delta=-2)],
+                             num_scheduled_tokens={"plain": 4, "mm": 6}, total_num_scheduled_tokens=10)
+    run.execute_model(so)
+    run.sample_tokens(None)
+    rope = eng.rope_seen[-1]
+    assert rope is not None and rope.shape == (3, 10) and rope.dtype == torch.int32
+    assert rope[:, :4].tolist() == [[0, 1, 2, 3]] * 3 and rope[:, 4:].tolist() == mp.tolist()
+    r_mm, r_plain = run.rows.index("mm"), run.rows.index("plain")
+    assert int(eng.rope_delta[r_mm]) == -2 and int(eng.rope_delta[r_plain]) == 0
+    # one decode step later the offsets still sit on the rows of their requests; a finished request's row is reset
+    run.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["plain", "mm"], new_block_ids=[None, None]),
+                                          num_scheduled_tokens={"plain": 1, "mm": 1}, total_num_scheduled_tokens=2))
+    run.sample_tokens(None)
+    assert int(eng.rope_delta[run.rows.index("mm")]) == -2
+    run.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["plain"], new_block_ids=[None]),
+                                          num_scheduled_tokens={"plain": 1}, total_num_scheduled_tokens=1, finished_req_ids={"mm"}))
+    run.sample_tokens(None)
+    assert "mm" not in run.rows and int(eng.rope_delta[run.rows.index("plain")]) == 0 and int(eng.rope_delta.abs().sum()) == 0
+    # an engine whose model has no mrope_section cannot honour differing rows
+    run2 = MI355XARModelRunner(FakeEngine(d, max_batch=4), use_graphs=False)
+    with pytest.raises(ValueError, match="mrope"):
+        run2.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[req("mm", 6, [2], mrope_positions=mp, mrope_position_delta=-2)],
+                                               num_scheduled_tokens={"mm": 6}, total_num_scheduled_tokens=6))
+    # ... while three identical plain rows are the same thing as no ids at all
+    ok = torch.arange(6).expand(3, -1)
+    run3 = MI355XARModelRunner(FakeEngine(d, max_batch=4), use_graphs=False)
+    run3.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[req("t", 6, [2], mrope_positions=ok, mrope_position_delta=0)],
+                                           num_scheduled_tokens={"t": 6}, total_num_scheduled_tokens=6))
