@@ -98,7 +98,7 @@ def test_missing_peer_times_out_instead_of_hanging():
 
 @pytest.mark.parametrize("model", ["tts-1.7b", "omni-moe-tiny"])
 @pytest.mark.parametrize("tp", [2])      # (one process: HIP maps streams onto 4 hardware queues; beyond ~3 "ranks" two of them
-def test_tp_engines_on_peer_allreduce_match_oracle(tp, model):      # share a queue and the waiting one blocks the other until it times out)
+def test_tp_engines_on_peer_allreduce_match_oracle(tp, model, monkeypatch):      # share a queue and the waiting one blocks the other until it times out)
     """Tensor parallel with the all-reduces INSIDE the native step (VERDICT r1 #4b): every rank engine of the group (one
     process, one GPU, one stream per rank) runs omni_talker_decode_step -- sharded GEMMs, this rank's KV heads, the
     one-shot all-reduce fused with the residual add and the sum(r^2) slabs, i.e. the norm-free stream kept under TP -- as
@@ -107,6 +107,9 @@ def test_tp_engines_on_peer_allreduce_match_oracle(tp, model):      # share a qu
     its partial in the peer-mapped buffer (omni_moe_experts_resid) -- a routing near-tie may flip a code, so most rows must agree."""
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
+    # the rank engines share this box's ONE GPU: two persistent code-predictor chains in flight together could each hold part of the
+    # CUs (DESIGN 6, co-residency) -- the ranks of a real group own a GPU each; here they keep the launch path
+    monkeypatch.setenv("OMNI_CP_CHAIN", "0")
     d = get_dims(model).with_(layers=2, cp_layers=1, num_code_groups=3, max_model_len=256)
     w = make_weights(d, seed=17, std=0.02 if model == "tts-1.7b" else 0.06)
     bs, nb, n_steps = 16, 32, 3
@@ -238,7 +241,8 @@ def test_two_processes_exchange_ipc_handles_and_allreduce():
 
 
 def _tp_worker_proc(rank, world, port, q, model="tts-1.7b"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMNI_DIST_BACKEND="gloo")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMNI_DIST_BACKEND="gloo",
+                      OMNI_CP_CHAIN="0")       # two ranks on ONE GPU: no two persistent chains in flight together (co-residency)
     from ht_vllm_omni_amd.payloads import (OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput, SamplingParams,
                                            serialize_additional_information)
     from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
