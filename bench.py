@@ -247,14 +247,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
 
     d, w, eng = build_engine(args, rank, world)
-    if os.environ.get("OMNI_EXTRA_TRIVIAL"):        # diagnostics: price of a trivial launch inside the real step
-        import ctypes
-        eng.lib.omni_debug_extra_trivial.argtypes = [ctypes.c_int]
-        eng.lib.omni_debug_extra_trivial(int(os.environ["OMNI_EXTRA_TRIVIAL"]))
-    if os.environ.get("OMNI_INT8_MAX_G"):           # diagnostics: q heads per workgroup of the int8-KV decode attention
-        import ctypes
-        eng.lib.omni_debug_int8_max_g.argtypes = [ctypes.c_int]
-        eng.lib.omni_debug_int8_max_g(int(os.environ["OMNI_INT8_MAX_G"]))
+    for env, sym in (("OMNI_EXTRA_TRIVIAL", "omni_debug_extra_trivial"),     # diagnostics: price of a trivial launch inside the real step
+                     ("OMNI_INT8_MAX_G", "omni_debug_int8_max_g")):        # diagnostics: q heads per workgroup of the int8-KV decode attention
+        if os.environ.get(env):
+            import ctypes
+            if not hasattr(eng.lib, sym):
+                raise SystemExit(f"{env} is a hook of the diagnostics build: run with OMNI_TALKER_DEBUG=1 (libomni_talker_debug.so), "
+                                 f"the product library does not export {sym}")
+            getattr(eng.lib, sym).argtypes = [ctypes.c_int]
+            getattr(eng.lib, sym)(int(os.environ[env]))
     B = args.batch
     if args.greedy:
         eng.set_sampling(greedy=1, cp_greedy=1)

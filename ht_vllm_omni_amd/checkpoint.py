@@ -61,6 +61,7 @@ def map_hf_talker_weights(named: Iterable[tuple[str, torch.Tensor]], dtype: torc
     w: dict[str, torch.Tensor] = {}
     extras: dict[str, torch.Tensor] = {}
     parts: dict[str, dict[int, torch.Tensor]] = {}          # fused tensors being assembled
+    unmapped: list[str] = []
     cp_embed: dict[int, torch.Tensor] = {}
     cp_head: dict[int, torch.Tensor] = {}
     for name, t in named:
@@ -86,7 +87,8 @@ def map_hf_talker_weights(named: Iterable[tuple[str, torch.Tensor]], dtype: torc
                 mm = re.match(r"^(self_attn|mlp)\.(\w+)\.weight$", leaf)
                 table = _ATTN if mm and mm.group(1) == "self_attn" else _MLP
                 if not mm or mm.group(2) not in table:
-                    raise KeyError(f"unmapped talker weight: {name}")
+                    unmapped.append(name)
+                    continue
                 key, slot = table[mm.group(2)]
                 if slot is None:
                     w[pre + key] = t
@@ -112,7 +114,9 @@ def map_hf_talker_weights(named: Iterable[tuple[str, torch.Tensor]], dtype: torc
         elif name.startswith(("talker.model.text_embedding.", "talker.text_projection.")):
             extras[name[len("talker."):].replace("model.text_embedding", "text_embedding")] = t      # talker.py:303-304
         else:
-            raise KeyError(f"unmapped talker weight: {name}")
+            unmapped.append(name)
+    if unmapped:       # every name at once: a checkpoint of another variant (biases, extra heads) shows its whole difference
+        raise KeyError(f"{len(unmapped)} unmapped talker weight(s): " + ", ".join(sorted(unmapped)))
     for key, sl in parts.items():
         need = 3 if key.endswith("wqkv") else 2
         if sorted(sl) != list(range(need)):

@@ -385,3 +385,46 @@ def test_ref_pin_mtp_rows_land_on_their_requests():
             if o.new_token_ids:
                 last_tok[o.request_id] = o.new_token_ids[-1]
     assert len(rows_seen) == 3 and len({next(iter(v)) for v in rows_seen.values()}) == 3          # three requests, three rows
+
+
+def test_cached_resume_route_with_a_batch_mate_keeps_the_text_table_in_step():
+    """b is preempted while a keeps decoding, then comes back through scheduled_cached_reqs
+    [resumed_from_preemption] -- a row is appended without any new / finished request in the step.  The per-step text rows are
+    one gather from a table built for the batch as it WAS: the resume must rebuild it (runner._resume -> _tt_flush), or b's
+    text_step row is stale and its queue position stops advancing."""
+    from ht_vllm_omni_amd.payloads import OmniCachedRequestData, OmniNewRequestData, OmniSchedulerOutput
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    reqs = {rid: _request(d, rid, n, tail=6, seed=s) for rid, n, s in (("a", 5, 1), ("b", 7, 2))}
+    new = [OmniNewRequestData(req_id=rid, prompt_token_ids=r.prompt_token_ids, block_ids=([1 + 2 * i, 2 + 2 * i],), sampling_params=r.sampling_params,
+                              additional_information=r.additional_information) for i, (rid, r) in enumerate(reqs.items())]
+    run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens={"a": 5, "b": 7}, total_num_scheduled_tokens=12))
+    run.sample_tokens(None)
+
+    def step(ids):
+        run.execute_model(OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=ids, new_block_ids=[None] * len(ids)),
+                                              num_scheduled_tokens={i: 1 for i in ids}, total_num_scheduled_tokens=len(ids)))
+        rows = {rid: eng.text_step[run.rows.index(rid)].clone() for rid in ids}
+        run.sample_tokens(None)
+        return rows
+    step(["a", "b"]); step(["a", "b"])
+    assert run.text_queue_pos("a") == 2 and run.text_queue_pos("b") == 2
+    run.execute_model(OmniSchedulerOutput(preempted_req_ids={"b"}, scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a"], new_block_ids=[None]),
+                                          num_scheduled_tokens={"a": 1}, total_num_scheduled_tokens=1))
+    run.sample_tokens(None)
+    assert run.rows == ["a"] and run.text_queue_pos("a") == 3
+    # b returns by the cached route with fresh blocks: prompt + its 2 decode inputs recomputed, then it decodes in the same step
+    so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[False, True],
+                                                                         new_block_ids=[None, ([7, 8],)], num_computed_tokens=[0, 0]),
+                             num_scheduled_tokens={"a": 1, "b": 7 + 2 + 1}, total_num_scheduled_tokens=11)
+    run.execute_model(so)
+    tb = reqs["b"].additional_information
+    from ht_vllm_omni_amd.payloads import decode_additional_information
+    tail_b = decode_additional_information(tb)["tailing_text_hidden"].to(BF16)
+    assert sorted(run.rows) == ["a", "b"]
+    assert torch.equal(eng.text_step[run.rows.index("b")].cpu(), tail_b[2]), "the resumed row must read ITS queue entry of this step"
+    run.sample_tokens(None)
+    assert run.text_queue_pos("b") == 3 and run.text_queue_pos("a") == 4
+    rows = step(["a", "b"])
+    assert torch.equal(rows["b"].cpu(), tail_b[3]) and run.text_queue_pos("b") == 4
