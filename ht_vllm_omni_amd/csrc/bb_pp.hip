@@ -86,7 +86,7 @@ __device__ __forceinline__ void pp_gate_wait(PpGate& g, uint32_t stages, int cod
 __device__ __forceinline__ void pp_gate_arrive(PpGate& g, uint32_t stages) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pp_barrier(g);
-    if ((threadIdx.x & (PP_GT - 1)) == 0) coh_st4(g.frs, blockIdx.x * 4, g.base + stages);
+    if ((threadIdx.x & (PP_GT - 1)) < 64) chain_flag_publish(g.frs, blockIdx.x, g.base + stages);
 }
 
 // One skinny-GEMM stage on a 4-wave group: K = KS * 128 (wave gw owns k-steps gw, gw + 4, ...), tile = NT n-tiles x MT m-tiles

@@ -279,7 +279,7 @@ __device__ __forceinline__ void xw_service(const uint16_t* __restrict__ norm_w, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     xw_barrier(c);                                                       // every service wave's stores are out; the partials are read
-    if (tg == 0) coh_st4(c.frs, blockIdx.x * 4, c.base + done_stages);
+    if (tg < 64) chain_flag_publish(c.frs, blockIdx.x, c.base + done_stages);
 }
 
 struct XwArgs {

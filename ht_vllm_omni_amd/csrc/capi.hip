@@ -6,6 +6,7 @@
 
 #include <vector>
 
+#include "coherent.cuh"
 #include "common.cuh"
 #include "kernels.h"
 
@@ -111,7 +112,7 @@ struct omni_talker {
     int64_t* cp_slots;
     std::vector<uint16_t*> cp_k, cp_v;
     int32_t* pf_seq;   // prefill scratch
-    uint32_t* chain_flags;              // stage flags of the persistent code-predictor chain [256] + error word at [320]
+    uint32_t* chain_flags;              // stage flags of the persistent chains: OMNI_FLAG_REPLICAS copies of [256] (coherent.cuh) + the error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
 };
@@ -169,7 +170,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->cp_seq = c.take<int32_t>((Q + 1) * B);
     t->cp_slots = c.take<int64_t>((Q + 1) * B);
     t->pf_seq = c.take<int32_t>(8);
-    t->chain_flags = c.take<uint32_t>(512);
+    t->chain_flags = c.take<uint32_t>(OMNI_FLAG_WORDS);
     if (d.moe_experts > 0) {
         const size_t k = d.moe_top_k, Im = d.moe_inter, Is = d.moe_shared_inter;
         t->normed_rm = c.take<uint16_t>(B * H);
@@ -290,7 +291,7 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
             slots[p * B + b] = (int64_t)b * t->cp_bs + p;
         }
     hipError_t e = hipMemcpy(t->cp_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(t->chain_flags, 0, 512 * 4);
+    if (e == hipSuccess) e = hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4);
     if (e == hipSuccess) e = hipMemcpy(t->cp_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->cp_seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->cp_slots, slots.data(), slots.size() * 8, hipMemcpyHostToDevice);
@@ -313,7 +314,7 @@ extern "C" int omni_talker_chain_error(omni_talker* t, int reset) {
         omni_set_error("omni_talker_chain_error: device read failed");
         return OMNI_EHIP;
     }
-    if (reset && hipMemset(t->chain_flags, 0, 512 * 4) != hipSuccess) return OMNI_EHIP;
+    if (reset && hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4) != hipSuccess) return OMNI_EHIP;
     return v;
 }
 extern "C" void* omni_talker_attn_out(omni_talker* t) { return t ? t->attn_out : nullptr; }

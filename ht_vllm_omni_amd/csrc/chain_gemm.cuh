@@ -61,9 +61,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     const int q = lane >> 4;
     const int m_base = by * (MT * 16);
     const int Mloc = min(M - m_base, MT * 16);
-    if (Mloc <= 0) {                      // no rows here (batch smaller than the grid's row range): keep the flag protocol only
-        if (wait) chain_gate_wait(g, code);
-        chain_gate_arrive(g);
+    if (Mloc <= 0) {                      // no rows here (batch smaller than the grid's row range): publish the stage, run ahead
+        chain_gate_skip(g);
         return;
     }
     // every operand load is a buffer load: lane part (lane * 16 bytes) in ONE VGPR, tile / k-step part in an SGPR offset -- no

@@ -16,6 +16,14 @@
 
 #define OMNI_AUX_SC1 16        // cache-policy bit of the raw buffer builtins: sc1 on gfx940+
 
+// The flag words are kept in OMNI_FLAG_REPLICAS copies, OMNI_FLAG_STRIDE words apart (lines of different memory channels): a
+// workgroup publishes to every copy with ONE store instruction (one lane per copy) and polls only the copy of its XCD
+// (blockIdx.x % 8).  With one copy, the 128 pollers of a flag domain read the same four 128-byte lines through the fabric at
+// once and the producers' flag stores queue behind them at one memory channel (MI355X_MICROARCH: a counter kept in R replicas).
+#define OMNI_FLAG_REPLICAS 8
+#define OMNI_FLAG_STRIDE 2048          // words between two copies (8 KB)
+#define OMNI_FLAG_WORDS (OMNI_FLAG_REPLICAS * OMNI_FLAG_STRIDE)
+
 typedef __amdgpu_buffer_rsrc_t coh_rsrc_t;
 
 __device__ __forceinline__ coh_rsrc_t coh_rsrc(const void* base) {
@@ -41,6 +49,14 @@ __device__ __forceinline__ void coh_st8(coh_rsrc_t rs, uint32_t byte_off, u32x2 
 __device__ __forceinline__ void coh_st4(coh_rsrc_t rs, uint32_t byte_off, uint32_t v) {
     __builtin_amdgcn_raw_buffer_store_b32(v, rs, byte_off, 0, OMNI_AUX_SC1);
 }
+
+// publish `value` as workgroup `wg`'s flag in every copy (called by the publishing wave: lanes 0 .. REPLICAS - 1 store)
+__device__ __forceinline__ void chain_flag_publish(coh_rsrc_t frs, int wg, uint32_t value) {
+    const int l = threadIdx.x & 63;
+    if (l < OMNI_FLAG_REPLICAS) coh_st4(frs, (uint32_t)(l * OMNI_FLAG_STRIDE + wg) * 4, value);
+}
+// byte offset of the copy this workgroup polls
+__device__ __forceinline__ uint32_t chain_flag_copy() { return (uint32_t)(blockIdx.x & (OMNI_FLAG_REPLICAS - 1)) * (OMNI_FLAG_STRIDE * 4); }
 
 // ---- grid-wide stage flags: flag[w] = number of stages workgroup w has completed since the engine was created (wraps).
 // A stage's dependent part starts once every flag has reached the epoch of the stage before it.  Spins are bounded: a
@@ -68,6 +84,7 @@ struct ChainGate {
     bool dead;             // a spin ran out (here or in an earlier launch): stop waiting
     int dom;               // log2 of the flag domain: 6 = the row group's 64 workgroups, 7 = a pair of groups, 8 = all 256
     int nap;               // s_sleep units (64 clocks) between two polls: 0, 1, 2, 4, 8
+    int ahead;             // stages this workgroup has passed without rows since it last waited (chain_gate_skip)
     int skip;              // debug library only (timing experiments, results garbage): 1 = fetch half of every weight slice, 2 = half of the activations
     // engine mode (NULL / unused in the plain chains): barriers among the 8 compute waves only, weights from the LDS FIFO
     EngSync* es;
@@ -131,6 +148,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
     g.dom = 8;
     g.nap = 1;
     g.skip = 0;
+    g.ahead = 0;
     g.es = nullptr; g.bgen = 0; g.fifo = nullptr; g.piece_base = 0; g.ready = 0;
 }
 
@@ -139,10 +157,16 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
 // every 16-row-tile stage, and no stage reads another row group's rows -- so a chain whose stages all use 16-row tiles needs
 // dom = 6 only (four independent chains of 64 workgroups); 32-row tiles tie two groups together (dom = 7).  Wave 0 polls,
 // the other waves wait at the barrier.
+// A workgroup without rows in a stage (a partly filled batch) does not wait there at all: it publishes the stage at once and
+// runs AHEAD of the others (chain_gate_skip) -- nobody ever waits for it, and it does not poll.  Polling idle workgroups hammer the
+// few memory lines the flags live in and the busy workgroups' flag stores queue behind them: at 48 of 64 rows the hand-off gap
+// grew from 1.2-1.9 to 3-6 us and the chain lost to the launch path.  When it reaches a stage where it HAS rows it is `ahead`
+// stages early: it sleeps ~2.5 us per skipped stage (a stage takes 3-5.5 us) before its first poll.
 __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
     if (threadIdx.x < 64 && !g.dead) {
+        for (int i = 0; i < g.ahead; ++i) __builtin_amdgcn_s_sleep(96);
         // (1 << dom) / 4 lanes x 4 flags each (the other lanes read copies)
-        const uint32_t off = ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
+        const uint32_t off = chain_flag_copy() + ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
         unsigned spins = 0;
         if (g.nap >= 16) {
             // two polls in flight, half a round trip apart: the flags are sampled twice as often as one load's latency allows
@@ -181,6 +205,7 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
             }
         }
     }
+    g.ahead = 0;
     chain_barrier(g);
 }
 
@@ -201,5 +226,12 @@ __device__ __forceinline__ void chain_gate_arrive(ChainGate& g) {
         chain_barrier(g);
     }
     g.epoch += 1;
-    if (threadIdx.x == 0) coh_st4(g.frs, blockIdx.x * 4, g.epoch);
+    if (threadIdx.x < 64) chain_flag_publish(g.frs, blockIdx.x, g.epoch);
+}
+
+// a stage in which this workgroup has no rows: no wait, no work -- publish it and run ahead (see chain_gate_wait)
+__device__ __forceinline__ void chain_gate_skip(ChainGate& g) {
+    g.ahead = g.ahead < 12 ? g.ahead + 1 : 12;
+    g.epoch += 1;
+    if (threadIdx.x < 64) chain_flag_publish(g.frs, blockIdx.x, g.epoch);
 }

@@ -62,6 +62,10 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
     CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
+    if ((int)blockIdx.x * 4 >= a.B * q_heads) {                 // none of this workgroup's four pairs is a live row
+        chain_gate_skip(g);
+        return;
+    }
     const int pair = blockIdx.x * 4 + (wave & 3);               // waves 4-7 do the work: wave 0 polls the flags, and a wave's
     const bool active = wave >= 4 && pair < a.B * q_heads;      // loads return in order -- history loads ahead of a poll delay it
     const int row = pair / q_heads, h = pair - row * q_heads;
@@ -169,6 +173,10 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
     const bool has_row = wi < rows_per_dom && b < a.B;              // workgroup-uniform
     const bool live = threadIdx.x < SMP_THREADS;
     const bool more = g < a.Q - 1 && a.ptab != nullptr;
+    if (!has_row) {
+        chain_gate_skip(gate);
+        return;
+    }
     CH_STAMP(stamps, sidx, 1);
     chain_gate_wait(gate, code);
     CH_STAMP(stamps, sidx, 2);
@@ -233,6 +241,19 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
     g.nap = a.nap;
     g.skip = a.skip;
     const int wg = blockIdx.x;
+    {
+        // a partly filled batch: a workgroup that owns no live row in ANY stage of the launch (its 16-row group, its 32-row gate_up
+        // pair, its four attention pairs, its sampler row) publishes the launch's final stage count at once and leaves -- the others
+        // find its flag ahead of every stage they wait for, and it never polls
+        const int rows_per_dom = 16 << (a.dom - 6), wi = wg & ((1 << a.dom) - 1);
+        const bool gemm16 = (wg >> 6) * 16 < a.B, gemm32 = GU_NARROW && (wg >> 7) * 32 < a.B, attn_ = wg * 4 < a.B * a.q_heads;
+        const bool smp = a.with_head && wi < rows_per_dom && (wg >> a.dom) * rows_per_dom + wi < a.B;
+        if (!(gemm16 || gemm32 || attn_ || smp)) {
+            const uint32_t total = (uint32_t)(a.g1 - a.g0) * (uint32_t)(a.layers * 5 + (a.with_head ? 2 : 0));
+            if (threadIdx.x < 64) chain_flag_publish(g.frs, wg, g.epoch + total);
+            return;
+        }
+    }
     int np = a.np_in;
     const int Hc = 1024, NQ = 4096, NI = 3072;
     for (int pass = a.g0; pass < a.g1; ++pass) {
@@ -321,11 +342,12 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
         a.ptab = (const uint16_t*)d.cp_proj_table;
     }
     a.dom = g_chain_dom < 6 ? 6 : (g_chain_dom > 8 ? 8 : g_chain_dom);
-    if (g_chain_gu_narrow && B > 32 && a.dom < 7) a.dom = 7;  // the 32-row tile ties two row groups together
+    const bool narrow = g_chain_gu_narrow == 2 || (g_chain_gu_narrow && B > 32);      // 2 (debug): the 32-row tile at any batch size
+    if (narrow && a.dom < 7) a.dom = 7;  // the 32-row tile ties two row groups together
     a.skip = g_chain_skip;
     // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: follow the launch path's tile
     // policy (32-row tiles only above 32 rows) so that both schedules produce the same bits
-    a.gu_narrow = g_chain_gu_narrow && B > 32;
+    a.gu_narrow = narrow;
     a.nap = g_chain_nap;
 #ifdef OMNI_DEBUG_HOOKS
     a.stamps = g_chain_stamps;

@@ -13,16 +13,17 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--model", default="tts-1.7b")
 ap.add_argument("--kv", default="fp8")
 ap.add_argument("--ctx", type=int, default=352)
+ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("settings", nargs="+")
 a = ap.parse_args()
-args = types.SimpleNamespace(allreduce="rccl", model=a.model, kv=a.kv, batch=64, num_blocks=8192, device_weights=True, parallel="tp", sub_batches=1,
+args = types.SimpleNamespace(allreduce="rccl", model=a.model, kv=a.kv, batch=a.batch, num_blocks=8192, device_weights=True, parallel="tp", sub_batches=1,
                              tp_force=False, prefill_gemm="tile", warmup=0, steps=a.steps * a.rounds * len(a.settings) + 64, ttfa_steps=0, ctx_extra=0, target_ctx=a.ctx)
 torch.cuda.set_device(0)
 d, w, eng = bench.build_engine(args, 0, 1)
 lib = eng.lib
 eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
 lens, _ = bench.setup_requests(d, eng, args)
-B = 64
+B = a.batch
 
 def apply(setting):
     for kv in setting.split(","):

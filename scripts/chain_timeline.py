@@ -47,11 +47,22 @@ seg = ["W issue", "flag wait", "slabs->rstd", "x+MFMA", "barrier", "epilogue", "
 print(f"B={B}; medians over 256 workgroups, us.  span = first workgroup entering -> last flag published; gap = this stage's median flag time -> next stage's median 'flags seen'")
 print(f"{'stage':12s} " + " ".join(f"{s:>11s}" for s in seg) + f" {'total':>8s} {'span':>8s} {'gap':>6s}")
 tot = 0.0
+grp = os.environ.get("GROUP")        # restrict the statistics to one 64-workgroup row group (partly filled batches)
+def live(x):                          # workgroups that stamped this stage (a workgroup without rows in a stage skips it)
+    m = (x[7] > 0) & (x[0] > 0)
+    if grp is not None:
+        g_ = torch.arange(NW) // 64 == int(grp)
+        m = m & g_
+    return m
 for s in range(NS):
-    x = t[s]
+    x = t[s][:, live(t[s])]
+    if x.shape[1] == 0:
+        print(nm(s) + "  (no workgroup of this selection has rows here)")
+        continue
     d_ = [(x[k + 1] - x[k]).median().item() for k in range(7)]
     span = (x[7].max() - x[0].min()).item()
-    gap = (t[s + 1][2].median() - x[7].median()).item() if s + 1 < NS else float("nan")
+    nx_ = t[s + 1][:, live(t[s + 1])] if s + 1 < NS else None
+    gap = (nx_[2].median() - x[7].median()).item() if nx_ is not None and nx_.shape[1] else float("nan")
     if s == 26:      # sampler: only the workgroups that own a row
         own = (x[4] > 0)
         x = x[:, own]
@@ -59,4 +70,5 @@ for s in range(NS):
               (x[6] - x[4]).median().item(), (x[7] - x[6]).median().item()]
     print(nm(s) + " " + " ".join(f"{v:11.2f}" for v in d_) + f" {sum(d_):8.2f} {span:8.2f} {gap:6.2f}")
     tot += sum(d_)
-print(f"whole pass: {(t[NS - 1][7].max() - t[0][0].min()).item():.1f} us for {NS} stages = {(t[NS - 1][7].max() - t[0][0].min()).item() / NS:.2f} us per stage")
+t0_, t1_ = t[0][0][t[0][0] > 0].min().item(), t[NS - 1][7].max().item()
+print(f"whole pass: {t1_ - t0_:.1f} us for {NS} stages = {(t1_ - t0_) / NS:.2f} us per stage")
