@@ -29,7 +29,7 @@ def _inputs(d, w, B, seed):
 
 @pytest.mark.parametrize("mode", [(2, 7, 1, 1), (1, 7, 1, 1), (2, 8, 1, 4), (2, 6, 0, 1)],
                          ids=["all-passes", "per-pass", "all-passes-all-flags-nap4", "all-passes-wide-gate_up"])
-@pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16), ("tts-1.7b", 32)])
+@pytest.mark.parametrize("model,B", [("tts-1.7b", 64), ("tts-1.7b", 37), ("tts-1.7b", 5), ("tts-0.6b", 16), ("tts-1.7b", 32), ("tts-1.7b", 48), ("tts-1.7b", 17)])
 def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
     """mode = (span, flag domain, gate_up tile, poll pause): span 1 = one persistent launch per pass (layer stack only), 2 = ONE
     launch for every pass with its head GEMM and sampler.  The 48-column gate_up tile sums the RMSNorm statistics in the
