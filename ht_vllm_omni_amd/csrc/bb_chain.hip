@@ -93,12 +93,13 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
                                                     wg >> 7, lds, g, true, 0x1004, a.stamps);
 }
 
-OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0;      // cross-stage prefetch: measured +0.4 ms per step, off
+OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 49;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
 extern "C" void omni_debug_bb_chain(int on) { g_bb_chain = on != 0; g_bb_prefetch = on == 2; }      // 2: with the cross-stage weight prefetch
 extern "C" void omni_debug_bb_stamps(void* buf) { g_bb_stamps = (unsigned long long*)buf; }
-extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }                                  // deeper activation / weight rings
+extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }
+extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; }                          // smallest batch the backbone chain takes                                  // deeper activation / weight rings
 #endif
 
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
@@ -110,7 +111,7 @@ bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
     }
     return g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
            d.hidden == 2048 && d.inter == 6144 && d.head_dim == 128 && d.q_heads * 128 == 2048 &&
-           (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B > 48 && B <= 64;
+           (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B >= g_bb_min_rows && B <= 64;
 }
 
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,

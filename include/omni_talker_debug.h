@@ -18,6 +18,7 @@ void omni_debug_chain_stamps(void* buf);                   /* device uint64 [40]
 void omni_debug_bb_chain(int on);                          /* backbone: o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer */
 void omni_debug_chain_skip(int mode);                      /* code-predictor chain timing experiment: 1 = fetch half of every weight slice, 2 = half of the activations (garbage results) */
 void omni_debug_bb_xw(int on);                             /* backbone segment with weights and activations on different waves (bb_xw.hip) */
+void omni_debug_bb_min_rows(int rows);                     /* backbone chain: smallest batch it takes (49: where its tiles are the launch path's) */
 void omni_debug_bb_deep(int mode);                         /* backbone chain: deeper rings (1: gate_up 4 / down 8 / qkv 8 k-steps; 2: 3 / 6 / 8; 3: 2 / 8 / 8) */
 void omni_debug_bb_pp(int on);                             /* backbone segment on two alternating wave groups (bb_pp.hip); 0 = the plain chain */
 void omni_debug_pp_stamps(void* buf);                      /* int64 [4][8][256] timeline stamps of the two-group chain (scripts/bb_timeline.py) */
