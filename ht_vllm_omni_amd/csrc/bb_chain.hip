@@ -11,7 +11,7 @@
 #include "common.cuh"
 #include "kernels.h"
 
-#define BB_LDS_BYTES ((CH_WAVES * 6 * 64 * 16) + CH_WAVES * 64 * 4)       // combine slots of one pass (gate_up: 12 tiles in two passes of 6) + rstd area
+#define BB_LDS_BYTES ((CH_WAVES * 12 * 64 * 16) + CH_WAVES * 64 * 4)      // combine slots (gate_up: 12 tiles, ONE pass since round 4) + rstd area
 
 struct BbArgs {
     const uint16_t *wo, *ln2, *wgu, *wdown, *ln1_next, *wqkv_next;      // *_next == NULL: last layer, no qkv stage
@@ -30,7 +30,9 @@ struct BbArgs {
 // the NEXT stage's weight loads issued by the compute waves themselves, behind their last activation load.)
 // GU_G / DN_G / QK_G: activation-ring depth (k-steps per wave in flight behind the flags) of gate_up (its weights ride in the same
 // ring) / down_proj / the next qkv; PF: the cross-stage weight prefetch arm
-template <int GU_G, int DN_G, int QK_G, bool PF>
+// GU1P: gate_up's 12 tiles combine in one pass (chain_gemm ONEPASS; round 4: epilogue 2.4 -> 1.0 us); GUW0: gate_up's whole weight
+// slice (96 registers) goes out at stage entry, ahead of the flags, instead of riding in the activation ring (A/B arm)
+template <int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     }
     chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                               false, 0x1001, a.stamps);
-    chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, GU_G, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
-                                                           true, 0x1002, a.stamps);
+    chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, GU_G, GUW0 ? 0 : 1, ChainNoPrefetch, GU1P>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I,
+                                                                                             a.eps, wg, 0, lds, g, true, 0x1002, a.stamps);
     chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, DN_G>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                   true, 0x1003, a.stamps);
     if (a.wqkv_next)
@@ -123,6 +125,8 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<4, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<3, 6, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         attr = true;
     }
     BbArgs a{};
@@ -140,6 +144,8 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
     else if (g_bb_deep == 1) BB_LAUNCH(4, 8, 8, false);
     else if (g_bb_deep == 2) BB_LAUNCH(3, 6, 8, false);
     else if (g_bb_deep == 3) BB_LAUNCH(2, 8, 8, false);
+    else if (g_bb_deep == 4) BB_LAUNCH(2, 4, 4, false, false);             // round 3's two-pass gate_up combine
+    else if (g_bb_deep == 5) BB_LAUNCH(2, 4, 4, false, true, true);        // gate_up weights ahead of the flags
     else BB_LAUNCH(2, 4, 4, false);
 #undef BB_LAUNCH
     OMNI_CHECK_LAUNCH("bb_chain");

@@ -112,6 +112,7 @@ struct omni_talker {
     int64_t* cp_slots;
     std::vector<uint16_t*> cp_k, cp_v;
     int32_t* pf_seq;   // prefill scratch
+    void* bb_table;                     // device table of the backbone layers' pointers (bb_all.hip)
     uint32_t* chain_flags;              // stage flags of the persistent chains: OMNI_FLAG_REPLICAS copies of [256] (coherent.cuh) + the error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
@@ -171,6 +172,9 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->cp_slots = c.take<int64_t>((Q + 1) * B);
     t->pf_seq = c.take<int32_t>(8);
     t->chain_flags = c.take<uint32_t>(OMNI_FLAG_WORDS);
+#ifdef OMNI_DEBUG_HOOKS
+    t->bb_table = c.take<char>(k_bb_all_table_bytes(d.layers > 0 ? d.layers : 1));
+#endif
     if (d.moe_experts > 0) {
         const size_t k = d.moe_top_k, Im = d.moe_inter, Is = d.moe_shared_inter;
         t->normed_rm = c.take<uint16_t>(B * H);
@@ -290,6 +294,14 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
             seq[p * B + b] = p + 1;
             slots[p * B + b] = (int64_t)b * t->cp_bs + p;
         }
+#ifdef OMNI_DEBUG_HOOKS      // round 4's one-launch backbone (bb_all.hip): an A/B arm of the debug library (it lost: DESIGN 6)
+    if (desc->moe_experts == 0 &&
+        k_bb_all_table(t->bb_table, t->d, t->layer.data(), t->k_cache.data(), t->v_cache.data(),
+                       desc->kv_dtype == OMNI_KV_INT8 ? t->k_scales.data() : nullptr, desc->kv_dtype == OMNI_KV_INT8 ? t->v_scales.data() : nullptr) != OMNI_OK) {
+        delete t;
+        return nullptr;
+    }
+#endif
     hipError_t e = hipMemcpy(t->cp_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4);
     if (e == hipSuccess) e = hipMemcpy(t->cp_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
@@ -837,6 +849,11 @@ extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
 // the backbone of one decode step (every layer; the residual stream in t->resid on entry, final residual on exit)
 static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
     const omni_talker_desc& d = t->d;
+#ifdef OMNI_DEBUG_HOOKS
+    if (k_bb_all_supported(d, io->B, t->has_ar))      // A/B arm: the whole stack, attention included, as one persistent launch
+        return k_bb_all(d, t->bb_table, io, t->attn, t->resid, t->part, t->act, t->qkv, t->chain_flags,
+                        reinterpret_cast<int32_t*>(t->chain_flags + 320), stream);
+#endif
     if (k_bb_chain_supported(d, io->B, t->has_ar) && d.layers > 0) {
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
         const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
@@ -848,6 +865,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
                                     t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
                                     t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
                                     d.max_model_len, d.frag_layout, -1, stream, io->num_live, io->rope_delta));
+#ifdef OMNI_DEBUG_HOOKS      // round-3 A/B arms (all slower): debug library only
             if (k_bb_engine_enabled())
                 TRY(k_bb_engine(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                                 t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
@@ -858,6 +876,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
                 TRY(k_bb_pp(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                             t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
             else
+#endif
             TRY(k_bb_chain(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
         }

@@ -42,7 +42,9 @@ struct ChainPrefetch {           // N = loads per wave that F issues
     static constexpr int LOADS = N;
     __device__ __forceinline__ void operator()() const { f(); }
 };
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch>
+// ONEPASS: more than 6 tiles still combine in ONE pass (the caller's LDS holds CH_WAVES * NT * MT KB of slots): one barrier
+// instead of three and twice the epilogue threads at work; same order of additions.
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -148,7 +150,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int e = 0; e < PE; ++e) s_ += pv[e];
         if (XROWS <= 32) s_ = xor32_sum(s_);
         if (XROWS <= 16) s_ = xor16_sum(s_);
-        float* red = lds + CH_WAVES * (NT * MT > 6 ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
+        float* red = lds + CH_WAVES * ((NT * MT > 6 && !ONEPASS) ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
         red[wave * 64 + lane] = s_;
         chain_barrier(g);
         float t = 0.f;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 
     // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores.  More than 6 tiles (the
     // backbone's gate_up: 12) go through the combine area in two passes of NT * MT / 2 tiles, so that it stays at 48 KB
-    constexpr int PASSES = NT * MT > 6 ? 2 : 1, TP = NT * MT / PASSES;
+    constexpr int PASSES = (NT * MT > 6 && !ONEPASS) ? 2 : 1, TP = NT * MT / PASSES;
     static_assert(NT * MT % PASSES == 0, "chain_gemm: tiles per combine pass");
     f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
     constexpr int LN = GU8 ? 32 : 64;

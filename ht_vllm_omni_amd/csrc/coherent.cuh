@@ -86,6 +86,7 @@ struct ChainGate {
     int nap;               // s_sleep units (64 clocks) between two polls: 0, 1, 2, 4, 8
     int ahead;             // stages this workgroup has passed without rows since it last waited (chain_gate_skip)
     int skip;              // debug library only (timing experiments, results garbage): 1 = fetch half of every weight slice, 2 = half of the activations
+    unsigned long long* stamps;   // debug library only: timeline stamps of the attention stage (pa_body.cuh, CHAIN), or NULL
     // engine mode (NULL / unused in the plain chains): barriers among the 8 compute waves only, weights from the LDS FIFO
     EngSync* es;
     unsigned bgen;         // compute-wave barriers this wave has passed
@@ -148,6 +149,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
     g.dom = 8;
     g.nap = 1;
     g.skip = 0;
+    g.stamps = nullptr;
     g.ahead = 0;
     g.es = nullptr; g.bgen = 0; g.fifo = nullptr; g.piece_base = 0; g.ready = 0;
 }

@@ -81,6 +81,15 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
                int B, float eps, uint32_t* flags, int32_t* err, void* stream);
+// the WHOLE backbone -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as one persistent launch
+// (bb_all.hip): the layer pointers live in a device table filled at engine creation
+size_t k_bb_all_table_bytes(int layers);
+int k_bb_all_table(void* table_dev, const omni_talker_desc& d, const omni_layer_weights* layers, void* const* k_cache, void* const* v_cache,
+                   float* const* k_scales, float* const* v_scales);
+int k_bb_all_set_scales(void* table_dev, int layers, const float* k, const float* v, void* stream);
+bool k_bb_all_supported(const omni_talker_desc& d, int B, bool has_ar);
+int k_bb_all(const omni_talker_desc& d, const void* table_dev, const omni_step_io* io, void* attn, void* resid, float* part, void* act, void* qkv,
+             uint32_t* flags, int32_t* err, void* stream);
 // the same segment with the operand streams on different waves (bb_xw.hip): 8 compute waves stream weights into registers, 4 service
 // waves poll, fetch + normalise the activations into an LDS ring, combine, store and publish
 bool k_bb_xw_enabled();

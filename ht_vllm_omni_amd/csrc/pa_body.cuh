@@ -1,0 +1,507 @@
+// Paged-attention decode body (query_len = 1; see paged_attn.hip for the design notes).
+#pragma once
+#include "attn_common.cuh"
+#include "coherent.cuh"
+#include "common.cuh"
+#include "gemm_frag.cuh"
+#include "kernels.h"
+
+#define PA_THREADS 256
+#define PA_WAVES 4
+#define PA_U 4                 // 8-token groups per load batch per wave
+#define PA_REC 130             // partial record: [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
+
+struct PAArgs {
+    const uint16_t* q;             // bf16 [rows, Hq*128]           (unfused)
+    const uint16_t* qkv;           // bf16 [rows, (Hq+2Hkv)*128]    (fused)
+    const uint16_t* qnorm_w; const uint16_t* knorm_w; const int32_t* positions; const int32_t* rope_delta; const uint16_t* cos_sin;
+    int64_t* slot_out; float eps;
+    void* k_cache; void* v_cache; float* k_scales; float* v_scales;
+    const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
+    uint16_t* out; float* partial;
+    int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
+    int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
+    int kv_rep;                    // decode kernel: grid.x = kv_heads * kv_rep "virtual" kv heads of q_heads / (kv_heads * kv_rep)
+                                   // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
+    int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
+    const int32_t* num_live;       // fused decode: rows >= *num_live (padding of a graph bucket) write no KV / slot (NULL: all live)
+};
+
+template <int KV>
+struct KVRaw { u32x4 a, b; };   // b: bf16 only (second 8 elements)
+
+// element index (0..127) of the e-th value (0..15) held by a lane with sub = lane & 7
+template <int KV>
+__device__ __forceinline__ int elem_of(int sub, int e) {
+    if (OMNI_KV_IS16(KV)) return (e < 8) ? (sub * 8 + e) : (64 + sub * 8 + (e - 8));
+    return sub * 16 + e;
+}
+
+// The cache pointers are GLOBAL-memory pointers.  hipcc infers that for pointers that come straight from the kernel arguments; the
+// persistent backbone launch reads them from a device table (a flat pointer to the compiler -> flat_load, which counts in
+// lgkmcnt too and returns out of order): say it explicitly.
+#define PA_GLOBAL __attribute__((address_space(1)))
+template <int KV>
+__device__ __forceinline__ KVRaw<KV> load_row(const void* base, size_t row, int sub) {
+    KVRaw<KV> r;
+    if (OMNI_KV_IS16(KV)) {
+        const PA_GLOBAL uint16_t* p = (const PA_GLOBAL uint16_t*)base + row * 128;
+        r.a = __builtin_nontemporal_load((const PA_GLOBAL u32x4*)(p + sub * 8));
+        r.b = __builtin_nontemporal_load((const PA_GLOBAL u32x4*)(p + 64 + sub * 8));
+    } else {
+        const PA_GLOBAL uint8_t* p = (const PA_GLOBAL uint8_t*)base + row * 128;
+        r.a = __builtin_nontemporal_load((const PA_GLOBAL u32x4*)(p + sub * 16));
+        r.b = (u32x4){0, 0, 0, 0};
+    }
+    return r;
+}
+
+template <int KV>
+__device__ __forceinline__ void to_f32(const KVRaw<KV>& r, float* f) {
+    if (KV == OMNI_KV_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = bf_lo(r.a[j]);
+            f[2 * j + 1] = bf_hi(r.a[j]);
+            f[8 + 2 * j] = bf_lo(r.b[j]);
+            f[8 + 2 * j + 1] = bf_hi(r.b[j]);
+        }
+    } else if (KV == OMNI_KV_FP16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = h_lo(r.a[j]);
+            f[2 * j + 1] = h_hi(r.a[j]);
+            f[8 + 2 * j] = h_lo(r.b[j]);
+            f[8 + 2 * j + 1] = h_hi(r.b[j]);
+        }
+    } else if (KV == OMNI_KV_FP8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) unpack_fp8x4(r.a[j], f + 4 * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = r.a[j] ^ 0x80808080u;       // signed byte + 128 as an unsigned byte: v_cvt_f32_ubyteN, then - 128
+            f[4 * j + 0] = (float)(w & 0xFF) - 128.0f;
+            f[4 * j + 1] = (float)((w >> 8) & 0xFF) - 128.0f;
+            f[4 * j + 2] = (float)((w >> 16) & 0xFF) - 128.0f;
+            f[4 * j + 3] = (float)(w >> 24) - 128.0f;
+        }
+    }
+}
+
+// The decode body, shared by the stand-alone launch (paged_attn.hip) and the attention stage of the persistent backbone launch
+// (bb_all.hip, CHAIN): one arithmetic, the same bits in both.  A "pair" = (row, virtual kv head[, KV split]) is worked by 4 waves
+// (`wave` 0..3, `tid` 0..255 inside the pair); `lds` = the pair's own scratch ([PA_WAVES][G][PA_REC] | q scratch | kv scratch).
+// CHAIN: `active` = false for a pair past the batch (the waves only keep the workgroup's barriers); batch 0 of the K / V history
+// goes out BEFORE the stage's flags (history is final since an earlier launch), the qkv rows -- written by another workgroup of
+// this launch -- are read behind them with sc1 loads, the attention output leaves with sc1 stores (coherent.cuh).
+// ---- batch 0 of a pair's K / V history issued AHEAD of the attention stage (bb_all.hip: behind the epilogue stores of the qkv
+// stage, so the rows are in flight through that stage's flag, the hand-off and this stage's poll).  The block ids of batch 0
+// depend on the block table only: loaded once per launch.  Same addresses as PA_LOAD at T0 = wave * 8 without a token limit.
+template <int KV>
+struct PaPre {
+    KVRaw<KV> k[PA_U], v[PA_U];
+    float ks[PA_U], vs[PA_U];
+};
+#define PA_PRE_LOADS(KV) (OMNI_KV_IS16(KV) ? 4 * PA_U : ((KV) == OMNI_KV_INT8 ? 4 * PA_U : 2 * PA_U))      // vector-memory loads per wave
+__device__ __forceinline__ void pa_pre_blocks(const PAArgs& a, int row, int wave, int (&blk)[PA_U]) {
+    const int tg = (threadIdx.x & 63) >> 3;
+    const int32_t* bt = a.block_table + (size_t)row * a.bt_stride;
+#pragma unroll
+    for (int u = 0; u < PA_U; ++u) blk[u] = bt[min((wave * 8 + u * PA_WAVES * 8 + tg) / a.bs, a.bt_stride - 1)];
+}
+template <int KV>
+__device__ __forceinline__ void pa_pre_issue(const PAArgs& a, int kvh, int wave, const int (&blk)[PA_U], PaPre<KV>& pre) {
+    const int lane = threadIdx.x & 63, sub = lane & 7, tg = lane >> 3;
+#pragma unroll
+    for (int u = 0; u < PA_U; ++u) {
+        const int t_ = wave * 8 + u * PA_WAVES * 8 + tg;
+        const size_t r_ = ((size_t)blk[u] * a.bs + t_ % a.bs) * a.kv_heads + kvh;
+        pre.k[u] = load_row<KV>(a.k_cache, r_, sub);
+        pre.v[u] = load_row<KV>(a.v_cache, r_, sub);
+        if (KV == OMNI_KV_INT8) { pre.ks[u] = a.k_scales[r_]; pre.vs[u] = a.v_scales[r_]; }
+    }
+}
+
+#ifdef OMNI_DEBUG_HOOKS      // timeline stamps of the attention stage (slot 1 of the per-layer stamp block of bb_all.hip; 100 MHz counter)
+#define PA_STAMP(k)                                                                                                  \
+    do {                                                                                                             \
+        if (CHAIN && gate->stamps != nullptr && threadIdx.x == 0)                                                    \
+            gate->stamps[((size_t)1 * 8 + (k)) * OMNI_CHAIN_WGS + blockIdx.x] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+#else
+#define PA_STAMP(k) do { } while (0)
+#endif
+
+template <int KV, int G, bool FUSED, bool CHAIN>
+__device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, const int vh, const int row_in, const int sp, const int wave,
+                                               const int tid, const bool active, ChainGate* gate, const int code,
+                                               const PaPre<KV>* pre = nullptr /* CHAIN: batch 0 already issued (pa_pre_issue) */) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 7, tg = lane >> 3;
+    const int row = active ? row_in : 0;
+    const int kvh = vh / a.kv_rep;
+    const int req = a.req_of_row ? a.req_of_row[row] : row;
+    const int kv_heads = a.kv_heads, bs = a.bs;
+    const int32_t* bt = a.block_table + (size_t)req * a.bt_stride;
+    const int max_blk = a.bt_stride - 1;
+
+    // ---- batch 0 of K/V loads goes out before anything else is known (speculative: tokens past the
+    // sequence end resolve to whatever block the table holds there -- block 0, the null block)
+    KVRaw<KV> k0[PA_U], v0[PA_U], k1[PA_U], v1[PA_U];
+    float ks0[PA_U], vs0[PA_U], ks1[PA_U], vs1[PA_U];
+    // token groups past the end of the history re-read its LAST row (one hot line) instead of whatever block the table
+    // holds further on: with blocks allocated ahead of the sequence those were real, cold HBM rows -- up to 127 tokens of
+    // wasted traffic per (row, head).  The speculative batch 0 goes out before the length is known and stays unclamped.
+    int t_lim = 0x7FFFFFFF;
+#define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
+    _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                       \
+        const int t_ = min((T0) + u * PA_WAVES * 8 + tg, t_lim);                             \
+        const int bi_ = min(t_ / bs, max_blk);                                               \
+        const size_t r_ = ((size_t)bt[bi_] * bs + t_ % bs) * kv_heads + kvh;                 \
+        KR[u] = load_row<KV>(a.k_cache, r_, sub);                                            \
+        VR[u] = load_row<KV>(a.v_cache, r_, sub);                                            \
+        if (KV == OMNI_KV_INT8) { KS[u] = a.k_scales[r_]; VS[u] = a.v_scales[r_]; }          \
+    }
+    const bool spec = (a.nsplit == 1);
+    PA_STAMP(0);
+    if (pre != nullptr) {
+#pragma unroll
+        for (int u = 0; u < PA_U; ++u) { k0[u] = pre->k[u]; v0[u] = pre->v[u]; ks0[u] = pre->ks[u]; vs0[u] = pre->vs[u]; }
+    } else if (spec && active) { PA_LOAD(k0, v0, ks0, vs0, wave * 8) }
+    PA_STAMP(1);
+    if (CHAIN) chain_gate_wait(*gate, code);                  // the qkv stage's flags; workgroup barrier inside
+    PA_STAMP(2);
+    if (active) {
+
+    const int seq_len = a.seq_lens[row] + (a.seq_from_pos ? 1 : 0);
+    int per = (seq_len + a.nsplit - 1) / a.nsplit;
+    per = (per + 31) & ~31;                       // 8-token groups never straddle splits
+    const int t_begin = sp * per;
+    const int cur = seq_len - 1;                  // the token computed this step
+    const int t_end = min(FUSED ? cur : seq_len, t_begin + per);
+    t_lim = max(t_end - 1, 0);
+    if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
+
+    // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
+    float qf[G][16];
+    const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? a.k_scale : 1.0f);
+    const int nslots = a.q_heads + 2 * kv_heads;
+    float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
+    // CHAIN: this row's q heads (and, in the wave that folds the new token, its k / v head) as one dword per lane each, all in one
+    // round trip behind the flags; the (l, l + 64) pairing of the norm + RoPE is restored through LDS
+    uint32_t kw_new = 0u, vw_new = 0u;
+    if (FUSED) {
+        const int pos = a.positions[row];
+        const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
+        if (CHAIN) {
+            const coh_rsrc_t qrs = coh_rsrc(a.qkv);
+            uint32_t qw[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) qw[g] = coh_ld4(qrs, (uint32_t)(((size_t)row * nslots + vh * G + g) * 128 + 2 * lane) * 2);
+            if (wave == 0) {
+                kw_new = coh_ld4(qrs, (uint32_t)(((size_t)row * nslots + a.q_heads + kvh) * 128 + 2 * lane) * 2);
+                vw_new = coh_ld4(qrs, (uint32_t)(((size_t)row * nslots + a.q_heads + kv_heads + kvh) * 128 + 2 * lane) * 2);
+            }
+            uint32_t* raw = reinterpret_cast<uint32_t*>(wq);
+#pragma unroll
+            for (int g = 0; g < G; ++g) raw[g * 64 + lane] = qw[g];
+            __builtin_amdgcn_wave_barrier();
+            const uint16_t* rq = reinterpret_cast<const uint16_t*>(raw);
+            float x0[G], x1[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { x0[g] = bf2f(rq[g * 128 + lane]); x1[g] = bf2f(rq[g * 128 + 64 + lane]); }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float y0, y1;
+                head_norm_rope_vals(x0[g], x1[g], a.qnorm_w, cs, a.eps, lane, y0, y1);
+                wq[g * 128 + lane] = y0;
+                wq[g * 128 + 64 + lane] = y1;
+            }
+        } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float y0, y1;
+            head_norm_rope(a.qkv + ((size_t)row * nslots + vh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
+            wq[g * 128 + lane] = y0;
+            wq[g * 128 + 64 + lane] = y1;
+        }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) qf[g][e] = wq[g * 128 + elem_of<KV>(sub, e)] * qs;
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint16_t* qp = a.q + ((size_t)row * a.q_heads + vh * G + g) * 128;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) qf[g][e] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
+        }
+    }
+    float m[G], l[G], acc[G][16];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    }
+
+    // ---- fused: the new token's K/V (wave 0 of the split that owns position `cur`) -- BEFORE the history loop: its loads,
+    // norm, quantisation and stores overlap the K/V batches already in flight instead of forming a tail after the loop; the
+    // running softmax state of token-group 0 simply starts from this token
+    if (FUSED) {
+        const int sp_cur = cur / per;
+        if (wave == 0 && sp == sp_cur) {
+            const int pos = a.positions[row];
+            const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
+            const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
+            // rows of a padded graph bucket past the live count may be live PREFILL rows of the persistent batch: they
+            // compute (results discarded) but leave the cache and the slot record alone
+            const bool live = !a.num_live || row < *a.num_live;
+            if (vh == 0 && lane == 0 && a.slot_out && live) a.slot_out[row] = slot;
+            const size_t crow = (size_t)slot * kv_heads + kvh;
+            const bool kv_writer = live && vh % a.kv_rep == 0;      // the other groups of this kv head fold the same values
+            float* kvs = lds + PA_WAVES * G * PA_REC + PA_WAVES * (G * 128);   // [2][128] dequantised new K, V
+            float kx0, kx1, vx0, vx1;
+            if (CHAIN) {
+                uint32_t* raw = reinterpret_cast<uint32_t*>(kvs);
+                raw[lane] = kw_new;
+                raw[64 + lane] = vw_new;
+                __builtin_amdgcn_wave_barrier();
+                const uint16_t* rk = reinterpret_cast<const uint16_t*>(raw);
+                const float rk0 = bf2f(rk[lane]), rk1 = bf2f(rk[lane + 64]);
+                vx0 = bf2f(rk[128 + lane]); vx1 = bf2f(rk[128 + lane + 64]);
+                __builtin_amdgcn_wave_barrier();
+                head_norm_rope_vals(rk0, rk1, a.knorm_w, cs, a.eps, lane, kx0, kx1);
+            } else {
+                head_norm_rope(a.qkv + ((size_t)row * nslots + a.q_heads + kvh) * 128, a.knorm_w, cs, a.eps, lane, kx0, kx1);
+                const uint16_t* vsrc = a.qkv + ((size_t)row * nslots + a.q_heads + kv_heads + kvh) * 128;
+                vx0 = bf2f(vsrc[lane]); vx1 = bf2f(vsrc[lane + 64]);
+            }
+            float ksc_new = 1.f, vsc_new = 1.f;
+            if (KV == OMNI_KV_BF16) {
+                uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
+                uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
+                if (kv_writer) {
+                    kd[lane] = f2bf(kx0); kd[lane + 64] = f2bf(kx1);
+                    vd[lane] = f2bf(vx0); vd[lane + 64] = f2bf(vx1);
+                }
+            } else if (KV == OMNI_KV_FP16) {
+                uint16_t* kd = reinterpret_cast<uint16_t*>(a.k_cache) + crow * 128;
+                uint16_t* vd = reinterpret_cast<uint16_t*>(a.v_cache) + crow * 128;
+                const uint16_t hk0 = f2h(kx0), hk1 = f2h(kx1), hv0 = f2h(vx0), hv1 = f2h(vx1);
+                if (kv_writer) {
+                    kd[lane] = hk0; kd[lane + 64] = hk1;
+                    vd[lane] = hv0; vd[lane + 64] = hv1;
+                }
+                kx0 = h2f(hk0); kx1 = h2f(hk1); vx0 = h2f(hv0); vx1 = h2f(hv1);     // what the cache now holds
+            } else if (KV == OMNI_KV_FP8) {
+                const float ik = a.k_scale, iv = a.v_scale;
+                const uint32_t pk = pack_fp8x4(ik == 1.f ? kx0 : kx0 / ik, ik == 1.f ? kx1 : kx1 / ik, 0.f, 0.f);
+                const uint32_t pv = pack_fp8x4(iv == 1.f ? vx0 : vx0 / iv, iv == 1.f ? vx1 : vx1 / iv, 0.f, 0.f);
+                uint8_t* kd = reinterpret_cast<uint8_t*>(a.k_cache) + crow * 128;
+                uint8_t* vd = reinterpret_cast<uint8_t*>(a.v_cache) + crow * 128;
+                if (kv_writer) {
+                    kd[lane] = (uint8_t)(pk & 0xFF); kd[lane + 64] = (uint8_t)((pk >> 8) & 0xFF);
+                    vd[lane] = (uint8_t)(pv & 0xFF); vd[lane + 64] = (uint8_t)((pv >> 8) & 0xFF);
+                }
+                float t4[4];
+                unpack_fp8x4(pk, t4); kx0 = t4[0]; kx1 = t4[1];       // what the cache now holds (unscaled)
+                unpack_fp8x4(pv, t4); vx0 = t4[0]; vx1 = t4[1];
+            } else {
+                const float ka = fmaxf(wave_max(fmaxf(fabsf(kx0), fabsf(kx1))), 1e-8f);
+                const float va = fmaxf(wave_max(fmaxf(fabsf(vx0), fabsf(vx1))), 1e-8f);
+                ksc_new = ka / 127.0f; vsc_new = va / 127.0f;
+                kx0 = fminf(fmaxf(rintf(kx0 / ksc_new), -127.f), 127.f); kx1 = fminf(fmaxf(rintf(kx1 / ksc_new), -127.f), 127.f);
+                vx0 = fminf(fmaxf(rintf(vx0 / vsc_new), -127.f), 127.f); vx1 = fminf(fmaxf(rintf(vx1 / vsc_new), -127.f), 127.f);
+                int8_t* kd = reinterpret_cast<int8_t*>(a.k_cache) + crow * 128;
+                int8_t* vd = reinterpret_cast<int8_t*>(a.v_cache) + crow * 128;
+                if (kv_writer) {
+                    kd[lane] = (int8_t)kx0; kd[lane + 64] = (int8_t)kx1;
+                    vd[lane] = (int8_t)vx0; vd[lane + 64] = (int8_t)vx1;
+                    if (lane == 0) { a.k_scales[crow] = ksc_new; a.v_scales[crow] = vsc_new; }
+                }
+            }
+            kvs[lane] = kx0; kvs[64 + lane] = kx1;
+            kvs[128 + lane] = vx0; kvs[192 + lane] = vx1;
+            // token-group 0 of this wave folds the new token into its running softmax state
+            float kf[16], vf[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                kf[e] = kvs[elem_of<KV>(sub, e)];
+                vf[e] = kvs[128 + elem_of<KV>(sub, e)];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
+                d = group8_sum(d);
+                if (KV == OMNI_KV_INT8) d *= ksc_new;
+                if (tg == 0) {
+                    const float mn = fmaxf(m[g], d);
+                    const float corr = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mn);
+                    float p = exp2f(d - mn);
+                    m[g] = mn;
+                    l[g] = l[g] * corr + p;
+                    if (KV == OMNI_KV_INT8) p *= vsc_new;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e] * corr);
+                }
+            }
+        }
+    }
+
+#define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
+    {                                                                                                \
+        float s_[PA_U][G], mx_[G];                                                                   \
+        bool ok_[PA_U];                                                                              \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
+            float kf_[16];                                                                           \
+            to_f32<KV>(KR[u], kf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float d_ = 0.f;                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
+                d_ = group8_sum(d_);       /* 3 DPP steps over the token's 8 lanes */                 \
+                if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
+                d_ = ok_[u] ? d_ : -INFINITY;                                                        \
+                s_[u][g] = d_;                                                                       \
+                mx_[g] = fmaxf(mx_[g], d_);                                                          \
+            }                                                                                        \
+        }                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                              \
+            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx_[g]);                 \
+            m[g] = mx_[g];                                                                           \
+            l[g] *= corr_;                                                                           \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+            float vf_[16];                                                                           \
+            to_f32<KV>(VR[u], vf_);                                                                  \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
+                float p_ = ok_[u] ? exp2f(s_[u][g] - m[g]) : 0.f;                                    \
+                l[g] += p_;                                                                          \
+                if (KV == OMNI_KV_INT8) p_ *= VS[u];                                                 \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p_, vf_[e], acc[g][e]); \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    // ---- main loop, loads one batch ahead
+    constexpr int STRIDE = PA_WAVES * 8 * PA_U;
+    for (int t0 = t_begin + wave * 8; t0 < t_end;) {
+        if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
+        PA_COMPUTE(k0, v0, ks0, vs0, t0)
+        t0 += STRIDE;
+        if (t0 >= t_end) break;
+        if (t0 + STRIDE < t_end) { PA_LOAD(k0, v0, ks0, vs0, t0 + STRIDE) }
+        PA_COMPUTE(k1, v1, ks1, vs1, t0)
+        t0 += STRIDE;
+    }
+#undef PA_LOAD
+#undef PA_COMPUTE
+    PA_STAMP(3);
+
+    // ---- combine: the 8 token-groups of a wave merge in registers (xor-shuffles over lane bits 3..5),
+    // then the 4 wave partials go through LDS
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float mw = m[g];
+        mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));
+        mw = xor32_max(xor16_max(mw));
+        const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
+        float lw = l[g] * sc;
+        lw += dpp_f<OMNI_DPP_ROR8>(lw);
+        lw = xor32_sum(xor16_sum(lw));
+        // the 16 partial outputs: lane ^ 8 as a DPP step, then two halving exchanges (each lane passes on the half its
+        // partner keeps) -- 12 ds_bpermute instead of 48; the lane ends with elements e0 .. e0 + 3, e0 = 8 b1 + 4 b2
+        float a16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[g][e] * sc;
+            a16[e] = v + dpp_f<OMNI_DPP_ROR8>(v);
+        }
+        const bool b1 = (lane & 16) != 0, b2 = (lane & 32) != 0;
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float keep = b1 ? a16[8 + e] : a16[e];
+            const float send = b1 ? a16[e] : a16[8 + e];
+            a8[e] = keep + xchg16(send, b1);
+        }
+        float* rec = lds + ((size_t)wave * G + g) * PA_REC;
+        const int e0 = (b1 ? 8 : 0) + (b2 ? 4 : 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float keep = b2 ? a8[4 + e] : a8[e];
+            const float send = b2 ? a8[e] : a8[4 + e];
+            const float v = keep + xchg32(send, b2);
+            if ((lane & 8) == 0) rec[2 + elem_of<KV>(sub, e0 + e)] = v;      // lanes ^ 8 hold the same values
+        }
+        if (lane == 0) {
+            rec[0] = mw;
+            rec[1] = lw;
+        }
+    }
+    }   // active
+    PA_STAMP(4);
+    __syncthreads();
+    PA_STAMP(5);
+    if (active) {
+        // one output element: merge of the 4 wave partials (fixed order)
+        auto merged = [&](int g, int d, float& M, float& L) -> float {
+            M = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < PA_WAVES; ++p) M = fmaxf(M, lds[((size_t)p * G + g) * PA_REC]);
+            L = 0.f;
+            float A = 0.f;
+#pragma unroll
+            for (int p = 0; p < PA_WAVES; ++p) {
+                const float* rec = lds + ((size_t)p * G + g) * PA_REC;
+                const float w = (rec[0] == -INFINITY) ? 0.f : exp2f(rec[0] - M);
+                L = fmaf(rec[1], w, L);
+                A = fmaf(rec[2 + d], w, A);
+            }
+            return A;
+        };
+        if (CHAIN) {
+            // write-through dword stores (two adjacent elements per thread): the o_proj stage reads them behind this stage's flag
+            const coh_rsrc_t ors = coh_rsrc(a.out);
+            const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
+            for (int it = tid; it < G * 64; it += PA_THREADS) {
+                const int g = it >> 6, d = 2 * (it & 63);
+                float M, L, M1, L1;
+                const float A0 = merged(g, d, M, L), A1 = merged(g, d + 1, M1, L1);
+                const int qh = vh * G + g;
+                const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
+                coh_st4(ors, (uint32_t)oo * 2, pack_bf2(L > 0.f ? (A0 / L) * vs : 0.f, L1 > 0.f ? (A1 / L1) * vs : 0.f));
+            }
+        } else
+        for (int it = tid; it < G * 128; it += PA_THREADS) {
+            const int g = it >> 7, d = it & 127;
+            float M, L;
+            const float A = merged(g, d, M, L);
+            const int qh = vh * G + g;
+            if (a.nsplit == 1) {
+                const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
+                const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
+                a.out[oo] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
+            } else {
+                float* rec = a.partial + (((size_t)row * a.q_heads + qh) * a.nsplit + sp) * PA_REC;
+                if (d == 0) {
+                    rec[0] = M;
+                    rec[1] = L;
+                }
+                rec[2 + d] = A;
+            }
+        }
+    }
+    PA_STAMP(6);
+    if (CHAIN) chain_gate_arrive(*gate);
+    PA_STAMP(7);
+}

@@ -148,6 +148,43 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
         assert torch.equal(x, y), f"KV cache of layer {l} differs"
 
 
+@pytest.mark.parametrize("base", ["launch-path", "layer-chain"])
+@pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16"), (57, "int8"), (64, "fp16"), (51, "fp8")])
+def test_whole_backbone_launch_against_the_launch_path(B, kv, base):
+    """The whole decoder stack -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as ONE persistent
+    launch (csrc/bb_all.hip: the paged attention is a stage of the grid, two (row, kv head) pairs per workgroup) against the
+    launch-per-op backbone and against round 3's per-layer chain of the same library: pa_body.cuh / chain_gemm.cuh are the launch
+    path's arithmetic, so logits, hidden state, sampled ids, codes, slot mapping and every KV byte of three decode steps are
+    identical; no flag wait times out.  Reference: the vLLM Qwen3 decoder stack behind qwen3_tts_talker.py:341,414-422."""
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
+    w = make_weights(d, seed=8, std=0.02)
+    res = {}
+    with L.debug_library() as lib:
+        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_all):
+            fn.argtypes = [C.c_int]; fn.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_bb_all(on)
+                lib.omni_debug_bb_chain(1 if (on or base == "layer-chain") else 0)
+                eng = _decode_engine(d, w, B, kv)
+                outs = []
+                for _ in range(3):
+                    eng.decode_step(B)
+                    outs.append((eng.logits[:B].clone(), eng.last_hidden[:B].clone(), eng.input_ids[:B].clone(), eng.audio_codes[:B].clone(),
+                                 eng.slot_mapping[:B].clone()))
+                torch.cuda.synchronize()
+                assert eng.chain_error() == 0
+                res[on] = (outs, [c.view(torch.uint8).clone() for c in eng.kv_caches])
+        finally:
+            lib.omni_debug_bb_chain(1)
+            lib.omni_debug_bb_all(0)
+    for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        for name, x, y in zip(("logits", "hidden", "ids", "codes", "slots"), a, b):
+            assert torch.equal(x, y), f"step {s}: {name} differ between the one-launch backbone and the {base}"
+    for l, (x, y) in enumerate(zip(res[1][1], res[0][1])):
+        assert torch.equal(x, y), f"KV cache of layer {l} differs"
+
+
 def test_chain_steps_replay_in_a_graph_and_stay_deterministic():
     """Whole decode steps with the chain inside a captured hipGraph: two engines fed the same requests produce the same
     codes step after step (flags and epochs advance on the device across replays), error word stays 0."""
