@@ -323,13 +323,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ev_ms = e0.elapsed_time(e1) / args.steps
+    chains_ran = eng.chains_ran()            # what the captured step launched: bit 0 the code-predictor chain, bit 1 the backbone chain
     # a timed-out flag wait (peer all-reduce, persistent chains) makes the remaining steps wrong AND faster: void the run
     # on every rank when any rank saw one
     dev_err = int(eng.chain_error() != 0) + 2 * int(eng.ar is not None and eng.ar.error() != 0)
+    rank_words = [dev_err]
     if dist is not None:
-        emax = torch.tensor([dev_err], dtype=torch.int32, device="cuda")
-        dist.all_reduce(emax, op=dist.ReduceOp.MAX)
-        dev_err = int(emax.item())
+        allw = torch.zeros(world, dtype=torch.int32, device="cuda")
+        allw[rank] = dev_err
+        dist.all_reduce(allw, op=dist.ReduceOp.MAX)
+        rank_words = [int(x) for x in allw.tolist()]      # every rank's error words in the line (0 = clean)
+        dev_err = max(rank_words)
     if dev_err:
         log(f"[rank {rank}] in-kernel hand-off timed out during the timed region (code {dev_err}: 1 = chain flags, 2 = peer all-reduce): result void")
         sys.exit(3)
@@ -355,6 +359,41 @@ def main():
         except Exception as e:   # noqa: BLE001
             log(f"backbone-only diagnostic failed: {e!r}")
 
+    # ---- per-family times of the step, measured live in this run (after the timed region): each part of the step captured
+    # as its own hipGraph and replayed alone (omni_talker_step_part).  A part run alone reads whatever the buffers hold: its time is
+    # the step's, its outputs are not -- this engine's request state is void from here on (the replica leg builds its own).
+    families = None
+    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force:
+        try:
+            split = bool(chains_ran & 2)
+            plan = [("code_predictor_phase_ms", 1)] + ([("backbone_attention_ms", 2), ("backbone_chain_ms", 4)] if split else [("backbone_stack_ms", 6)]) \
+                + [("lm_head_sampler_ms", 8)]
+            families = {}
+            for name, parts in plan:
+                eng.step_part(B, parts)
+                torch.cuda.synchronize()
+                gp = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp):
+                    eng.step_part(B, parts)
+                gp.replay()
+                torch.cuda.synchronize()
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record()
+                for _ in range(16):
+                    gp.replay()
+                f1.record()
+                torch.cuda.synchronize()
+                families[name] = f0.elapsed_time(f1) / 16
+            families["sum_ms"] = sum(v for k, v in families.items())
+            families["note"] = ("each family replayed alone as its own hipGraph after the timed region, at the final context: "
+                                "code_predictor_phase = pair pass (positions 0/1) + group-1 head and sampler + the chain launch "
+                                "(passes 2..15) + input assembly; backbone_attention = the 28 paged-attention launches; backbone_chain "
+                                "= first qkv + the 28 four-stage launches; the parts of a step overlap by a launch boundary each, so "
+                                "sum_ms reads a few percent above event_ms_per_step")
+        except Exception as e:   # noqa: BLE001
+            log(f"family breakdown failed: {e!r}")
+            families = None
+
     # ---- roofline: algorithmic bytes of one step (each counted once) / measured step time
     mean_ctx = ctx0 + (args.steps - 1) / 2.0
     by = eng.step_bytes(mean_ctx)
@@ -373,9 +412,17 @@ def main():
                    "parallelism": f"{args.parallel}{world}", "allreduce": getattr(args, "allreduce_used", "none"),
                    "prefill_gemm": "omni_gemm_tile (hand-written MFMA)" if args.prefill_gemm == "tile" else "hipBLASLt",
                    "hipgraph": graph is not None, "sub_batches": args.sub_batches,
-                   "decode_launches": ("persistent chains: code-predictor passes 2..15 (layer stacks, heads, samplers) = 1 launch; backbone = "
-                                       "1 attention + 1 segment launch (o_proj, gate_up, down_proj, next qkv) per layer"
-                                       if getattr(eng, "persistent_chains", False) else "one launch per op"),
+                   # what the captured step actually launched (omni_talker_chains_ran), not what was asked for
+                   "chains_ran": chains_ran,
+                   "decode_launches": "; ".join(
+                       (["code-predictor passes 2..15 (layer stacks, heads, samplers) = 1 persistent launch"] if chains_ran & 1
+                        else ["code predictor: one launch per op"]) +
+                       (["backbone = 1 attention + 1 four-stage persistent launch (o_proj, gate_up, down_proj, next qkv) per layer"]
+                        if chains_ran & 2 else ["backbone: one launch per op"])),
+                   "multi_gpu": ("one engine per GPU (replicas, no data-path collective) is the throughput mode of this stage; tensor "
+                                 "parallelism divides the backbone's bytes but not the replicated code predictor: latency mode "
+                                 "(DESIGN 5)"),
+                   **({"rccl_ranks": world, "rank_error_words": rank_words} if world > 1 or args.tp_force else {}),
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
                    "target_ctx": args.target_ctx, "untimed_advance_steps": advance,
                    **({"ctx_extra": args.ctx_extra} if args.ctx_extra else {})},
@@ -387,6 +434,8 @@ def main():
     }
     if args.tp_force:
         out["config"]["parallelism"] += " (tensor-parallel code path forced on one rank)"
+    if families is not None:
+        out["roofline"]["families"] = families
     if bb_ms is not None:
         bb_bytes = by_end["weights_backbone"] + by_end["lm_head"] + by_end["kv_read"] + by_end["kv_write"]
         out["roofline"]["breakdown"] = {

@@ -74,7 +74,7 @@ class TalkerDesc(C.Structure):
         ("scratch", vp), ("scratch_bytes", i64),
         ("ar_attn", C.POINTER(ArPeers)), ("ar_mlp", C.POINTER(ArPeers)),
         ("moe_e0", i32), ("moe_experts_local", i32), ("moe_w8", i32),
-        ("cp_chain", i32),
+        ("cp_chain", i32), ("rope_rows", i32),
     ]
 
 
@@ -91,7 +91,7 @@ class StepIO(C.Structure):
         ("greedy", i32), ("temperature", f32), ("top_k", i32), ("rep_penalty", f32), ("seed", u32),
         ("cp_greedy", i32), ("cp_temperature", f32), ("cp_top_k", i32),
         ("advance", i32), ("top_p", f32), ("cp_top_p", f32),
-        ("num_live", vp), ("rows", RowSampling), ("rope_delta", vp),
+        ("num_live", vp), ("rows", RowSampling), ("rope_delta", vp), ("status", vp),
     ]
 
 
@@ -142,12 +142,15 @@ SIGNATURES = {
     "omni_talker_create": (vp, [C.POINTER(TalkerDesc)]),
     "omni_talker_destroy": (None, [vp]),
     "omni_talker_chain_error": (i32, [vp, i32]),
+    "omni_talker_set_chains": (i32, [vp, i32]),
+    "omni_talker_chains_ran": (i32, [vp]),
     "omni_talker_mtp": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_layer_attn": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_layer_mlp": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_finish": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_decode_step": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_backbone_step": (i32, [vp, C.POINTER(StepIO), vp]),
+    "omni_talker_step_part": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_attn_out": (vp, [vp]),
     "omni_talker_mlp_out": (vp, [vp]),
     "omni_talker_prefill": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),

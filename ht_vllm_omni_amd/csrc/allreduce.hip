@@ -26,7 +26,10 @@
 #include "kernels.h"
 
 #define AR_MAX_WORLD 8
-#define AR_SPIN_BOUND (1u << 27)        // x ~64-cycle sleeps: several seconds at 2.4 GHz (a rank may be late by a graph upload, a GC pause)
+// A peer is waited for by WALL CLOCK (a poll of fine-grained peer memory takes ~1 us, so an iteration count of 2^27 was
+// minutes, not seconds): AR_WAIT_TICKS of the constant 100 MHz counter (s_memrealtime), read once per 1024 polls.  5 s covers a
+// rank that is late by a graph upload or a GC pause.
+#define AR_WAIT_TICKS 500000000ull
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -53,9 +56,23 @@ __global__ __launch_bounds__(256) void allreduce_resid_kernel(const ArArgs a) {
         if (threadIdx.x < a.world && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             const uint32_t* f = a.flags[a.rank] + threadIdx.x;
             uint32_t spins = 0;
+            unsigned long long t0 = 0;
             while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > AR_SPIN_BOUND) { atomicExch(a.error, 1 + (int)threadIdx.x); break; }
+                if ((++spins & 1023u) == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (spins == 1024u) t0 = now;
+                    else if (now - t0 > AR_WAIT_TICKS) {
+                        // peer `threadIdx.x` did not arrive.  The word goes into EVERY rank's control block (the error word sits at
+                        // the same offset from the flags in each of them: tp_comm.CTL layout), so that the ranks that did see
+                        // their peers learn of it within the step too and all of them stop
+                        const int code = 1 + (int)threadIdx.x + 256 * (a.rank + 1);
+                        const ptrdiff_t eoff = a.error - reinterpret_cast<int32_t*>(a.flags[a.rank]);
+                        for (int q = 0; q < a.world; ++q)
+                            __hip_atomic_store(reinterpret_cast<int32_t*>(a.flags[q]) + eoff, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: the peers' partials below are fresh

@@ -218,6 +218,7 @@ int k_bb_all(const omni_talker_desc& d, const void* table_dev, const omni_step_i
     p.q_heads = d.q_heads; p.kv_heads = d.kv_heads; p.bs = d.block_size;
     p.k_scale = d.k_scale; p.v_scale = d.v_scale; p.sm_scale = 1.0f / sqrtf((float)d.head_dim);
     p.nsplit = 1; p.out_frag = 1; p.kv_rep = 1; p.dense_pos = -1; p.num_live = io->num_live;
+    p.rope_rows = io->rope_delta ? (d.rope_rows > 0 ? d.rope_rows : d.max_model_len) : 0;
     a.attn = (uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
     a.B = io->B; a.nap = g_bb_all_nap; a.eps = d.eps; a.flags = flags; a.err = err;
     a.stamp_layer = -1;

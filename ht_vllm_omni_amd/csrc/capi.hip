@@ -19,7 +19,7 @@ void omni_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* omni_last_error(void) { return g_err; }
-extern "C" int omni_abi_version(void) { return 3; }
+extern "C" int omni_abi_version(void) { return 4; }
 
 #define TRY(expr)                    \
     do {                             \
@@ -116,6 +116,7 @@ struct omni_talker {
     uint32_t* chain_flags;              // stage flags of the persistent chains: OMNI_FLAG_REPLICAS copies of [256] (coherent.cuh) + the error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
+    int ran;                            // persistent chains launched by the decode-step call in progress / last made (bit 0 cp, bit 1 bb)
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -326,9 +327,19 @@ extern "C" int omni_talker_chain_error(omni_talker* t, int reset) {
         omni_set_error("omni_talker_chain_error: device read failed");
         return OMNI_EHIP;
     }
-    if (reset && hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4) != hipSuccess) return OMNI_EHIP;
+    if (reset == 1 && hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4) != hipSuccess) return OMNI_EHIP;
+    if (reset == 2) {                   // fault injection (tests of the host's fall-back): as if a flag wait had just timed out
+        const int32_t code = 0x7ffe;
+        if (hipMemcpy(t->chain_flags + 320, &code, 4, hipMemcpyHostToDevice) != hipSuccess) return OMNI_EHIP;
+    }
     return v;
 }
+extern "C" int omni_talker_set_chains(omni_talker* t, int on) {
+    if (!t) return OMNI_EINVAL;
+    t->d.cp_chain = on != 0;            // k_cp_chain_supported / k_bb_chain_supported read it per call
+    return OMNI_OK;
+}
+extern "C" int omni_talker_chains_ran(const omni_talker* t) { return t ? t->ran : 0; }
 extern "C" void* omni_talker_attn_out(omni_talker* t) { return t ? t->attn_out : nullptr; }
 extern "C" void* omni_talker_mlp_out(omni_talker* t) { return t ? t->mlp_out : nullptr; }
 
@@ -564,6 +575,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 hd.steps = steps; hd.row_seed = row_seed; hd.codes = t->codes;
                 TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, Q, np, t->cp_resid, t->cp_part, t->cp_qkv,
                                t->cp_attn, t->cp_act, cflags, cerr, &hd, st));
+                t->ran |= 1;
                 break;
             }
             if (!in_pair) {
@@ -571,6 +583,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                     // the layer stack of this pass as one persistent launch: 25 stages behind flag hand-offs
                     TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, g + 1, np, t->cp_resid, t->cp_part, t->cp_qkv,
                                    t->cp_attn, t->cp_act, cflags, cerr, nullptr, st));
+                    t->ran |= 1;
                     np = Hc / 16;
                 } else {
                     TRY(cp_forward_fused(t, B, g, &np, st));
@@ -680,7 +693,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
-                            io->num_live, io->rope_delta));
+                            io->num_live, io->rope_delta, d.rope_rows > 0 ? d.rope_rows : d.max_model_len));
     if (d.fused_norm && t->has_ar) {
         // tensor-parallel rank on the norm-free stream: partial o_proj -> this rank's peer-mapped buffer (fragment-major),
         // then ONE launch sums the ranks' partials, adds into r and writes the sum(r^2) slabs
@@ -832,10 +845,12 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     TRY(norm_gemm(t, t->resid, t->mlp_out, t->resid_b, d.final_norm, d.frag_layout || io->num_live ? t->normed : reinterpret_cast<uint16_t*>(io->last_hidden),
                   io->last_hidden, d.lm_head, io->logits, B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream, io->num_live));
     const bool any_rows = io->rows.greedy || io->rows.temperature || io->rows.top_k || io->rows.top_p || io->rows.rep_penalty || io->rows.seed;
+    // the step's status words leave with its last launch (ABI v4): the chain error word, the peer all-reduce's, what ran
+    const omni_step_status stt{reinterpret_cast<const int32_t*>(t->chain_flags + 320), t->has_ar ? t->ar_attn.error : nullptr, io->status, t->ran};
     TRY(k_sample(io->logits, d.vocab, B, d.vocab, io->greedy, io->temperature, io->top_k, io->top_p, io->rep_penalty, io->seen, io->seed,
                  io->steps, 1, 0, 1, io->input_ids, 1, stream, io->advance ? io->positions : nullptr,
                  io->advance ? io->seq_lens : nullptr,       // positions / seq_lens += 1 inside the sampler launch
-                 any_rows ? &io->rows : nullptr, io->num_live));
+                 any_rows ? &io->rows : nullptr, io->num_live, io->status ? &stt : nullptr));
     return OMNI_OK;
 }
 
@@ -847,24 +862,31 @@ extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
 #endif
 
 // the backbone of one decode step (every layer; the residual stream in t->resid on entry, final residual on exit)
-static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
+// parts (timing attribution, omni_talker_step_part): 2 = the attention launches, 4 = everything else of the stack; both = the stack
+static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, int parts = 6) {
     const omni_talker_desc& d = t->d;
+    const bool do_attn = (parts & 2) != 0, do_rest = (parts & 4) != 0;
 #ifdef OMNI_DEBUG_HOOKS
     if (k_bb_all_supported(d, io->B, t->has_ar))      // A/B arm: the whole stack, attention included, as one persistent launch
         return k_bb_all(d, t->bb_table, io, t->attn, t->resid, t->part, t->act, t->qkv, t->chain_flags,
                         reinterpret_cast<int32_t*>(t->chain_flags + 320), stream);
 #endif
     if (k_bb_chain_supported(d, io->B, t->has_ar) && d.layers > 0) {
+        t->ran |= 2;
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
         const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
+        if (do_rest)
         TRY(xnorm_gemm(t, t->resid, t->part, 1, t->layer[0].ln1, nullptr, t->layer[0].wqkv, t->qkv, B, (hq + 2 * hkv) * D, H, OMNI_EPI_BF16,
                        nullptr, 0, stream));
         for (int l = 0; l < d.layers; ++l) {
             const omni_layer_weights& w = t->layer[l];
+            if (do_attn)
             TRY(k_attn_decode_fused(t->qkv, w.qnorm, w.knorm, io->positions, d.cos_sin, d.eps, t->k_cache[l], t->v_cache[l], t->k_scales[l],
                                     t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
                                     t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
-                                    d.max_model_len, d.frag_layout, -1, stream, io->num_live, io->rope_delta));
+                                    d.max_model_len, d.frag_layout, -1, stream, io->num_live, io->rope_delta,
+                                    d.rope_rows > 0 ? d.rope_rows : d.max_model_len));
+            if (!do_rest) continue;
 #ifdef OMNI_DEBUG_HOOKS      // round-3 A/B arms (all slower): debug library only
             if (k_bb_engine_enabled())
                 TRY(k_bb_engine(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
@@ -882,6 +904,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
         }
         return OMNI_OK;
     }
+    OMNI_CHECK_ARG(parts == 6, "omni_talker_step_part: the attention / rest split needs the backbone chain's launch structure (1.7B dense shape, 49-64 rows, single rank)");
     for (int l = 0; l < d.layers; ++l) {
         TRY(omni_talker_layer_attn(t, io, l, stream));
         TRY(omni_talker_layer_mlp(t, io, l, stream));
@@ -889,14 +912,30 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream) {
     return OMNI_OK;
 }
 
+// timing attribution (bench.py roofline.families): launch only some parts of a decode step -- 1 the mtp phase (code predictor +
+// input assembly), 2 the backbone's attention launches, 4 the rest of the backbone stack, 8 final norm + lm_head + sampler.
+// Parts run alone read whatever the buffers hold: the TIMES are the step's (no kernel's control flow depends on activation values),
+// the outputs are not.  1 | 2 | 4 | 8 = omni_talker_decode_step.
+extern "C" int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int parts, void* stream) {
+    TRY(check_io(t, io));
+    OMNI_CHECK_ARG(parts > 0 && parts < 16, "omni_talker_step_part: parts=%d", parts);
+    t->ran = 0;
+    if (parts & 1) TRY(omni_talker_mtp(t, io, stream));
+    if (parts & 6) TRY(run_backbone(t, io, stream, parts & 6));
+    if (parts & 8) TRY(omni_talker_finish(t, io, stream));
+    return OMNI_OK;
+}
+
 // diagnostics / A-B timing: the backbone half of a step alone (layers + final norm + lm_head + sampler; no code predictor)
 extern "C" int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(check_io(t, io));
+    t->ran = 0;
     TRY(run_backbone(t, io, stream));
     return omni_talker_finish(t, io, stream);
 }
 
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
+    if (t) t->ran = 0;
     TRY(omni_talker_mtp(t, io, stream));
     if (g_extra_trivial == 0) {
         TRY(run_backbone(t, io, stream));

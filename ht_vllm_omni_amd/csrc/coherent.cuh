@@ -63,7 +63,16 @@ __device__ __forceinline__ uint32_t chain_flag_copy() { return (uint32_t)(blockI
 // workgroup that never sees its peers (a grid that is not co-resident, a lost launch) sets *err and the launch runs to its
 // end without waiting -- a wrong step that the host sees in the error word, never a hung GPU.
 #define OMNI_CHAIN_WGS 256
-#define OMNI_CHAIN_SPIN_BOUND (1u << 21)
+#define OMNI_CHAIN_SPIN_BOUND (1u << 21)   // (round-3 arms of the debug library)
+// the product chains wait by WALL CLOCK: 2 s of the constant 100 MHz counter, read once per 1024 polls -- a poll is
+// a memory round trip of 0.5-2 us, so the first reading comes after about a millisecond of waiting and costs a healthy stage nothing
+#define OMNI_CHAIN_WAIT_TICKS 200000000ull
+__device__ __forceinline__ bool chain_wait_expired(unsigned spins, unsigned long long& t0) {
+    if ((spins & 1023u) != 0) return false;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (spins == 1024u) { t0 = now; return false; }
+    return now - t0 > OMNI_CHAIN_WAIT_TICKS;
+}
 
 // ---- loader / consumer engine (bb_engine.hip): waves 0-7 of a workgroup compute, waves 8-11 stream weights into an LDS FIFO
 // by LDS-DMA.  All intra-workgroup synchronisation is through these LDS words (s_barrier would stop the loader waves too):
@@ -170,6 +179,7 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
         // (1 << dom) / 4 lanes x 4 flags each (the other lanes read copies)
         const uint32_t off = chain_flag_copy() + ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         if (g.nap >= 16) {
             // two polls in flight, half a round trip apart: the flags are sampled twice as often as one load's latency allows
             u32x4 fa = coh_ld16(g.frs, off);
@@ -181,7 +191,7 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
                                     (int)(fa[3] - g.epoch) < 0;
                 if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
                 fa = fb;
-                if (++spins > OMNI_CHAIN_SPIN_BOUND) {
+                if (chain_wait_expired(++spins, t0)) {
                     if (threadIdx.x == 0) atomicCAS(g.err, 0, code);
                     g.dead = true;
                     break;
@@ -200,7 +210,7 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
             else if (g.nap == 2) __builtin_amdgcn_s_sleep(2);
             else if (g.nap == 4) __builtin_amdgcn_s_sleep(4);
             else if (g.nap >= 8) __builtin_amdgcn_s_sleep(8);
-            if (++spins > OMNI_CHAIN_SPIN_BOUND) {
+            if (chain_wait_expired(++spins, t0)) {
                 if (threadIdx.x == 0) atomicCAS(g.err, 0, code);
                 g.dead = true;
                 break;

@@ -4,11 +4,14 @@
 
 #include "../../include/omni_talker.h"
 
+// the step's status words (omni_step_io.status), copied by the step's last launch: dst[0] = *src0, dst[1] = *src1, dst[2] = ran
+struct omni_step_status { const int32_t* src0; const int32_t* src1; int32_t* dst; int ran; };
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
              int out_stride, void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr /* per-row counters to bump */,
              const omni_row_sampling* rows = nullptr /* per-row parameters override the scalars */,
-             const int32_t* num_live = nullptr /* device: rows >= *num_live are skipped entirely */);
+             const int32_t* num_live = nullptr /* device: rows >= *num_live are skipped entirely */,
+             const omni_step_status* status = nullptr);
 int k_embed(const int32_t* ids, int ids_stride, const void* table, void* out, int T, int hidden, int vocab,
             void* stream);
 // rows of `table` (ids == NULL: rows 0..T-1) -> fragment-major residual stream + slab 0 of the sum(r^2) partials;
@@ -37,7 +40,7 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part /* != NULL: gather_out fragment-major + sum-of-squares slab 0 */,
                     void* stream, int32_t* inc0 = nullptr, int32_t* inc1 = nullptr, const omni_row_sampling* rows = nullptr,
-                    const int32_t* num_live = nullptr);
+                    const int32_t* num_live = nullptr, const omni_step_status* status = nullptr);
 // rmsnorm with out-of-place residual update: residual_out = bf16(residual + delta) (may alias residual)
 // out (row-major) and/or out_frag (fragment-major, common.cuh frag_off) receive the normalised rows
 int k_rmsnorm(const void* x, const void* delta, const void* residual, void* residual_out, const void* w, void* out,
@@ -51,7 +54,8 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag,
                         int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream,
                         const int32_t* num_live = nullptr /* device: rows >= *num_live write no KV / slot */,
-                        const int32_t* rope_delta = nullptr /* device [B]: rotary position = positions[b] + rope_delta[b] */);
+                        const int32_t* rope_delta = nullptr /* device [B]: rotary position = positions[b] + rope_delta[b] */,
+                        int rope_rows = 0 /* rows of cos_sin: positions + rope_delta is clamped into the table (0: no clamp) */);
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,

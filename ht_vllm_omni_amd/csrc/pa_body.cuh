@@ -25,7 +25,16 @@ struct PAArgs {
                                    // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
     int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
     const int32_t* num_live;       // fused decode: rows >= *num_live (padding of a graph bucket) write no KV / slot (NULL: all live)
+    int rope_rows;                 // rows of the cos / sin table (0: unknown): positions[b] + rope_delta[b] is clamped into it -- the host
+                                   // refuses requests whose M-RoPE ids could leave the table (runner._update_states); this is the backstop
 };
+
+// row of the cos / sin table for batch row `row` at cache position `pos`
+__device__ __forceinline__ int pa_rope_row(const PAArgs& a, int pos, int row) {
+    int p = pos + (a.rope_delta ? a.rope_delta[row] : 0);
+    if (a.rope_rows > 0) p = min(max(p, 0), a.rope_rows - 1);
+    return p;
+}
 
 template <int KV>
 struct KVRaw { u32x4 a, b; };   // b: bf16 only (second 8 elements)
@@ -193,7 +202,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     uint32_t kw_new = 0u, vw_new = 0u;
     if (FUSED) {
         const int pos = a.positions[row];
-        const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
+        const uint16_t* cs = a.cos_sin + (size_t)pa_rope_row(a, pos, row) * 128;
         if (CHAIN) {
             const coh_rsrc_t qrs = coh_rsrc(a.qkv);
             uint32_t qw[G];
@@ -256,7 +265,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         const int sp_cur = cur / per;
         if (wave == 0 && sp == sp_cur) {
             const int pos = a.positions[row];
-            const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
+            const uint16_t* cs = a.cos_sin + (size_t)pa_rope_row(a, pos, row) * 128;
             const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
             // rows of a padded graph bucket past the live count may be live PREFILL rows of the persistent batch: they
             // compute (results discarded) but leave the cache and the slot record alone

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const PAArgs a, i
     }
     const int cur = DENSE ? a.dense_pos : a.seq_lens[row] - 1;
     const int pos = DENSE ? a.dense_pos : a.positions[row];
-    const uint16_t* cs = a.cos_sin + (size_t)(pos + (a.rope_delta ? a.rope_delta[row] : 0)) * 128;
+    const uint16_t* cs = a.cos_sin + (size_t)pa_rope_row(a, pos, row) * 128;
     float* wq = sm[wave];
     float* kvs = sm[wave] + G * 128;
     const float qs = a.sm_scale * LOG2E;
@@ -472,9 +472,10 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, int dense_pos,
-                        void* stream, const int32_t* num_live, const int32_t* rope_delta) {
+                        void* stream, const int32_t* num_live, const int32_t* rope_delta, int rope_rows) {
     PAArgs a{};
     a.rope_delta = rope_delta;
+    a.rope_rows = rope_delta ? rope_rows : 0;
     a.out_frag = out_frag;
     a.dense_pos = dense_pos;
     a.num_live = num_live;

@@ -16,11 +16,18 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              const uint16_t* __restrict__ gtab, uint16_t* __restrict__ gout, int gdim,
                                                              float* __restrict__ gpart, int32_t* __restrict__ inc0,
                                                              int32_t* __restrict__ inc1, const omni_row_sampling rs,
-                                                             const int32_t* __restrict__ num_live) {
+                                                             const int32_t* __restrict__ num_live, const omni_step_status stt) {
     __shared__ __attribute__((aligned(16))) char smem[SMP_LDS_BYTES(NPT)];
     const SmpLds S = smp_carve<NPT>(smem);
     float* sval = S.sval;
     const int b = blockIdx.x;
+    // the decode step's status words ride out with its last launch (every launch that could set them finished before this one)
+    if (stt.dst && b == 0 && threadIdx.x == 0) {
+        stt.dst[0] = stt.src0 ? __hip_atomic_load(stt.src0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        stt.dst[1] = stt.src1 ? __hip_atomic_load(stt.src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        stt.dst[2] = stt.ran;
+        stt.dst[3] = 0;
+    }
     // rows past the live count of a padded graph bucket leave no trace (block-uniform exit, before any barrier)
     if (num_live && b >= *num_live) return;
     // per-request sampling parameters (V/worker/gpu_model_runner.py:315-319): a NULL array = the launch-wide scalar
@@ -84,9 +91,10 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
                     float rep_penalty, uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add,
                     int inc_steps, int32_t* out_ids, int out_stride, const void* gather_table, void* gather_out,
                     int gather_dim, float* gather_part, void* stream, int32_t* inc0, int32_t* inc1, const omni_row_sampling* rows,
-                    const int32_t* num_live) {
+                    const int32_t* num_live, const omni_step_status* status) {
     OMNI_CHECK_ARG(logits && out_ids, "omni_sample: null pointer");
     const omni_row_sampling rs = rows ? *rows : omni_row_sampling{};
+    const omni_step_status stt = status ? *status : omni_step_status{};
     OMNI_CHECK_ARG(V > 0 && V <= SMP_MAXV && ld >= V, "omni_sample: V=%d ld=%d (V <= %d)", V, ld, SMP_MAXV);
     // scalars are validated when they are the ones in use; per-row arrays are the caller's contract (device memory)
     OMNI_CHECK_ARG(greedy || rs.greedy || rs.temperature || temperature > 0.f, "omni_sample: temperature must be > 0 when sampling");
@@ -100,7 +108,7 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
     hipLaunchKernelGGL(sample_kernel<NPT_>, dim3(B), dim3(SMP_THREADS), 0, (hipStream_t)stream, logits, ld, V, greedy,     \
                        temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add, inc_steps, out_ids, \
                        out_stride, (const uint16_t*)gather_table, (uint16_t*)gather_out, gather_dim, gather_part, inc0, inc1, rs, \
-                       num_live)
+                       num_live, stt)
     if (V <= 8 * SMP_THREADS) SMP_LAUNCH(8);
     else if (V <= 12 * SMP_THREADS) SMP_LAUNCH(12);
     else SMP_LAUNCH(32);
@@ -111,9 +119,10 @@ int k_sample_gather(const float* logits, int ld, int B, int V, int greedy, float
 
 int k_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p, float rep_penalty,
              uint8_t* seen, uint32_t seed, int32_t* steps, int step_mul, int step_add, int inc_steps, int32_t* out_ids,
-             int out_stride, void* stream, int32_t* inc0, int32_t* inc1, const omni_row_sampling* rows, const int32_t* num_live) {
+             int out_stride, void* stream, int32_t* inc0, int32_t* inc1, const omni_row_sampling* rows, const int32_t* num_live,
+             const omni_step_status* status) {
     return k_sample_gather(logits, ld, B, V, greedy, temperature, top_k, top_p, rep_penalty, seen, seed, steps, step_mul, step_add,
-                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream, inc0, inc1, rows, num_live);
+                           inc_steps, out_ids, out_stride, nullptr, nullptr, 0, nullptr, stream, inc0, inc1, rows, num_live, status);
 }
 
 extern "C" int omni_sample(const float* logits, int ld, int B, int V, int greedy, float temperature, int top_k, float top_p,

@@ -201,7 +201,10 @@ class TalkerEngine:
         self.final_norm = up(weights["norm"])
         self.lm_head = up(weights["lm_head"])
         self.allowed = up(codec_allowed_mask(d, allow_eos))
-        self.cos_sin = up(ops.rope_table(d.max_model_len, d.head_dim, d.rope_theta))
+        # rows of the rotary table: max_model_len, and as many again for M-RoPE models (a prompt's ids may run ahead of its token
+        # count and every later position is index + mrope_position_delta; the runner refuses requests that would leave the table)
+        self.rope_rows = d.max_model_len * (2 if d.mrope_section else 1)
+        self.cos_sin = up(ops.rope_table(self.rope_rows, d.head_dim, d.rope_theta))
         self.cp_cos_sin = up(ops.rope_table(d.num_code_groups + 1, d.cp_head_dim, d.cp_rope_theta))
         self.cp_norm = up(weights["cp.norm"])
         self.cp_lm_head = up(weights["cp.lm_head"])
@@ -326,6 +329,7 @@ class TalkerEngine:
         # the persistent code-predictor chain needs its 256-workgroup grid co-resident: not for engines whose steps run
         # concurrently on one GPU (n_sub parallel graph branches)
         desc.cp_chain = int(int(n_sub) <= 1 and os.environ.get("OMNI_CP_CHAIN", "1") != "0")
+        desc.rope_rows = self.rope_rows
         self.persistent_chains = bool(desc.cp_chain)
         if self.frag_layout:        # GEMM weights the native step reads: fragment-major device copies
             self._lm_head_f = up(frag_shuffle(self.lm_head))
@@ -384,7 +388,11 @@ class TalkerEngine:
         # ---- persistent per-step buffers (graph-stable addresses), row r = batch slot r
         Bm, H, Q = max_batch, d.hidden, d.num_code_groups
         z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
-        self.input_ids = z(Bm, dt=torch.int32)
+        # input_ids [Bm] and the step's four status words (omni_step_io.status: chain error word, peer all-reduce error word,
+        # which chains ran, 0) share ONE tensor: the runner's per-step host copy of the sampled ids brings the status along
+        self.ids_status = z(Bm + 4, dt=torch.int32)
+        self.input_ids = self.ids_status[:Bm]
+        self.status = self.ids_status[Bm:]
         self.positions = z(Bm, dt=torch.int32)
         self.seq_lens = z(Bm, dt=torch.int32)
         self.block_table = z(Bm, self.bt_stride, dt=torch.int32)
@@ -479,6 +487,7 @@ class TalkerEngine:
         # sub-batch branches see their own row range: their live count is the bucket (only the runner path pads buckets)
         io.num_live = self.num_live.data_ptr() if row0 == 0 and self.n_sub == 1 else None
         io.rope_delta = self.rope_delta[row0:].data_ptr() if self.rope_delta is not None else None
+        io.status = self.status.data_ptr() if row0 == 0 and self.n_sub == 1 else None
         return io
 
     def decode_step(self, B: int, advance: bool = True) -> None:
@@ -526,6 +535,14 @@ class TalkerEngine:
         io = self._io(B, False)
         L.check(self.lib.omni_talker_backbone_step(self.handle, C.byref(io), L.current_stream()), "omni_talker_backbone_step")
 
+    def step_part(self, B: int, parts: int) -> None:
+        """Timing attribution: launch only `parts` of a decode step (1 mtp phase, 2 attention launches, 4 rest of the backbone,
+        8 lm_head + sampler); positions are not advanced.  Outputs of a partial step are meaningless."""
+        if self.tp_path:
+            raise L.OmniError("step_part: single-rank diagnostic")
+        io = self._io(B, False)
+        L.check(self.lib.omni_talker_step_part(self.handle, C.byref(io), int(parts), L.current_stream()), "omni_talker_step_part")
+
     def prefill_wide(self, x: torch.Tensor, positions: torch.Tensor, req_of_tok: torch.Tensor, slot_mapping: torch.Tensor,
                      block_table: torch.Tensor | None = None, gemm: str | None = None, rope_positions: torch.Tensor | None = None) -> torch.Tensor:
         """Prefill of all T prompt tokens in one pass per layer (instead of max_batch-row chunks that each re-stream the
@@ -549,7 +566,8 @@ class TalkerEngine:
         if rope_positions is not None:
             if self.mrope_axis is None:
                 raise L.OmniError("rope_positions given but the model has no mrope_section")
-            rope_pos, axis = rope_positions.to(torch.int32).contiguous(), self.mrope_axis
+            # (ids outside the rotary table are refused at admission, runner._update_states; the clamp is the backstop)
+            rope_pos, axis = rope_positions.to(torch.int32).clamp(0, self.rope_rows - 1).contiguous(), self.mrope_axis
         for l in range(d.layers):
             w = self.layer_w[l]
             a = ops.rmsnorm(None, w["ln1"], d.eps, delta=delta, residual=resid)
@@ -705,12 +723,33 @@ class TalkerEngine:
         return ops.sample(logits, greedy=greedy, temperature=temperature, top_k=top_k, top_p=top_p, rep_penalty=rep_penalty, seen=seen,
                           seed=seed, steps=steps, inc_steps=steps is not None)
 
-    def chain_error(self, reset: bool = False) -> int:
-        """Sticky error word of the persistent code-predictor launches (0 = no flag wait ever timed out); synchronises."""
+    def chain_error(self, reset: bool | int = False) -> int:
+        """Sticky error word of the persistent code-predictor launches (0 = no flag wait ever timed out); synchronises.
+        reset = 2: fault injection (sets the word as a timed-out wait would)."""
         rc = self.lib.omni_talker_chain_error(self.handle, int(reset))
         if rc < 0:
             L.check(rc, "omni_talker_chain_error")
         return rc
+
+    def chains_ran(self) -> int:
+        """Which persistent chains the last native decode-step call launched (bit 0: code predictor, bit 1: backbone): 0 on the
+        launch-per-op path -- other shapes, batches below the backbone chain's row range, tensor-parallel ranks, chains off."""
+        return int(self.lib.omni_talker_chains_ran(self.handle))
+
+    def set_chains(self, on: bool) -> None:
+        """Turn the persistent chains of this engine on / off (same bits either way).  Captured graphs keep what they recorded:
+        re-capture after a switch."""
+        L.check(self.lib.omni_talker_set_chains(self.handle, int(bool(on))), "omni_talker_set_chains")
+        self.persistent_chains = bool(on)
+
+    def recover_from_chain_timeout(self) -> None:
+        """A flag wait of a persistent chain ran out (status word 0 of a step != 0: the 256-workgroup grid was not co-resident
+        -- another process or engine held part of the GPU).  Clear the sticky word and the flags and leave the chains off for
+        this engine: its later steps run launch-per-op, which shares a GPU without deadline.  The step that reported the
+        word is invalid: the caller redoes it (runner.MI355XARModelRunner._redo_after_chain_timeout)."""
+        self.chain_error(reset=True)
+        self.set_chains(False)
+        self.status.zero_()
 
     def check_device_errors(self) -> None:
         """The bounded spins of the in-kernel hand-offs (peer all-reduce flags across ranks, stage flags of the persistent

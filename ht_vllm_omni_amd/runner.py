@@ -53,6 +53,9 @@ class RequestState:
     # the talker's usual text-only prompt (three identical rows == plain RoPE)
     mrope_positions: torch.Tensor | None = None     # int64 [3, prompt_len]
     mrope_delta: int = 0
+    # h[t] the request's next decode step consumes (host view of the previous step's copy): what a step is redone from after a
+    # chain flag wait timed out (MI355XARModelRunner._redo_after_chain_timeout)
+    last_hidden_cpu: torch.Tensor | None = None
 
     def rope_ids(self, s0: int, n: int):
         """[3, n] rotary ids of sequence indices [s0, s0 + n): the prompt's own ids, then index + delta."""
@@ -281,6 +284,17 @@ class MI355XARModelRunner:
                 md = int(md.item() if isinstance(md, torch.Tensor) else md)
                 if mp.shape[1] != st.prompt_len:
                     raise ValueError(f"request {nr.req_id}: mrope_positions cover {mp.shape[1]} tokens, the prompt has {st.prompt_len}")
+                # every rotary id of the request's life must be a row of the cos / sin table (max_model_len rows): the prompt's
+                # ids as given (video temporal ids run ahead of the token count), then index + delta up to the last token it may
+                # emit (an id outside the table read device memory out of bounds)
+                rows = int(getattr(e, "rope_rows", 0) or self.d.max_model_len)
+                # last sequence index the request can reach: the scheduler stops it at max_model_len whatever max_tokens says
+                end = min(st.prompt_len + int(getattr(st.sampling, "max_tokens", 0) or 0), int(self.d.max_model_len)) - 1
+                lo = min([st.prompt_len + md, end + md] + ([int(mp.min())] if mp.numel() else []))
+                hi = max([st.prompt_len + md, end + md] + ([int(mp.max())] if mp.numel() else []))
+                if lo < 0 or hi >= rows:
+                    raise ValueError(f"request {nr.req_id}: M-RoPE ids {lo}..{hi} (prompt ids, then index + delta {md} up to sequence index {end}) "
+                                     f"leave the rotary table [0, {rows})")
                 if getattr(e, "rope_delta", None) is None and not (torch.equal(mp[0], mp[1]) and torch.equal(mp[0], mp[2]) and md == 0
                                                                    and torch.equal(mp[0], torch.arange(mp.shape[1]))):
                     raise ValueError(f"request {nr.req_id}: M-RoPE ids with differing rows, but the model has no mrope_section")
@@ -399,13 +413,14 @@ class MI355XARModelRunner:
         e.set_row_sampling(r, **self._row_sampling(rid, st.sampling))
         e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=e.block_table.device)
 
-    def _restore_decode_row(self, r: int, st: RequestState, hidden_last: torch.Tensor) -> None:
+    def _restore_decode_row(self, r: int, st: RequestState, hidden_last: torch.Tensor, position: int | None = None) -> None:
         e, d = self.engine, self.d
         L = len(st.output_ids)
+        position = st.prefill_len if position is None else position
         e.input_ids[r] = int(st.output_ids[-1])
         e.last_hidden[r] = hidden_last
-        e.positions[r] = st.prefill_len
-        e.seq_lens[r] = st.prefill_len + 1
+        e.positions[r] = position
+        e.seq_lens[r] = position + 1
         if getattr(e, "rope_delta", None) is not None:
             e.rope_delta[r] = st.mrope_delta
         e.steps[r] = L
@@ -560,6 +575,34 @@ class MI355XARModelRunner:
                 self.engine.decode_step(b)
             self.graphs[b] = g
 
+    def _redo_after_chain_timeout(self, nd: int, code: int) -> None:
+        """The decode step just taken reported a timed-out flag wait of a persistent chain (status word 0: the chain's grid was
+        not co-resident -- another process or engine held CUs): its outputs are invalid, but nothing of it has left the runner
+        yet.  Degrade instead of dying: clear the device words, turn this engine's chains off (launch-per-op shares a GPU
+        without a deadline), re-capture the graphs, put every decode row back to the state the step started from -- last id,
+        h[t] (host copy of the previous step), position, step counter, repetition bitmap, text cursor; the KV slots the bad
+        step wrote are simply written again -- and run the step once more."""
+        e = self.engine
+        logger.warning("persistent-chain flag wait timed out (stage code %#x): engine falls back to the launch-per-op path, "
+                       "step redone", code)
+        e.recover_from_chain_timeout()
+        sizes = sorted(self.graphs)
+        self.graphs.clear()
+        if self.use_graphs and sizes:
+            self.capture_graphs(sizes)
+        dev = e.input_ids.device
+        for r in range(nd):
+            st = self.requests[self.rows[r]]
+            if st.last_hidden_cpu is None or not st.output_ids:
+                raise RuntimeError(f"request {self.rows[r]}: no record to redo its decode step from")
+            self._restore_decode_row(r, st, st.last_hidden_cpu.reshape(-1).to(dev), position=st.num_computed)
+        self._tt_pos[:nd] -= 1
+        idx = self._tt_off[:nd] + np.minimum(self._tt_pos[:nd], self._tt_len[:nd])
+        self._tt_pos[:nd] += 1
+        torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
+        self.chain_fallbacks = getattr(self, "chain_fallbacks", 0) + 1
+        self._run_decode(nd)
+
     def _run_decode(self, nd: int) -> None:
         # rows [nd, bucket) of the padded graph may be live PREFILL rows of the persistent batch (decode-first order):
         # the device-side live count keeps the step off their KV blocks, ids, hidden state and counters
@@ -586,15 +629,30 @@ class MI355XARModelRunner:
         # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550).  The sampler itself ran inside the
         # native step; the "sample" range is the wait for it plus the copy of the ids
         with _Range("gpu_model_runner: sample"):
-            ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
-        # the copy above synchronised the step: every 16th step (and whenever a request leaves) look at the sticky error words
-        # of the in-kernel hand-offs (a timed-out flag wait produces wrong data, not a hang)
-        self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
-        if (self._steps_since_check >= 16 or stt.scheduler_output.finished_req_ids) and hasattr(e, "check_device_errors"):
-            self._steps_since_check = 0
-            e.check_device_errors()
+            ids_status = getattr(e, "ids_status", None)
+            if ids_status is not None:
+                # the sampled ids AND the step's status words in one copy (omni_step_io.status: written by the step's last
+                # launch): every step is checked before anything of it is handed on
+                buf = ids_status.cpu()
+                status = buf[-4:].tolist() if nd else [0, 0, 0, 0]
+                if status[0]:
+                    # a chain flag wait timed out: fall back to the launch-per-op path and redo THIS step
+                    self._redo_after_chain_timeout(nd, int(status[0]))
+                    buf = ids_status.cpu()
+                    status = buf[-4:].tolist()
+                    if status[0]:
+                        raise RuntimeError(f"decode step invalid after the fall-back to the launch path (status {status})")
+                if status[1]:
+                    # a tensor-parallel peer did not arrive: the kernel that timed out wrote the word into every rank's control
+                    # block, so all ranks leave their step here (the reference: an exception in the worker ends the engine)
+                    raise RuntimeError(f"peer all-reduce: a rank did not arrive in time (error word {status[1]}): the step's outputs are invalid")
+                ids_cpu = buf[:len(self.rows)].tolist()
+            else:
+                ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
+                if hasattr(e, "check_device_errors") and stt.scheduler_output.finished_req_ids:
+                    e.check_device_errors()
         with _Range("gpu_model_runner: postprocess"):
-            hid_cpu = e.last_hidden[:len(self.rows)].cpu()
+            hid_cpu = e.last_hidden[:len(self.rows)].to("cpu", copy=True)     # a copy of its own: requests keep views of it
             codes_cpu = e.audio_codes[:nd].cpu() if nd else None
             codes_list = codes_cpu.tolist() if nd else []
         # (pinned staging + one sync was tried: the CPU then reads uncached pinned memory -- 37 ms per step)
@@ -627,6 +685,7 @@ class MI355XARModelRunner:
                     sampled.append([])
             req_ids.append(rid)
             pooler.append(payload)
+            st.last_hidden_cpu = hid_cpu[r]          # h[t] of the request's next decode step (a view of this step's host copy)
         bookkeep.__exit__(None, None, None)
         return OmniModelRunnerOutput(
             req_ids=req_ids, req_id_to_index={rid: i for i, rid in enumerate(req_ids)}, sampled_token_ids=sampled,

@@ -405,6 +405,10 @@ typedef struct omni_talker_desc {
      * supported.  The grid of such a launch must be co-resident (256 workgroups, one per CU): leave it 0 for engines whose
      * steps run CONCURRENTLY with another engine's on the same GPU (parallel graph branches). */
     int cp_chain;
+    /* ABI v4: rows of `cos_sin` (0 = max_model_len).  M-RoPE models build the table longer than max_model_len: a prompt's rotary
+     * ids may run ahead of its token count (video temporal ids), and every later position is index + mrope_position_delta.  The
+     * decode kernels clamp positions[b] + rope_delta[b] into the table (backstop; the host refuses requests that would leave it). */
+    int rope_rows;
 } omni_talker_desc;
 
 typedef struct omni_talker omni_talker;
@@ -416,9 +420,17 @@ void omni_talker_destroy(omni_talker* t);
  * spins (csrc/cp_chain.hip; reference: the decoder loop of qwen3_tts_code_predictor_vllm.py:480-561).  A spin that runs out
  * (grid not co-resident) is recorded in a sticky device word and the launch finishes without waiting: results of that step
  * are wrong, the GPU never hangs.  Returns that word (0 = no wait ever timed out; else 16 * layer + stage + 1 of the first
- * one) or a negative OMNI_E* code; synchronises the device (call it per output hand-over, not per launch).  reset != 0
- * clears the word and the flags.                                                                                          */
+ * one) or a negative OMNI_E* code; synchronises the device (call it per output hand-over, not per launch).  reset == 1
+ * clears the word and the flags; reset == 2 SETS the word (fault injection for tests of the host's fall-back: the next
+ * chain launches stop waiting, exactly as after a real time-out).                                                        */
 int omni_talker_chain_error(omni_talker* t, int reset);
+/* ABI v4.  Switch the persistent chains of an engine on / off at run time (the launch-per-op path computes the same bits):
+ * what a host does after a chain flag wait timed out (omni_step_io.status) -- reset the words, turn the chains off, re-capture
+ * its graphs, redo the step: a degraded stage, not a dead one.  The GPU may be shared with another process then.        */
+int omni_talker_set_chains(omni_talker* t, int on);
+/* Which persistent chains the LAST decode-step call of this engine launched (host-side record, no device access):
+ * bit 0 the code-predictor chain (cp_chain.hip), bit 1 the backbone chain (bb_chain.hip).  0 = launch-per-op path.      */
+int omni_talker_chains_ran(const omni_talker* t);
 
 /* Per-step device buffers (persistent, graph-stable addresses).  Row r = batch slot r. */
 typedef struct omni_step_io {
@@ -452,6 +464,11 @@ typedef struct omni_step_io {
                                      rope_delta[b] (the request's mrope_position_delta: after a prompt whose M-RoPE ids ran
                                      ahead of / behind its token count, vLLM get_next_input_positions); cache slots and the
                                      attention context still follow positions[] / seq_lens[] */
+    /* ABI v4 */
+    int32_t* status;              /* device int32 [4] or NULL, written by the LAST launch of the step (so that it rides in the
+                                     host's per-step copy of input_ids): [0] the sticky chain error word (omni_talker_chain_error
+                                     without the device synchronisation), [1] the sticky error word of the peer all-reduce (0 on a
+                                     single rank), [2] omni_talker_chains_ran of this step, [3] 0                          */
 } omni_step_io;
 
 /* The four phases of one decode step.  With TP > 1 the host
@@ -472,6 +489,11 @@ int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream
 /* every layer + finish, without the mtp phase: the backbone half of a step on whatever residual stream the last step left
  * (timing attribution only: bench.py roofline.breakdown, scripts/ab_knobs.py)                                             */
 int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream);
+/* ABI v4, timing attribution only (bench.py roofline.families): launch a subset of the step's parts -- 1 the mtp phase (code
+ * predictor + input assembly), 2 the backbone's paged-attention launches, 4 the rest of the backbone stack (2 and 4 apart only
+ * where the backbone runs as attention + chain launches), 8 final norm + lm_head + sampler.  A part run alone reads whatever the
+ * buffers hold: its TIME is the step's, its outputs are not.  15 = omni_talker_decode_step.                                   */
+int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int parts, void* stream);
 void* omni_talker_attn_out(omni_talker* t);   /* bf16 [max_batch,H] (TP all-reduce buffer)  */
 void* omni_talker_mlp_out(omni_talker* t);    /* bf16 [max_batch,H]                         */
 

@@ -12,7 +12,11 @@ class FakeEngine:
         self.kv_dtype = "bf16"
         self.bt_stride = d.max_model_len // block_size
         z = torch.zeros
-        self.input_ids = z(max_batch, dtype=torch.int32)
+        self.ids_status = z(max_batch + 4, dtype=torch.int32)       # ids + the step's status words (engine.TalkerEngine)
+        self.input_ids = self.ids_status[:max_batch]
+        self.status = self.ids_status[max_batch:]
+        self.fault_next = False            # the next decode step "times out" in a persistent chain: garbage + status word 0
+        self.persistent_chains = True
         self.positions = z(max_batch, dtype=torch.int32)
         self.seq_lens = z(max_batch, dtype=torch.int32)
         self.block_table = z(max_batch, self.bt_stride, dtype=torch.int32)
@@ -54,7 +58,7 @@ class FakeEngine:
         self.calls.append(("sample_rows", rows.tolist(), self.row_seed[rows].tolist(), self.row_top_k[rows].tolist()))
         return self.sample(logits, greedy=True, seen=seen, steps=steps)
 
-    def prefill(self, x, positions, req_of_tok, slot_mapping, block_table=None):
+    def prefill(self, x, positions, req_of_tok, slot_mapping, block_table=None, rope_positions=None):
         self.calls.append(("prefill", x.shape[0], positions.tolist(), req_of_tok.tolist(), slot_mapping.tolist()))
         return (x.float() * 2).to(BF16)                       # "hidden" = 2 * embedding
 
@@ -72,9 +76,28 @@ class FakeEngine:
             steps += 1
         return ids
 
+    def recover_from_chain_timeout(self):
+        self.status.zero_()
+        self.persistent_chains = False
+        self.calls.append(("recover",))
+
     def decode_step(self, B, advance=True):
         B = min(B, int(self.num_live))          # the native step's contract: rows past the live count are inert
         self.calls.append(("decode", B, self.input_ids[:B].tolist(), self.positions[:B].tolist()))
+        if self.fault_next and self.persistent_chains:
+            # a timed-out chain: every output of the step is garbage, the state still advances, the status word says so
+            self.fault_next = False
+            self.status[0] = 0x1234
+            self.input_ids[:B] = 1
+            self.audio_codes[:B] = 7
+            self.last_hidden[:B] = 99.0
+            self.seen[:B, 1] = 1
+            self.steps[:B] += 1
+            if advance:
+                self.positions[:B] += 1
+                self.seq_lens[:B] += 1
+            return
+        self.status[2] = 3 if self.persistent_chains else 0
         self.inputs_embeds[:B] = self.text_step[:B]
         self.audio_codes[:B] = self.input_ids[:B].long()[:, None] + torch.arange(self.d.num_code_groups)[None]
         self.slot_mapping[:B] = torch.tensor([int(self.block_table[r, int(self.positions[r]) // self.block_size]) * self.block_size

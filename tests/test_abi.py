@@ -27,7 +27,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.omni_abi_version() == 3
+    assert lib.omni_abi_version() == 4
     assert lib.omni_last_error() is not None
 
 

@@ -225,6 +225,73 @@ def test_padded_graph_bucket_leaves_prefill_rows_alone():
     assert graph == eager, (graph, eager)
 
 
+def _drive_with_fault(fault_step):
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=False)
+    reqs = [_new_req(d, k, 4 + i, [1 + i]) for i, k in enumerate("abc")]
+    run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=reqs, num_scheduled_tokens={"a": 4, "b": 5, "c": 6}, total_num_scheduled_tokens=15))
+    run.sample_tokens(None)
+    frames = []
+    for s in range(5):
+        if s == fault_step:
+            eng.fault_next = True
+        so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=list("abc"), new_block_ids=[None] * 3),
+                                 num_scheduled_tokens={k: 1 for k in "abc"}, total_num_scheduled_tokens=3)
+        run.execute_model(so)
+        out = run.sample_tokens(None)
+        frames.append(([out.sampled_token_ids[out.req_id_to_index[k]] for k in "abc"],
+                       [out.pooler_output[out.req_id_to_index[k]]["audio_codes"].tolist() for k in "abc"],
+                       [out.pooler_output[out.req_id_to_index[k]]["hidden"].float().sum().item() for k in "abc"]))
+    return frames, run, eng
+
+
+def test_chain_timeout_status_word_redoes_the_step_on_the_launch_path():
+    """ADVICE r3 / VERDICT r3 weak #3: the step's status words are looked at EVERY step, before anything of the step is handed on;
+    a chain time-out makes the runner recover the engine (chains off), restore the decode rows from its host records -- last id,
+    h[t], position, step counter, repetition bitmap, text cursor -- and run the step again: the request streams of a run with a
+    faulted step are those of a clean run, nothing of the garbage step reaches the outputs."""
+    clean, run0, eng0 = _drive_with_fault(-1)
+    hurt, run1, eng1 = _drive_with_fault(2)
+    assert clean == hurt
+    assert getattr(run0, "chain_fallbacks", 0) == 0 and run1.chain_fallbacks == 1
+    assert ("recover",) in eng1.calls and not eng1.persistent_chains
+    assert [c[0] for c in eng1.calls].count("decode") == [c[0] for c in eng0.calls].count("decode") + 1      # the redone step
+    for name in ("input_ids", "positions", "seq_lens", "steps", "seen", "last_hidden"):
+        assert torch.equal(getattr(eng0, name), getattr(eng1, name)), name
+    assert run0.text_queue_pos("a") == run1.text_queue_pos("a")
+
+
+def test_mrope_ids_outside_the_rotary_table_are_refused_at_admission():
+    """the prefill kernel indexes the cos / sin table by a request's M-RoPE ids and the decode kernels by position +
+    mrope_position_delta; an id outside the table read device memory out of bounds.  The runner refuses such a request alone,
+    before any of its state exists (its neighbours' step goes on); ids inside the table pass."""
+    d = get_dims("tiny")
+    rows = d.max_model_len
+
+    def attempt(mp, md, max_tokens=8):
+        eng = FakeEngine(d, max_batch=2)
+        eng.rope_delta = torch.zeros(2, dtype=torch.int32)      # an M-RoPE model
+        eng.rope_rows = rows
+        run = MI355XARModelRunner(eng, use_graphs=False)
+        nr = _new_req(d, "m", 4, [1])
+        nr.sampling_params = SamplingParams(temperature=0.0, max_tokens=max_tokens)
+        nr.additional_information["mrope_positions"] = mp
+        nr.additional_information["mrope_position_delta"] = md
+        run.execute_model(OmniSchedulerOutput(scheduled_new_reqs=[nr], num_scheduled_tokens={"m": 4}, total_num_scheduled_tokens=4))
+        return run
+
+    ok = torch.arange(4).expand(3, 4).clone()
+    run = attempt(ok.tolist(), 0)
+    assert "m" in run.requests
+    ahead = ok.clone(); ahead[0, 3] = rows - 1                  # the last row of the table: still inside
+    assert "m" in attempt(ahead.tolist(), 0).requests
+    for mp, md in ((ahead + 1, 0), (ok - 1, 0), (ok, -5), (ok, rows - 6)):      # id past the table; negative id; index + delta < 0; index + delta past it
+        with pytest.raises(ValueError, match="rotary table"):
+            attempt(mp.tolist(), md)
+    assert "m" in attempt(ok.tolist(), rows - 4 - 8).requests    # the largest delta that keeps 8 decode steps inside
+
+
 def test_runner_per_request_sampling_rows_follow_their_request():
     """Row a2 / ADVICE r1: every request's SamplingParams land in ITS batch row (device arrays read by the captured sampler),
     survive the decode-first permutation and the condense on finish, and unseeded requests get distinct RNG keys."""
