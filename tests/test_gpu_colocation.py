@@ -1,0 +1,100 @@
+"""The reference's shipped TTS deployment puts the talker stage AND the code2wav stage on device "0", two processes
+(V/model_executor/stage_configs/qwen3_tts.yaml:7,39).  The persistent chains are 256-workgroup launches whose workgroups wait for
+each other: next to another process's kernels they must still complete -- their waits are bounded by wall clock, and the stage
+degrades to the launch path if one ever runs out (tests/test_gpu_fallback.py) -- and must produce the same bits.
+
+A child process (started with the `spawn` method: a fresh interpreter, never a re-exec of a process that holds the GPU) decodes
+50-frame windows through the full-size Code2Wav decoder in a loop on the same GPU while this process replays captured decode
+steps of the 1.7B-shaped talker with both chains on."""
+import time
+
+import pytest
+import torch
+
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.weights import make_weights
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _code2wav_loop(ready, stop, count):
+    import torch as T
+    from ht_vllm_omni_amd.code2wav import Code2WavDecoder
+    from tests.codec_util import FULL_CODEC, make_codec_state
+    T.cuda.set_device(0)
+    dec = Code2WavDecoder(FULL_CODEC, make_codec_state(FULL_CODEC, 0, device="cuda"))
+    codes = T.randint(0, 2048, (1, 16, 50), device="cuda")
+    dec(codes)
+    T.cuda.synchronize()
+    ready.set()
+    n = 0
+    while not stop.is_set():
+        for _ in range(4):
+            dec(codes)
+        T.cuda.synchronize()
+        n += 4
+    count.value = n
+
+
+def _replay(d, w, B, steps):
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=64 * 40 + 2, max_batch=64)
+    g = torch.Generator().manual_seed(9)
+    eng.input_ids[:B] = torch.randint(1, d.codebook, (B,), generator=g).to(torch.int32).cuda()
+    eng.last_hidden[:B] = torch.randn(B, d.hidden, generator=g).to(BF16).cuda()
+    eng.text_step[:B] = (torch.randn(B, d.hidden, generator=g) * 0.02).to(BF16).cuda()
+    eng.positions[:B] = 17
+    eng.seq_lens[:B] = 18
+    nb = (18 + steps + 40) // 16 + 1
+    for b in range(B):
+        eng.block_table[b, :nb] = torch.arange(1 + nb * b, 1 + nb * (b + 1), dtype=torch.int32)
+    eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+    eng.decode_step(B)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        eng.decode_step(B)
+    hist = torch.empty(steps, B, d.num_code_groups, dtype=torch.int64, device="cuda")
+    stat = torch.zeros(steps, 4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        gr.replay()
+        hist[s] = eng.audio_codes[:B]
+        stat[s] = eng.status
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return hist.cpu(), stat.cpu(), dt / steps * 1e3, eng.chain_error(), eng.chains_ran()
+
+
+@pytest.mark.timeout(900)
+def test_chained_steps_beside_a_code2wav_process_on_the_same_gpu():
+    import json
+    import os
+    import torch.multiprocessing as mp
+    d = get_dims("tts-1.7b").with_(layers=4, max_model_len=1024)
+    w = make_weights(d, seed=4, std=0.02)
+    B, steps = 64, 500
+    solo, st0, ms0, err0, ran0 = _replay(d, w, B, steps)
+    assert err0 == 0 and ran0 == 3 and int(st0[:, :2].abs().sum()) == 0
+    ctx = mp.get_context("spawn")
+    ready, stop, count = ctx.Event(), ctx.Event(), ctx.Value("i", 0)
+    child = ctx.Process(target=_code2wav_loop, args=(ready, stop, count))
+    child.start()
+    try:
+        assert ready.wait(300), "the code2wav process did not come up"
+        both, st1, ms1, err1, ran1 = _replay(d, w, B, steps)
+    finally:
+        stop.set()
+        child.join(120)
+    assert child.exitcode == 0
+    assert count.value > 0, "the code2wav process decoded nothing while the talker ran: no co-location was tested"
+    assert err1 == 0 and ran1 == 3, f"chain error word {err1:#x} beside the code2wav process (chains ran: {ran1})"
+    assert int(st1[:, :2].abs().sum()) == 0, "a step reported a status word"
+    assert torch.equal(solo, both), "codes differ between the solo run and the run beside the code2wav process"
+    rep = {"steps": steps, "batch": B, "layers": d.layers, "solo_ms_per_step": ms0, "colocated_ms_per_step": ms1, "slowdown": ms1 / ms0,
+           "code2wav_windows_decoded_meanwhile": int(count.value), "chain_error_word": err1}
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/colocation.json", "w"), indent=1)
+    print(rep)

@@ -139,6 +139,102 @@ def test_full_depth_three_way_accuracy_against_fp32_activations():
     json.dump(report, open("gpurun_out/three_way_parity.json", "w"), indent=1)
 
 
+def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
+    """the PRODUCT path at the BASELINE batch -- 64 rows, all 28 backbone layers on bb_chain.hip, the 5-layer /
+    16-group code predictor on cp_chain.hip, fp8 KV -- against the oracle DIRECTLY (until round 4 it was tied to it only through
+    chain == launch path at 3 layers and launch path ~ oracle at 8 rows).  One decode step behind a prefill:
+      * asserted on what the native step reports it launched (omni_talker_chains_ran == 3), status words clean;
+      * backbone: the three-way accuracy statement of the test above at 64 rows (HIP no farther from fp32-activation arithmetic
+        than the reference's own bf16 rounding is, x 1.3, mean and p99, hidden states and logits);
+      * code predictor: ALL 15 groups of all 64 rows against the oracle's greedy codes -- a row may leave the oracle's path only at
+        a group whose two best logits are a near-tie (checked on the oracle's logits of that group); at least half the rows agree
+        on the whole frame; and for EVERY group index the rows still on the oracle's path agree at that group in >= 85 % of cases
+        and their group logits meet the end-to-end bound (a broken stage of any pass would show at its group).
+    Reference: qwen3_tts_talker.py:414-443, qwen3_tts_code_predictor_vllm.py:480-561."""
+    import json
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    d = get_dims("tts-1.7b").with_(max_model_len=512)
+    w = make_weights(d, seed=1234, std=0.02)
+    B, bs, nb = 64, 16, 2 * 64 + 2
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(6, 22, (B,), generator=g).tolist()
+    prompts = [torch.randn(n, d.hidden, generator=g).to(BF16) for n in lens]
+    bts = [[1 + 2 * r, 2 + 2 * r] for r in range(B)]
+    x = torch.cat(prompts, 0)
+    pos = torch.cat([torch.arange(n) for n in lens])
+    req = [r for r, n in enumerate(lens) for _ in range(n)]
+    slots = torch.tensor([bts[req[t]][int(pos[t]) // bs] * bs + int(pos[t]) % bs for t in range(x.shape[0])])
+    last = torch.tensor(np.cumsum(lens) - 1)
+
+    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, max_batch=B)
+    bt = torch.zeros(eng.max_batch, eng.bt_stride, dtype=torch.int32)
+    for r in range(B):
+        bt[r, :2] = torch.tensor(bts[r])
+    eng.block_table.copy_(bt)
+    hid_gpu = eng.prefill(x.cuda(), pos.to(torch.int32).cuda(), torch.tensor(req, dtype=torch.int32).cuda(), slots.cuda()).cpu()
+    lg_gpu = eng.compute_logits(hid_gpu[last].cuda()).cpu()
+    ids0 = lg_gpu.argmax(-1)
+    eng.input_ids[:B] = ids0.to(torch.int32).cuda()
+    eng.last_hidden[:B] = hid_gpu[last].cuda()
+    eng.positions[:B] = torch.tensor(lens, dtype=torch.int32).cuda()
+    eng.seq_lens[:B] = (torch.tensor(lens, dtype=torch.int32) + 1).cuda()
+    eng.text_step[:B] = torch.stack([torch.randn(d.hidden, generator=g).to(BF16) * 0.02 for _ in range(B)]).cuda()
+    eng.set_sampling(greedy=1, cp_greedy=1)
+    eng.decode_step(B)
+    torch.cuda.synchronize()
+    assert eng.chains_ran() == 3, f"both persistent chains must run at 64 rows of the 1.7B shape (ran {eng.chains_ran()})"
+    assert eng.status.cpu().tolist() == [0, 0, 3, 0] and eng.chain_error() == 0
+    x_t = eng.inputs_embeds[:B].cpu()
+    dec_h_gpu, dec_lg_gpu, codes_gpu = eng.last_hidden[:B].cpu(), eng.logits[:B].cpu(), eng.audio_codes[:B].cpu()
+
+    # ---- code predictor: all 15 groups
+    orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+    ref_codes, ref_lg = orc.code_predictor(ids0, w["embed"][ids0], hid_gpu[last], do_sample=False, return_logits=True)
+    assert torch.equal(codes_gpu[:, 0], ids0), "layer-0 code = the sampled id"
+    on_path = torch.ones(B, dtype=torch.bool)
+    per_group = []
+    for grp in range(1, d.num_code_groups):
+        same = codes_gpu[:, grp] == ref_codes[:, grp]
+        n_on = int(on_path.sum())
+        assert n_on >= B // 2, f"group {grp}: only {n_on} of {B} rows still on the oracle's greedy path"
+        for b in (on_path & ~same).nonzero().flatten().tolist():
+            top = torch.topk(ref_lg[b, grp - 1].float(), 2).values
+            tie = 3.0 * 2.0 ** (int(np.floor(np.log2(max(float(top[0].abs()), 1e-30)))) - 7)
+            assert float(top[0] - top[1]) <= tie, f"row {b}: code group {grp} differs without a near-tie (margin {float(top[0] - top[1]):.4g} > {tie:.4g})"
+        agree = float((same & on_path).sum()) / n_on
+        per_group.append(agree)
+        assert agree >= 0.85, f"group {grp}: {agree:.2f} of the rows on the oracle's path agree"
+        on_path &= same
+    frames = float(on_path.float().mean())
+    assert frames >= 0.5, f"only {frames:.2f} of the rows decoded the oracle's whole frame"
+
+    # ---- backbone at 64 rows: three-way accuracy of the decode step the chains computed
+    def oracle_run(act_dtype):
+        keep = O.BF16
+        O.BF16 = act_dtype
+        try:
+            o2 = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+            o2.backbone(x.to(act_dtype), pos, req, bts, lens)
+            hd = o2.backbone(x_t.to(act_dtype), torch.tensor(lens), list(range(B)), bts, [n + 1 for n in lens])
+            return hd.float(), o2.compute_logits(hd)
+        finally:
+            O.BF16 = keep
+    hd16, dlg16 = oracle_run(torch.bfloat16)
+    hd32, dlg32 = oracle_run(torch.float32)
+    report = {"frames_equal": frames, "per_group_agreement": per_group}
+    for name, got, ref16, ref32 in (("decode hidden", dec_h_gpu, hd16, hd32), ("decode logits", dec_lg_gpu, dlg16, dlg32)):
+        fin = torch.isfinite(ref32)
+        assert torch.equal(torch.isfinite(got), fin), f"{name}: mask pattern"
+        e_hip, e_ref = (got.float()[fin] - ref32[fin]).abs(), (ref16.float()[fin] - ref32[fin]).abs()
+        q = lambda e: float(torch.quantile(e[torch.randperm(e.numel(), generator=torch.Generator().manual_seed(1))[:200000]], 0.99))
+        report[name] = {"hip_mean": float(e_hip.mean()), "ref_mean": float(e_ref.mean()), "hip_p99": q(e_hip), "ref_p99": q(e_ref),
+                        "hip_vs_bf16_oracle_mean": float((got.float()[fin] - ref16.float()[fin]).abs().mean()), "scale": float(ref32[fin].abs().max())}
+        assert e_hip.mean() <= 1.3 * e_ref.mean(), (name, report[name])
+        assert report[name]["hip_p99"] <= 1.3 * report[name]["ref_p99"], (name, report[name])
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/b64_chain_parity.json", "w"), indent=1)
+
+
 def test_config2_0p6b_decode_bf16_kv_matches_oracle():
     """BASELINE config #2: Qwen3-TTS-0.6B dimensions, bf16 weights, the KV cache in the model dtype (vLLM kv_cache_dtype
     "auto" -- a bf16 model cannot be given an fp16 cache there), TP = 1: 2 backbone layers, the whole 16-group code
