@@ -144,6 +144,7 @@ SIGNATURES = {
     "omni_talker_chain_error": (i32, [vp, i32]),
     "omni_talker_set_chains": (i32, [vp, i32]),
     "omni_talker_chains_ran": (i32, [vp]),
+    "omni_talker_set_kv_scales": (i32, [vp, vp, vp, vp]),
     "omni_talker_mtp": (i32, [vp, C.POINTER(StepIO), vp]),
     "omni_talker_layer_attn": (i32, [vp, C.POINTER(StepIO), i32, vp]),
     "omni_talker_layer_mlp": (i32, [vp, C.POINTER(StepIO), i32, vp]),

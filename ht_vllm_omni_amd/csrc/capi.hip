@@ -112,6 +112,8 @@ struct omni_talker {
     int64_t* cp_slots;
     std::vector<uint16_t*> cp_k, cp_v;
     int32_t* pf_seq;   // prefill scratch
+    float* kv_scale_dev;                // fp8 KV: device [layers][2] = {k_scale, v_scale} per layer, read by the decode step's attention launches
+    std::vector<float> ksc_h, vsc_h;    // the same on the host (arguments of the eager prefill launches)
     void* bb_table;                     // device table of the backbone layers' pointers (bb_all.hip)
     uint32_t* chain_flags;              // stage flags of the persistent chains: OMNI_FLAG_REPLICAS copies of [256] (coherent.cuh) + the error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
@@ -173,6 +175,7 @@ static int carve(omni_talker* t, char* base, size_t* total) {
     t->cp_slots = c.take<int64_t>((Q + 1) * B);
     t->pf_seq = c.take<int32_t>(8);
     t->chain_flags = c.take<uint32_t>(OMNI_FLAG_WORDS);
+    t->kv_scale_dev = c.take<float>(2 * (size_t)(d.layers > 0 ? d.layers : 1));
 #ifdef OMNI_DEBUG_HOOKS
     t->bb_table = c.take<char>(k_bb_all_table_bytes(d.layers > 0 ? d.layers : 1));
 #endif
@@ -304,6 +307,13 @@ extern "C" omni_talker* omni_talker_create(const omni_talker_desc* desc) {
     }
 #endif
     hipError_t e = hipMemcpy(t->cp_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice);
+    t->ksc_h.assign(desc->layers, desc->k_scale);
+    t->vsc_h.assign(desc->layers, desc->v_scale);
+    {
+        std::vector<float> sc(2 * (size_t)desc->layers);
+        for (int l = 0; l < desc->layers; ++l) { sc[2 * l] = desc->k_scale; sc[2 * l + 1] = desc->v_scale; }
+        if (e == hipSuccess && desc->layers > 0) e = hipMemcpy(t->kv_scale_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemset(t->chain_flags, 0, OMNI_FLAG_WORDS * 4);
     if (e == hipSuccess) e = hipMemcpy(t->cp_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->cp_seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice);
@@ -340,6 +350,28 @@ extern "C" int omni_talker_set_chains(omni_talker* t, int on) {
     return OMNI_OK;
 }
 extern "C" int omni_talker_chains_ran(const omni_talker* t) { return t ? t->ran : 0; }
+// per-layer fp8 KV scales (host arrays [layers]) after a calibration pass: the device copy the captured decode steps read, and the
+// host copy the eager prefill launches pass as arguments
+extern "C" int omni_talker_set_kv_scales(omni_talker* t, const float* k_scale, const float* v_scale, void* stream) {
+    OMNI_CHECK_ARG(t && k_scale && v_scale, "omni_talker_set_kv_scales: null pointer");
+    const int L = t->d.layers;
+    std::vector<float> sc(2 * (size_t)L);
+    for (int l = 0; l < L; ++l) {
+        OMNI_CHECK_ARG(k_scale[l] > 0.f && v_scale[l] > 0.f, "omni_talker_set_kv_scales: layer %d: scales must be > 0", l);
+        t->ksc_h[l] = k_scale[l]; t->vsc_h[l] = v_scale[l];
+        sc[2 * l] = k_scale[l]; sc[2 * l + 1] = v_scale[l];
+    }
+    // synchronous on purpose: a set-up call (once per engine), and `sc` is a stack buffer
+    if (L > 0 && (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+                  hipMemcpy(t->kv_scale_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        omni_set_error("omni_talker_set_kv_scales: upload failed");
+        return OMNI_EHIP;
+    }
+#ifdef OMNI_DEBUG_HOOKS
+    if (t->d.moe_experts == 0) TRY(k_bb_all_set_scales(t->bb_table, L, k_scale, v_scale, stream));
+#endif
+    return OMNI_OK;
+}
 extern "C" void* omni_talker_attn_out(omni_talker* t) { return t ? t->attn_out : nullptr; }
 extern "C" void* omni_talker_mlp_out(omni_talker* t) { return t ? t->mlp_out : nullptr; }
 
@@ -693,7 +725,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
                             t->k_scales[l], t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens,
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
-                            io->num_live, io->rope_delta, d.rope_rows > 0 ? d.rope_rows : d.max_model_len));
+                            io->num_live, io->rope_delta, d.rope_rows > 0 ? d.rope_rows : d.max_model_len, t->kv_scale_dev + 2 * l));
     if (d.fused_norm && t->has_ar) {
         // tensor-parallel rank on the norm-free stream: partial o_proj -> this rank's peer-mapped buffer (fragment-major),
         // then ONE launch sums the ranks' partials, adds into r and writes the sum(r^2) slabs
@@ -716,10 +748,10 @@ static int layer_attn_prefill(omni_talker* t, int l, int rows, const int32_t* po
     TRY(norm_gemm(t, t->resid, l == 0 ? nullptr : t->mlp_out, t->resid_b, w.ln1, t->normed, nullptr, w.wqkv, t->qkv, rows,
                   (hq + 2 * hkv) * D, H, OMNI_EPI_BF16, nullptr, 0, st));
     TRY(omni_qknorm_rope_kvwrite(t->qkv, w.qnorm, w.knorm, positions, d.cos_sin, slots, t->q, t->k_cache[l], t->v_cache[l],
-                                 t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, d.k_scale, d.v_scale, st));
+                                 t->k_scales[l], t->v_scales[l], rows, hq, hkv, D, d.eps, d.kv_dtype, t->ksc_h[l], t->vsc_h[l], st));
     TRY(k_paged_attn_prefill(t->q, t->k_cache[l], t->v_cache[l], t->k_scales[l], t->v_scales[l], block_table, d.bt_stride,
-                             req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale,
-                             d.v_scale, 1.0f / sqrtf((float)D), d.frag_layout, st));
+                             req_of_tok, positions, t->attn, rows, hq, hkv, D, d.block_size, d.kv_dtype, t->ksc_h[l],
+                             t->vsc_h[l], 1.0f / sqrtf((float)D), d.frag_layout, st));
     TRY(act_gemm(t, t->attn, w.wo, nullptr, t->attn_out, rows, H, hq * D, st));
     return OMNI_OK;
 }
@@ -885,7 +917,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
                                     t->v_scales[l], io->block_table, d.bt_stride, io->seq_lens, l == 0 ? io->slot_mapping : nullptr, t->attn,
                                     t->attn_ws, B, hq, hkv, D, d.block_size, d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D),
                                     d.max_model_len, d.frag_layout, -1, stream, io->num_live, io->rope_delta,
-                                    d.rope_rows > 0 ? d.rope_rows : d.max_model_len));
+                                    d.rope_rows > 0 ? d.rope_rows : d.max_model_len, t->kv_scale_dev + 2 * l));
             if (!do_rest) continue;
 #ifdef OMNI_DEBUG_HOOKS      // round-3 A/B arms (all slower): debug library only
             if (k_bb_engine_enabled())

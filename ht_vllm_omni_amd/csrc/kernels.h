@@ -55,7 +55,8 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         int dense_pos /* >= 0: every row at this position of its own block (no index loads); else -1 */, void* stream,
                         const int32_t* num_live = nullptr /* device: rows >= *num_live write no KV / slot */,
                         const int32_t* rope_delta = nullptr /* device [B]: rotary position = positions[b] + rope_delta[b] */,
-                        int rope_rows = 0 /* rows of cos_sin: positions + rope_delta is clamped into the table (0: no clamp) */);
+                        int rope_rows = 0 /* rows of cos_sin: positions + rope_delta is clamped into the table (0: no clamp) */,
+                        const float* scale_dev = nullptr /* fp8 KV: device {k_scale, v_scale} read at run time instead of the arguments */);
 int k_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const float* k_scales,
                          const float* v_scales, const int32_t* block_table, int bt_stride, const int32_t* req_of_tok,
                          const int32_t* positions, void* out, int T, int q_heads, int kv_heads, int head_dim, int block_size,

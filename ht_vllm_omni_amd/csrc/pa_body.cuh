@@ -20,6 +20,8 @@ struct PAArgs {
     const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
     uint16_t* out; float* partial;
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
+    const float* scale_dev;        // fp8 KV: device {k_scale, v_scale} of this layer, read at run time instead of the two launch arguments
+                                   // (calibrated scales reach captured graphs this way: omni_talker_set_kv_scales); NULL: the arguments
     int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
     int kv_rep;                    // decode kernel: grid.x = kv_heads * kv_rep "virtual" kv heads of q_heads / (kv_heads * kv_rep)
                                    // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
@@ -149,6 +151,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, tg = lane >> 3;
     const int row = active ? row_in : 0;
+    const float k_scale = a.scale_dev ? a.scale_dev[0] : a.k_scale, v_scale = a.scale_dev ? a.scale_dev[1] : a.v_scale;
     const int kvh = vh / a.kv_rep;
     const int req = a.req_of_row ? a.req_of_row[row] : row;
     const int kv_heads = a.kv_heads, bs = a.bs;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
     float qf[G][16];
-    const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? a.k_scale : 1.0f);
+    const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;
     float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
     // CHAIN: this row's q heads (and, in the wave that folds the new token, its k / v head) as one dword per lane each, all in one
@@ -308,7 +311,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
                 }
                 kx0 = h2f(hk0); kx1 = h2f(hk1); vx0 = h2f(hv0); vx1 = h2f(hv1);     // what the cache now holds
             } else if (KV == OMNI_KV_FP8) {
-                const float ik = a.k_scale, iv = a.v_scale;
+                const float ik = k_scale, iv = v_scale;
                 const uint32_t pk = pack_fp8x4(ik == 1.f ? kx0 : kx0 / ik, ik == 1.f ? kx1 : kx1 / ik, 0.f, 0.f);
                 const uint32_t pv = pack_fp8x4(iv == 1.f ? vx0 : vx0 / iv, iv == 1.f ? vx1 : vx1 / iv, 0.f, 0.f);
                 uint8_t* kd = reinterpret_cast<uint8_t*>(a.k_cache) + crow * 128;
@@ -481,7 +484,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         if (CHAIN) {
             // write-through dword stores (two adjacent elements per thread): the o_proj stage reads them behind this stage's flag
             const coh_rsrc_t ors = coh_rsrc(a.out);
-            const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
+            const float vs = (KV == OMNI_KV_FP8) ? v_scale : 1.0f;
             for (int it = tid; it < G * 64; it += PA_THREADS) {
                 const int g = it >> 6, d = 2 * (it & 63);
                 float M, L, M1, L1;
@@ -497,7 +500,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             const float A = merged(g, d, M, L);
             const int qh = vh * G + g;
             if (a.nsplit == 1) {
-                const float vs = (KV == OMNI_KV_FP8) ? a.v_scale : 1.0f;
+                const float vs = (KV == OMNI_KV_FP8) ? v_scale : 1.0f;
                 const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
                 a.out[oo] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
             } else {

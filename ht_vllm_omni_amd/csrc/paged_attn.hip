@@ -357,7 +357,8 @@ int k_attn_pair01(const void* qkv, int row1_off, const void* qnorm_w, const void
 // merge KV splits: one 128-thread block per (row, q-head)
 __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ partial,
                                                                uint16_t* __restrict__ out, int nsplit, float v_mul,
-                                                               int q_heads, int out_frag) {
+                                                               int q_heads, int out_frag, const float* __restrict__ v_mul_dev) {
+    if (v_mul_dev) v_mul = v_mul_dev[1];           // fp8 KV with device-resident scales: {k_scale, v_scale}
     const size_t rh = blockIdx.x;
     const int d = threadIdx.x;
     const float* base = partial + rh * nsplit * PA_REC;
@@ -417,7 +418,8 @@ static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     OMNI_CHECK_LAUNCH("omni_paged_attn_decode");
     if (a.nsplit > 1) {
         hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(rows * a.q_heads), dim3(128), 0, st, (const float*)a.partial,
-                           a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f, a.q_heads, a.out_frag);
+                           a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f, a.q_heads, a.out_frag,
+                           KV == OMNI_KV_FP8 ? a.scale_dev : nullptr);
         OMNI_CHECK_LAUNCH("omni_paged_attn_merge");
     }
     return OMNI_OK;
@@ -472,10 +474,11 @@ int k_attn_decode_fused(const void* qkv, const void* qnorm_w, const void* knorm_
                         const int32_t* block_table, int bt_stride, const int32_t* seq_lens, int64_t* slot_out, void* out,
                         void* workspace, int B, int q_heads, int kv_heads, int head_dim, int block_size, int kv_dtype,
                         float k_scale, float v_scale, float sm_scale, int max_seq_len, int out_frag, int dense_pos,
-                        void* stream, const int32_t* num_live, const int32_t* rope_delta, int rope_rows) {
+                        void* stream, const int32_t* num_live, const int32_t* rope_delta, int rope_rows, const float* scale_dev) {
     PAArgs a{};
     a.rope_delta = rope_delta;
     a.rope_rows = rope_delta ? rope_rows : 0;
+    a.scale_dev = kv_dtype == OMNI_KV_FP8 ? scale_dev : nullptr;
     a.out_frag = out_frag;
     a.dense_pos = dense_pos;
     a.num_live = num_live;

@@ -144,7 +144,8 @@ class TalkerEngine:
     def __init__(self, dims: TalkerDims, weights: dict, *, kv_dtype: str = "fp8", num_blocks: int = 1024,
                  block_size: int = 16, max_batch: int = 64, device: str = "cuda:0", tp_rank: int = 0, tp_size: int = 1,
                  k_scale: float = 1.0, v_scale: float = 1.0, allow_eos: bool = True, masked_logit: float = 0.0, tp_group=None, n_sub: int = 1, tp_force: bool = False, frag_layout: bool = True,
-                 fused_norm: bool | None = None, peer_allreduce=None, moe_fp8: bool = False, prefill_gemm: str = "tile"):
+                 fused_norm: bool | None = None, peer_allreduce=None, moe_fp8: bool = False, prefill_gemm: str = "tile",
+                 calculate_kv_scales: bool = False):
         if not torch.cuda.is_available():
             raise L.OmniError("TalkerEngine needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
         self.lib = L.load()
@@ -339,6 +340,12 @@ class TalkerEngine:
         desc.max_batch, desc.block_size, desc.kv_dtype = (min(max_batch, 64) if int(n_sub) > 1 else max_batch), block_size, self.kv_code
         desc.max_model_len, desc.bt_stride = d.max_model_len, self.bt_stride
         desc.k_scale, desc.v_scale = k_scale, v_scale
+        # fp8 KV scales per layer (host copy = what the eager prefill launches pass; the native engine keeps a device table for the
+        # captured decode steps).  calculate_kv_scales (vLLM cache_config; the reference's first forward runs eager for it,
+        # V/worker/gpu_ar_model_runner.py:122,269-275): the FIRST prefill pass of this engine sets k = max|k| / 200, v = max|v| / 100 per
+        # layer from its own tokens, before its cache write (oracle: talker_oracle.TalkerOracle(calculate_kv_scales=True))
+        self.k_scale_l, self.v_scale_l = [float(k_scale)] * d.layers, [float(v_scale)] * d.layers
+        self.calibrate_pending = bool(calculate_kv_scales) and self.kv_code == L.KV_FP8
         desc.masked_logit = float(masked_logit)      # 0: -inf (TTS); -1e9: the Omni talker's finite suppression value
         desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
         desc.layer = C.cast(self._layers, C.POINTER(L.LayerWeights))
@@ -568,20 +575,33 @@ class TalkerEngine:
                 raise L.OmniError("rope_positions given but the model has no mrope_section")
             # (ids outside the rotary table are refused at admission, runner._update_states; the clamp is the backstop)
             rope_pos, axis = rope_positions.to(torch.int32).clamp(0, self.rope_rows - 1).contiguous(), self.mrope_axis
+        calibrate = self.calibrate_pending
+        if calibrate:
+            T = x.shape[0]
+            tmp_k = torch.empty(T, hkv, D, dtype=BF16, device=x.device)      # this pass's K (after q/k-norm + RoPE) and V, unquantised
+            tmp_v = torch.empty_like(tmp_k)
+            tmp_slots = torch.arange(T, dtype=torch.int64, device=x.device)
         for l in range(d.layers):
             w = self.layer_w[l]
             a = ops.rmsnorm(None, w["ln1"], d.eps, delta=delta, residual=resid)
             qkv = ops.gemm_tile(a, w["wqkv_f"]) if tile else F.linear(a, w["wqkv"])
             kc, vc = self.kv_caches[l][0], self.kv_caches[l][1]
             ks = self.kv_scales[l] if self.kv_scales is not None else None
+            if calibrate:
+                # the same kernel into a bf16 scratch "cache" (slot t = token t): max|k|, max|v| of this pass -> this layer's scales
+                ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], rope_pos, self.cos_sin, tmp_slots, tmp_k, tmp_v, q_heads=hq,
+                                        kv_heads=hkv, head_dim=D, eps=d.eps, kv_dtype=L.KV_BF16, mrope_axis=axis)
+                ka, va = tmp_k.float().abs().max(), tmp_v.float().abs().max()
+                self.k_scale_l[l] = float(ka / 200.0) if float(ka) > 0 else 1.0          # fp32 divisions (the oracle's)
+                self.v_scale_l[l] = float(va / 100.0) if float(va) > 0 else 1.0
             q = ops.qknorm_rope_kvwrite(qkv, w["qnorm"], w["knorm"], rope_pos, self.cos_sin, slot_mapping, kc, vc,
                                         q_heads=hq, kv_heads=hkv, head_dim=D, eps=d.eps, kv_dtype=self.kv_code,
-                                        k_scale=self._desc.k_scale, v_scale=self._desc.v_scale,
+                                        k_scale=self.k_scale_l[l], v_scale=self.v_scale_l[l],
                                         k_scales=None if ks is None else ks[0], v_scales=None if ks is None else ks[1],
                                         mrope_axis=axis)
             o = ops.paged_attn_prefill(q, kc, vc, bt, req_of_tok, positions, q_heads=hq, kv_heads=hkv, head_dim=D,
-                                       block_size=self.block_size, kv_dtype=self.kv_code, k_scale=self._desc.k_scale,
-                                       v_scale=self._desc.v_scale, k_scales=None if ks is None else ks[0],
+                                       block_size=self.block_size, kv_dtype=self.kv_code, k_scale=self.k_scale_l[l],
+                                       v_scale=self.v_scale_l[l], k_scales=None if ks is None else ks[0],
                                        v_scales=None if ks is None else ks[1])
             o = ops.gemm_tile(o, w["wo_f"]) if tile else F.linear(o, w["wo"])
             if self.tp_path:
@@ -595,7 +615,23 @@ class TalkerEngine:
                 delta = F.linear(ops.silu_mul(F.linear(a, w["wgu"])), w["wdown"])
             if self.tp_path:
                 torch.distributed.all_reduce(delta, group=self.tp_group)
+        if calibrate:
+            self.set_kv_scales(self.k_scale_l, self.v_scale_l)
+            self.calibrate_pending = False
         return ops.rmsnorm(None, self.final_norm, d.eps, delta=delta, residual=resid)
+
+    def set_kv_scales(self, k_scale, v_scale) -> None:
+        """Per-layer fp8 KV scales into the native engine(s): the device table the captured decode steps read and the arguments
+        of later prefill launches.  Graphs captured before the call pick the new scales up (they read the table)."""
+        if self.kv_code != L.KV_FP8:
+            raise L.OmniError("set_kv_scales: fp8 KV only")
+        n = self.d.layers
+        self.k_scale_l, self.v_scale_l = [float(v) for v in k_scale], [float(v) for v in v_scale]
+        if len(self.k_scale_l) != n or len(self.v_scale_l) != n:
+            raise ValueError(f"set_kv_scales: {n} layers")
+        ka, va = (C.c_float * n)(*self.k_scale_l), (C.c_float * n)(*self.v_scale_l)
+        for h in [self.handle] + [hk for hk, _, _ in self._sub]:
+            L.check(self.lib.omni_talker_set_kv_scales(h, ka, va, L.current_stream()), "omni_talker_set_kv_scales")
 
     def prefill_blas(self, x, positions, req_of_tok, slot_mapping, block_table=None):
         return self.prefill_wide(x, positions, req_of_tok, slot_mapping, block_table, gemm="blas")
@@ -686,7 +722,7 @@ class TalkerEngine:
         T = x.shape[0]
         if use_blas is None:
             use_blas = T > self.max_batch
-        if use_blas or rope_positions is not None:
+        if use_blas or rope_positions is not None or self.calibrate_pending:      # the calibration pass is the all-tokens pass
             return self.prefill_wide(x, positions, req_of_tok, slot_mapping, bt, gemm=gemm, rope_positions=rope_positions)
         out = torch.empty_like(x)
         st = L.current_stream()

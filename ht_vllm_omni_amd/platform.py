@@ -29,6 +29,12 @@ class MI355XOmniPlatform:
     def is_cuda(self) -> bool:
         return False
 
+    def is_npu(self) -> bool:            # V/platforms/interface.py:32-35
+        return False
+
+    def is_xpu(self) -> bool:
+        return False
+
     @classmethod
     def get_omni_ar_worker_cls(cls) -> str:
         return AR_WORKER_QUALNAME
@@ -38,6 +44,23 @@ class MI355XOmniPlatform:
         # code2wav one-shot stage: the reference's own generation worker / runner host it; the decoder module it runs is
         # code2wav.Code2WavDecoder (swapped in Qwen3TTSCode2Wav._ensure_speech_tokenizer_loaded)
         return "vllm_omni.worker.gpu_generation_worker.GPUGenerationWorker"
+
+    @classmethod
+    def get_default_stage_config_path(cls) -> str:
+        # V/platforms/interface.py:53 (ROCm: "vllm_omni/platforms/rocm/stage_configs"): the directory of this package's stage
+        # YAMLs -- qwen3_tts.yaml puts stage 0 on MI355XARWorker
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage_configs")
+
+    @classmethod
+    def get_profiler_cls(cls) -> str:
+        # V/platforms/interface.py:129-136: the reference's torch-profiler wrapper serves this stage unchanged (the worker's
+        # profile() also names its phases with the reference's five range names, runner._Range)
+        return "vllm_omni.profiler.omni_torch_profiler.OmniTorchProfilerWrapper"
+
+    @classmethod
+    def supports_cpu_offload(cls) -> bool:
+        # V/platforms/interface.py:113: weights and KV of this stage are device-resident by design (288 GB of HBM per GPU)
+        return False
 
     @classmethod
     def supports_torch_inductor(cls) -> bool:

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import logging
 import os
+from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Any
 
@@ -30,7 +31,7 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                 max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
                 num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
                 connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None,
-                prompt_builder: dict | None = None, model_path: str | None = None) -> SimpleNamespace:
+                prompt_builder: dict | None = None, model_path: str | None = None, calculate_kv_scales: bool = False) -> SimpleNamespace:
     if model_path and isinstance(model, str) and model == "tts-1.7b" and os.path.exists(os.path.join(model_path, "config.json")):
         from .checkpoint import dims_from_hf_config
         model = dims_from_hf_config(os.path.join(model_path, "config.json"))          # dimensions come from the checkpoint
@@ -38,7 +39,7 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                            tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
                            num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
                            enforce_eager=enforce_eager, default_sampling_params=default_sampling_params,
-                           prompt_builder=prompt_builder, model_path=model_path)
+                           prompt_builder=prompt_builder, model_path=model_path, calculate_kv_scales=calculate_kv_scales)
 
 
 _PRESET_HINTS = (("omni", "omni-talker"), ("1.7b", "tts-1.7b"), ("0.6b", "tts-0.6b"))
@@ -100,9 +101,26 @@ def config_from_vllm(vllm_config) -> SimpleNamespace:
         tensor_parallel_size=int(getattr(pc, "tensor_parallel_size", 1) or 1),
         gpu_memory_utilization=float(getattr(cc, "gpu_memory_utilization", 0.9) or 0.9),
         num_gpu_blocks_override=getattr(cc, "num_gpu_blocks_override", None), weights=extra.get("weights"),
+        calculate_kv_scales=bool(getattr(cc, "calculate_kv_scales", False)),
         seed=int(getattr(mc, "seed", 1234) or 0), connector=extra.get("connector"),
         enforce_eager=bool(getattr(mc, "enforce_eager", False)), default_sampling_params=extra.get("default_sampling_params"),
         prompt_builder=extra.get("prompt_builder"), model_path=path)
+
+
+@dataclass(frozen=True)
+class AttentionSpec:
+    """The fields of vLLM's FullAttentionSpec this boundary uses: one layer's share of a KV block ("page") = K and V of
+    block_size tokens (+ the int8 cache's per-(token, head) fp32 scales)."""
+    block_size: int
+    num_kv_heads: int
+    head_size: int
+    dtype: torch.dtype
+    scale_bytes_per_token: int = 0
+
+    @property
+    def page_size_bytes(self) -> int:
+        return self.block_size * (2 * self.num_kv_heads * self.head_size * torch.empty((), dtype=self.dtype).element_size()
+                                  + self.scale_bytes_per_token)
 
 
 class MI355XARWorker:
@@ -157,20 +175,36 @@ class MI355XARWorker:
         budget = int(self.init_total * float(getattr(self.vllm_config, "gpu_memory_utilization", 0.9)))
         return max(budget - resident - (self.init_total - self.init_free), 0)
 
-    def kv_bytes_per_block(self) -> int:
-        d = self.dims
-        per_elem = 2 if self.vllm_config.kv_cache_dtype in ("bf16", "auto", "fp16", "float16", "half") else 1
+    # ---- KV cache spec (vLLM Worker.get_kv_cache_spec -> {layer name: KVCacheSpec}; the executor sizes the cache from the
+    # specs' page sizes and hands the result back as a KVCacheConfig, V/worker/base.py:78-156, gpu_ar_model_runner.py:118-124)
+    def get_kv_cache_spec(self) -> dict[str, "AttentionSpec"]:
+        d, cfg = self.dims, self.vllm_config
+        store = {"bf16": torch.bfloat16, "auto": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+                 "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8}[cfg.kv_cache_dtype]
         hkv = max(d.kv_heads // self.tp_size, 1)
-        b = d.layers * 2 * self.vllm_config.block_size * hkv * d.head_dim * per_elem
-        if self.vllm_config.kv_cache_dtype == "int8":
-            b += d.layers * 2 * self.vllm_config.block_size * hkv * 4
-        return b
+        spec = AttentionSpec(block_size=int(cfg.block_size), num_kv_heads=hkv, head_size=d.head_dim, dtype=store,
+                             scale_bytes_per_token=2 * hkv * 4 if cfg.kv_cache_dtype == "int8" else 0)
+        return {f"model.layers.{l}.self_attn.attn": spec for l in range(d.layers)}
+
+    def kv_bytes_per_block(self) -> int:
+        return sum(s.page_size_bytes for s in self.get_kv_cache_spec().values())
 
     def initialize_from_config(self, kv_cache_config: Any = None) -> None:
         from .engine import TalkerEngine
         from .runner import MI355XARModelRunner
         cfg = self.vllm_config
+        # a KVCacheConfig-shaped object: .num_blocks, or .kv_cache_tensors = [{size, shared_by: [layer names]}] (one per layer in
+        # vLLM's default layout): the smallest tensor bounds the block count
         nb = getattr(kv_cache_config, "num_blocks", None) or cfg.num_gpu_blocks_override
+        tensors = getattr(kv_cache_config, "kv_cache_tensors", None)
+        if nb is None and tensors:
+            specs = self.get_kv_cache_spec()
+            per = []
+            for tns in tensors:
+                names = list(getattr(tns, "shared_by", None) or [])
+                page = sum(specs[n].page_size_bytes for n in names if n in specs) or next(iter(specs.values())).page_size_bytes
+                per.append(int(getattr(tns, "size")) // page)
+            nb = min(per)
         if nb is None:
             nb = max(self.determine_available_memory() // self.kv_bytes_per_block(), 2)
         # tensor-parallel ranks: the all-reduce of the step is a kernel of the step (peer-mapped buffers over hipIpc, fused with
@@ -183,7 +217,8 @@ class MI355XARWorker:
                                                        log=logger.info)
         self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(nb),
                                    block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
-                                   tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce)
+                                   tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce,
+                                   calculate_kv_scales=bool(getattr(cfg, "calculate_kv_scales", False)))
         embed_table = self._weights["embed"]
         self._weights = None
         conn = OmniConnectorFactory.create_connector(cfg.connector) if getattr(cfg, "connector", None) else None

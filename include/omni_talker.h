@@ -431,6 +431,12 @@ int omni_talker_set_chains(omni_talker* t, int on);
 /* Which persistent chains the LAST decode-step call of this engine launched (host-side record, no device access):
  * bit 0 the code-predictor chain (cp_chain.hip), bit 1 the backbone chain (bb_chain.hip).  0 = launch-per-op path.      */
 int omni_talker_chains_ran(const omni_talker* t);
+/* ABI v4.  Per-layer fp8 KV scales (host arrays [layers], all > 0) -- the result of a `calculate_kv_scales` pass: the reference
+ * runs its first forward eager so that vLLM's attention layers can set k_scale = max|k| / 200, v_scale = max|v| / 100 from that
+ * pass (V/worker/gpu_ar_model_runner.py:122,269-275).  The decode step's attention launches read the scales
+ * from a device table (so graphs captured BEFORE the call see them), the engine's eager prefill launches take them as arguments.
+ * Until the call every layer uses desc.k_scale / desc.v_scale.  Synchronises `stream`.                                      */
+int omni_talker_set_kv_scales(omni_talker* t, const float* k_scale, const float* v_scale, void* stream);
 
 /* Per-step device buffers (persistent, graph-stable addresses).  Row r = batch slot r. */
 typedef struct omni_step_io {

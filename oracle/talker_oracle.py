@@ -42,6 +42,10 @@ Numeric conventions (the GPU path follows the same rounding points):
     PV in fp32, output rounded to bf16;
   * fp8 KV: OCP e4m3fn, ``q = sat(x / scale)`` (clamp to +-448, round-nearest-even),
     read ``float(q) * scale``; per-layer scalar k_scale / v_scale, default 1.0;
+    ``calculate_kv_scales`` (the reference forces its FIRST forward eager for it, V/worker/gpu_ar_model_runner.py:122,269-275;
+    the arithmetic is vLLM's attention layer, source absent -- SURVEY Appendix A): the first backbone pass sets, per layer,
+    ``k_scale = max|k| / 200`` and ``v_scale = max|v| / 100`` over that pass's tokens (k after q/k-norm and RoPE; an all-zero
+    tensor keeps scale 1), BEFORE the pass's own cache write; the scales stay fixed afterwards;
   * int8 KV (no reference semantics): per (token, kv-head) symmetric,
     ``scale = max(absmax, 1e-8) / 127`` held in fp32, ``q = rne(x / scale)``;
   * logits: fp32 accumulate, rounded to bf16 (vLLM ``LogitsProcessor`` returns the
@@ -356,10 +360,16 @@ class OracleState:
     rope_delta: int = 0                            # mrope_position_delta of the prompt: decode rotary position = index + delta
 
 
+K_SCALE_CONSTANT, V_SCALE_CONSTANT = 200.0, 100.0       # vLLM envs.K_SCALE_CONSTANT / V_SCALE_CONSTANT
+
+
 class TalkerOracle:
     def __init__(self, dims, weights: dict, kv_dtype: str = "bf16", num_blocks: int = 64,
-                 block_size: int = 16, k_scale: float = 1.0, v_scale: float = 1.0, masked_logit: float = float("-inf")):
+                 block_size: int = 16, k_scale: float = 1.0, v_scale: float = 1.0, masked_logit: float = float("-inf"),
+                 calculate_kv_scales: bool = False):
         self.d, self.w = dims, weights
+        # fp8 KV: scales from the first backbone pass (module header); False = the constructor's constants
+        self.calculate_kv_scales = bool(calculate_kv_scales) and kv_dtype == "fp8"
         # TTS: -inf (qwen3_tts_talker.py:424-443); the Omni talker suppresses with -1e9 (qwen3_omni.py:1143-1149)
         self.masked_logit = masked_logit
         self.block_size = block_size
@@ -412,6 +422,10 @@ class TalkerOracle:
             trace = getattr(self, "trace", None)        # tests: per-layer intermediates (golden G2 pins them to HF Qwen3Model)
             if trace is not None:
                 trace.append({"layer": li, "q": q.clone(), "k": k.clone(), "v": v.clone()})
+            if self.calculate_kv_scales:
+                ka, va = k.float().abs().max(), v.float().abs().max()          # fp32 tensors: the division below is an fp32 division
+                self.kv[li].k_scale = float(ka / K_SCALE_CONSTANT) if float(ka) > 0 else 1.0
+                self.kv[li].v_scale = float(va / V_SCALE_CONSTANT) if float(va) > 0 else 1.0
             self.kv[li].write(slots, k, v)
             o = torch.empty(T, hq, D, dtype=BF16)
             for r in sorted(set(req_of_tok)):
@@ -432,6 +446,7 @@ class TalkerOracle:
             gu = linear(a, w[p + "wgu"])
             act = silu_mul(gu[:, : d.inter], gu[:, d.inter:])
             h = resid + linear(act, w[p + "wdown"])
+        self.calculate_kv_scales = False           # first pass only
         return rms_norm(h, w["norm"], d.eps)
 
     def compute_logits(self, hidden: torch.Tensor, round_bf16: bool = True) -> torch.Tensor:

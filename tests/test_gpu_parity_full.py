@@ -139,7 +139,8 @@ def test_full_depth_three_way_accuracy_against_fp32_activations():
     json.dump(report, open("gpurun_out/three_way_parity.json", "w"), indent=1)
 
 
-def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
+@pytest.mark.parametrize("calibrate", [False, True], ids=["unit-scales", "calculate_kv_scales"])
+def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles(calibrate):
     """the PRODUCT path at the BASELINE batch -- 64 rows, all 28 backbone layers on bb_chain.hip, the 5-layer /
     16-group code predictor on cp_chain.hip, fp8 KV -- against the oracle DIRECTLY (until round 4 it was tied to it only through
     chain == launch path at 3 layers and launch path ~ oracle at 8 rows).  One decode step behind a prefill:
@@ -150,7 +151,9 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
         a group whose two best logits are a near-tie (checked on the oracle's logits of that group); at least half the rows agree
         on the whole frame; and for EVERY group index the rows still on the oracle's path agree at that group in >= 85 % of cases
         and their group logits meet the end-to-end bound (a broken stage of any pass would show at its group).
-    Reference: qwen3_tts_talker.py:414-443, qwen3_tts_code_predictor_vllm.py:480-561."""
+    calculate_kv_scales: the same with the fp8 scales set per layer by the prefill pass (max|k| / 200, max|v| / 100: NON-unit scales
+    through the chained decode step, which reads them from the device table), oracles likewise.
+    Reference: qwen3_tts_talker.py:414-443, qwen3_tts_code_predictor_vllm.py:480-561, gpu_ar_model_runner.py:122,269-275."""
     import json
     from ht_vllm_omni_amd.engine import TalkerEngine
     d = get_dims("tts-1.7b").with_(max_model_len=512)
@@ -166,7 +169,7 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
     slots = torch.tensor([bts[req[t]][int(pos[t]) // bs] * bs + int(pos[t]) % bs for t in range(x.shape[0])])
     last = torch.tensor(np.cumsum(lens) - 1)
 
-    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, max_batch=B)
+    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, max_batch=B, calculate_kv_scales=calibrate)
     bt = torch.zeros(eng.max_batch, eng.bt_stride, dtype=torch.int32)
     for r in range(B):
         bt[r, :2] = torch.tensor(bts[r])
@@ -213,8 +216,13 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
         keep = O.BF16
         O.BF16 = act_dtype
         try:
-            o2 = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
+            o2 = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, calculate_kv_scales=calibrate)
             o2.backbone(x.to(act_dtype), pos, req, bts, lens)
+            if calibrate and act_dtype == torch.bfloat16:
+                for l in range(d.layers):
+                    # max|k|, max|v| of two bf16 pipelines, 1..28 layers deep: the extreme element differs by a few ulps
+                    assert abs(eng.k_scale_l[l] / o2.kv[l].k_scale - 1) <= 2 ** -4 and abs(eng.v_scale_l[l] / o2.kv[l].v_scale - 1) <= 2 ** -4, l
+                assert max(abs(k - 1.0) for k in eng.k_scale_l) > 0.5, f"non-unit scales expected: {eng.k_scale_l[:4]}"
             hd = o2.backbone(x_t.to(act_dtype), torch.tensor(lens), list(range(B)), bts, [n + 1 for n in lens])
             return hd.float(), o2.compute_logits(hd)
         finally:
@@ -232,7 +240,7 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles():
         assert e_hip.mean() <= 1.3 * e_ref.mean(), (name, report[name])
         assert report[name]["hip_p99"] <= 1.3 * report[name]["ref_p99"], (name, report[name])
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(report, open("gpurun_out/b64_chain_parity.json", "w"), indent=1)
+    json.dump(report, open(f"gpurun_out/b64_chain_parity{'_calibrated' if calibrate else ''}.json", "w"), indent=1)
 
 
 def test_config2_0p6b_decode_bf16_kv_matches_oracle():
