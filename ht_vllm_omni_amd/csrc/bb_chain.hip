@@ -95,6 +95,41 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
                                                     wg >> 7, lds, g, true, 0x1004, a.stamps);
 }
 
+// ---- the 0.6B backbone shape (hidden 1024, 16 x 128 attention width over 8 kv heads, intermediate 3072: BASELINE config #2) --
+// the dimensions of the code predictor's layers, so the segment runs on the stage set of cp_chain.hip: 16-row tiles, four
+// independent row groups of 64 workgroups (gate_up on 32-row tiles above 32 rows, as the launch path picks them: same bits), any
+// batch size 1..64; a workgroup without rows in any stage publishes the launch's stage count and leaves.  Launch-per-op this
+// layer is five launches of 7-11 us for 25 MB of weights (profiles/r03_other_configs.txt: 56 us per layer).
+#define BBS_LDS_FLOATS ((CH_WAVES * 6 * 4 * 64) + CH_WAVES * 64)
+template <bool GU_NARROW>
+__global__ __launch_bounds__(CH_THREADS) void bb_chain_small_kernel(const BbArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[BBS_LDS_FLOATS];
+    ChainGate g;
+    chain_gate_init(g, a.flags, a.err);
+    g.dom = GU_NARROW ? 7 : 6;          // 32-row gate_up tiles tie two 16-row groups together
+    g.nap = a.nap;
+    const int wg = blockIdx.x;
+    constexpr int H = 1024, I = 3072, NQ = 4096, KO = 2048;
+    if (!((wg >> 6) * 16 < a.B || (GU_NARROW && (wg >> 7) * 32 < a.B))) {
+        if (threadIdx.x < 64) chain_flag_publish(g.frs, wg, g.epoch + (a.wqkv_next ? 4u : 3u));
+        return;
+    }
+    static_assert(KO == 8 * 256 && H == 4 * 256 && I == 12 * 256, "bb_chain_small: k-steps per wave");
+    chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 63, wg >> 6, lds, g, false, 0x1001,
+                                           a.stamps);
+    if (GU_NARROW)
+        chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg & 127, wg >> 7, lds, g,
+                                                      true, 0x1002, a.stamps);
+    else
+        chain_gemm<1, 6, 4, 2, OMNI_EPI_SILU_MUL_GU8>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg & 63, wg >> 6, lds, g,
+                                                      true, 0x1002, a.stamps);
+    chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 63, wg >> 6, lds, g, true, 0x1003,
+                                            a.stamps);
+    if (a.wqkv_next)
+        chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
+                                              true, 0x1004, a.stamps);
+}
+
 OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 49;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
@@ -111,13 +146,32 @@ bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
         hipDeviceProp_t p;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
     }
-    return g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
-           d.hidden == 2048 && d.inter == 6144 && d.head_dim == 128 && d.q_heads * 128 == 2048 &&
-           (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B >= g_bb_min_rows && B <= 64;
+    const bool common = g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
+                        d.head_dim == 128 && d.q_heads * 128 == 2048 && (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B <= 64;
+    if (common && k_bb_chain_small(d)) return B >= 1;                          // 0.6B shape: 16-row tiles, every batch size
+    return common && d.hidden == 2048 && d.inter == 6144 && B >= g_bb_min_rows;    // 1.7B shape: the launch path's 32 / 64-row tiles
 }
+bool k_bb_chain_small(const omni_talker_desc& d) { return d.hidden == 1024 && d.inter == 3072; }
 
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-               int B, float eps, uint32_t* flags, int32_t* err, void* stream) {
+               int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small) {
+    if (small) {
+        BbArgs a{};
+        a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
+        a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
+        a.wqkv_next = next ? (const uint16_t*)next->wqkv : nullptr;
+        a.attn = (const uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
+        a.B = B; a.nap = g_bb_nap; a.eps = eps; a.flags = flags; a.err = err;
+#ifdef OMNI_DEBUG_HOOKS
+        a.stamps = g_bb_stamps;
+#endif
+        // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: the launch path's policy (32-row
+        // tiles above 32 rows), so that both schedules produce the same bits
+        if (B > 32) hipLaunchKernelGGL(bb_chain_small_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(bb_chain_small_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        OMNI_CHECK_LAUNCH("bb_chain_small");
+        return OMNI_OK;
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);

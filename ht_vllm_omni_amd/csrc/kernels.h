@@ -84,8 +84,9 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
 // the backbone between two attention launches (o_proj -> gate_up -> down_proj -> next layer's qkv) as one persistent launch
 // (bb_chain.hip); supported = the 1.7B dense shape at 49-64 rows on a single rank
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
+bool k_bb_chain_small(const omni_talker_desc& d);       // the 0.6B shape: the segment on the code predictor's 16-row stage set, any batch
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-               int B, float eps, uint32_t* flags, int32_t* err, void* stream);
+               int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small = false);
 // the WHOLE backbone -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as one persistent launch
 // (bb_all.hip): the layer pointers live in a device table filled at engine creation
 size_t k_bb_all_table_bytes(int layers);

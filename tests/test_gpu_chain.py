@@ -148,6 +148,40 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
         assert torch.equal(x, y), f"KV cache of layer {l} differs"
 
 
+@pytest.mark.parametrize("B", [64, 37, 32, 16, 5, 1])
+def test_backbone_segment_chain_at_the_0p6b_shape_against_the_launch_path(B):
+    """BASELINE config #2's backbone (hidden 1024, intermediate 3072: the code predictor's layer dimensions) runs the per-layer
+    segment on the code predictor's 16-row stage set (csrc/bb_chain.hip bb_chain_small_kernel) at EVERY batch size; against the
+    launch-per-op backbone of the same library: logits, hidden state, sampled ids, codes and every KV byte of three decode steps
+    identical, no flag wait times out, and the native step reports both chains as launched.
+    Reference shape: configuration_qwen3_tts.py:192-216,376-409 (read from the checkpoint, never hard-coded: the chain is chosen
+    by the shape, every other shape keeps the launch path)."""
+    d = get_dims("tts-0.6b").with_(layers=3, max_model_len=256)
+    w = make_weights(d, seed=8, std=0.02)
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_bb_chain.argtypes = [C.c_int]; lib.omni_debug_bb_chain.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_bb_chain(on)
+                eng = _decode_engine(d, w, B, "bf16")
+                outs = []
+                for _ in range(3):
+                    eng.decode_step(B)
+                    outs.append((eng.logits[:B].clone(), eng.last_hidden[:B].clone(), eng.input_ids[:B].clone(), eng.audio_codes[:B].clone()))
+                torch.cuda.synchronize()
+                assert eng.chain_error() == 0
+                assert eng.chains_ran() == (3 if on else 1), (on, eng.chains_ran())
+                res[on] = (outs, [c.view(torch.uint8).clone() for c in eng.kv_caches])
+        finally:
+            lib.omni_debug_bb_chain(1)
+    for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        for name, x, y in zip(("logits", "hidden", "ids", "codes"), a, b):
+            assert torch.equal(x, y), f"step {s}: {name} differ between the 0.6B backbone chain and the launch path"
+    for l, (x, y) in enumerate(zip(res[1][1], res[0][1])):
+        assert torch.equal(x, y), f"KV cache of layer {l} differs"
+
+
 @pytest.mark.parametrize("base", ["launch-path", "layer-chain"])
 @pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16"), (57, "int8"), (64, "fp16"), (51, "fp8")])
 def test_whole_backbone_launch_against_the_launch_path(B, kv, base):
