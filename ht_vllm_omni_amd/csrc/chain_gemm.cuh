@@ -23,6 +23,11 @@
 #define CH_STAMP(buf, sidx, k) do { (void)(buf); (void)(sidx); } while (0)
 #endif
 
+// PRO 3 (round 4; an A/B arm): the RMSNorm's rstd OFF the critical path.  PRO 2 needs rstd before the first MFMA
+// (x = w * bf16(r * rstd)): slab loads -> LDS reduction -> barrier sit between the flags and the arithmetic.  PRO 3 feeds the MFMAs
+// bf16(w * r) -- no rstd -- and scales the fp32 sums by rstd[row] in the epilogue: the slab reduction shares the combine barrier.
+// One rounding point moves (bf16(w * bf16(r * rstd)) -> rstd * sum(W * bf16(w * r))): NOT the reference's bits; gated on the accuracy
+// tests, never on bit-identity.
 // ---- one skinny GEMM stage.  K = NTW * 256 (every wave owns NTW k-steps: wave, wave + 8, ...), workgroup tile = NT 16-row
 // n-tiles x MT 16-row m-tiles at (bx, by).  PRO 2 = RMSNorm folded into the x fragments (slabs part_in), EPI as gemm.hip.
 // XG = k-steps of x (and norm weights) in flight per wave behind the flags: 0 = the wave's whole share at once (small K), else
@@ -51,7 +56,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
                                            unsigned long long* stamps, const u32x4 (*Wpre)[NT] = nullptr, PF prefetch = PF()) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int G = (XG == 0 || XG > NTW) ? NTW : XG;
-    constexpr bool NW_EARLY = PRO == 2 && G == NTW && NT * NTW < 24;      // norm weights ahead of the flags (registers permitting)
+    constexpr bool NORM = PRO == 2 || PRO == 3, DEFER = PRO == 3;
+    constexpr bool NW_EARLY = NORM && G == NTW && NT * NTW < 24;      // norm weights ahead of the flags (registers permitting)
     constexpr int K = NTW * CH_WAVES * 32;
     constexpr int nsteps = K / 32;
     constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
@@ -69,7 +75,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     }
     // every operand load is a buffer load: lane part (lane * 16 bytes) in ONE VGPR, tile / k-step part in an SGPR offset -- no
     // 64-bit per-load address pairs (they cost the wide gate_up tile its last registers)
-    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out), wrs = coh_rsrc(W), nrs = coh_rsrc(PRO == 2 ? norm_w : W);
+    const coh_rsrc_t xrs = coh_rsrc(x), ors = coh_rsrc(out), wrs = coh_rsrc(W), nrs = coh_rsrc(NORM ? norm_w : W);
     const uint32_t lane16 = lane * 16;
     CH_STAMP(stamps, sidx, 0);                                           // 0: stage entered
 
@@ -109,7 +115,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     // ---- behind the flags: the slabs (first: they return first) and the activation fragments, all in one round trip
     constexpr int XROWS = MT * 16, NCH = CH_THREADS / XROWS, PE = 128 / NCH;
     float pv[PE];
-    if (PRO == 2) {
+    if (NORM) {
         const coh_rsrc_t prs = coh_rsrc(part_in);
         const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
 #pragma unroll
@@ -126,7 +132,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             for (int j = 0; j < NT; ++j)
                 Wq[d % G][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + wave + d * CH_WAVES) * 1024), 0);
         }
-        if (PRO == 2 && !NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
+        if (NORM && !NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
 #ifdef OMNI_DEBUG_HOOKS
         if (g.skip == 2 && d >= (NTW + 1) / 2) {           // ingest experiment: half of the activation fragments are not fetched
 #pragma unroll
@@ -143,15 +149,17 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     for (int d = 0; d < G; ++d) load_x(d);
 
     float rstd[MT];
-    if (PRO == 2) {
+    float* red = lds + CH_WAVES * ((NT * MT > 6 && !ONEPASS) ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
+    if (NORM) {
         // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
         float s_ = 0.f;
 #pragma unroll
         for (int e = 0; e < PE; ++e) s_ += pv[e];
         if (XROWS <= 32) s_ = xor32_sum(s_);
         if (XROWS <= 16) s_ = xor16_sum(s_);
-        float* red = lds + CH_WAVES * ((NT * MT > 6 && !ONEPASS) ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
         red[wave * 64 + lane] = s_;
+    }
+    if (PRO == 2) {
         chain_barrier(g);
         float t = 0.f;
 #pragma unroll
@@ -171,7 +179,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     for (int d = 0; d < NTW; ++d) {
         u32x4 Xn[MT], Wn[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) Xn[i] = PRO == 2 ? xnorm_frag(Xq[d % G][i], NWq[d % G], rstd[i]) : Xq[d % G][i];
+        for (int i = 0; i < MT; ++i)
+            Xn[i] = PRO == 2 ? xnorm_frag(Xq[d % G][i], NWq[d % G], rstd[i]) : (DEFER ? xw_frag(Xq[d % G][i], NWq[d % G]) : Xq[d % G][i]);
         if (WFIFO) {
             const unsigned first = g.piece_base + (unsigned)d * (8 * NT);
             eng_wait_ready(g, first + (NT - 1) * 8 + wave + 1);               // this wave's last piece of the round (pieces land in order)
@@ -223,6 +232,15 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int w = 0; w < CH_WAVES; ++w) {
             sum += lds4[(w * TP + tl) * 64 + l];
             if (GU8) sum2 += lds4[(w * TP + tl) * 64 + l + 32];
+        }
+        if (DEFER) {
+            // rstd of this item's row: the eight wave partials of the slab reduction, in wave order (the combine barrier covered them)
+            float tsum = 0.f;
+#pragma unroll
+            for (int w = 0; w < CH_WAVES; ++w) tsum += red[w * 64 + ml];
+            const float rl = 1.0f / sqrtf(tsum / (float)K + eps);
+            sum *= rl;
+            if (GU8) sum2 *= rl;
         }
 #ifdef OMNI_DEBUG_HOOKS
         if (g.skip == 3 && sum[0] != 12345.678f) continue;       // timing experiment: no epilogue stores (results garbage)

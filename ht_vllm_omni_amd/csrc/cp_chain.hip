@@ -231,7 +231,9 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
     CH_STAMP(stamps, sidx, 7);
 }
 
-template <bool GU_NARROW>
+// DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm: its
+// normalised rows are an output) -- round 4's A/B arm of VERDICT r3 item 1b
+template <bool GU_NARROW, bool DEFER = false>
 __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
     static_assert(CH_LDS_FLOATS * 4 >= SMP_LDS_BYTES(8), "sampler working set must fit the chain's LDS");
@@ -260,18 +262,18 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
         const int pc = pass << 8;            // error-word stage codes: (pass << 8) | (16 * layer + stage + 1); head 0xF1, sampler 0xF2
         for (int l = 0; l < a.layers; ++l) {
             const ChainLayer& L = a.layer[l];
-            chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
-                                                  l > 0 || pass > a.g0, pc | (16 * l + 1), a.stamps);
+            chain_gemm<1, 4, 4, DEFER ? 3 : 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
+                                                              l > 0 || pass > a.g0, pc | (16 * l + 1), a.stamps);
             chain_attn(a, L, pass, lds, g, pc | (16 * l + 2));
             chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
                                                    true, pc | (16 * l + 3), a.stamps);
             np = Hc / 16;
             if (GU_NARROW)
-                chain_gemm<2, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7,
-                                                              lds, g, true, pc | (16 * l + 4), a.stamps);
+                chain_gemm<2, 3, 4, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7,
+                                                                          lds, g, true, pc | (16 * l + 4), a.stamps);
             else   // 16 rows x 48 act columns: half the in-register RMSNorm per workgroup, a weight slice twice as wide (prefetched)
-                chain_gemm<1, 6, 4, 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6,
-                                                              lds, g, true, pc | (16 * l + 4), a.stamps);
+                chain_gemm<1, 6, 4, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6,
+                                                                          lds, g, true, pc | (16 * l + 4), a.stamps);
             chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
                                                     true, pc | (16 * l + 5), a.stamps);
         }
@@ -286,10 +288,11 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0, g_chain_defer = 0;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
-extern "C" void omni_debug_chain_skip(int mode) { g_chain_skip = mode; }      // timing experiment: 1 = half the weight bytes, 2 = half the activation bytes (results garbage)
+extern "C" void omni_debug_chain_skip(int mode) { g_chain_skip = mode; }
+extern "C" void omni_debug_chain_defer(int on) { g_chain_defer = on; }          // timing arm: rstd in the epilogues (not the reference's rounding)      // timing experiment: 1 = half the weight bytes, 2 = half the activation bytes (results garbage)
 static unsigned long long* g_chain_stamps = nullptr;
 // 0: launch per op; 1: one persistent launch per pass (layer stack only); 2: one persistent launch for all passes incl. heads + samplers
 extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on != 0; g_chain_span = on; }
@@ -351,6 +354,14 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
     a.nap = g_chain_nap;
 #ifdef OMNI_DEBUG_HOOKS
     a.stamps = g_chain_stamps;
+#endif
+#ifdef OMNI_DEBUG_HOOKS
+    if (g_chain_defer) {
+        if (a.gu_narrow) hipLaunchKernelGGL((cp_chain_kernel<true, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((cp_chain_kernel<false, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        OMNI_CHECK_LAUNCH("cp_chain(deferred rstd)");
+        return OMNI_OK;
+    }
 #endif
     if (a.gu_narrow) hipLaunchKernelGGL(cp_chain_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cp_chain_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);

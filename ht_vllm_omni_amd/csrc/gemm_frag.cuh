@@ -35,6 +35,17 @@ __device__ __forceinline__ u32x4 xnorm_frag(u32x4 v, u32x4 nw, float rstd) {
     return v;
 }
 
+// PRO 3 (chain_gemm.cuh): the fragment times the norm weight only -- x = bf16(w * r), the row's rstd multiplies the fp32 sums later
+__device__ __forceinline__ u32x4 xw_frag(u32x4 v, u32x4 nw) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2 a = {bf_lo(v[e]), bf_hi(v[e])};
+        a = a * (f32x2){bf_lo(nw[e]), bf_hi(nw[e])};
+        v[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t));
+    }
+    return v;
+}
+
 // SiLU(gate) * up with the bf16 rounding points of HF's bf16 modules (each op rounds)
 __device__ __forceinline__ float silu_mul_bf16(float gate_acc, float up_acc) {
     const float gt = bfround(gate_acc);

@@ -8,7 +8,9 @@
 
 #define PA_THREADS 256
 #define PA_WAVES 4
+#ifndef PA_U
 #define PA_U 4                 // 8-token groups per load batch per wave
+#endif
 #define PA_REC 130             // partial record: [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
 
 struct PAArgs {
