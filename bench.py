@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-diagnostics", action="store_true", help="profiler runs: skip the untimed per-family / backbone-only replays "
+                    "behind the timed region (their launches would be counted into the profile)")
     ap.add_argument("--device-weights", action="store_true", help="profiler runs only: draw weights on the GPU (no H2D copy)")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
@@ -340,7 +342,7 @@ def main():
 
     # ---- diagnostics (after the timed region): the backbone half of the step alone, as its own graph
     bb_ms = None
-    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force:
+    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force and not args.no_diagnostics:
         try:
             g2 = torch.cuda.CUDAGraph()
             eng.backbone_step(B)
@@ -363,7 +365,7 @@ def main():
     # as its own hipGraph and replayed alone (omni_talker_step_part).  A part run alone reads whatever the buffers hold: its time is
     # the step's, its outputs are not -- this engine's request state is void from here on (the replica leg builds its own).
     families = None
-    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force:
+    if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force and not args.no_diagnostics:
         try:
             split = bool(chains_ran & 2)
             plan = [("code_predictor_phase_ms", 1)] + ([("backbone_attention_ms", 2), ("backbone_chain_ms", 4)] if split else [("backbone_stack_ms", 6)]) \

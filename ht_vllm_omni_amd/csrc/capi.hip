@@ -557,6 +557,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
     const omni_row_sampling* cpr = row_seed ? &cp_rows : nullptr;
     if (d.cp_fused_norm) {
         int np = 1;
+        bool pair_chain = false;
         const bool pair = cp_pair01_ok(t, B);
         const int Bp = (B + 15) & ~15;
         // rows of the stream / slabs that position 1 (and the head GEMM after it) uses: behind the position-0 block in the pair pass
@@ -581,6 +582,20 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 else
                     TRY(k_gather_frag(nullptr, 0, layer0_embed, r1, part1, B, d.hidden, 0, st, 1, 128));
             }
+            if (d.cp_chain && k_cp_pair_supported(d, B, greedy, top_k, top_p)) {
+                // positions 0 / 1 (25 stages) + group 1's head GEMM and sampler as ONE persistent launch (cp_chain.hip cp_pair_kernel)
+                omni_chain_head hd{};
+                hd.logits = cp_logits_out ? cp_logits_out : t->cp_logits;
+                hd.logits_ld = cp_logits_out ? (Q - 1) * d.codebook : d.codebook;
+                hd.logits_pass = cp_logits_out ? d.codebook : 0;
+                hd.greedy = greedy; hd.top_k = top_k; hd.temperature = temperature; hd.top_p = top_p; hd.seed = seed;
+                hd.steps = steps; hd.row_seed = row_seed; hd.codes = t->codes;
+                TRY(k_cp_pair(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, np, t->cp_resid, t->cp_part, t->cp_qkv, t->cp_attn, t->cp_act,
+                              t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), &hd, st));
+                t->ran |= 1;
+                pair_chain = true;
+                np = 1;
+            } else
             TRY(cp_forward_pair01(t, B, &np, st));
         } else {
             TRY(cp_project_fused(t, last_hidden, B, &np, st));
@@ -594,7 +609,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         }
         uint32_t* cflags = t->chain_flags;
         int32_t* cerr = reinterpret_cast<int32_t*>(t->chain_flags + 320);
-        for (int g = 1; g < Q; ++g) {
+        for (int g = pair_chain ? 2 : 1; g < Q; ++g) {
             const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
             if (!in_pair && d.cp_chain && k_cp_chain_all_supported(d, g, greedy, top_k, top_p)) {

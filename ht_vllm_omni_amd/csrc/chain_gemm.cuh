@@ -49,7 +49,8 @@ struct ChainPrefetch {           // N = loads per wave that F issues
 };
 // ONEPASS: more than 6 tiles still combine in ONE pass (the caller's LDS holds CH_WAVES * NT * MT KB of slots): one barrier
 // instead of three and twice the epilogue threads at work; same order of additions.
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false>
+// PS: rows per sum(r^2) slab (64; 128 for the code predictor's two-position pass, whose stream holds 128 rows)
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false, int PS = 64>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -121,7 +122,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
             const int p = ch + e * NCH;
-            pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * 64 + m_base + row) * 4);
+            pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * PS + m_base + row) * 4);
             if (p >= np_in) pv[e] = 0.f;
         }
     }
@@ -261,7 +262,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3])});
             float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
             ss = xor32_sum(xor16_sum(ss));
-            if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * 64 + m) * 4, __float_as_uint(ss));
+            if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * PS + m) * 4, __float_as_uint(ss));
         } else if (EPI == OMNI_EPI_F32_BF16RND) {
             // logits: fp32 cells holding bf16-rounded values (the reference's bf16 head output), row-major
             const int n = (bx * NT + j) * 16 + 4 * (l >> 4);

@@ -49,6 +49,7 @@ struct ChainArgs {
     const uint16_t* ptab;                 // folded projection tables [Q - 1][codebook][Hc]: pass g < Q - 1 gathers row `code` of table g - 1
     uint32_t* flags;
     int32_t* err;
+    int Bp;                               // pair kernel: rows of position 1 start at Bp (B rounded up to 16) in the 128-row stream
     int skip;                             // debug library: ingest experiment (coherent.cuh ChainGate::skip)
     int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
     unsigned long long* stamps;           // debug library only: [stage][CH_NSTAMP][256] s_memrealtime ticks (100 MHz) of wave 0, or NULL
@@ -231,6 +232,100 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
     CH_STAMP(stamps, sidx, 7);
 }
 
+// ---- positions 0 and 1 of the predictor as stages too (round 4; they were 25 launches + the group-1 head and sampler launches):
+// the two-block stream of cp_forward_pair01 (capi.hip) -- rows [0, B) = position 0 (the talker's last hidden state), rows [Bp, Bp + B)
+// = position 1 (the layer-0 code embedding), slabs 128 rows wide -- through 5 x { qkv, pair attention, o_proj, gate_up, down_proj },
+// then the group-1 head GEMM on the position-1 rows and the sampler (which gathers the input of pass 2 into rows [0, B)).  Tiles =
+// the launch path's at 128 rows (pick_tile: qkv 32 x 64, o / down 32 x 16, gate_up 64 x 24): same bits.
+// The pair attention: one wave per (row, q head) as attn_pair01_kernel (paged_attn.hip) -- position 0 attends to itself (output = its
+// V row), position 1 to both; q / k / v cross from the qkv stage with sc1 dword loads (elements 2 l, 2 l + 1 per lane: V needs no
+// other layout; the (l, l + 64) pairing of the norm + RoPE is restored through LDS), K / V of both positions go to the private cache.
+__device__ __forceinline__ void chain_attn_pair(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
+    if ((int)blockIdx.x * 4 >= a.B * q_heads) {
+        chain_gate_skip(g);
+        return;
+    }
+    const int pair = blockIdx.x * 4 + (wave & 3);               // waves 4-7 work, wave 0 polls (chain_attn)
+    const bool active = wave >= 4 && pair < a.B * q_heads;
+    const int row = pair / q_heads, h = pair - row * q_heads;
+    const int ratio = q_heads / kv_heads, kvh = h / ratio;
+    const int nslots = q_heads + 2 * kv_heads;
+    const coh_rsrc_t krs = coh_rsrc(L.kc), vrs = coh_rsrc(L.vc), qrs = coh_rsrc(a.qkv), ars = coh_rsrc(a.attn);
+    chain_gate_wait(g, code);
+    if (active) {
+        const uint32_t r0 = (uint32_t)row * nslots * 128, r1 = (uint32_t)(a.Bp + row) * nslots * 128;
+        const uint32_t ko = (uint32_t)(q_heads + kvh) * 128, vo = (uint32_t)(q_heads + kv_heads + kvh) * 128;
+        const uint32_t k0w = coh_ld4(qrs, (r0 + ko + 2 * lane) * 2), k1w = coh_ld4(qrs, (r1 + ko + 2 * lane) * 2);
+        const uint32_t q1w = coh_ld4(qrs, (r1 + (uint32_t)h * 128 + 2 * lane) * 2);
+        const uint32_t v0w = coh_ld4(qrs, (r0 + vo + 2 * lane) * 2), v1w = coh_ld4(qrs, (r1 + vo + 2 * lane) * 2);
+        uint32_t* raw = reinterpret_cast<uint32_t*>(lds + (wave & 3) * 256);        // three heads of raw dwords: k(pos 0) | k(pos 1) | q(pos 1)
+        raw[lane] = k0w; raw[64 + lane] = k1w; raw[128 + lane] = q1w;
+        __builtin_amdgcn_wave_barrier();
+        const uint16_t* rh = reinterpret_cast<const uint16_t*>(raw);
+        float k00, k01, k10, k11, q0, q1;
+        head_norm_rope_vals(bf2f(rh[lane]), bf2f(rh[lane + 64]), L.knorm, a.cos_sin, a.eps, lane, k00, k01);
+        head_norm_rope_vals(bf2f(rh[128 + lane]), bf2f(rh[128 + lane + 64]), L.knorm, a.cos_sin + 128, a.eps, lane, k10, k11);
+        head_norm_rope_vals(bf2f(rh[256 + lane]), bf2f(rh[256 + lane + 64]), L.qnorm, a.cos_sin + 128, a.eps, lane, q0, q1);
+        if (h % ratio == 0) {
+            // K / V of both positions into the private cache, one dword per lane (chain_attn's pairing of the two halves)
+            const bool odd = (lane & 1) != 0;
+            const uint32_t elem = odd ? 64 + lane - 1 : lane;
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz) {
+                const uint32_t crow = ((uint32_t)(row * bs + pz) * kv_heads + kvh) * 128;
+                const uint32_t kb0 = f2bf(pz ? k10 : k00), kb1 = f2bf(pz ? k11 : k01);
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kb0, OMNI_DPP_XOR1, 0xF, 0xF, true);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kb1, OMNI_DPP_XOR1, 0xF, 0xF, true);
+                coh_st4(krs, (crow + elem) * 2, odd ? (n1 | (kb1 << 16)) : (kb0 | (n0 << 16)));
+                coh_st4(vrs, (crow + 2 * lane) * 2, pz ? v1w : v0w);
+            }
+        }
+        const float qs = a.sm_scale * LOG2E;
+        const float s0 = wave_sum(fmaf(q0 * qs, k00, (q1 * qs) * k01));
+        const float s1 = wave_sum(fmaf(q0 * qs, k10, (q1 * qs) * k11));
+        const float m = fmaxf(s0, s1);
+        const float p0 = exp2f(s0 - m), p1 = exp2f(s1 - m);
+        const float inv = 1.0f / (p0 + p1);
+        const int width = q_heads * 128, col = h * 128 + 2 * lane;
+        coh_st4(ars, (uint32_t)frag_off(row, col, width) * 2, v0w);
+        coh_st4(ars, (uint32_t)frag_off(a.Bp + row, col, width) * 2,
+                pack_bf2(fmaf(p1, bf_lo(v1w), p0 * bf_lo(v0w)) * inv, fmaf(p1, bf_hi(v1w), p0 * bf_hi(v0w)) * inv));
+    }
+    chain_gate_arrive(g);
+}
+
+__global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
+    ChainGate g;
+    chain_gate_init(g, a.flags, a.err);
+    g.dom = 8;                            // 64-row gate_up tiles and the (row, head) pairs tie every row together
+    g.nap = a.nap;
+    const int wg = blockIdx.x;
+    const int Hc = 1024, NQ = 4096, NI = 3072;
+    const int M2 = a.Bp + a.B;
+    int np = a.np_in;
+    for (int l = 0; l < a.layers; ++l) {
+        const ChainLayer& L = a.layer[l];
+        chain_gemm<2, 4, 4, 2, OMNI_EPI_BF16, 0, 0, ChainNoPrefetch, false, 128>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, M2, NQ, a.eps, wg & 63,
+                                                                                 wg >> 6, lds, g, l > 0, 0x0100 | (16 * l + 1), nullptr);
+        chain_attn_pair(a, L, lds, g, 0x0100 | (16 * l + 2));
+        chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps, wg & 63,
+                                                                                  wg >> 6, lds, g, true, 0x0100 | (16 * l + 3), nullptr);
+        np = Hc / 16;
+        chain_gemm<4, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8, 0, 0, ChainNoPrefetch, false, 128>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, M2, NI, a.eps,
+                                                                                         wg & 127, wg >> 7, lds, g, true, 0x0100 | (16 * l + 4), nullptr);
+        chain_gemm<2, 1, 12, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps,
+                                                                                   wg & 63, wg >> 6, lds, g, true, 0x0100 | (16 * l + 5), nullptr);
+    }
+    // group 1: head GEMM on the position-1 rows (fragment-major tiles Bp / 16 onwards; their slabs start at row Bp), then the sampler
+    chain_gemm<1, 2, 4, 2, OMNI_EPI_F32_BF16RND, 0, 0, ChainNoPrefetch, false, 128>(a.lm_head, a.cp_norm, a.resid + (size_t)a.Bp * Hc, a.part + a.Bp, np,
+                                                                                    a.logits, a.logits_ld, nullptr, a.B, a.codebook, a.eps, wg & 63, wg >> 6,
+                                                                                    lds, g, true, 0x0156, nullptr);
+    chain_sample(a, 1, lds, g, 0x01F2);
+}
+
 // DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm: its
 // normalised rows are an output) -- round 4's A/B arm of VERDICT r3 item 1b
 template <bool GU_NARROW, bool DEFER = false>
@@ -288,11 +383,12 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0, g_chain_defer = 0;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0, g_chain_defer = 0, g_chain_pair = 1;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
 extern "C" void omni_debug_chain_skip(int mode) { g_chain_skip = mode; }
-extern "C" void omni_debug_chain_defer(int on) { g_chain_defer = on; }          // timing arm: rstd in the epilogues (not the reference's rounding)      // timing experiment: 1 = half the weight bytes, 2 = half the activation bytes (results garbage)
+extern "C" void omni_debug_chain_defer(int on) { g_chain_defer = on; }
+extern "C" void omni_debug_chain_pair(int on) { g_chain_pair = on; }            // positions 0 / 1 + group 1 as a persistent launch (0: the launch path's pair pass)          // timing arm: rstd in the epilogues (not the reference's rounding)      // timing experiment: 1 = half the weight bytes, 2 = half the activation bytes (results garbage)
 static unsigned long long* g_chain_stamps = nullptr;
 // 0: launch per op; 1: one persistent launch per pass (layer stack only); 2: one persistent launch for all passes incl. heads + samplers
 extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on != 0; g_chain_span = on; }
@@ -317,6 +413,40 @@ bool k_cp_chain_supported(const omni_talker_desc& d, int pos) {
 bool k_cp_chain_all_supported(const omni_talker_desc& d, int g0, int greedy, int top_k, float top_p) {
     return g_chain_span >= 2 && k_cp_chain_supported(d, g0) && d.codebook == 2048 && d.cp_proj_table != nullptr && d.cp_lm_head != nullptr &&
            d.num_code_groups <= 16 && (greedy || !(top_p > 0.f && top_p < 1.f) || (top_k > 0 && top_k <= SMP_PCAP));
+}
+
+// positions 0 / 1 of every row + group 1's head and sampler as ONE persistent launch (cp_pair_kernel); supported where the all-pass
+// chain is, with the projected inputs already in the two-block stream (capi.hip run_code_predictor)
+bool k_cp_pair_supported(const omni_talker_desc& d, int B, int greedy, int top_k, float top_p) {
+    return g_chain_pair && k_cp_chain_all_supported(d, 1, greedy, top_k, top_p) && d.cp_layers <= CH_MAX_LAYERS && B >= 1 && ((B + 15) & ~15) + B <= 128;
+}
+int k_cp_pair(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B, int np_in,
+              uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags, int32_t* err, const omni_chain_head* head,
+              void* stream) {
+    ChainArgs a{};
+    for (int l = 0; l < d.cp_layers; ++l) {
+        const omni_layer_weights& w = layers[l];
+        a.layer[l] = ChainLayer{(const uint16_t*)w.ln1, (const uint16_t*)w.wqkv, (const uint16_t*)w.qnorm, (const uint16_t*)w.knorm,
+                                (const uint16_t*)w.wo, (const uint16_t*)w.ln2, (const uint16_t*)w.wgu, (const uint16_t*)w.wdown,
+                                k_cache[l], v_cache[l]};
+    }
+    a.layers = d.cp_layers; a.B = B; a.Bp = (B + 15) & ~15; a.g0 = 0; a.g1 = 2; a.bs = d.num_code_groups + 1; a.np_in = np_in;
+    a.q_heads = d.cp_q_heads; a.kv_heads = d.cp_kv_heads;
+    a.eps = d.eps; a.sm_scale = 1.0f / sqrtf((float)d.cp_head_dim);
+    a.resid = resid; a.part = part; a.qkv = qkv; a.attn = attn; a.act = act;
+    a.cos_sin = (const uint16_t*)d.cp_cos_sin;
+    a.flags = flags; a.err = err;
+    a.with_head = 1;
+    a.cp_norm = (const uint16_t*)d.cp_norm; a.lm_head = (const uint16_t*)d.cp_lm_head;
+    a.logits = head->logits; a.logits_ld = head->logits_ld; a.logits_pass = head->logits_pass;
+    a.greedy = head->greedy; a.top_k = head->top_k; a.Q = d.num_code_groups; a.codebook = d.codebook;
+    a.temperature = head->temperature; a.top_p = head->top_p; a.seed = head->seed;
+    a.steps = head->steps; a.row_seed = head->row_seed; a.codes = head->codes;
+    a.ptab = (const uint16_t*)d.cp_proj_table;
+    a.dom = 8; a.nap = g_chain_nap;
+    hipLaunchKernelGGL(cp_pair_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+    OMNI_CHECK_LAUNCH("cp_pair");
+    return OMNI_OK;
 }
 
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,

@@ -76,6 +76,10 @@ struct omni_chain_head {
     const int32_t* steps; const uint32_t* row_seed;
     int32_t* codes;                                 // [B][Q]
 };
+bool k_cp_pair_supported(const omni_talker_desc& d, int B, int greedy, int top_k, float top_p);
+int k_cp_pair(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B, int np_in,
+              uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags, int32_t* err, const omni_chain_head* head,
+              void* stream);
 bool k_cp_chain_supported(const omni_talker_desc& d, int pos);
 bool k_cp_chain_all_supported(const omni_talker_desc& d, int g0, int greedy, int top_k, float top_p);
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,

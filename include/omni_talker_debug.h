@@ -19,6 +19,7 @@ void omni_debug_bb_chain(int on);                          /* backbone: o_proj -
 void omni_debug_bb_all(int on);                            /* backbone: the whole decoder stack, attention included, as ONE persistent launch (bb_all.hip) */
 void omni_debug_bb_all_stamps(void* buf, int layer);       /* uint64 [8][8][256] timeline stamps of one layer's stages of that launch (NULL: off) */
 void omni_debug_chain_defer(int on);                       /* code-predictor chain A/B arm: RMSNorm rstd applied in the qkv / gate_up epilogues (another rounding point than the reference's; timing + accuracy experiments) */
+void omni_debug_chain_pair(int on);                        /* code predictor: positions 0 / 1 + group 1's head and sampler as one persistent launch (cp_pair_kernel) */
 void omni_debug_chain_skip(int mode);                      /* code-predictor chain timing experiment: 1 = fetch half of every weight slice, 2 = half of the activations (garbage results) */
 void omni_debug_bb_xw(int on);                             /* backbone segment with weights and activations on different waves (bb_xw.hip) */
 void omni_debug_bb_min_rows(int rows);                     /* backbone chain: smallest batch it takes (49: where its tiles are the launch path's) */
