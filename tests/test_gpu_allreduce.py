@@ -85,13 +85,16 @@ def test_missing_peer_times_out_instead_of_hanging():
     out = torch.zeros(4, 256, dtype=BF16, device="cuda")
     ars[0].all_reduce(0, out=out, M=4)               # rank 1 never launches
     torch.cuda.synchronize()
-    assert ars[0].error() == 2                       # 1 + index of the absent peer
+    # 1 + index of the absent peer, + 256 * (1 + the rank that gave up waiting); the wait is bounded by WALL CLOCK (5 s)
+    assert ars[0].error() == 2 + 256 * 1
+    # the word went into EVERY rank's control block, so that the ranks that did see their peers stop in the same step too
+    assert ars[1].error() == 2 + 256 * 1
     import time
     t0 = time.perf_counter()
     for _ in range(50):                              # the error is sticky: later launches do not wait for the dead peer again
         ars[0].all_reduce(0, out=out, M=4)
     torch.cuda.synchronize()
-    assert time.perf_counter() - t0 < 0.5 and ars[0].error() == 2
+    assert time.perf_counter() - t0 < 0.5 and ars[0].error() == 2 + 256
     for a in ars:
         a.close()
 
