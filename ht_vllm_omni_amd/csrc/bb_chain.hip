@@ -131,13 +131,37 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_small_kernel(const BbArgs
                                               true, 0x1004, a.stamps);
 }
 
-OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 49;      // cross-stage prefetch: measured +0.4 ms per step, off
+// ---- the 1.7B shape at 1-32 rows (round 4): the launch path's tiles at those batch sizes -- 16-row tiles for qkv / o_proj / down_proj
+// (128 column tiles x 2 row tiles), gate_up on 16 rows x 24 columns up to 16 rows and 32 x 24 above (the rstd summation order follows the
+// rows per tile: same bits as the launch path).  33-48 rows keep the launch path (its gate_up tile there is 64 rows, its qkv tile 16:
+// 384 tiles for 256 workgroups).
+template <int GU_MT>
+__global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ChainGate g;
+    chain_gate_init(g, a.flags, a.err);
+    g.dom = 8;
+    g.nap = a.nap;
+    const int wg = blockIdx.x;
+    constexpr int H = 2048, I = 6144, NQ = 4096;
+    chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g, false, 0x1001,
+                                              a.stamps);
+    chain_gemm<GU_MT, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, 2, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g, true, 0x1002,
+                                                            a.stamps);
+    chain_gemm<1, 1, 24, 0, OMNI_EPI_RESID, 4>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g, true, 0x1003,
+                                               a.stamps);
+    if (a.wqkv_next)
+        chain_gemm<1, 2, 8, 2, OMNI_EPI_BF16, 4>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
+                                                 true, 0x1004, a.stamps);
+}
+
+OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 49, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
 extern "C" void omni_debug_bb_chain(int on) { g_bb_chain = on != 0; g_bb_prefetch = on == 2; }      // 2: with the cross-stage weight prefetch
 extern "C" void omni_debug_bb_stamps(void* buf) { g_bb_stamps = (unsigned long long*)buf; }
 extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }
-extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; }                          // smallest batch the backbone chain takes                                  // deeper activation / weight rings
+extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; g_bb_b32 = rows <= 49; }                          // smallest batch the backbone chain takes                                  // deeper activation / weight rings
 #endif
 
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
@@ -150,7 +174,7 @@ bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
     const bool common = g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
                         d.head_dim == 128 && d.q_heads * 128 == 2048 && (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B <= 64;
     if (common && k_bb_chain_small(d)) return B >= 1;                          // 0.6B shape: 16-row tiles, every batch size
-    return common && d.hidden == 2048 && d.inter == 6144 && B >= g_bb_min_rows;    // 1.7B shape: the launch path's 32 / 64-row tiles
+    return common && d.hidden == 2048 && d.inter == 6144 && (B >= g_bb_min_rows || (g_bb_b32 && B <= 32));    // 1.7B shape: the launch path's tiles
 }
 bool k_bb_chain_small(const omni_talker_desc& d) { return d.hidden == 1024 && d.inter == 3072; }
 
@@ -175,6 +199,8 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
     }
     static bool attr = false;
     if (!attr) {
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<4, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
@@ -196,6 +222,12 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
     a.stamps = g_bb_stamps;
 #endif
 #define BB_LAUNCH(...) hipLaunchKernelGGL((bb_chain_kernel<__VA_ARGS__>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a)
+    if (B <= 32) {
+        if (B <= 16) hipLaunchKernelGGL((bb_chain_b32_kernel<1>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((bb_chain_b32_kernel<2>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a);
+        OMNI_CHECK_LAUNCH("bb_chain_b32");
+        return OMNI_OK;
+    }
     if (a.pf) BB_LAUNCH(2, 4, 4, true);
     else if (g_bb_deep == 1) BB_LAUNCH(4, 8, 8, false);
     else if (g_bb_deep == 2) BB_LAUNCH(3, 6, 8, false);

@@ -148,6 +148,38 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
         assert torch.equal(x, y), f"KV cache of layer {l} differs"
 
 
+@pytest.mark.parametrize("B,kv", [(32, "fp8"), (23, "bf16"), (16, "fp8"), (9, "int8"), (1, "fp8")])
+def test_backbone_segment_chain_at_1_to_32_rows_against_the_launch_path(B, kv):
+    """Round 4: the 1.7B backbone segment as a persistent launch at 1-32 rows too (csrc/bb_chain.hip bb_chain_b32_kernel: the launch
+    path's tiles at those batch sizes -- 16-row qkv / o / down tiles, gate_up on 16 rows up to 16 and 32 rows above, so the rstd
+    summation order and with it every bit is the launch path's).  Three decode steps: logits, hidden, ids, codes, KV bytes identical;
+    both chains reported as launched."""
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
+    w = make_weights(d, seed=8, std=0.02)
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_bb_chain.argtypes = [C.c_int]; lib.omni_debug_bb_chain.restype = None
+        try:
+            for on in (0, 1):
+                lib.omni_debug_bb_chain(on)
+                eng = _decode_engine(d, w, B, kv)
+                outs = []
+                for _ in range(3):
+                    eng.decode_step(B)
+                    outs.append((eng.logits[:B].clone(), eng.last_hidden[:B].clone(), eng.input_ids[:B].clone(), eng.audio_codes[:B].clone()))
+                torch.cuda.synchronize()
+                assert eng.chain_error() == 0
+                assert eng.chains_ran() == (3 if on else 1), (on, eng.chains_ran())
+                res[on] = (outs, [c.view(torch.uint8).clone() for c in eng.kv_caches])
+        finally:
+            lib.omni_debug_bb_chain(1)
+    for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        for name, x, y in zip(("logits", "hidden", "ids", "codes"), a, b):
+            assert torch.equal(x, y), f"step {s}: {name} differ between the small-batch backbone chain and the launch path"
+    for l, (x, y) in enumerate(zip(res[1][1], res[0][1])):
+        assert torch.equal(x, y), f"KV cache of layer {l} differs"
+
+
 @pytest.mark.parametrize("B", [64, 37, 32, 16, 5, 1])
 def test_backbone_segment_chain_at_the_0p6b_shape_against_the_launch_path(B):
     """BASELINE config #2's backbone (hidden 1024, intermediate 3072: the code predictor's layer dimensions) runs the per-layer
