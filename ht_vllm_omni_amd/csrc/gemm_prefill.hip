@@ -373,7 +373,8 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
     const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
     OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
-    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 2, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
+    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 4, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
+    OMNI_CHECK_ARG(g->tile_hint < 3 || g->N % 256 == 0, "omni_gemm_tile: tile_hint=%d needs N %% 256 == 0", g->tile_hint);
     OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2 && !g->out_f32), "omni_gemm_tile: SiLU-mul takes out only");
     OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
     const int nout = gu8 ? g->N / 2 : g->N;
@@ -408,8 +409,26 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
         const bool small = g->tile_hint == 2 || (g->tile_hint == 0 && big_tiles < 96 && g->N >= 64);
         if (small) return gu8 ? launch_tile<4, 2, 2, true>(a, st, groups) : launch_tile<4, 2, 2, false>(a, st, groups);
     }
-    if (gu8) return N % 256 == 0 ? launch_tile<2, 8, 4, true>(a, st, groups) : launch_tile<1, 8, 4, true>(a, st, groups);
-    if (N % 256 == 0) return launch_tile<2, 8, 4, false>(a, st, groups);
+    // 256-column tiles come in three heights.  One workgroup per CU (the ring takes most of the LDS), so a grid runs in rounds of
+    // 256 tiles and a round costs ~ the tile's rows: 6.4 k prompt tokens x 2048 columns are 208 tiles of 256 rows (one round, 48 CUs
+    // idle) or 232 tiles of 224 rows (one round, 12.5 % shorter).  Same accumulation order in every geometry: bit-identical results.
+    if (N % 256 == 0) {
+        int bm = 256;
+        if (g->tile_hint == 3) bm = 224;
+        else if (g->tile_hint == 4) bm = 192;
+        else if (g->tile_hint == 0 && groups == 1) {
+            long long best = -1;
+            for (int cand : {256, 224, 192}) {
+                const long long tiles = (long long)((g->M + cand - 1) / cand) * (N / 256);
+                const long long cost = ((tiles + 255) / 256) * (cand + 16);
+                if (best < 0 || cost < best) { best = cost; bm = cand; }
+            }
+        }
+        if (bm == 224) return gu8 ? launch_tile<4, 4, 7, true>(a, st, groups) : launch_tile<4, 4, 7, false>(a, st, groups);
+        if (bm == 192) return gu8 ? launch_tile<4, 4, 6, true>(a, st, groups) : launch_tile<4, 4, 6, false>(a, st, groups);
+        return gu8 ? launch_tile<2, 8, 4, true>(a, st, groups) : launch_tile<2, 8, 4, false>(a, st, groups);
+    }
+    if (gu8) return launch_tile<1, 8, 4, true>(a, st, groups);
     if (N % 192 == 0) return launch_tile<2, 6, 4, false>(a, st, groups);
     if (N % 128 == 0) return launch_tile<1, 8, 4, false>(a, st, groups);
     if (N % 96 == 0) return launch_tile<1, 6, 4, false>(a, st, groups);

@@ -40,6 +40,12 @@ def main():
             ta.append(timed(a, 20)); tb.append(timed(b, 20))
         ta, tb = min(ta), min(tb)
         rows.append((f"prefill {name} M={M} N={N} K={K}", ta, tb, flops))
+        if os.environ.get("HINTS", "0") == "1":            # each tile height of the 256-column geometry (1: 256, 3: 224, 4: 192 rows)
+            for hint in (1, 3, 4):
+                h = (lambda hint=hint: ops.gemm_tile(x, wf, act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)) if gu else \
+                    (lambda hint=hint: ops.gemm_tile(x, wf, tile_hint=hint))
+                th = min(timed(h, 20) for _ in range(5))
+                rows.append((f"   {name} tile_hint {hint}", th, tb, flops))
     # Code2Wav decoder shapes at a 325-frame window (T4 = 1300 rows after the 2 x 2 upsample)
     T4 = 1300
     for name, T, Cin, Cout, taps, dil in (("dec.conv7 1024->1536", T4, 1024, 1536, 7, 1), ("blk0 res conv7 768 d3", T4 * 8, 768, 768, 7, 3),

@@ -41,6 +41,10 @@ def test_plain_gemm_every_tile_configuration(M, N, K):
         outs.append(ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), tile_hint=hint))
         _close(outs[-1], ref, mag, f"gemm {M}x{N}x{K} hint {hint}")
     assert torch.equal(outs[0], outs[1])      # same k order per output element in both geometries: bit-identical
+    assert torch.equal(outs[0], outs[2])
+    if N % 256 == 0:                           # the 224- and 192-row tiles of the 256-column geometry
+        for hint in (3, 4):
+            assert torch.equal(outs[0], ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), tile_hint=hint)), hint
 
 
 @pytest.mark.parametrize("Cin,Cout,taps,dil,T", [(96, 96, 7, 1, 700), (96, 96, 7, 9, 531), (192, 192, 7, 3, 400), (512, 1024, 3, 1, 77),
@@ -126,6 +130,9 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     out = ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=1)
     assert out.shape == (M, I)
     assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=2))
+    if (2 * I) % 256 == 0:
+        for hint in (3, 4):
+            assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)), hint
     gu = (x.double() @ w.double().T)
     ga, up = gu[:, :I].float().to(BF16), gu[:, I:].float().to(BF16)
     ref = torch.nn.functional.silu(ga) * up                       # torch bf16 semantics: silu rounds, the product rounds
