@@ -17,7 +17,7 @@
 #include "kernels.h"
 #include "pa_body.cuh"
 
-#define BBA_PAIR_FLOATS (PA_WAVES * 2 * PA_REC + PA_WAVES * 2 * 128 + 256)      // one (row, kv head) pair's attention scratch (G = 2)
+#define BBA_PAIR_FLOATS PA_LDS_FLOATS(2)      // one (row, kv head) pair's attention scratch (G = 2)
 #define BBA_LDS_BYTES ((CH_WAVES * 12 * 64 * 16) + CH_WAVES * 64 * 4)           // the GEMM stages' combine slots (gate_up: 12 tiles in ONE pass) + rstd area
 static_assert(2 * BBA_PAIR_FLOATS * 4 <= BBA_LDS_BYTES, "bb_all: two attention pairs must fit the chain's LDS");
 
@@ -215,7 +215,7 @@ int k_bb_all(const omni_talker_desc& d, const void* table_dev, const omni_step_i
     p.qkv = (const uint16_t*)qkv; p.positions = io->positions; p.rope_delta = io->rope_delta; p.cos_sin = (const uint16_t*)d.cos_sin;
     p.slot_out = io->slot_mapping; p.eps = d.eps;
     p.block_table = io->block_table; p.bt_stride = d.bt_stride; p.seq_lens = io->seq_lens; p.out = (uint16_t*)attn;
-    p.q_heads = d.q_heads; p.kv_heads = d.kv_heads; p.bs = d.block_size;
+    p.q_heads = d.q_heads; p.kv_heads = d.kv_heads; p.bs = d.block_size; p.bs_shift = __builtin_ctz((unsigned)d.block_size);
     p.k_scale = d.k_scale; p.v_scale = d.v_scale; p.sm_scale = 1.0f / sqrtf((float)d.head_dim);
     p.nsplit = 1; p.out_frag = 1; p.kv_rep = 1; p.dense_pos = -1; p.num_live = io->num_live;
     p.rope_rows = io->rope_delta ? (d.rope_rows > 0 ? d.rope_rows : d.max_model_len) : 0;

@@ -205,6 +205,7 @@ static int check_desc(const omni_talker_desc* d) {
     OMNI_CHECK_ARG(d, "omni_talker: null descriptor");
     OMNI_CHECK_ARG(d->head_dim == 128 && d->cp_head_dim == 128, "omni_talker: head_dim must be 128");
     OMNI_CHECK_ARG(d->max_batch >= 1 && d->max_batch <= 64, "omni_talker: max_batch=%d outside 1..64", d->max_batch);
+    OMNI_CHECK_ARG(d->block_size > 0 && (d->block_size & (d->block_size - 1)) == 0, "omni_talker: block_size=%d must be a power of two", d->block_size);
     OMNI_CHECK_ARG(d->num_code_groups >= 1 && d->num_code_groups <= 63, "omni_talker: num_code_groups=%d", d->num_code_groups);
     OMNI_CHECK_ARG(d->hidden % 32 == 0 && d->inter % 32 == 0 && d->cp_hidden % 32 == 0 && d->cp_inter % 32 == 0,
                    "omni_talker: hidden/intermediate sizes must be multiples of 32");

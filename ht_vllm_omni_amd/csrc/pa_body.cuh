@@ -12,6 +12,11 @@
 #define PA_U 4                 // 8-token groups per load batch per wave
 #endif
 #define PA_REC 130             // partial record: [0]=m (log2 domain) [1]=l [2..129]=acc (unnormalised)
+// the pair's LDS scratch, in floats: [PA_WAVES][G][PA_REC] records | q scratch [PA_WAVES][G][128] | new K, V [2][128] | merge images
+// [PA_WAVES][8 token groups][PA_MG_PITCH]
+#define PA_MG_PITCH 132
+#define PA_LDS_MERGE_OFF(G) (PA_WAVES * (G) * PA_REC + PA_WAVES * (G) * 128 + 256)
+#define PA_LDS_FLOATS(G) (PA_LDS_MERGE_OFF(G) + PA_WAVES * 8 * PA_MG_PITCH)
 
 struct PAArgs {
     const uint16_t* q;             // bf16 [rows, Hq*128]           (unfused)
@@ -22,6 +27,8 @@ struct PAArgs {
     const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
     uint16_t* out; float* partial;
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
+    int bs_shift;                  // log2(bs): the paged kernels take power-of-two blocks (vLLM's 8 ... 256) -- token -> (block, offset)
+                                   // by shift and mask; a runtime division cost every (token group, batch) ~20 quarter-rate instructions
     const float* scale_dev;        // fp8 KV: device {k_scale, v_scale} of this layer, read at run time instead of the two launch arguments
                                    // (calibrated scales reach captured graphs this way: omni_talker_set_kv_scales); NULL: the arguments
     int out_frag;                  // output in fragment-major layout (x operand of the o_proj GEMM, K = Hq*128)
@@ -40,8 +47,18 @@ __device__ __forceinline__ int pa_rope_row(const PAArgs& a, int pos, int row) {
     return p;
 }
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// 2^x for x <= 0 (softmax weights and rescale factors): the bare v_exp_f32.  exp2f() wraps it in a range test and a rescale so that
+// results below 2^-126 come out as denormals instead of 0 -- four more instructions per call for weights of 1e-38.
+__device__ __forceinline__ float pa_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 template <int KV>
 struct KVRaw { u32x4 a, b; };   // b: bf16 only (second 8 elements)
+
+// cache row (= [block][offset][kv head]) of token t of a sequence whose block id is blk: 32-bit arithmetic -- 2^32 rows of >= 128 bytes
+// are more than the 288 GB of HBM hold
+__device__ __forceinline__ uint32_t pa_cache_row(const PAArgs& a, int blk, int t, int kvh) {
+    return (((uint32_t)blk << a.bs_shift) | ((uint32_t)t & (uint32_t)(a.bs - 1))) * (uint32_t)a.kv_heads + (uint32_t)kvh;
+}
 
 // element index (0..127) of the e-th value (0..15) held by a lane with sub = lane & 7
 template <int KV>
@@ -121,7 +138,7 @@ __device__ __forceinline__ void pa_pre_blocks(const PAArgs& a, int row, int wave
     const int tg = (threadIdx.x & 63) >> 3;
     const int32_t* bt = a.block_table + (size_t)row * a.bt_stride;
 #pragma unroll
-    for (int u = 0; u < PA_U; ++u) blk[u] = bt[min((wave * 8 + u * PA_WAVES * 8 + tg) / a.bs, a.bt_stride - 1)];
+    for (int u = 0; u < PA_U; ++u) blk[u] = bt[min((wave * 8 + u * PA_WAVES * 8 + tg) >> a.bs_shift, a.bt_stride - 1)];
 }
 template <int KV>
 __device__ __forceinline__ void pa_pre_issue(const PAArgs& a, int kvh, int wave, const int (&blk)[PA_U], PaPre<KV>& pre) {
@@ -129,7 +146,7 @@ __device__ __forceinline__ void pa_pre_issue(const PAArgs& a, int kvh, int wave,
 #pragma unroll
     for (int u = 0; u < PA_U; ++u) {
         const int t_ = wave * 8 + u * PA_WAVES * 8 + tg;
-        const size_t r_ = ((size_t)blk[u] * a.bs + t_ % a.bs) * a.kv_heads + kvh;
+        const size_t r_ = pa_cache_row(a, blk[u], t_, kvh);
         pre.k[u] = load_row<KV>(a.k_cache, r_, sub);
         pre.v[u] = load_row<KV>(a.v_cache, r_, sub);
         if (KV == OMNI_KV_INT8) { pre.ks[u] = a.k_scales[r_]; pre.vs[u] = a.v_scales[r_]; }
@@ -171,8 +188,8 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 #define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
     _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                       \
         const int t_ = min((T0) + u * PA_WAVES * 8 + tg, t_lim);                             \
-        const int bi_ = min(t_ / bs, max_blk);                                               \
-        const size_t r_ = ((size_t)bt[bi_] * bs + t_ % bs) * kv_heads + kvh;                 \
+        const int bi_ = min(t_ >> a.bs_shift, max_blk);                                      \
+        const size_t r_ = pa_cache_row(a, bt[bi_], t_, kvh);                                 \
         KR[u] = load_row<KV>(a.k_cache, r_, sub);                                            \
         VR[u] = load_row<KV>(a.v_cache, r_, sub);                                            \
         if (KV == OMNI_KV_INT8) { KS[u] = a.k_scales[r_]; VS[u] = a.v_scales[r_]; }          \
@@ -198,7 +215,14 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
 
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
-    float qf[G][16];
+    // heads in PAIRS: {head 2p, head 2p + 1} at element e share one 64-bit register pair, so that a K element multiplies both heads in
+    // one v_pk_fma_f32 (the K operand broadcast by op_sel): per head the same chain of FMAs in the same order as a scalar loop
+    constexpr int GP = (G + 1) / 2;
+    f32x2v qf[GP][16];
+    if (G & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qf[GP - 1][e] = (f32x2v){0.f, 0.f};
+    }
     const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;
     float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
@@ -230,28 +254,28 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             for (int g = 0; g < G; ++g) {
                 float y0, y1;
                 head_norm_rope_vals(x0[g], x1[g], a.qnorm_w, cs, a.eps, lane, y0, y1);
-                wq[g * 128 + lane] = y0;
-                wq[g * 128 + 64 + lane] = y1;
+                wq[lane * G + g] = y0;                 // element-major [128][G]: a head pair of one element = one 8-byte read
+                wq[(64 + lane) * G + g] = y1;
             }
         } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float y0, y1;
             head_norm_rope(a.qkv + ((size_t)row * nslots + vh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
-            wq[g * 128 + lane] = y0;
-            wq[g * 128 + 64 + lane] = y1;
+            wq[lane * G + g] = y0;
+            wq[(64 + lane) * G + g] = y1;
         }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) qf[g][e] = wq[g * 128 + elem_of<KV>(sub, e)] * qs;
+            for (int e = 0; e < 16; ++e) qf[g >> 1][e][g & 1] = wq[elem_of<KV>(sub, e) * G + g] * qs;
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const uint16_t* qp = a.q + ((size_t)row * a.q_heads + vh * G + g) * 128;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) qf[g][e] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
+            for (int e = 0; e < 16; ++e) qf[g >> 1][e][g & 1] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
         }
     }
     float m[G], l[G], acc[G][16];
@@ -271,7 +295,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         if (wave == 0 && sp == sp_cur) {
             const int pos = a.positions[row];
             const uint16_t* cs = a.cos_sin + (size_t)pa_rope_row(a, pos, row) * 128;
-            const int64_t slot = (int64_t)bt[min(pos / bs, max_blk)] * bs + pos % bs;
+            const int64_t slot = ((int64_t)bt[min(pos >> a.bs_shift, max_blk)] << a.bs_shift) + (pos & (bs - 1));
             // rows of a padded graph bucket past the live count may be live PREFILL rows of the persistent batch: they
             // compute (results discarded) but leave the cache and the slot record alone
             const bool live = !a.num_live || row < *a.num_live;
@@ -352,13 +376,13 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             for (int g = 0; g < G; ++g) {
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e], kf[e], d);
+                for (int e = 0; e < 16; ++e) d = fmaf(qf[g >> 1][e][g & 1], kf[e], d);
                 d = group8_sum(d);
                 if (KV == OMNI_KV_INT8) d *= ksc_new;
                 if (tg == 0) {
                     const float mn = fmaxf(m[g], d);
-                    const float corr = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mn);
-                    float p = exp2f(d - mn);
+                    const float corr = (m[g] == -INFINITY) ? 0.f : pa_exp2(m[g] - mn);
+                    float p = pa_exp2(d - mn);
                     m[g] = mn;
                     l[g] = l[g] * corr + p;
                     if (KV == OMNI_KV_INT8) p *= vsc_new;
@@ -374,22 +398,39 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         float s_[PA_U][G], mx_[G];                                                                   \
         bool ok_[PA_U];                                                                              \
         _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
+        float r_[PA_U][G];                                                                           \
         _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
             ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
             float kf_[16];                                                                           \
             to_f32<KV>(KR[u], kf_);                                                                  \
+            _Pragma("unroll") for (int p = 0; p < GP; ++p) {                                         \
+                f32x2v dd_ = (f32x2v){0.f, 0.f};                                                     \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                     \
+                    if constexpr (G == 1) dd_[0] = fmaf(qf[p][e][0], kf_[e], dd_[0]);                \
+                    else dd_ = __builtin_elementwise_fma(qf[p][e], (f32x2v){kf_[e], kf_[e]}, dd_);   \
+                }                                                                                    \
+                r_[u][2 * p] = dd_[0];                                                               \
+                if (2 * p + 1 < G) r_[u][2 * p + 1] = dd_[1];                                        \
+            }                                                                                        \
+        }                                                                                            \
+        /* the token's 8 lanes: 3 DPP steps, each over all PA_U * G sums (a DPP read 2 wait states behind its producer: */ \
+        /* step by step the other sums fill them) -- group8_sum's order of additions */              \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_XOR1>(r_[u][g]); \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_XOR2>(r_[u][g]); \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_HALF_MIRROR>(r_[u][g]); \
+        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
-                float d_ = 0.f;                                                                      \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) d_ = fmaf(qf[g][e], kf_[e], d_);      \
-                d_ = group8_sum(d_);       /* 3 DPP steps over the token's 8 lanes */                 \
+                float d_ = r_[u][g];                                                                 \
                 if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
                 d_ = ok_[u] ? d_ : -INFINITY;                                                        \
                 s_[u][g] = d_;                                                                       \
                 mx_[g] = fmaxf(mx_[g], d_);                                                          \
             }                                                                                        \
-        }                                                                                            \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                              \
-            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : exp2f(m[g] - mx_[g]);                 \
+            const float corr_ = (mx_[g] == -INFINITY) ? 1.0f : pa_exp2(m[g] - mx_[g]);                 \
             m[g] = mx_[g];                                                                           \
             l[g] *= corr_;                                                                           \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
@@ -398,7 +439,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             float vf_[16];                                                                           \
             to_f32<KV>(VR[u], vf_);                                                                  \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
-                float p_ = ok_[u] ? exp2f(s_[u][g] - m[g]) : 0.f;                                    \
+                float p_ = ok_[u] ? pa_exp2(s_[u][g] - m[g]) : 0.f;                                    \
                 l[g] += p_;                                                                          \
                 if (KV == OMNI_KV_INT8) p_ *= VS[u];                                                 \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] = fmaf(p_, vf_[e], acc[g][e]); \
@@ -428,35 +469,30 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         float mw = m[g];
         mw = fmaxf(mw, dpp_f<OMNI_DPP_ROR8>(mw));
         mw = xor32_max(xor16_max(mw));
-        const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - mw);
+        const float sc = (m[g] == -INFINITY) ? 0.f : pa_exp2(m[g] - mw);
         float lw = l[g] * sc;
         lw += dpp_f<OMNI_DPP_ROR8>(lw);
         lw = xor32_sum(xor16_sum(lw));
-        // the 16 partial outputs: lane ^ 8 as a DPP step, then two halving exchanges (each lane passes on the half its
-        // partner keeps) -- 12 ds_bpermute instead of 48; the lane ends with elements e0 .. e0 + 3, e0 = 8 b1 + 4 b2
-        float a16[16];
+        // the 16 partial outputs of the 8 token groups meet in this wave's LDS image [token group][128 + 4 (pad: the groups' 16-byte
+        // stores on different banks)]: four 16-byte stores per lane, then lane L sums elements 2 L, 2 L + 1 over the groups as the
+        // balanced tree ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) -- the order of the lane ^ 8 / ^ 16 / ^ 32 butterfly this replaces
+        // (~200 DPP / permlane / select instructions per head), so the bits are unchanged.  A wave's LDS operations execute in order.
+        float* mg = lds + PA_LDS_MERGE_OFF(G) + wave * (8 * PA_MG_PITCH);
+        __builtin_amdgcn_wave_barrier();                                     // the previous head's reads are issued
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v = acc[g][e] * sc;
-            a16[e] = v + dpp_f<OMNI_DPP_ROR8>(v);
-        }
-        const bool b1 = (lane & 16) != 0, b2 = (lane & 32) != 0;
-        float a8[8];
+        for (int c = 0; c < 4; ++c) {
+            f32x4 v4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float keep = b1 ? a16[8 + e] : a16[e];
-            const float send = b1 ? a16[e] : a16[8 + e];
-            a8[e] = keep + xchg16(send, b1);
+            for (int e = 0; e < 4; ++e) v4[e] = acc[g][4 * c + e] * sc;
+            *reinterpret_cast<f32x4*>(mg + tg * PA_MG_PITCH + elem_of<KV>(sub, 4 * c)) = v4;
         }
+        __builtin_amdgcn_wave_barrier();
+        f32x2v t8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) t8[t] = *reinterpret_cast<const f32x2v*>(mg + t * PA_MG_PITCH + 2 * lane);
+        const f32x2v o2 = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
         float* rec = lds + ((size_t)wave * G + g) * PA_REC;
-        const int e0 = (b1 ? 8 : 0) + (b2 ? 4 : 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float keep = b2 ? a8[4 + e] : a8[e];
-            const float send = b2 ? a8[e] : a8[4 + e];
-            const float v = keep + xchg32(send, b2);
-            if ((lane & 8) == 0) rec[2 + elem_of<KV>(sub, e0 + e)] = v;      // lanes ^ 8 hold the same values
-        }
+        *reinterpret_cast<f32x2v*>(rec + 2 + 2 * lane) = o2;
         if (lane == 0) {
             rec[0] = mw;
             rec[1] = lw;
@@ -477,7 +513,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 #pragma unroll
             for (int p = 0; p < PA_WAVES; ++p) {
                 const float* rec = lds + ((size_t)p * G + g) * PA_REC;
-                const float w = (rec[0] == -INFINITY) ? 0.f : exp2f(rec[0] - M);
+                const float w = (rec[0] == -INFINITY) ? 0.f : pa_exp2(rec[0] - M);
                 L = fmaf(rec[1], w, L);
                 A = fmaf(rec[2 + d], w, A);
             }

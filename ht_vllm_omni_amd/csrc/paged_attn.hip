@@ -406,7 +406,7 @@ static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     while (G > max_g && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }
     if (rows * a.kv_heads * a.kv_rep >= 512) a.nsplit = 1;      // the virtual heads already fill the chip: no KV split
     dim3 grid(a.kv_heads * a.kv_rep, rows, a.nsplit), block(PA_THREADS);
-    const size_t lds = ((size_t)PA_WAVES * G * PA_REC + PA_WAVES * G * 128 + 256) * sizeof(float);
+    const size_t lds = (size_t)PA_LDS_FLOATS(G) * sizeof(float);
 #define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
     switch (G) {
         case 1: LAUNCH(1); break;
@@ -431,7 +431,8 @@ static int pa_dispatch(PAArgs& a, int rows, int head_dim, int kv_dtype, bool fus
                    "omni_paged_attn: null q / qkv inputs");
     OMNI_CHECK_ARG(head_dim == 128, "omni_paged_attn: head_dim=%d (only 128)", head_dim);
     OMNI_CHECK_ARG(a.kv_heads > 0 && a.q_heads % a.kv_heads == 0, "omni_paged_attn: q_heads=%d kv_heads=%d", a.q_heads, a.kv_heads);
-    OMNI_CHECK_ARG(a.bs > 0 && a.bt_stride > 0, "omni_paged_attn: block_size=%d bt_stride=%d", a.bs, a.bt_stride);
+    OMNI_CHECK_ARG(a.bs > 0 && (a.bs & (a.bs - 1)) == 0 && a.bt_stride > 0, "omni_paged_attn: block_size=%d (a power of two) bt_stride=%d", a.bs, a.bt_stride);
+    a.bs_shift = __builtin_ctz((unsigned)a.bs);
     OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (a.k_scales && a.v_scales), "omni_paged_attn: int8 needs scale arrays");
     OMNI_CHECK_ARG(a.nsplit == 1 || a.partial, "omni_paged_attn: workspace required for KV splits");
     OMNI_CHECK_ARG(a.k_scale > 0.f && a.v_scale > 0.f, "omni_paged_attn: scales must be > 0");
