@@ -34,6 +34,7 @@ struct PFArgs {
     const void* k_cache; const void* v_cache; const float* k_scales; const float* v_scales;
     const int32_t* block_table; int bt_stride; const int32_t* req_of_tok; const int32_t* positions;
     uint16_t* out; int T, q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int out_frag;
+    int bs_shift;                  // log2(bs): blocks are powers of two (token -> block / offset by shift and mask)
 };
 
 __device__ __forceinline__ f32x4 pf_mfma(u32x4 a, u32x4 b, f32x4 c) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * G) void paged_attn_prefill_mfma_kernel(const P
             for (int it = threadIdx.x; it < PF_BN * CH; it += NT) {
                 const int kk = it / CH, ch = it - kk * CH;
                 const int key = min(k0 + kk, nkeys - 1);           // tail keys: valid address, masked below
-                const size_t row = ((size_t)bt[key / a.bs] * a.bs + key % a.bs) * a.kv_heads + kvh;
+                const size_t row = (((size_t)bt[key >> a.bs_shift] << a.bs_shift) + (key & (a.bs - 1))) * a.kv_heads + kvh;
                 pf_stage<KV>(sK + kk * PF_ROWB, a.k_cache, row, ch);
                 pf_stage<KV>(sV + kk * PF_ROWB, a.v_cache, row, ch);
                 if (KV == OMNI_KV_INT8 && ch == 0) { sKs[kk] = a.k_scales[row]; sVs[kk] = a.v_scales[row]; }
@@ -244,13 +245,13 @@ int k_prefill_mfma(const void* q, const void* k_cache, const void* v_cache, cons
                    int T, int q_heads, int kv_heads, int block_size, int kv_dtype, float k_scale, float v_scale, float sm_scale,
                    int out_frag, void* stream) {
     OMNI_CHECK_ARG(q && k_cache && v_cache && block_table && req_of_tok && positions && out, "omni_paged_attn_prefill: null pointer");
-    OMNI_CHECK_ARG(block_size > 0 && bt_stride > 0, "omni_paged_attn_prefill: block_size / bt_stride");
+    OMNI_CHECK_ARG(block_size > 0 && (block_size & (block_size - 1)) == 0 && bt_stride > 0, "omni_paged_attn_prefill: block_size=%d (a power of two) / bt_stride", block_size);
     OMNI_CHECK_ARG(kv_dtype != OMNI_KV_INT8 || (k_scales && v_scales), "omni_paged_attn_prefill: int8 KV needs scales");
     if (T <= 0) return OMNI_OK;
     PFArgs a{};
     a.q = (const uint16_t*)q; a.k_cache = k_cache; a.v_cache = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
     a.block_table = block_table; a.bt_stride = bt_stride; a.req_of_tok = req_of_tok; a.positions = positions;
-    a.out = (uint16_t*)out; a.T = T; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size;
+    a.out = (uint16_t*)out; a.T = T; a.q_heads = q_heads; a.kv_heads = kv_heads; a.bs = block_size; a.bs_shift = __builtin_ctz((unsigned)block_size);
     a.k_scale = k_scale; a.v_scale = v_scale; a.sm_scale = sm_scale; a.out_frag = out_frag;
     const int G = q_heads / kv_heads;
     hipStream_t st = (hipStream_t)stream;

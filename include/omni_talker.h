@@ -21,6 +21,8 @@
  *     [2][num_blocks][block_size][n_kv_heads][head_dim]  (+ for INT8 a float
  *     scale array [2][num_blocks][block_size][n_kv_heads])
  * slot = block_table[row][pos / block_size] * block_size + pos % block_size.
+ * block_size is a power of two (vLLM's 8 ... 256): the attention kernels split a position by shift and mask and refuse
+ * any other value.
  */
 #ifndef OMNI_TALKER_H
 #define OMNI_TALKER_H
