@@ -216,7 +216,12 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
     // heads in PAIRS: {head 2p, head 2p + 1} at element e share one 64-bit register pair, so that a K element multiplies both heads in
-    // one v_pk_fma_f32 (the K operand broadcast by op_sel): per head the same chain of FMAs in the same order as a scalar loop
+    // one v_pk_fma_f32 (the K operand broadcast by op_sel): per head the same chain of FMAs in the same order as a scalar loop.
+    // THE BROADCAST OPERAND GOES FIRST (src0).  Written as fma(q pair, k splat, acc) hipcc put the splat -- a register pair fresh
+    // out of v_cvt_pk_f32_fp8 -- into src1 with op_sel (op_sel:[0,1,0] / op_sel_hi:[1,0,1]); that build was bit-stable alone on the GPU
+    // and gave DIFFERENT low bits next to another process's kernels (tests/test_gpu_colocation.py; scripts/coloc_probe.py: 4 of 4
+    // runs diverged within 10 steps; the scalar, the dim-paired and this src0 form: 0 of 6).  Not root-caused (no erratum list here);
+    // tests/test_build_rules.py keeps the src1 form out of the attention kernels.
     constexpr int GP = (G + 1) / 2;
     f32x2v qf[GP][16];
     if (G & 1) {
@@ -407,7 +412,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
                 f32x2v dd_ = (f32x2v){0.f, 0.f};                                                     \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                     \
                     if constexpr (G == 1) dd_[0] = fmaf(qf[p][e][0], kf_[e], dd_[0]);                \
-                    else dd_ = __builtin_elementwise_fma(qf[p][e], (f32x2v){kf_[e], kf_[e]}, dd_);   \
+                    else dd_ = __builtin_elementwise_fma((f32x2v){kf_[e], kf_[e]}, qf[p][e], dd_);   \
                 }                                                                                    \
                 r_[u][2 * p] = dd_[0];                                                               \
                 if (2 * p + 1 < G) r_[u][2 * p + 1] = dd_[1];                                        \

@@ -368,8 +368,8 @@ __global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __re
     for (int s = 0; s < nsplit; ++s) {
         const float* rec = base + s * PA_REC;
         const float w = (rec[0] == -INFINITY) ? 0.f : exp2f(rec[0] - M);
-        L = fmaf(rec[1], w, L);
-        A = fmaf(rec[2 + d], w, A);
+        L = fmaf(w, rec[1], L);           // (the shared factor FIRST: see the note on packed FMAs in pa_body.cuh)
+        A = fmaf(w, rec[2 + d], A);
     }
     const int row = (int)(rh / q_heads), qh = (int)(rh % q_heads);
     out[out_frag ? frag_off(row, qh * 128 + d, q_heads * 128) : rh * 128 + d] = f2bf(L > 0.f ? (A / L) * v_mul : 0.f);
