@@ -18,23 +18,26 @@ pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
 
 
-def _code2wav_loop(ready, stop, count):
+def _code2wav_loop(ready, stop, count, unstable=None):
     import torch as T
     from ht_vllm_omni_amd.code2wav import Code2WavDecoder
     from tests.codec_util import FULL_CODEC, make_codec_state
     T.cuda.set_device(0)
     dec = Code2WavDecoder(FULL_CODEC, make_codec_state(FULL_CODEC, 0, device="cuda"))
     codes = T.randint(0, 2048, (1, 16, 50), device="cuda")
-    dec(codes)
+    first = dec(codes).clone()
     T.cuda.synchronize()
     ready.set()
-    n = 0
+    n = bad = 0
     while not stop.is_set():
         for _ in range(4):
-            dec(codes)
+            out = dec(codes)
+        bad += int(not T.equal(out, first))          # the vocoder's own bits beside the talker's kernels
         T.cuda.synchronize()
         n += 4
     count.value = n
+    if unstable is not None:
+        unstable.value = bad
 
 
 def _replay(d, w, B, steps):
@@ -98,3 +101,49 @@ def test_chained_steps_beside_a_code2wav_process_on_the_same_gpu():
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/colocation.json", "w"), indent=1)
     print(rep)
+
+
+def _prefill_once(d, w, T_tok, reqs):
+    """The all-tokens prefill (omni_gemm_tile, the MFMA prefill attention, norm / RoPE / KV-write kernels) of `reqs` equal prompts."""
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=reqs * (T_tok // 16 + 2) + 2, max_batch=64)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(reqs * T_tok, d.hidden, generator=g) * 0.5).to(BF16).cuda()
+    pos = torch.arange(T_tok, dtype=torch.int32).repeat(reqs).cuda()
+    req = torch.arange(reqs, dtype=torch.int32).repeat_interleave(T_tok).cuda()
+    nb = T_tok // 16 + 1
+    for b in range(reqs):
+        eng.block_table[b, :nb] = torch.arange(1 + nb * b, 1 + nb * (b + 1), dtype=torch.int32)
+    slots = (eng.block_table[req.long(), (pos // 16).long()].long() * 16 + (pos % 16).long())
+    outs = []
+    for _ in range(6):
+        outs.append(eng.prefill(x, pos, req, slots, use_blas=True).clone())
+    torch.cuda.synchronize()
+    kv = [c.clone() for c in eng.kv_caches]
+    return outs, kv
+
+
+@pytest.mark.timeout(900)
+def test_prefill_and_vocoder_bits_beside_each_other():
+    """The same question for the rest of the path: the all-tokens prefill repeated beside the looping Code2Wav process gives
+    the solo run's bits (hidden states and every KV byte), and the vocoder's windows keep THEIR bits meanwhile."""
+    import torch.multiprocessing as mp
+    d = get_dims("tts-1.7b").with_(layers=4, max_model_len=1024)
+    w = make_weights(d, seed=4, std=0.02)
+    solo, kv0 = _prefill_once(d, w, 96, 32)
+    assert all(torch.equal(solo[0], o) for o in solo[1:]), "the prefill is not run-to-run stable even alone"
+    ctx = mp.get_context("spawn")
+    ready, stop, count, unstable = ctx.Event(), ctx.Event(), ctx.Value("i", 0), ctx.Value("i", -1)
+    child = ctx.Process(target=_code2wav_loop, args=(ready, stop, count, unstable))
+    child.start()
+    try:
+        assert ready.wait(300), "the code2wav process did not come up"
+        both, kv1 = _prefill_once(d, w, 96, 32)
+        _replay(d, w, 64, 200)                       # keep the talker busy for a while longer: the vocoder checks itself meanwhile
+    finally:
+        stop.set()
+        child.join(120)
+    assert child.exitcode == 0 and count.value > 0
+    assert all(torch.equal(solo[0], o) for o in both), "prefill hidden states differ beside the code2wav process"
+    assert all(torch.equal(a, b) for a, b in zip(kv0, kv1)), "prefill KV bytes differ beside the code2wav process"
+    assert unstable.value == 0, f"{unstable.value} code2wav windows differed from the first one while the talker ran"
