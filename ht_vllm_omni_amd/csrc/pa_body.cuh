@@ -220,8 +220,9 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     // THE BROADCAST OPERAND GOES FIRST (src0).  Written as fma(q pair, k splat, acc) hipcc put the splat -- a register pair fresh
     // out of v_cvt_pk_f32_fp8 -- into src1 with op_sel (op_sel:[0,1,0] / op_sel_hi:[1,0,1]); that build was bit-stable alone on the GPU
     // and gave DIFFERENT low bits next to another process's kernels (tests/test_gpu_colocation.py; scripts/coloc_probe.py: 4 of 4
-    // runs diverged within 10 steps; the scalar, the dim-paired and this src0 form: 0 of 6).  Not root-caused (no erratum list here);
-    // tests/test_build_rules.py keeps the src1 form out of the attention kernels.
+    // runs diverged within 10 steps; the scalar, the dim-paired and this src0 form: 0 of 18).  Not root-caused: the instruction forms alone
+    // (scripts/probes/pkfma_src1.hip) and NaN-poisoned registers / LDS (scripts/probes/attn_poison_probe.py) do not reproduce it.
+    // tests/test_build_rules.py keeps the src1 form out of the attention kernels; tests/test_gpu_colocation.py is the detector.
     constexpr int GP = (G + 1) / 2;
     f32x2v qf[GP][16];
     if (G & 1) {
