@@ -214,21 +214,16 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     t_lim = max(t_end - 1, 0);
     if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
 
-    // ---- q for the G heads of this kv head, pre-scaled into the log2 domain
-    // heads in PAIRS: {head 2p, head 2p + 1} at element e share one 64-bit register pair, so that a K element multiplies both heads in
-    // one v_pk_fma_f32 (the K operand broadcast by op_sel): per head the same chain of FMAs in the same order as a scalar loop.
-    // THE BROADCAST OPERAND GOES FIRST (src0).  Written as fma(q pair, k splat, acc) hipcc put the splat -- a register pair fresh
-    // out of v_cvt_pk_f32_fp8 -- into src1 with op_sel (op_sel:[0,1,0] / op_sel_hi:[1,0,1]); that build was bit-stable alone on the GPU
-    // and gave DIFFERENT low bits next to another process's kernels (tests/test_gpu_colocation.py; scripts/coloc_probe.py: 4 of 4
-    // runs diverged within 10 steps; the scalar, the dim-paired and this src0 form: 0 of 18).  Not root-caused: the instruction forms alone
-    // (scripts/probes/pkfma_src1.hip) and NaN-poisoned registers / LDS (scripts/probes/attn_poison_probe.py) do not reproduce it.
-    // tests/test_build_rules.py keeps the src1 form out of the attention kernels; tests/test_gpu_colocation.py is the detector.
-    constexpr int GP = (G + 1) / 2;
-    f32x2v qf[GP][16];
-    if (G & 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) qf[GP - 1][e] = (f32x2v){0.f, 0.f};
-    }
+    // ---- q for the G heads of this kv head, pre-scaled into the log2 domain, as PAIRS OF ADJACENT DIMENSIONS: a head's QK product is 8
+    // v_pk_fma_f32 on {k[2i], k[2i+1]} x {q[2i], q[2i+1]} (even dims in the low half, odd in the high half, one add at the end) -- both
+    // operands are natural register pairs (K straight out of v_cvt_pk_f32_fp8, q out of a 16-byte LDS read): NO op_sel.
+    // Why not two heads per FMA with the K element broadcast by op_sel (tried first: the scalar loop's bits, same count): hipcc let the
+    // destination pair overlap the broadcast source pair, and beside another process's kernels the LOW half then came out as garbage
+    // in ~10 % of the launches (even heads only, |error| up to the fp8 range; never alone on the GPU, never with NaN-poisoned
+    // registers / LDS, never in a micro-kernel of the same instructions: scripts/probes/*, NOTEBOOK "Round 4").  A packed fp32
+    // operation whose destination overlaps a source that the OTHER half reads through op_sel is kept out of these kernels
+    // (tests/test_build_rules.py); tests/test_gpu_colocation.py is the detector.
+    f32x2v qf[G][8];
     const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;
     float* wq = lds + PA_WAVES * G * PA_REC + wave * (G * 128);
@@ -260,28 +255,28 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             for (int g = 0; g < G; ++g) {
                 float y0, y1;
                 head_norm_rope_vals(x0[g], x1[g], a.qnorm_w, cs, a.eps, lane, y0, y1);
-                wq[lane * G + g] = y0;                 // element-major [128][G]: a head pair of one element = one 8-byte read
-                wq[(64 + lane) * G + g] = y1;
+                wq[g * 128 + lane] = y0 * qs;          // (scaled here, one scalar multiply each: the read side stays free of packed
+                wq[g * 128 + 64 + lane] = y1 * qs;     //  multiplies whose destination would overlap their broadcast operand)
             }
         } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float y0, y1;
             head_norm_rope(a.qkv + ((size_t)row * nslots + vh * G + g) * 128, a.qnorm_w, cs, a.eps, lane, y0, y1);
-            wq[lane * G + g] = y0;
-            wq[(64 + lane) * G + g] = y1;
+            wq[g * 128 + lane] = y0 * qs;
+            wq[g * 128 + 64 + lane] = y1 * qs;
         }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) qf[g >> 1][e][g & 1] = wq[elem_of<KV>(sub, e) * G + g] * qs;
+            for (int e = 0; e < 16; ++e) qf[g][e >> 1][e & 1] = wq[g * 128 + elem_of<KV>(sub, e)];
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const uint16_t* qp = a.q + ((size_t)row * a.q_heads + vh * G + g) * 128;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) qf[g >> 1][e][g & 1] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
+            for (int e = 0; e < 16; ++e) qf[g][e >> 1][e & 1] = bf2f(qp[elem_of<KV>(sub, e)]) * qs;
         }
     }
     float m[G], l[G], acc[G][16];
@@ -382,7 +377,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             for (int g = 0; g < G; ++g) {
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d = fmaf(qf[g >> 1][e][g & 1], kf[e], d);
+                for (int e = 0; e < 16; ++e) d = fmaf(qf[g][e >> 1][e & 1], kf[e], d);
                 d = group8_sum(d);
                 if (KV == OMNI_KV_INT8) d *= ksc_new;
                 if (tg == 0) {
@@ -409,14 +404,11 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
             float kf_[16];                                                                           \
             to_f32<KV>(KR[u], kf_);                                                                  \
-            _Pragma("unroll") for (int p = 0; p < GP; ++p) {                                         \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
                 f32x2v dd_ = (f32x2v){0.f, 0.f};                                                     \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                     \
-                    if constexpr (G == 1) dd_[0] = fmaf(qf[p][e][0], kf_[e], dd_[0]);                \
-                    else dd_ = __builtin_elementwise_fma((f32x2v){kf_[e], kf_[e]}, qf[p][e], dd_);   \
-                }                                                                                    \
-                r_[u][2 * p] = dd_[0];                                                               \
-                if (2 * p + 1 < G) r_[u][2 * p + 1] = dd_[1];                                        \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i)                                        \
+                    dd_ = __builtin_elementwise_fma(qf[g][i], (f32x2v){kf_[2 * i], kf_[2 * i + 1]}, dd_); \
+                r_[u][g] = dd_[0] + dd_[1];                                                          \
             }                                                                                        \
         }                                                                                            \
         /* the token's 8 lanes: 3 DPP steps, each over all PA_U * G sums (a DPP read 2 wait states behind its producer: */ \

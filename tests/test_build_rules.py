@@ -1,10 +1,14 @@
 """Build rules the GPU found the hard way, checked on the CPU by cross-compiling to gfx950 assembly.
 
-Rule 1 (round 4): no `v_pk_fma_f32` of the attention kernels takes a BROADCAST VGPR pair in src1.  The decode attention's QK
-product packs two heads per FMA with the K element broadcast by op_sel; with the splat in src1 (op_sel:[0,1,0] /
-op_sel_hi:[1,0,1] on a pair fresh out of v_cvt_pk_f32_fp8) the kernel was bit-stable alone on the GPU and produced different low
-bits beside another process's kernels (tests/test_gpu_colocation.py; scripts/coloc_probe.py), with the same arithmetic and the
-splat in src0 it is stable.  The operand order in pa_body.cuh decides which form hipcc emits: this test keeps it decided."""
+Rule 1 (round 4): in the attention kernels no packed fp32 operation (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) has a destination
+pair that overlaps a source pair whose HIGH dword the LOW half reads through op_sel (nor a destination that overlaps a source pair
+by one register).  The decode attention's QK product once packed two
+heads per FMA with the K element broadcast by op_sel; hipcc let the destination overlap the broadcast source, and that build --
+bit-stable alone on the GPU, parity-green -- produced garbage in the LOW half in ~10 % of the launches beside another process's
+kernels (tests/test_gpu_colocation.py; scripts/probes/attn_coloc_probe.py).  The QK product now pairs adjacent dimensions (no
+selector at all); this test keeps the pattern from coming back through a later edit or a compiler's register allocation.
+(The mirror pattern -- the HIGH half reading the low dword of an overlapping source, op_sel_hi = 0 -- is what hipcc makes of
+scalar-times-pair code all over these kernels since round 2; it has never shown the effect, alone or co-located, and is allowed.)"""
 import os
 import re
 import shutil
@@ -24,31 +28,41 @@ def _asm(name, tmp_path):
     return open(out).read().split("\n")
 
 
-def _src1_broadcasts(lines):
+def _cross_half_overlaps(lines):
+    """(kernel, instruction) of every packed fp32 op whose destination pair is a VGPR source pair of which the LOW lane reads the
+    high dword (op_sel[i] = 1), or overlaps a source pair by one register."""
     bad = []
     kernel = None
     for l in lines:
         k = re.match(r"^(_Z\S+):", l)
         if k:
             kernel = k.group(1)
-        m = re.match(r"\s*v_pk_fma_f32 \S+, \S+, (\S+?), \S+?(?: (op_sel.*))?$", l.rstrip())
-        if not m or not m.group(1).startswith("v["):
+        m = re.match(r"\s*v_pk_(?:fma|mul|add)_f32 v\[(\d+):(\d+)\], (.*)$", l.rstrip())
+        if not m:
             continue
-        mods = m.group(2) or ""
+        d0 = int(m.group(1))
+        rest = m.group(3)
+        mods = rest[rest.index("op_sel"):] if "op_sel" in rest else ""
+        srcs = [t.strip() for t in (rest[:rest.index("op_sel")] if mods else rest).split(",") if t.strip()]
         sel, sel_hi = [0, 0, 0], [1, 1, 1]
         for name, dst in (("op_sel", sel), ("op_sel_hi", sel_hi)):
             mm = re.search(name + r":\[([0-9,]+)\]", mods)
             if mm:
                 v = [int(x) for x in mm.group(1).split(",")]
                 dst[:len(v)] = v
-        if sel[1] == sel_hi[1]:                      # both halves read the same dword of src1
-            bad.append((kernel, l.strip()))
+        for i, t in enumerate(srcs[:3]):
+            ms = re.match(r"v\[(\d+):(\d+)\]", t)
+            if not ms:
+                continue
+            s0 = int(ms.group(1))
+            if (s0 == d0 and sel[i] == 1) or abs(s0 - d0) == 1:
+                bad.append((kernel, l.strip()))
     return bad
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-def test_attention_kernels_keep_packed_fma_broadcasts_out_of_src1(tmp_path):
+def test_attention_kernels_have_no_packed_op_overlapping_a_cross_read_source(tmp_path):
     lines = _asm("paged_attn.hip", str(tmp_path))
     assert sum("v_pk_fma_f32" in l for l in lines) > 500, "the packed QK / PV products are gone: the rule has nothing to check"
-    bad = _src1_broadcasts(lines)
-    assert not bad, f"{len(bad)} v_pk_fma_f32 with a broadcast VGPR pair in src1, e.g. {bad[:3]}"
+    bad = _cross_half_overlaps(lines)
+    assert not bad, f"{len(bad)} packed fp32 ops whose destination overlaps a source read across halves, e.g. {bad[:4]}"

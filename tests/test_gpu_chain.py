@@ -134,7 +134,9 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
             lib.omni_debug_bb_deep(0)
     if mode == "ping-pong":
         (lg1, h1, ids1, _), (lg0, h0, ids0, _) = res[1][0][0], res[0][0][0]
-        assert_e2e_close(h1.cpu(), h0.cpu(), mean_tol=3e-3, max_ulps=3, what="two-group chain vs launch path: hidden, step 0")
+        # (the two 32-row groups run the attention with KV splits, the 64-row launch path without: another order of additions.  The
+        #  bound is on rounding-level agreement, widened from 3 to 4 ulps when the QK product went to dimension pairs in round 4)
+        assert_e2e_close(h1.cpu(), h0.cpu(), mean_tol=3e-3, max_ulps=4, what="two-group chain vs launch path: hidden, step 0")
         fin = torch.isfinite(lg0.cpu()).all(0)
         assert_e2e_close(lg1.cpu()[:, fin], lg0.cpu()[:, fin], mean_tol=3e-3, max_ulps=8, what="two-group chain vs launch path: logits, step 0")
         assert (ids1 == ids0).float().mean().item() >= 0.9
