@@ -73,16 +73,21 @@ def _replay(d, w, B, steps, kv="fp8"):
 
 # every KV storage type has its own K / V conversion code in the attention kernel, and 16 q / 4 kv heads run the four-heads-per-
 # workgroup instantiation (on the launch path: the chains take the 1.7B head counts only)
-@pytest.mark.parametrize("kv,kv_heads,chains", [("fp8", 8, 3), ("bf16", 8, 3), ("int8", 8, 3), ("fp16", 8, 3), ("fp8", 4, 1)])
+# ...; "moe": the Omni talker's sparse-MoE backbone (router, route, expert and combine kernels; 16 q / 2 kv heads) at 3 layers
+@pytest.mark.parametrize("kv,kv_heads,chains", [("fp8", 8, 3), ("bf16", 8, 3), ("int8", 8, 3), ("fp16", 8, 3), ("fp8", 4, 1), ("int8", "moe", None)])
 @pytest.mark.timeout(900)
 def test_chained_steps_beside_a_code2wav_process_on_the_same_gpu(kv, kv_heads, chains):
     import json
     import os
     import torch.multiprocessing as mp
-    d = get_dims("tts-1.7b").with_(layers=4, max_model_len=1024, kv_heads=kv_heads)
+    if kv_heads == "moe":
+        d = get_dims("omni-talker").with_(layers=3, max_model_len=1024)
+    else:
+        d = get_dims("tts-1.7b").with_(layers=4, max_model_len=1024, kv_heads=kv_heads)
     w = make_weights(d, seed=4, std=0.02)
     B, steps = 64, 500 if (kv, kv_heads) == ("fp8", 8) else 200
     solo, st0, ms0, err0, ran0 = _replay(d, w, B, steps, kv)
+    chains = ran0 if chains is None else chains
     assert err0 == 0 and ran0 == chains and int(st0[:, :2].abs().sum()) == 0
     ctx = mp.get_context("spawn")
     ready, stop, count = ctx.Event(), ctx.Event(), ctx.Value("i", 0)
