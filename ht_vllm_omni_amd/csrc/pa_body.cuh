@@ -217,12 +217,12 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain, as PAIRS OF ADJACENT DIMENSIONS: a head's QK product is 8
     // v_pk_fma_f32 on {k[2i], k[2i+1]} x {q[2i], q[2i+1]} (even dims in the low half, odd in the high half, one add at the end) -- both
     // operands are natural register pairs (K straight out of v_cvt_pk_f32_fp8, q out of a 16-byte LDS read): NO op_sel.
-    // Why not two heads per FMA with the K element broadcast by op_sel (tried first: the scalar loop's bits, same count): hipcc let the
-    // destination pair overlap the broadcast source pair, and beside another process's kernels the LOW half then came out as garbage
-    // in ~10 % of the launches (even heads only, |error| up to the fp8 range; never alone on the GPU, never with NaN-poisoned
-    // registers / LDS, never in a micro-kernel of the same instructions: scripts/probes/*, NOTEBOOK "Round 4").  A packed fp32
-    // operation whose destination overlaps a source that the OTHER half reads through op_sel is kept out of these kernels
-    // (tests/test_build_rules.py); tests/test_gpu_colocation.py is the detector.
+    // Why not two heads per FMA with the K element broadcast by op_sel (tried first: the scalar loop's bits, same count): hipcc read
+    // the odd K elements as "high dword of src1 into the low lane" (op_sel:[0,1,0]).  On this GPU that selector -- and only that one, for
+    // v_pk_fma_f32 and v_pk_mul_f32 alike -- returns wrong results ~4 times per million executions WHILE ANOTHER PROCESS'S KERNELS
+    // RUN BESIDE THE WAVE, and never alone (scripts/probes/pkfma_src1.hip, profiles/r04_pkfma_probe.txt): the attention was
+    // parity-green and bit-stable alone and gave garbage in one head of a pair in ~10 % of its launches beside the vocoder
+    // (tests/test_gpu_colocation.py caught it; NOTEBOOK "Round 4").  tests/test_build_rules.py keeps op_sel[1] = 1 out of every kernel.
     f32x2v qf[G][8];
     const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;
