@@ -219,10 +219,12 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     // operands are natural register pairs (K straight out of v_cvt_pk_f32_fp8, q out of a 16-byte LDS read): NO op_sel.
     // Why not two heads per FMA with the K element broadcast by op_sel (tried first: the scalar loop's bits, same count): hipcc read
     // the odd K elements as "high dword of src1 into the low lane" (op_sel:[0,1,0]).  On this GPU that selector -- and only that one, for
-    // v_pk_fma_f32 and v_pk_mul_f32 alike -- returns wrong results ~4 times per million executions WHILE ANOTHER PROCESS'S KERNELS
-    // RUN BESIDE THE WAVE, and never alone (scripts/probes/pkfma_src1.hip, profiles/r04_pkfma_probe.txt): the attention was
-    // parity-green and bit-stable alone and gave garbage in one head of a pair in ~10 % of its launches beside the vocoder
-    // (tests/test_gpu_colocation.py caught it; NOTEBOOK "Round 4").  tests/test_build_rules.py keeps op_sel[1] = 1 out of every kernel.
+    // v_pk_fma_f32 and v_pk_mul_f32 alike -- returns wrong results WHILE ANOTHER WAVE ON THE SIMD ISSUES MFMAs (5 % of the executions
+    // beside a pure MFMA loop; ~4 per million beside the vocoder's GEMMs; never beside loads, LDS traffic, LDS-DMA or VALU-only
+    // kernels: scripts/probes/pkfma_src1.hip + aggressor.hip, profiles/r04_pkfma_probe.txt).  This kernel has no MFMA and a stream runs
+    // one kernel at a time, so the attention was parity-green and bit-stable alone -- and gave garbage in one head of a pair in ~10 %
+    // of its launches beside the Code2Wav process (tests/test_gpu_colocation.py caught it; NOTEBOOK "Round 4").
+    // tests/test_build_rules.py keeps op_sel[1] = 1 out of every kernel.
     f32x2v qf[G][8];
     const float qs = a.sm_scale * LOG2E * (KV == OMNI_KV_FP8 ? k_scale : 1.0f);
     const int nslots = a.q_heads + 2 * kv_heads;

@@ -3,8 +3,10 @@
 Rule 1 (round 4): no packed fp32 operation (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) reads the HIGH dword of a VGPR src1 pair in
 its LOW lane (op_sel[1] = 1).  Measured on MI355X (scripts/probes/pkfma_src1.hip, profiles/r04_pkfma_probe.txt): every broadcast
 form of these instructions -- src0 / src1 / src2, low or high dword -- agrees with the scalar instruction on 1e12 executions when
-the process is alone on the GPU; beside another process's kernels (the Code2Wav loop of tests/test_gpu_colocation.py) exactly the
-two forms with op_sel[1] = 1 return wrong results, ~4 per million executions, all the others still none.  The decode attention's
+the process is alone on the GPU; while ANOTHER WAVE ON THE SAME SIMD ISSUES MFMAs (another process's GEMM: the Code2Wav loop of
+tests/test_gpu_colocation.py, or a bare MFMA loop: scripts/probes/aggressor.hip) exactly the two forms with op_sel[1] = 1 return wrong
+results -- 5 % of the executions beside the bare loop, ~4 per million beside the vocoder -- and all the others still none; loads, LDS
+traffic, LDS-DMA and VALU-only neighbours do nothing.  The decode attention's
 first packed QK product (two heads per FMA, K broadcast from the high dword of src1) hit it: parity-green and bit-stable alone,
 garbage in one head of a pair in ~10 % of its launches beside the vocoder (scripts/probes/attn_coloc_probe.py).  hipcc chooses the
 operand order and the selector: this test keeps the form out of every kernel of the library."""
