@@ -3,10 +3,10 @@
 cd "$GRAFT_REPO_ROOT"
 hipcc --offload-arch=gfx950 -O2 -o /tmp/pkfma_src1 scripts/probes/pkfma_src1.hip 2>/dev/null || exit 1
 hipcc --offload-arch=gfx950 -O2 -o /tmp/aggressor scripts/probes/aggressor.hip 2>/dev/null || exit 1
-for mode in ldsdma mfma setprio lds vmem; do
+for mode in ${MODES:-ldsdma mfma setprio lds vmem}; do
   /tmp/aggressor $mode 14 > /tmp/agg_$mode.txt 2>&1 &
   co=$!
   sleep 4
-  echo "== beside: $mode"; /tmp/pkfma_src1 6 | grep "launches\|src1 high"
+  echo "== beside: $mode"; /tmp/pkfma_src1 6 
   wait $co; cat /tmp/agg_$mode.txt
 done
