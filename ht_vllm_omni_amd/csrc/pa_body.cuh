@@ -179,14 +179,17 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 
     // ---- batch 0 of K/V loads goes out before anything else is known (speculative: tokens past the
     // sequence end resolve to whatever block the table holds there -- block 0, the null block)
-    KVRaw<KV> k0[PA_U], v0[PA_U], k1[PA_U], v1[PA_U];
-    float ks0[PA_U], vs0[PA_U], ks1[PA_U], vs1[PA_U];
+    // token groups per load batch: 4 (PA_U), or 2 where four would push the instantiation past 256 registers and down to ONE wave per
+    // SIMD -- the 16-bit caches (a row is two 16-byte loads per lane) with two or more heads, and every four-head instantiation
+    constexpr int U = (!CHAIN && ((OMNI_KV_IS16(KV) && G >= 2) || G >= 4)) ? 2 : PA_U;
+    KVRaw<KV> k0[U], v0[U], k1[U], v1[U];
+    float ks0[U], vs0[U], ks1[U], vs1[U];
     // token groups past the end of the history re-read its LAST row (one hot line) instead of whatever block the table
     // holds further on: with blocks allocated ahead of the sequence those were real, cold HBM rows -- up to 127 tokens of
     // wasted traffic per (row, head).  The speculative batch 0 goes out before the length is known and stays unclamped.
     int t_lim = 0x7FFFFFFF;
 #define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
-    _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                       \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                       \
         const int t_ = min((T0) + u * PA_WAVES * 8 + tg, t_lim);                             \
         const int bi_ = min(t_ >> a.bs_shift, max_blk);                                      \
         const size_t r_ = pa_cache_row(a, bt[bi_], t_, kvh);                                 \
@@ -198,7 +201,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     PA_STAMP(0);
     if (pre != nullptr) {
 #pragma unroll
-        for (int u = 0; u < PA_U; ++u) { k0[u] = pre->k[u]; v0[u] = pre->v[u]; ks0[u] = pre->ks[u]; vs0[u] = pre->vs[u]; }
+        for (int u = 0; u < U; ++u) { k0[u] = pre->k[u]; v0[u] = pre->v[u]; ks0[u] = pre->ks[u]; vs0[u] = pre->vs[u]; }
     } else if (spec && active) { PA_LOAD(k0, v0, ks0, vs0, wave * 8) }
     PA_STAMP(1);
     if (CHAIN) chain_gate_wait(*gate, code);                  // the qkv stage's flags; workgroup barrier inside
@@ -398,11 +401,11 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
 
 #define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
     {                                                                                                \
-        float s_[PA_U][G], mx_[G];                                                                   \
-        bool ok_[PA_U];                                                                              \
+        float s_[U][G], mx_[G];                                                                   \
+        bool ok_[U];                                                                              \
         _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
-        float r_[PA_U][G];                                                                           \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+        float r_[U][G];                                                                           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
             ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
             float kf_[16];                                                                           \
             to_f32<KV>(KR[u], kf_);                                                                  \
@@ -413,15 +416,15 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
                 r_[u][g] = dd_[0] + dd_[1];                                                          \
             }                                                                                        \
         }                                                                                            \
-        /* the token's 8 lanes: 3 DPP steps, each over all PA_U * G sums (a DPP read 2 wait states behind its producer: */ \
+        /* the token's 8 lanes: 3 DPP steps, each over all U * G sums (a DPP read 2 wait states behind its producer: */ \
         /* step by step the other sums fill them) -- group8_sum's order of additions */              \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
             _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_XOR1>(r_[u][g]); \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
             _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_XOR2>(r_[u][g]); \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
             _Pragma("unroll") for (int g = 0; g < G; ++g) r_[u][g] += dpp_f<OMNI_DPP_HALF_MIRROR>(r_[u][g]); \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u)                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
                 float d_ = r_[u][g];                                                                 \
                 if (KV == OMNI_KV_INT8) d_ *= KS[u];                                                 \
@@ -435,7 +438,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
             l[g] *= corr_;                                                                           \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[g][e] *= corr_;                       \
         }                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < PA_U; ++u) {                                           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
             float vf_[16];                                                                           \
             to_f32<KV>(VR[u], vf_);                                                                  \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
@@ -448,7 +451,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     }
 
     // ---- main loop, loads one batch ahead
-    constexpr int STRIDE = PA_WAVES * 8 * PA_U;
+    constexpr int STRIDE = PA_WAVES * 8 * U;
     for (int t0 = t_begin + wave * 8; t0 < t_end;) {
         if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
         PA_COMPUTE(k0, v0, ks0, vs0, t0)
