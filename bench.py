@@ -111,8 +111,8 @@ def setup_requests(d, eng, args):
 
 def cpu_baseline(d, w, args, lens):
     """The oracle (CPU restatement of the reference's algorithm, kind 'port') timed on the host cores on a bounded
-    sample of the same workload: the first `cpu_batch` of the 64 requests, fp8 KV pre-filled with random bytes at the
-    W3 mean context, `cpu_steps` decode steps (no prefill; fp32 weight views built before the clock starts).
+    sample of the same workload: `cpu_batch` (default: all 64) of the 64 requests, fp8 KV pre-filled with random bytes at the
+    W3 mean context, `cpu_steps` full decode steps (no prefill; fp32 weight views built before the clock starts).
     A reported baseline, not the optimisation target."""
     from oracle import talker_oracle as O
     B, bs = args.cpu_batch, 16
@@ -144,9 +144,80 @@ def cpu_baseline(d, w, args, lens):
     dt = time.perf_counter() - t0
     O.clear_weight_cache()
     return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_steps} decode step(s) of the CPU oracle (re-prefill code predictor as in the reference) on the first "
-                      f"{B} of the 64 requests (SURVEY 8d asked for all 64 x 32 steps = ~40 min of CPU: bounded to ~20 s here), "
+            "sample": f"{n_steps} full decode step(s) of the CPU oracle (re-prefill code predictor as in the reference) on "
+                      + (f"all {B} requests of the batch" if B == args.batch else f"the first {B} of the {args.batch} requests")
+                      + f" (SURVEY 8d's 64 x 32 steps would be ~25 min of CPU: bounded to {n_steps} step(s), ~{dt:.0f} s), "
                       f"fp8 KV, mean ctx {int(np.mean(ctx))}, no prefill; {dt / n_steps * 1e3:.0f} ms/step"}
+
+
+def engine_loop(d, w, args, lens, async_on, n_steps=200):
+    """The number a drop-in stage delivers: wall time per decode step THROUGH the reference's own loop -- scheduler.schedule ->
+    worker.execute_model -> worker.sample_tokens (-> AsyncStepOutput.get_output) -> scheduler.update_from_output -- on the same
+    workload, same context window as the bare hipGraph replay of `value`.  async_on = the stage config's `async_scheduling: true`
+    (stage_configs/qwen3_tts.yaml:16): step t + 1 is dispatched before step t's outputs are read."""
+    from ht_vllm_omni_amd.payloads import SamplingParams, encode_tensor
+    from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+    from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
+    B, bs = args.batch, 16
+    sp = SamplingParams(temperature=0.9, top_k=50, repetition_penalty=1.05, seed=42, max_tokens=100000, stop_token_ids=())
+    cfg = make_config(d, kv_cache_dtype=args.kv, block_size=bs, max_num_seqs=B, num_gpu_blocks_override=args.num_blocks, weights=w,
+                      default_sampling_params=sp, async_scheduling=async_on)
+    wk = MI355XARWorker(cfg, local_rank=torch.cuda.current_device(), rank=0)
+    wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+    wk.engine.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+    wk.compile_or_warm_up_model()
+    sched = MI355XARScheduler(num_blocks=args.num_blocks, block_size=bs, max_num_seqs=B, max_num_batched_tokens=8192,
+                              max_model_len=d.max_model_len, need_send_cache=False, async_scheduling=async_on)
+    core = TalkerStageEngine(wk, sched)
+    g = torch.Generator().manual_seed(7)
+    for r, n in enumerate(lens):
+        info = {"talker_prompt_embeds": encode_tensor((torch.randn(n, d.hidden, generator=g) * 0.05).to(torch.bfloat16)),
+                "tts_pad_embed": encode_tensor((torch.randn(d.hidden, generator=g) * 0.05).to(torch.bfloat16))}
+        core.add_request(Request(request_id=f"s{r}", num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp,
+                                 additional_information=info, ignore_eos=True))
+    advance = max(8, int(round(args.target_ctx - float(np.mean(lens)) - n_steps / 2.0))) if args.target_ctx > 0 else 16
+    for _ in range(advance):
+        core.step()
+    torch.cuda.synchronize()
+    run = wk.model_runner
+    t_sched = t_upd = t_disp = t_get = 0.0
+    n_tok = 0
+    t0 = time.perf_counter()
+    for _ in range(n_steps):              # TalkerStageEngine.step, unrolled for the per-phase clocks
+        a = time.perf_counter()
+        so = sched.schedule()
+        b = time.perf_counter()
+        core.inflight.append((so, core._dispatch(so)))
+        c = time.perf_counter()
+        t_sched += b - a
+        t_disp += c - b
+        if async_on and len(core.inflight) < core.max_inflight:
+            continue
+        so0, h = core.inflight.popleft()
+        out = h.get_output() if hasattr(h, "get_output") else h
+        e_ = time.perf_counter()
+        outs = sched.update_from_output(so0, out)
+        f = time.perf_counter()
+        t_get += e_ - c
+        t_upd += f - e_
+        n_tok += sum(len(o.new_token_ids) for o in outs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx = float(wk.engine.seq_lens[:B].float().mean().item()) - n_steps / 2.0
+    while core.inflight:
+        so0, h = core.inflight.popleft()
+        sched.update_from_output(so0, h.get_output() if hasattr(h, "get_output") else h)
+    words = wk.engine.status.cpu().tolist()
+    res = {"ms_per_step": dt / n_steps * 1e3, "tokens_per_s": B * n_steps / dt, "steps": n_steps, "mean_ctx": ctx,
+           "async_scheduling": bool(async_on),
+           "runner_ms": (t_disp + t_get) / n_steps * 1e3, "runner_dispatch_ms": t_disp / n_steps * 1e3,
+           "runner_get_output_ms": t_get / n_steps * 1e3,
+           "scheduler_ms": (t_sched + t_upd) / n_steps * 1e3, "tokens_seen": n_tok, "chains_ran": int(words[2]),
+           "chain_fallbacks": int(run.chain_fallbacks), "replays": int(run.cudagraph_stats["replays"])}
+    wk.shutdown()
+    del core, sched, wk
+    torch.cuda.empty_cache()
+    return res
 
 
 def copy_probe_gbs():
@@ -181,11 +252,13 @@ def main():
     ap.add_argument("--num-blocks", type=int, default=8192)
     ap.add_argument("--ttfa-steps", type=int, default=16, help="initial_chunk_size at full load (chunk_size_utils.py:12-33)")
     ap.add_argument("--cpu-steps", type=int, default=1)
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="profiler runs: skip the untimed per-family / backbone-only replays "
                     "behind the timed region (their launches would be counted into the profile)")
+    ap.add_argument("--no-engine-loop", action="store_true", help="skip the untimed-for-`value` leg that runs the step through the "
+                    "scheduler / worker loop (reported under \"engine_loop\")")
     ap.add_argument("--device-weights", action="store_true", help="profiler runs only: draw weights on the GPU (no H2D copy)")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent row ranges run as parallel graph branches")
     ap.add_argument("--greedy", action="store_true")
@@ -513,6 +586,25 @@ def main():
             out["roofline"]["copy_probe_gbs"] = copy_probe_gbs()
         except Exception as e:   # noqa: BLE001
             log(f"copy probe failed: {e!r}")
+        if world == 1 and args.sub_batches == 1 and not args.tp_force and not args.no_diagnostics and not args.no_engine_loop:
+            # outside `value`: the same step through the reference's scheduler / worker loop, async scheduling on (the shipped
+            # stage config) and off
+            try:
+                eng = None
+                graph = None
+                torch.cuda.empty_cache()
+                el = engine_loop(d, w, args, lens, True)
+                el["bare_replay_ms"] = ev_ms
+                el["over_bare_replay_ms"] = el["ms_per_step"] - ev_ms
+                el["synchronous"] = engine_loop(d, w, args, lens, False)
+                el["note"] = ("scheduler.schedule -> worker.execute_model -> sample_tokens -> AsyncStepOutput.get_output -> "
+                              "update_from_output around every step (host copy of ids + status, code frames and hidden states, "
+                              "per-request bookkeeping and stop checks included); runner_ms / scheduler_ms are HOST time, which "
+                              "async scheduling hides under the GPU's next step")
+                out["engine_loop"] = el
+            except Exception as e:   # noqa: BLE001
+                log(f"engine-loop leg failed: {e!r}")
+                out["engine_loop"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 eng = None

@@ -397,17 +397,20 @@ class TalkerEngine:
         z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         # input_ids [Bm] and the step's four status words (omni_step_io.status: chain error word, peer all-reduce error word,
         # which chains ran, 0) share ONE tensor: the runner's per-step host copy of the sampled ids brings the status along
-        self.ids_status = z(Bm + 4, dt=torch.int32)
+        # ... and ids + status, the step's code frames and h[t] share ONE allocation, the step's OUTPUT RECORD: what the runner
+        # hands on per step is one copy (async scheduling: one device-to-device snapshot behind the step, runner._snapshot)
+        al = lambda n: (n + 255) // 256 * 256  # noqa: E731
+        self._rec_off = (0, al((Bm + 4) * 4), al((Bm + 4) * 4) + al(Bm * Q * 8))
+        self.out_record = z(self._rec_off[2] + Bm * H * 2, dt=torch.uint8)
+        self.ids_status, self.audio_codes, self.last_hidden = self.split_out_record(self.out_record)
         self.input_ids = self.ids_status[:Bm]
         self.status = self.ids_status[Bm:]
         self.positions = z(Bm, dt=torch.int32)
         self.seq_lens = z(Bm, dt=torch.int32)
         self.block_table = z(Bm, self.bt_stride, dt=torch.int32)
         self.slot_mapping = z(Bm, dt=torch.int64)
-        self.last_hidden = z(Bm, H, dt=BF16)
         self.text_step = z(Bm, H, dt=BF16)
         self.inputs_embeds = z(Bm, H, dt=BF16)
-        self.audio_codes = z(Bm, Q, dt=torch.int64)
         self.logits = z(Bm, d.vocab, dt=torch.float32)
         self.seen = z(Bm, d.vocab, dt=torch.uint8)
         self.steps = z(Bm, dt=torch.int32)
@@ -431,6 +434,14 @@ class TalkerEngine:
                              cp_temperature=0.9, cp_top_k=50, cp_top_p=1.0)
         self._attn_out = self._scratch_view(self.lib.omni_talker_attn_out(self.handle), Bm * H).view(Bm, H)
         self._mlp_out = self._scratch_view(self.lib.omni_talker_mlp_out(self.handle), Bm * H).view(Bm, H)
+
+    def split_out_record(self, rec: torch.Tensor):
+        """(ids + 4 status words [Bm + 4] int32, audio codes [Bm, Q] int64, h [Bm, H] bf16) as views of an output record --
+        the engine's own (device) or a host copy of it."""
+        Bm, H, Q = self.max_batch, self.d.hidden, self.d.num_code_groups
+        o0, o1, o2 = self._rec_off
+        return (rec[o0:o0 + (Bm + 4) * 4].view(torch.int32), rec[o1:o1 + Bm * Q * 8].view(torch.int64).view(Bm, Q),
+                rec[o2:o2 + Bm * H * 2].view(BF16).view(Bm, H))
 
     def _scratch_view(self, p: int, n_bf16: int) -> torch.Tensor:
         off = p - self.scratch.data_ptr()

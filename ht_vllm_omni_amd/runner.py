@@ -19,6 +19,7 @@ from __future__ import annotations
 import logging
 import os
 import zlib
+from collections import deque
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -54,8 +55,11 @@ class RequestState:
     mrope_positions: torch.Tensor | None = None     # int64 [3, prompt_len]
     mrope_delta: int = 0
     # h[t] the request's next decode step consumes (host view of the previous step's copy): what a step is redone from after a
-    # chain flag wait timed out (MI355XARModelRunner._redo_after_chain_timeout)
+    # chain flag wait timed out (MI355XARModelRunner._redo_step)
     last_hidden_cpu: torch.Tensor | None = None
+    # tokens sampled for the request so far, INCLUDING those of steps whose host copy has not been read yet (async scheduling:
+    # output_ids trails by the steps in flight; the device rows -- ids, h, positions -- are always current)
+    n_sampled: int = 0
 
     def rope_ids(self, s0: int, n: int):
         """[3, n] rotary ids of sequence indices [s0, s0 + n): the prompt's own ids, then index + delta."""
@@ -89,6 +93,39 @@ class _StepState:
     prefill_done: dict[int, torch.Tensor]      # row -> hidden [H] of the last prompt token
     prefill_sampled: torch.Tensor | None       # ids for prefill_done rows (device)
     prefill_spans: dict[int, tuple[int, int, torch.Tensor]]  # row -> (start, n, hidden[n,H])
+    # the scheduled rows AS DISPATCHED, in row order: (row, request id, request state).  The bookkeeping of a step may run after
+    # later steps were dispatched (async scheduling): by then rows have moved and finished requests have left `requests`, so it
+    # reads this snapshot, never `self.rows`
+    sched_rows: list = field(default_factory=list)
+    n_rows: int = 0
+
+
+@dataclass
+class _HostRecord:
+    """One step's outputs on the host, indexed by the step's OWN row numbers (those of _StepState.sched_rows)."""
+    ids: list[int]
+    status: list[int]
+    hidden: torch.Tensor                        # [n_rows, H] bf16
+    codes: torch.Tensor | None                  # [nd, Q] int64
+    spans: dict[int, torch.Tensor]              # row -> hidden [n, H] of its prefill span
+    dropped: set = field(default_factory=set)   # rows whose decode output of this step does not exist (redo: they had left)
+
+
+class AsyncStepOutput:
+    """What ``sample_tokens`` returns under async scheduling: the reference's ``AsyncGPUModelRunnerOutput``
+    (gpu_ar_model_runner.py:641-660; vLLM ``AsyncModelRunnerOutput.get_output``).  The step's device outputs were snapshotted in
+    stream order when it was dispatched; ``get_output()`` waits for that snapshot only -- not for the steps dispatched since --
+    reads it, checks the step's status words, does the bookkeeping and returns the ``OmniModelRunnerOutput``."""
+
+    def __init__(self, runner, stt: _StepState, pending, kv_extracted):
+        self.runner, self.stt, self.pending, self.kv_extracted = runner, stt, pending, kv_extracted
+        self.record: _HostRecord | None = None       # set early by a redo cascade (an earlier step of the queue was invalid)
+        self._out = None
+
+    def get_output(self) -> OmniModelRunnerOutput:
+        if self._out is None:
+            self._out = self.runner._finish_step(self)
+        return self._out
 
 
 class _Range:
@@ -129,8 +166,20 @@ _ROW_BUFFERS = ("input_ids", "positions", "seq_lens", "block_table", "last_hidde
 
 class MI355XARModelRunner:
     def __init__(self, engine, *, kv_transfer: OmniKVTransferManager | None = None, use_graphs: bool = True,
-                 engine_output_type: str = "latent", prompt_builder=None):
+                 engine_output_type: str = "latent", prompt_builder=None, async_scheduling: bool = False):
         self.engine = engine
+        # async scheduling (stage_configs/qwen3_tts.yaml:16): sample_tokens returns an AsyncStepOutput at once, the step's outputs
+        # are snapshotted in stream order and read in get_output() -- after the NEXT step has been enqueued.  Everything
+        # execute_model needs of a step (ids, h, positions, counters) is device-resident and advanced on the device; the host
+        # fields it reads (num_computed, n_sampled, text cursor) are advanced at DISPATCH, not at bookkeeping
+        self.async_scheduling = bool(async_scheduling)
+        self._inflight: deque = deque()                 # AsyncStepOutput handles not yet finished, oldest first
+        self._stage_dev: list = []                      # device snapshot slots of the step's output record
+        self._stage_i = 0
+        self._copy_stream = None
+        self._pin: dict[str, list] = {}                 # pinned host rings for the dispatch-side H2D copies (async, never blocking)
+        self._pin_i = 0
+        self.chain_fallbacks = 0
         # Qwen3-Omni requests arrive with the thinker's outputs instead of ready talker_prompt_embeds: the builder
         # (prompt_builder_omni.OmniTalkerPromptBuilder = the reference's talker_preprocess_prefill) turns them into the
         # prompt embeddings + the queue of text steps on the device
@@ -398,6 +447,10 @@ class MI355XARModelRunner:
             raise RuntimeError(f"batch overflow: max_num_seqs={self.max_num_seqs}")
         P = st.prompt_len
         L = len(st.output_ids)
+        if st.n_sampled != L:
+            # (cannot happen behind this package's scheduler: no admission in a preempting step, and the output of the step
+            # in flight is read before the next schedule)
+            raise RuntimeError(f"request {rid}: resumed with {st.n_sampled - L} sampled token(s) still in flight")
         J = max(L - 1, 0)
         if len(st.codes_hist) < J:
             raise RuntimeError(f"request {rid}: {len(st.codes_hist)} decode steps recorded, {J} needed to recompute")
@@ -463,7 +516,7 @@ class MI355XARModelRunner:
             if n - npre[rid] > 1:
                 raise RuntimeError("decode requests are scheduled one token per step (no spec decode on this path)")
             if n - npre[rid] == 1:
-                if npre[rid] and not st.output_ids:
+                if npre[rid] and not st.n_sampled:
                     raise RuntimeError(f"request {rid}: scheduled past its prompt before its first token was sampled")
                 dec.append(i)
         decs = set(dec)
@@ -509,7 +562,7 @@ class MI355XARModelRunner:
                 spans[r] = (s0, n, hid[o:o + n])
                 st.num_computed = s0 + n
                 if st.in_decode:
-                    if st.output_ids:      # resumed after preemption: nothing to sample, the row picks up where it was
+                    if st.n_sampled:       # resumed after preemption: nothing to sample, the row picks up where it was
                         self._restore_decode_row(r, st, hid[o + n - 1])
                     else:
                         prefill_done[r] = hid[o + n - 1]
@@ -536,11 +589,43 @@ class MI355XARModelRunner:
             if len(idx) != nd:
                 raise RuntimeError(f"text-step table covers {len(idx)} rows, the step has {nd} decode rows (stale table)")
             self._tt_pos[:nd] += 1
-            torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
+            torch.index_select(self._tt, 0, self._h2d("tt_idx", idx, torch.int64), out=e.text_step[:nd])
             with _Range("gpu_model_runner: forward"):      # the native step: talker_mtp, backbone, compute_logits AND the sampler
                 self._run_decode(nd)
-        self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans)
+        # host counters move at DISPATCH (the scheduler advances num_computed_tokens when it schedules, too): the next
+        # execute_model may run before this step's ids have been read
+        sched_rows = []
+        for r, rid in enumerate(self.rows):
+            if sched.get(rid, 0) <= 0:
+                continue
+            st = self.requests[rid]
+            if r < nd:
+                st.num_computed += 1
+                st.n_sampled += 1
+            elif r in prefill_done:
+                st.n_sampled += 1
+            sched_rows.append((r, rid, st))
+        self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans, sched_rows, len(self.rows))
         return None
+
+    def _h2d(self, key: str, values, dtype) -> torch.Tensor:
+        """A small host array onto the device WITHOUT stalling the host: a pageable source makes the copy wait until the stream
+        has drained (measured: profiles/r05_pinned_read_probe.txt -- the host would sit out the step in flight instead of running
+        ahead of it); a pinned source is queued behind it.  One ring of pinned buffers per call site: a buffer is rewritten
+        eight calls later, long after its copy ran (at most two steps are in flight)."""
+        dev = self.engine.input_ids.device
+        arr = np.ascontiguousarray(values)
+        if dev.type != "cuda":
+            return torch.as_tensor(arr, dtype=dtype, device=dev)
+        n = int(arr.size)
+        ring = self._pin.get(key)
+        if ring is None or ring[0].numel() < n or ring[0].dtype != dtype:
+            cap = max(64, 1 << (max(n, 1) - 1).bit_length())
+            ring = self._pin[key] = [torch.empty(cap, dtype=dtype).pin_memory() for _ in range(8)]
+        self._pin_i += 1
+        buf = ring[self._pin_i % len(ring)]
+        buf[:n].copy_(torch.from_numpy(arr.reshape(-1)).to(dtype))
+        return buf[:n].to(dev, non_blocking=True).reshape(arr.shape)
 
     def _sample_prefill(self, rows: list[int], logits: torch.Tensor) -> torch.Tensor:
         """First token of the requests whose prompt completed this step, each with ITS request's sampling parameters
@@ -575,33 +660,68 @@ class MI355XARModelRunner:
                 self.engine.decode_step(b)
             self.graphs[b] = g
 
-    def _redo_after_chain_timeout(self, nd: int, code: int) -> None:
-        """The decode step just taken reported a timed-out flag wait of a persistent chain (status word 0: the chain's grid was
-        not co-resident -- another process or engine held CUs): its outputs are invalid, but nothing of it has left the runner
-        yet.  Degrade instead of dying: clear the device words, turn this engine's chains off (launch-per-op shares a GPU
-        without a deadline), re-capture the graphs, put every decode row back to the state the step started from -- last id,
-        h[t] (host copy of the previous step), position, step counter, repetition bitmap, text cursor; the KV slots the bad
-        step wrote are simply written again -- and run the step once more."""
+    def _redo_step(self, stt: _StepState, rec: _HostRecord, code: int) -> None:
+        """The decode part of step `stt` is invalid: a persistent chain's flag wait timed out in it (status word 0: the chain's
+        grid was not co-resident -- another process or engine held CUs), or it ran behind such a step (async scheduling: it was
+        dispatched on that step's garbage).  Nothing of it has left the runner.  Degrade instead of dying: drain the device,
+        clear its error words and turn this engine's chains off (launch-per-op shares a GPU without a deadline), re-capture the
+        graphs, put every decode row of the step back to the state the step started from -- last id, h[t], position, step
+        counter, repetition bitmap, text step, all from the host records of the steps BEFORE it (bookkept by now) -- and run the
+        step again, synchronously; `rec` gets the redone rows' outputs.  The KV slots the bad step wrote are written again.
+        Rows of the step that have since left the batch (preempted at the next dispatch) are dropped from its output: the
+        scheduler and the runner both simply never see that token, the request recomputes and carries on from the one before."""
         e = self.engine
-        logger.warning("persistent-chain flag wait timed out (stage code %#x): engine falls back to the launch-per-op path, "
-                       "step redone", code)
-        e.recover_from_chain_timeout()
-        sizes = sorted(self.graphs)
-        self.graphs.clear()
-        if self.use_graphs and sizes:
-            self.capture_graphs(sizes)
         dev = e.input_ids.device
-        for r in range(nd):
-            st = self.requests[self.rows[r]]
-            if st.last_hidden_cpu is None or not st.output_ids:
-                raise RuntimeError(f"request {self.rows[r]}: no record to redo its decode step from")
-            self._restore_decode_row(r, st, st.last_hidden_cpu.reshape(-1).to(dev), position=st.num_computed)
-        self._tt_pos[:nd] -= 1
-        idx = self._tt_off[:nd] + np.minimum(self._tt_pos[:nd], self._tt_len[:nd])
-        self._tt_pos[:nd] += 1
-        torch.index_select(self._tt, 0, torch.as_tensor(idx, device=self._tt.device), out=e.text_step[:nd])
-        self.chain_fallbacks = getattr(self, "chain_fallbacks", 0) + 1
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if getattr(e, "persistent_chains", False) or code:
+            logger.warning("persistent-chain flag wait timed out (stage code %#x): engine falls back to the launch-per-op path, "
+                           "step redone", code)
+            e.recover_from_chain_timeout()
+            sizes = sorted(self.graphs)
+            self.graphs.clear()
+            if self.use_graphs and sizes:
+                e.num_live.fill_(0)             # the capture's eager warm-up pass must not touch live rows (ADVICE r4)
+                self.capture_graphs(sizes)
+            self.chain_fallbacks += 1
+        dec = [(r, rid, st) for r, rid, st in stt.sched_rows if r < len(stt.decode_rows)]
+        live = [(r, rid, st) for r, rid, st in dec if self.requests.get(rid) is st and rid in self.rows]
+        rec.dropped = {r for r, _, _ in dec} - {r for r, _, _ in live}
+        nd = len(live)
+        if not nd:
+            return
+        cur = [self.rows.index(rid) for _, rid, _ in live]
+        rest = [i for i in range(len(self.rows)) if i not in set(cur)]
+        self._permute_rows(cur + rest)              # the step's decode rows first, in the step's own order
+        text = []
+        for k, (r, rid, st) in enumerate(live):
+            L = len(st.output_ids)
+            if not L:
+                raise RuntimeError(f"request {rid}: no record to redo its decode step from")
+            span = stt.prefill_spans.get(r)         # resumed after preemption: recomputed AND decoded in this step (ADVICE r4)
+            hid = span[2][span[1] - 1] if span is not None else st.last_hidden_cpu
+            if hid is None:
+                raise RuntimeError(f"request {rid}: no record to redo its decode step from")
+            self._restore_decode_row(k, st, hid.reshape(-1).to(dev), position=st.prompt_len + L - 1)
+            j, nt = L - 1, 0 if st.tail is None else int(st.tail.shape[0])       # decode step j of the request reads text row j
+            text.append(st.tail[j] if j < nt else st.tts_pad)
+        e.text_step[:nd] = torch.stack(text)
         self._run_decode(nd)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        buf = e.ids_status.cpu() if getattr(e, "ids_status", None) is not None else None
+        ids = buf[:nd].tolist() if buf is not None else e.input_ids[:nd].cpu().tolist()
+        status = buf[-4:].tolist() if buf is not None else [0, 0, 0, 0]
+        if status[0]:
+            raise RuntimeError(f"decode step invalid after the fall-back to the launch path (status {status})")
+        hid_cpu = e.last_hidden[:nd].to("cpu", copy=True)
+        codes_cpu = e.audio_codes[:nd].cpu()
+        rec.hidden, rec.codes = rec.hidden.clone(), rec.codes.clone()
+        for k, (r, _, _) in enumerate(live):        # back into the record at the step's own row numbers
+            rec.ids[r] = ids[k]
+            rec.hidden[r] = hid_cpu[k]
+            rec.codes[r] = codes_cpu[k]
+        rec.status = [0, status[1], status[2], 0]
 
     def _run_decode(self, nd: int) -> None:
         # rows [nd, bucket) of the padded graph may be live PREFILL rows of the persistent batch (decode-first order):
@@ -616,77 +736,143 @@ class MI355XARModelRunner:
             self.cudagraph_stats["eager_steps"] += 1
 
     # ------------------------------------------------------------------ phase 2
+    def _snapshot(self, stt: _StepState):
+        """Put the step's device outputs where the next step cannot overwrite them, in stream order, and return what
+        `_collect` needs to bring them to the host.  Sync mode / CPU engines: nothing to do (the buffers are read at once)."""
+        e = self.engine
+        dev = e.input_ids.device
+        if not self.async_scheduling:
+            return None
+        n, nd = stt.n_rows, len(stt.decode_rows)
+        if dev.type != "cuda":
+            ids = e.ids_status.clone() if getattr(e, "ids_status", None) is not None else e.input_ids[:n].clone()
+            return ("host", ids, e.last_hidden[:n].clone(), e.audio_codes[:nd].clone() if nd else None, dict(stt.prefill_spans))
+        rec = getattr(e, "out_record", None)
+        if rec is None:
+            raise RuntimeError("async scheduling needs an engine with a packed output record (engine.out_record)")
+        if not self._stage_dev:
+            self._stage_dev = [torch.empty_like(rec) for _ in range(4)]
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        self._stage_i += 1
+        slot = self._stage_dev[self._stage_i % len(self._stage_dev)]
+        slot.copy_(rec, non_blocking=True)           # ONE device-to-device copy behind the step: ids + status, codes, h
+        ev = torch.cuda.Event()
+        ev.record()
+        return ("dev", slot, ev, dict(stt.prefill_spans))
+
+    def _collect(self, stt: _StepState, pending) -> _HostRecord:
+        """The step's outputs on the host.  Async: waits for the step's snapshot only -- the copy runs on a side stream behind
+        the snapshot's event, into pageable memory (a pinned target reads at ~0.5 GB/s from the CPU: profiles/r05_pinned_read_probe.txt)."""
+        e = self.engine
+        n, nd = stt.n_rows, len(stt.decode_rows)
+        if pending is None:
+            # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550); the ids bring the status words along
+            ids_status = getattr(e, "ids_status", None)
+            if ids_status is not None:
+                buf = ids_status.cpu()
+                ids, status = buf[:n].tolist(), (buf[-4:].tolist() if nd else [0, 0, 0, 0])
+            else:
+                ids, status = e.input_ids[:n].cpu().tolist(), [0, 0, 0, 0]
+            hid = e.last_hidden[:n].to("cpu", copy=True)          # a copy of its own: requests keep views of it
+            codes = e.audio_codes[:nd].cpu() if nd else None
+            spans = {r: h.cpu() for r, (_, _, h) in stt.prefill_spans.items()}
+            return _HostRecord(ids, status, hid, codes, spans)
+        if pending[0] == "host":
+            _, buf, hid, codes, sp = pending
+            has_status = getattr(e, "ids_status", None) is not None
+            ids = buf[:n].tolist()
+            status = buf[-4:].tolist() if (has_status and nd) else [0, 0, 0, 0]
+            return _HostRecord(ids, status, hid, codes, {r: h.cpu() for r, (_, _, h) in sp.items()})
+        _, slot, ev, sp = pending
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ev)
+            host = slot.cpu()                        # blocks on the side stream alone: the step after this one keeps running
+            spans = {r: h.cpu() for r, (_, _, h) in sp.items()}
+        ids_all, codes_all, hid_all = e.split_out_record(host)
+        ids = ids_all[:n].tolist()
+        status = ids_all[-4:].tolist() if nd else [0, 0, 0, 0]
+        return _HostRecord(ids, status, hid_all[:n], codes_all[:nd] if nd else None, spans)
+
     @torch.inference_mode()
-    def sample_tokens(self, grammar_output=None) -> OmniModelRunnerOutput | None:
+    def sample_tokens(self, grammar_output=None):
+        """Phase 2 of the step (gpu_ar_model_runner.py:403-660).  The sampler itself ran inside the native step; this is the
+        hand-over of its outputs: at once (an OmniModelRunnerOutput), or -- async scheduling -- as an AsyncStepOutput whose
+        get_output() the engine core calls after it has dispatched the next step (:641-660)."""
         kv_extracted = self.kv_extracted_req_ids
         self.kv_extracted_req_ids = None
         if self.execute_model_state is None:
             return None
         stt, self.execute_model_state = self.execute_model_state, None
-        e = self.engine
+        handle = AsyncStepOutput(self, stt, self._snapshot(stt), kv_extracted)
+        if not self.async_scheduling:
+            return handle.get_output()
+        self._inflight.append(handle)
+        return handle
+
+    def _finish_step(self, handle: AsyncStepOutput) -> OmniModelRunnerOutput:
+        if self._inflight and self._inflight[0] is not handle and handle in self._inflight:
+            for h in list(self._inflight):           # outputs are finished in dispatch order (records build on each other)
+                if h is handle:
+                    break
+                h.get_output()
+        stt = handle.stt
+        nd = len(stt.decode_rows)
+        with _Range("gpu_model_runner: sample"):     # the wait for the step plus the copy of its outputs
+            rec = handle.record if handle.record is not None else self._collect(stt, handle.pending)
+        redone = False
+        if handle.record is None and nd and rec.status[0]:
+            # a chain flag wait timed out: fall back to the launch-per-op path and redo THIS step
+            self._redo_step(stt, rec, int(rec.status[0]))
+            redone = True
+        if rec.status[1]:
+            # a tensor-parallel peer did not arrive: the kernel that timed out wrote the word into every rank's control
+            # block, so all ranks leave their step here (the reference: an exception in the worker ends the engine)
+            raise RuntimeError(f"peer all-reduce: a rank did not arrive in time (error word {rec.status[1]}): the step's outputs are invalid")
+        out = self._bookkeep(stt, rec, handle.kv_extracted)
+        if handle in self._inflight:
+            self._inflight.remove(handle)
+        if redone:
+            # the steps dispatched since ran on this step's garbage: redo each of them now, oldest first, on the records just
+            # written (their own get_output() then only does the bookkeeping)
+            for h in list(self._inflight):
+                h.record = self._collect(h.stt, h.pending)
+                self._redo_step(h.stt, h.record, 0)
+                if h is not self._inflight[-1]:
+                    h.get_output()
+        return out
+
+    def _bookkeep(self, stt: _StepState, rec: _HostRecord, kv_extracted) -> OmniModelRunnerOutput:
         nd = len(stt.decode_rows)
         Q = self.d.num_code_groups
-        # one D2H for the whole batch (the reference syncs on hidden_states.to("cpu"), :550).  The sampler itself ran inside the
-        # native step; the "sample" range is the wait for it plus the copy of the ids
-        with _Range("gpu_model_runner: sample"):
-            ids_status = getattr(e, "ids_status", None)
-            if ids_status is not None:
-                # the sampled ids AND the step's status words in one copy (omni_step_io.status: written by the step's last
-                # launch): every step is checked before anything of it is handed on
-                buf = ids_status.cpu()
-                status = buf[-4:].tolist() if nd else [0, 0, 0, 0]
-                if status[0]:
-                    # a chain flag wait timed out: fall back to the launch-per-op path and redo THIS step
-                    self._redo_after_chain_timeout(nd, int(status[0]))
-                    buf = ids_status.cpu()
-                    status = buf[-4:].tolist()
-                    if status[0]:
-                        raise RuntimeError(f"decode step invalid after the fall-back to the launch path (status {status})")
-                if status[1]:
-                    # a tensor-parallel peer did not arrive: the kernel that timed out wrote the word into every rank's control
-                    # block, so all ranks leave their step here (the reference: an exception in the worker ends the engine)
-                    raise RuntimeError(f"peer all-reduce: a rank did not arrive in time (error word {status[1]}): the step's outputs are invalid")
-                ids_cpu = buf[:len(self.rows)].tolist()
-            else:
-                ids_cpu = e.input_ids[:len(self.rows)].cpu().tolist()
-                if hasattr(e, "check_device_errors") and stt.scheduler_output.finished_req_ids:
-                    e.check_device_errors()
-        with _Range("gpu_model_runner: postprocess"):
-            hid_cpu = e.last_hidden[:len(self.rows)].to("cpu", copy=True)     # a copy of its own: requests keep views of it
-            codes_cpu = e.audio_codes[:nd].cpu() if nd else None
-            codes_list = codes_cpu.tolist() if nd else []
-        # (pinned staging + one sync was tried: the CPU then reads uncached pinned memory -- 37 ms per step)
-        sched = stt.scheduler_output.num_scheduled_tokens
+        with _Range("gpu_model_runner: postprocess"):       # the step's frames as host lists (the request records keep them)
+            codes_list = rec.codes.tolist() if nd else []
         req_ids, sampled, pooler = [], [], []
-        bookkeep = _Range("gpu_model_runner: bookkeep")
-        bookkeep.__enter__()
-        for r, rid in enumerate(self.rows):
-            if rid not in sched or sched[rid] <= 0:
-                continue
-            st = self.requests[rid]
-            payload: dict[str, Any] = {}
-            if r < nd:
-                tok = int(ids_cpu[r])
-                st.num_computed += 1
-                st.output_ids.append(tok)
-                sampled.append([tok])
-                payload["hidden"] = hid_cpu[r:r + 1]                     # views of this step's own host copies
-                payload["audio_codes"] = codes_cpu[r:r + 1]              # frame [c0..c15][t] (talker.py:1642)
-                st.codes_hist.append(codes_list[r])
-            else:
-                s0, n, hid = stt.prefill_spans[r]
-                payload["hidden"] = hid.cpu()
-                payload["audio_codes"] = torch.zeros(n, Q, dtype=torch.long)   # prefill rows: zero codes (607-612)
-                if r in stt.prefill_done:
-                    tok = int(ids_cpu[r])
+        with _Range("gpu_model_runner: bookkeep"):
+            for r, rid, st in stt.sched_rows:
+                payload: dict[str, Any] = {}
+                if r < nd:
+                    if r in rec.dropped:
+                        st.n_sampled -= 1                # the token never existed (see _redo_step): the request recomputes without it
+                        continue
+                    tok = int(rec.ids[r])
                     st.output_ids.append(tok)
                     sampled.append([tok])
+                    payload["hidden"] = rec.hidden[r:r + 1]                    # views of this step's own host copies
+                    payload["audio_codes"] = rec.codes[r:r + 1]                # frame [c0..c15][t] (talker.py:1642)
+                    st.codes_hist.append(codes_list[r])
                 else:
-                    sampled.append([])
-            req_ids.append(rid)
-            pooler.append(payload)
-            st.last_hidden_cpu = hid_cpu[r]          # h[t] of the request's next decode step (a view of this step's host copy)
-        bookkeep.__exit__(None, None, None)
+                    s0, n, _ = stt.prefill_spans[r]
+                    payload["hidden"] = rec.spans[r]
+                    payload["audio_codes"] = torch.zeros(n, Q, dtype=torch.long)   # prefill rows: zero codes (607-612)
+                    if r in stt.prefill_done:
+                        tok = int(rec.ids[r])
+                        st.output_ids.append(tok)
+                        sampled.append([tok])
+                    else:
+                        sampled.append([])
+                req_ids.append(rid)
+                pooler.append(payload)
+                st.last_hidden_cpu = rec.hidden[r]       # h[t] of the request's next decode step (a view of this step's host copy)
         return OmniModelRunnerOutput(
             req_ids=req_ids, req_id_to_index={rid: i for i, rid in enumerate(req_ids)}, sampled_token_ids=sampled,
             pooler_output=pooler if self.engine_output_type != "text" else None, kv_extracted_req_ids=kv_extracted,

@@ -68,6 +68,9 @@ class Request:
     num_computed_tokens: int = 0
     output_token_ids: list[int] = field(default_factory=list)
     stop_reason: int | None = None
+    # async scheduling (vLLM Request.num_output_placeholders): tokens this request has been scheduled to sample whose ids the
+    # scheduler has not seen yet -- the step that samples them is still in flight while the next one is scheduled
+    num_output_placeholders: int = 0
 
     def __post_init__(self):
         if self.external_req_id is None:
@@ -101,7 +104,12 @@ class EngineCoreOutput:
 class MI355XARScheduler:
     def __init__(self, *, num_blocks: int, block_size: int = 16, max_num_seqs: int = 64, max_num_batched_tokens: int = 8192,
                  max_model_len: int = 4096, kv_transfer_criteria: dict | None = None, need_send_cache: bool = False,
-                 chunk_streamer=None, stage_id: int = 0):
+                 chunk_streamer=None, stage_id: int = 0, async_scheduling: bool = False):
+        # async_scheduling (stage_configs/qwen3_tts.yaml:16; vLLM's AsyncScheduler): step t + 1 is scheduled before step t's
+        # sampled ids are known -- a running request counts its in-flight token as a placeholder and is given its next decode
+        # token at once; a stop is seen one step late (the surplus frame is dropped in update_from_output), a length cap is not
+        # (the cap is known ahead: no step is scheduled past it)
+        self.async_scheduling = bool(async_scheduling)
         self.block_size, self.max_num_seqs = block_size, max_num_seqs
         self.max_num_batched_tokens, self.max_model_len = max_num_batched_tokens, max_model_len
         self.pool = BlockPool(num_blocks, block_size)
@@ -137,6 +145,7 @@ class MI355XARScheduler:
         elif req in self.waiting:
             self.waiting.remove(req)
         req.status = RequestStatus.FINISHED_ABORTED
+        req.num_output_placeholders = 0          # whatever is still in flight for it is dropped on arrival (request finished)
         self._free_request(req)
 
     def has_unfinished_requests(self) -> bool:
@@ -176,7 +185,11 @@ class MI355XARScheduler:
         i = 0
         while i < len(self.running) and budget > 0:
             req = self.running[i]
-            n = min(req.num_tokens - req.num_computed_tokens, budget)
+            ph = req.num_output_placeholders
+            if ph and (len(req.output_token_ids) + ph >= req.sampling_params.max_tokens or req.num_tokens + ph >= self.max_model_len):
+                i += 1          # the token in flight is its last (length cap, known ahead): nothing more to schedule for it
+                continue
+            n = min(req.num_tokens + ph - req.num_computed_tokens, budget)
             if n <= 0:
                 i += 1
                 continue
@@ -204,6 +217,8 @@ class MI355XARScheduler:
         # 2) waiting requests, FCFS, unless this step preempted
         while self.waiting and not self._preempted and budget > 0 and len(self.running) < self.max_num_seqs:
             req = self.waiting[0]
+            if req.num_output_placeholders:      # preempted with a token still in flight: it comes back once that has arrived
+                break
             n = min(req.num_tokens - req.num_computed_tokens, budget)
             need = self.pool.blocks_needed(req.num_computed_tokens + n) - len(self.pool.block_ids(req.request_id))
             if need > self.pool.num_free:
@@ -223,7 +238,10 @@ class MI355XARScheduler:
             budget -= n
         # vLLM advances num_computed_tokens at schedule time (_update_after_schedule)
         for rid, n in num_sched.items():
-            self.requests[rid].num_computed_tokens += n
+            req = self.requests[rid]
+            req.num_computed_tokens += n
+            if self.async_scheduling and req.num_computed_tokens == req.num_tokens + req.num_output_placeholders:
+                req.num_output_placeholders += 1         # this step samples a token for it (AsyncScheduler._update_after_schedule)
         out = OmniSchedulerOutput(
             scheduled_new_reqs=new_reqs, scheduled_cached_reqs=cached, num_scheduled_tokens=num_sched,
             total_num_scheduled_tokens=sum(num_sched.values()), finished_req_ids=self.finished_req_ids,
@@ -255,14 +273,20 @@ class MI355XARScheduler:
         if c.get("type") == "prefill_finished":
             if req.num_computed_tokens >= req.num_prompt_tokens:
                 self.transfer_triggered_requests.add(req.request_id)
-                self._mark_request_for_kv_transfer(req.request_id, req.num_computed_tokens)
+                self._mark_request_for_kv_transfer(req.request_id, self._settled_tokens(req))
         elif c.get("type") == "special_token":
             tok = c.get("token_id")
             if tok is not None and tok in new_token_ids:
                 self.transfer_triggered_requests.add(req.request_id)
                 exclude = len(new_token_ids) - (new_token_ids.index(tok) + 1)
-                self._mark_request_for_kv_transfer(req.request_id, req.num_computed_tokens - exclude)
+                self._mark_request_for_kv_transfer(req.request_id, self._settled_tokens(req) - exclude)
         return False      # these criteria never stop the request
+
+    @staticmethod
+    def _settled_tokens(req: Request) -> int:
+        """Tokens of the request whose KV the steps seen so far have written: what was scheduled minus what is still in flight
+        (equal to num_computed_tokens without async scheduling -- the lengths shipped are the same in both modes)."""
+        return req.num_computed_tokens - req.num_output_placeholders
 
     def _free_request(self, req: Request) -> dict | None:
         rid = req.request_id
@@ -274,7 +298,7 @@ class MI355XARScheduler:
                     return None
             else:
                 self.waiting_for_transfer_free.add(rid)
-                self._mark_request_for_kv_transfer(rid, req.num_computed_tokens)
+                self._mark_request_for_kv_transfer(rid, self._settled_tokens(req))
                 data = self.requests_needing_kv_transfer.get(rid)
                 if data is not None:
                     return {"past_key_values": data["block_ids"],
@@ -312,6 +336,8 @@ class MI355XARScheduler:
             if idx is None:
                 continue
             new_ids = list(runner_output.sampled_token_ids[idx]) if runner_output.sampled_token_ids else []
+            if req.num_output_placeholders and new_ids:
+                req.num_output_placeholders = max(req.num_output_placeholders - len(new_ids), 0)
             pooled = runner_output.pooler_output[idx] if runner_output.pooler_output else None
             stopped = False
             kept: list[int] = []
@@ -325,7 +351,15 @@ class MI355XARScheduler:
                 self._process_kv_transfer_trigger(req, kept)
             kv_params = None
             if stopped:
-                self.running.remove(req)
+                if req in self.running:
+                    self.running.remove(req)
+                elif req in self.waiting:        # preempted while the step that sampled its stop token was in flight
+                    self.waiting.remove(req)
+                if req.num_output_placeholders:
+                    # a surplus step is in flight for it (scheduled before the stop was seen): its blocks are freed now -- the
+                    # surplus step's KV write precedes any later owner's in stream order -- and its output is dropped on arrival
+                    req.num_computed_tokens -= req.num_output_placeholders
+                    req.num_output_placeholders = 0
                 kv_params = self._free_request(req)
             if kept or pooled is not None or stopped:
                 outs.append(EngineCoreOutput(rid, kept, pooled, req.get_finished_reason(), req.stop_reason, kv_params))
@@ -349,27 +383,58 @@ class MI355XARScheduler:
 
 class TalkerStageEngine:
     """schedule -> execute_model -> sample_tokens -> update_from_output: the engine-core loop of one AR stage
-    (what vLLM's EngineCore.step does around the worker), for tests and stand-alone serving of the talker."""
+    (what vLLM's EngineCore.step does around the worker), for tests and stand-alone serving of the talker.
 
-    def __init__(self, worker, scheduler: MI355XARScheduler):
+    With ``async_scheduling`` (stage_configs/qwen3_tts.yaml:16) it is vLLM's ``step_with_batch_queue`` at depth 2: step t + 1
+    is scheduled and handed to the worker BEFORE step t's output is waited for -- the worker's ``sample_tokens`` returns an
+    ``AsyncModelRunnerOutput``-shaped handle (gpu_ar_model_runner.py:641-660) whose ``get_output()`` blocks on the step's host
+    copy -- so the host side of step t (copy, bookkeeping, stop checks, this scheduler) runs under the GPU's step t + 1."""
+
+    def __init__(self, worker, scheduler: MI355XARScheduler, async_scheduling: bool | None = None):
         self.worker, self.scheduler = worker, scheduler
+        self.async_scheduling = scheduler.async_scheduling if async_scheduling is None else bool(async_scheduling)
+        if self.async_scheduling != scheduler.async_scheduling:
+            raise ValueError("the engine loop and its scheduler must agree on async_scheduling")
+        self.inflight: deque = deque()          # (scheduler_output, runner output or handle), oldest first
+        self.max_inflight = 2
 
     def add_request(self, request: Request) -> None:
         self.scheduler.add_request(request)
 
+    @staticmethod
+    def _has_work(so: OmniSchedulerOutput) -> bool:
+        return bool(so.total_num_scheduled_tokens or so.finished_req_ids or so.preempted_req_ids
+                    or so.finished_requests_needing_kv_transfer)
+
+    def _dispatch(self, so: OmniSchedulerOutput):
+        first = self.worker.execute_model(so)
+        return first if first is not None else self.worker.sample_tokens(None)
+
     def step(self) -> list[EngineCoreOutput]:
         so = self.scheduler.schedule()
-        if so.total_num_scheduled_tokens == 0 and not so.finished_req_ids and not so.finished_requests_needing_kv_transfer:
+        if not self.async_scheduling:
+            if not self._has_work(so):
+                return []
+            return self.scheduler.update_from_output(so, self._dispatch(so))
+        if self._has_work(so):
+            self.inflight.append((so, self._dispatch(so)))
+            if len(self.inflight) < self.max_inflight:
+                return []                                   # queue not full: schedule the next step before waiting for this one
+        if not self.inflight:
             return []
-        first = self.worker.execute_model(so)
-        out = first if first is not None else self.worker.sample_tokens(None)
-        return self.scheduler.update_from_output(so, out)
+        so0, handle = self.inflight.popleft()
+        out = handle.get_output() if hasattr(handle, "get_output") else handle
+        return self.scheduler.update_from_output(so0, out)
+
+    def has_work(self) -> bool:
+        s = self.scheduler
+        return bool(self.inflight or s.has_unfinished_requests() or s.finished_req_ids or s.requests_needing_kv_transfer
+                    or s.waiting_for_transfer_free)
 
     def run(self, max_steps: int = 1 << 30) -> dict[str, list[int]]:
         tokens: dict[str, list[int]] = {}
         for _ in range(max_steps):
-            if not self.scheduler.has_unfinished_requests() and not self.scheduler.finished_req_ids \
-                    and not self.scheduler.requests_needing_kv_transfer and not self.scheduler.waiting_for_transfer_free:
+            if not self.has_work():
                 break
             for o in self.step():
                 tokens.setdefault(o.request_id, []).extend(o.new_token_ids)

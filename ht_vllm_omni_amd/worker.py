@@ -31,7 +31,8 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                 max_num_seqs: int = 64, tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9,
                 num_gpu_blocks_override: int | None = None, weights: dict | None = None, seed: int = 1234,
                 connector: str | None = None, enforce_eager: bool = False, default_sampling_params=None,
-                prompt_builder: dict | None = None, model_path: str | None = None, calculate_kv_scales: bool = False) -> SimpleNamespace:
+                prompt_builder: dict | None = None, model_path: str | None = None, calculate_kv_scales: bool = False,
+                async_scheduling: bool = False) -> SimpleNamespace:
     if model_path and isinstance(model, str) and model == "tts-1.7b" and os.path.exists(os.path.join(model_path, "config.json")):
         from .checkpoint import dims_from_hf_config
         model = dims_from_hf_config(os.path.join(model_path, "config.json"))          # dimensions come from the checkpoint
@@ -39,7 +40,8 @@ def make_config(model: str | TalkerDims = "tts-1.7b", *, kv_cache_dtype: str = "
                            tensor_parallel_size=tensor_parallel_size, gpu_memory_utilization=gpu_memory_utilization,
                            num_gpu_blocks_override=num_gpu_blocks_override, weights=weights, seed=seed, connector=connector,
                            enforce_eager=enforce_eager, default_sampling_params=default_sampling_params,
-                           prompt_builder=prompt_builder, model_path=model_path, calculate_kv_scales=calculate_kv_scales)
+                           prompt_builder=prompt_builder, model_path=model_path, calculate_kv_scales=calculate_kv_scales,
+                           async_scheduling=bool(async_scheduling))
 
 
 _PRESET_HINTS = (("omni", "omni-talker"), ("1.7b", "tts-1.7b"), ("0.6b", "tts-0.6b"))
@@ -77,7 +79,7 @@ def config_from_vllm(vllm_config) -> SimpleNamespace:
       model_config.model / .hf_config / .seed / .enforce_eager / .max_model_len      gpu_ar_worker.py:63,78
       cache_config.cache_dtype / .block_size / .gpu_memory_utilization / .num_gpu_blocks_override   gpu_ar_model_runner.py:118-124
       parallel_config.tensor_parallel_size                                                        gpu_ar_worker.py:44-46
-      scheduler_config.max_num_seqs                                                               chunk_size_utils.py:5-33
+      scheduler_config.max_num_seqs / .async_scheduling                          chunk_size_utils.py:5-33, gpu_ar_model_runner.py:641
       additional_config: {connector, prompt_builder, default_sampling_params, weights}            (stage YAML engine_args)
     A namespace that is already flat (make_config) is returned unchanged."""
     if not hasattr(vllm_config, "model_config"):
@@ -104,7 +106,9 @@ def config_from_vllm(vllm_config) -> SimpleNamespace:
         calculate_kv_scales=bool(getattr(cc, "calculate_kv_scales", False)),
         seed=int(getattr(mc, "seed", 1234) or 0), connector=extra.get("connector"),
         enforce_eager=bool(getattr(mc, "enforce_eager", False)), default_sampling_params=extra.get("default_sampling_params"),
-        prompt_builder=extra.get("prompt_builder"), model_path=path)
+        prompt_builder=extra.get("prompt_builder"), model_path=path,
+        # scheduler_config.async_scheduling (stage_configs/qwen3_tts.yaml:16): sample_tokens returns an AsyncStepOutput
+        async_scheduling=bool(getattr(sc, "async_scheduling", False)))
 
 
 @dataclass(frozen=True)
@@ -231,7 +235,8 @@ class MI355XARWorker:
             pw.setdefault("codec_embed", embed_table)        # talker.embed_input_ids = the talker's own codec table
             builder = OmniTalkerPromptBuilder(pw, ids, self.device)
         self.model_runner = MI355XARModelRunner(self.engine, kv_transfer=OmniKVTransferManager(conn),
-                                                use_graphs=not getattr(cfg, "enforce_eager", False), prompt_builder=builder)
+                                                use_graphs=not getattr(cfg, "enforce_eager", False), prompt_builder=builder,
+                                                async_scheduling=bool(getattr(cfg, "async_scheduling", False)))
 
     def compile_or_warm_up_model(self) -> None:
         # sampling parameters are per-request device rows read inside the captured step (a request without any gets the

@@ -1,0 +1,154 @@
+"""Async scheduling of the talker stage (stage_configs/qwen3_tts.yaml:16 `async_scheduling: true`; the reference's
+`AsyncGPUModelRunnerOutput` hand-over, gpu_ar_model_runner.py:641-660, and vLLM's batch queue of depth 2 around it): step t + 1 is
+scheduled and dispatched BEFORE step t's outputs are read.  Host logic on the CPU stand-in engine: the request streams, code
+frames, KV hand-off lengths and stop behaviour are those of the synchronous loop; a stop is seen one step late and the surplus
+frame dropped; a length cap is not overrun; a chain time-out found in get_output() redoes that step AND the one dispatched on
+its garbage."""
+import pytest
+import torch
+
+from ht_vllm_omni_amd.config import get_dims
+from ht_vllm_omni_amd.connectors import InProcConnector, OmniKVTransferManager
+from ht_vllm_omni_amd.payloads import SamplingParams, encode_tensor
+from ht_vllm_omni_amd.runner import AsyncStepOutput, MI355XARModelRunner
+from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+from tests.fakes import FakeEngine
+
+BF16 = torch.bfloat16
+
+
+def _request(d, rid, n_prompt, *, max_tokens=8, stop=(), tail=1, seed=0):
+    g = torch.Generator().manual_seed(seed + n_prompt)
+    info = {"talker_prompt_embeds": encode_tensor(torch.randn(n_prompt, d.hidden, generator=g).to(BF16)),
+            "tailing_text_hidden": encode_tensor(torch.randn(tail, d.hidden, generator=g).to(BF16)),
+            "tts_pad_embed": encode_tensor(torch.zeros(d.hidden).to(BF16))}
+    sp = SamplingParams(temperature=0.0, max_tokens=max_tokens, stop_token_ids=tuple(stop))
+    return Request(request_id=rid, num_prompt_tokens=n_prompt, prompt_token_ids=[d.codec_pad_id] * n_prompt,
+                   sampling_params=sp, additional_information=info)
+
+
+class _Worker:
+    def __init__(self, runner):
+        self.model_runner = runner
+        self.handles = []
+
+    def execute_model(self, so):
+        return self.model_runner.execute_model(so)
+
+    def sample_tokens(self, g):
+        out = self.model_runner.sample_tokens(g)
+        self.handles.append(out)
+        return out
+
+
+def _run(async_on, *, num_blocks=64, n_req=6, max_tokens=14, stop=(), fault_at=(), kv=False, max_batch=4, late=()):
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=max_batch, num_blocks=num_blocks)
+    conn = InProcConnector()
+    run = MI355XARModelRunner(eng, use_graphs=False, async_scheduling=async_on, kv_transfer=OmniKVTransferManager(conn) if kv else None)
+    s = MI355XARScheduler(num_blocks=num_blocks, block_size=16, max_num_seqs=max_batch, max_num_batched_tokens=48, max_model_len=512,
+                          async_scheduling=async_on, need_send_cache=kv)
+    wk = _Worker(run)
+    core = TalkerStageEngine(wk, s)
+    for i in range(n_req):
+        core.add_request(_request(d, f"r{i}", 9 + 5 * i, max_tokens=max_tokens, tail=3, seed=i, stop=stop))
+    late = dict(late)
+    streams, codes, hidden, finish, kvp = {}, {}, {}, {}, {}
+    decodes = 0
+    for it in range(600):
+        if it in late:
+            core.add_request(_request(d, late[it], 7, max_tokens=max_tokens, tail=2, seed=77, stop=stop))
+        if not core.has_work():
+            break
+        n0 = sum(1 for c in eng.calls if c[0] == "decode")
+        if n0 in fault_at and eng.persistent_chains:
+            eng.fault_next = True
+        for o in core.step():
+            streams.setdefault(o.request_id, []).extend(o.new_token_ids)
+            if o.pooling_output is not None and o.new_token_ids and o.pooling_output["audio_codes"].shape[0] == 1 \
+                    and int(o.pooling_output["audio_codes"].abs().sum()) > 0:
+                codes.setdefault(o.request_id, []).append(o.pooling_output["audio_codes"][0].tolist())
+                hidden.setdefault(o.request_id, []).append(float(o.pooling_output["hidden"].float().sum()))
+            if o.finished:
+                finish[o.request_id] = (o.finish_reason, o.stop_reason)
+                if o.kv_transfer_params:
+                    kvp[o.request_id] = o.kv_transfer_params["kv_metadata"]["seq_len"]
+        decodes = max(decodes, n0)
+    assert not core.has_work(), "engine loop did not drain"
+    return dict(streams=streams, codes=codes, hidden=hidden, finish=finish, kv=kvp, run=run, eng=eng, sched=s, wk=wk, conn=conn)
+
+
+def test_async_loop_matches_the_synchronous_loop():
+    a, b = _run(False), _run(True)
+    assert a["streams"] == b["streams"] and a["codes"] == b["codes"] and a["hidden"] == b["hidden"] and a["finish"] == b["finish"]
+    assert all(len(v) == 14 for v in b["streams"].values())
+    # the handles really were AsyncModelRunnerOutput-shaped, and a step was dispatched before its predecessor was read
+    assert all(isinstance(h, AsyncStepOutput) for h in b["wk"].handles if h is not None and not hasattr(h, "req_ids"))
+    assert any(isinstance(h, AsyncStepOutput) for h in b["wk"].handles)
+    assert not b["run"].requests and not b["run"].preempted and not b["run"]._inflight
+    assert b["sched"].pool.num_free == a["sched"].pool.num_free
+
+
+def test_async_length_cap_is_not_overrun_and_a_stop_costs_one_surplus_step():
+    # length cap: known ahead -> the async loop runs exactly the decode steps the synchronous one does
+    a, b = _run(False, n_req=3, max_tokens=6), _run(True, n_req=3, max_tokens=6)
+    na, nb = (sum(1 for c in r["eng"].calls if c[0] == "decode") for r in (a, b))
+    assert a["streams"] == b["streams"] and nb <= na + 1, (na, nb)
+    # stop token: find one the streams really emit, rerun with it as a stop id: same truncated streams in both modes, the surplus
+    # frame (sampled behind the stop, one step late) never reaches the outputs
+    tok = a["streams"]["r1"][3]
+    a2, b2 = _run(False, n_req=3, max_tokens=12, stop=(tok,)), _run(True, n_req=3, max_tokens=12, stop=(tok,))
+    assert a2["streams"] == b2["streams"] and a2["finish"] == b2["finish"] and a2["codes"] == b2["codes"]
+    assert a2["finish"]["r1"] == ("stop", tok) and a2["streams"]["r1"][-1] == tok
+    assert not b2["run"].requests and b2["sched"].pool.num_free == a2["sched"].pool.num_free
+
+
+def test_async_preemption_recomputes_and_joins_the_same_streams():
+    ref = _run(False, num_blocks=64)
+    a, b = _run(False, num_blocks=8), _run(True, num_blocks=8)
+    assert a["streams"] == ref["streams"] and b["streams"] == ref["streams"]
+    assert b["codes"] == ref["codes"]
+    assert not b["run"].preempted and not b["run"].requests
+
+
+def test_async_kv_handoff_ships_the_same_lengths():
+    a, b = _run(False, kv=True, n_req=3, max_tokens=5), _run(True, kv=True, n_req=3, max_tokens=5)
+    assert a["kv"] == b["kv"] and len(a["kv"]) == 3
+    assert a["streams"] == b["streams"]
+    for rid in a["kv"]:
+        ka, _ = a["conn"].get("0", "1", f"omni_0_to_1_kv_cache_{rid}")
+        kb, _ = b["conn"].get("0", "1", f"omni_0_to_1_kv_cache_{rid}")
+        assert ka["layer_blocks"]["key_cache"][0].shape == kb["layer_blocks"]["key_cache"][0].shape
+    assert b["sched"].pool.num_free == a["sched"].pool.num_free and not b["sched"].waiting_for_transfer_free
+
+
+@pytest.mark.parametrize("fault_at", [(3,), (1,), (6,)])
+def test_async_chain_timeout_redoes_the_step_and_the_one_dispatched_behind_it(fault_at):
+    """The status word of step t is read in get_output(t), when step t + 1 has already been dispatched on step t's garbage: both
+    are redone (t from the host records of t - 1, t + 1 from the records the redone t just wrote), the streams are those of a
+    clean run -- with late arrivals and finishing requests changing the batch between the two steps."""
+    late = ((4, "late0"), (7, "late1"))
+    clean = _run(True, n_req=3, max_tokens=9, late=late)
+    hurt = _run(True, n_req=3, max_tokens=9, late=late, fault_at=fault_at)
+    assert hurt["run"].chain_fallbacks == 1 and clean["run"].chain_fallbacks == 0
+    assert ("recover",) in hurt["eng"].calls and not hurt["eng"].persistent_chains
+    assert clean["streams"] == hurt["streams"] and clean["codes"] == hurt["codes"] and clean["hidden"] == hurt["hidden"]
+    sync = _run(False, n_req=3, max_tokens=9, late=late, fault_at=fault_at)
+    assert sync["streams"] == clean["streams"] and sync["run"].chain_fallbacks == 1
+
+
+def test_get_output_is_idempotent_and_ordered():
+    d = get_dims("tiny")
+    eng = FakeEngine(d, max_batch=4)
+    run = MI355XARModelRunner(eng, use_graphs=False, async_scheduling=True)
+    s = MI355XARScheduler(num_blocks=64, block_size=16, max_num_seqs=4, max_num_batched_tokens=48, max_model_len=512, async_scheduling=True)
+    s.add_request(_request(d, "a", 6, max_tokens=5))
+    so1 = s.schedule(); run.execute_model(so1); h1 = run.sample_tokens(None)
+    so2 = s.schedule(); run.execute_model(so2); h2 = run.sample_tokens(None)
+    assert isinstance(h1, AsyncStepOutput) and so2.num_scheduled_tokens == {"a": 1}       # scheduled on a placeholder
+    o2 = h2.get_output()                # asking for the younger step first finishes the older one before it
+    o1 = h1.get_output()
+    assert h1.get_output() is o1 and len(o1.sampled_token_ids[0]) == 1 and len(o2.sampled_token_ids[0]) == 1
+    assert run.requests["a"].output_ids == o1.sampled_token_ids[0] + o2.sampled_token_ids[0]
+    s.update_from_output(so1, o1); s.update_from_output(so2, o2)
+    assert s.requests["a"].num_output_placeholders == 0 and s.requests["a"].output_token_ids == run.requests["a"].output_ids

@@ -18,11 +18,11 @@ pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
 
 
-def _drive(d, w, B, steps, fault_at, graphs):
+def _drive(d, w, B, steps, fault_at, graphs, async_on=False):
     bs, nb = 16, 4 * B + 8
     eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs, max_batch=64)
     eng.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
-    run = MI355XARModelRunner(eng, use_graphs=graphs)
+    run = MI355XARModelRunner(eng, use_graphs=graphs, async_scheduling=async_on)
     if graphs:
         run.capture_graphs([64])
     pool = BlockPool(nb, bs)
@@ -40,8 +40,8 @@ def _drive(d, w, B, steps, fault_at, graphs):
                                       sampling_params=sp, additional_information=info))
     so = OmniSchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens=dict(plen), total_num_scheduled_tokens=sum(plen.values()))
     assert run.execute_model(so) is None
-    outs = [run.sample_tokens(None)]
-    ran = []
+    handles = [run.sample_tokens(None)]
+    outs, ran = [], []
     for s in range(steps):
         nbk = []
         for k in keys:
@@ -50,24 +50,34 @@ def _drive(d, w, B, steps, fault_at, graphs):
         so = OmniSchedulerOutput(scheduled_cached_reqs=OmniCachedRequestData(req_ids=list(keys), new_block_ids=nbk),
                                  num_scheduled_tokens={k: 1 for k in keys}, total_num_scheduled_tokens=B)
         if s == fault_at:
+            torch.cuda.synchronize()
             eng.chain_error(reset=2)          # as if a flag wait had timed out: the step's chains stop waiting -> garbage
         run.execute_model(so)
-        outs.append(run.sample_tokens(None))
-        ran.append(eng.chains_ran())
+        handles.append(run.sample_tokens(None))
+        if async_on:                          # the engine core's order: the step just dispatched runs while its predecessor is read
+            outs.append(handles[-2].get_output())
+            torch.cuda.synchronize()
+        else:
+            outs.append(handles[-2])
+        ran.append(int(eng.status[2]))
+    outs.append(handles[-1].get_output() if async_on else handles[-1])
     return outs, ran, run, eng
 
 
-@pytest.mark.parametrize("graphs", [True, False])
-def test_chain_timeout_falls_back_to_the_launch_path_and_redoes_the_step(graphs):
+@pytest.mark.parametrize("graphs,async_on", [(True, False), (False, False), (True, True)])
+def test_chain_timeout_falls_back_to_the_launch_path_and_redoes_the_step(graphs, async_on):
+    """async_on: the status word of step t is read in get_output(t) -- after step t + 1 was dispatched on step t's garbage: both
+    are redone, t from the host records of t - 1, t + 1 from the records the redone t wrote."""
     d = get_dims("tts-1.7b").with_(layers=2, max_model_len=256)
     w = make_weights(d, seed=12, std=0.02)
     B, steps = 64, 5
-    clean, ran0, run0, eng0 = _drive(d, w, B, steps, fault_at=-1, graphs=graphs)
+    clean, ran0, run0, eng0 = _drive(d, w, B, steps, fault_at=-1, graphs=graphs, async_on=async_on)
     assert all(r == 3 for r in ran0), f"both chains must run at the 1.7B shape with 64 rows (chains_ran per step: {ran0})"
     assert getattr(run0, "chain_fallbacks", 0) == 0
-    hurt, ran1, run1, eng1 = _drive(d, w, B, steps, fault_at=2, graphs=graphs)
+    hurt, ran1, run1, eng1 = _drive(d, w, B, steps, fault_at=2, graphs=graphs, async_on=async_on)
     assert run1.chain_fallbacks == 1
-    assert ran1[:2] == [3, 3] and all(r == 0 for r in ran1[2:]), f"after the fall-back the steps run launch-per-op: {ran1}"
+    k = 3 if async_on else 2       # async: the step behind the faulted one had been dispatched (chains still on) before the word was read
+    assert all(r == 3 for r in ran1[:k - (1 if async_on else 0)]) and all(r == 0 for r in ran1[k:]), f"after the fall-back the steps run launch-per-op: {ran1}"
     assert eng1.chain_error() == 0 and not eng1.persistent_chains
     for s, (a, b) in enumerate(zip(clean, hurt)):
         assert a.req_ids == b.req_ids

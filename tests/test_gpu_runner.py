@@ -311,6 +311,73 @@ def test_engine_core_loop_scheduler_worker_oracle():
     wk.shutdown()
 
 
+def test_engine_core_loop_async_scheduling_is_bit_identical_to_the_synchronous_loop():
+    """the async output path (sample_tokens -> AsyncStepOutput, get_output() after the next dispatch) hands
+    on the same ids, code frames, hidden states and KV hand-offs as the synchronous loop the oracle test above pins -- at the
+    1.7B width with sampling on, chunked prefill, a finishing request per few steps and late arrivals."""
+    from ht_vllm_omni_amd.scheduler import MI355XARScheduler, Request, TalkerStageEngine
+    from ht_vllm_omni_amd.runner import AsyncStepOutput
+    d = get_dims("tts-1.7b").with_(layers=2, max_model_len=512)
+    w = make_weights(d, seed=9, std=0.02)
+    bs, nb = 16, 256
+
+    def run_once(async_on):
+        sp0 = SamplingParams(temperature=0.9, top_k=50, repetition_penalty=1.05, seed=5)
+        cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=64, num_gpu_blocks_override=nb, weights=w,
+                          default_sampling_params=sp0, async_scheduling=async_on)
+        wk = MI355XARWorker(cfg, local_rank=0, rank=0)
+        wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
+        conn = InProcConnector()
+        wk.model_runner.kv_transfer_manager = OmniKVTransferManager(conn)
+        wk.engine.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
+        wk.compile_or_warm_up_model()
+        sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=64, max_num_batched_tokens=512,
+                                  max_model_len=d.max_model_len, need_send_cache=True, async_scheduling=async_on)
+        core = TalkerStageEngine(wk, sched)
+        g = torch.Generator().manual_seed(4)
+        pending = []
+        for i in range(72):
+            n = int(torch.randint(3, 40, (1,), generator=g))
+            m = int(torch.randint(2, 14, (1,), generator=g))
+            sp = SamplingParams(temperature=0.9, top_k=50, repetition_penalty=1.05, seed=5 + i, max_tokens=m, stop_token_ids=())
+            info = {"talker_prompt_embeds": encode_tensor((torch.randn(n, d.hidden, generator=g) * 0.5).to(BF16)),
+                    "tts_pad_embed": encode_tensor((torch.randn(d.hidden, generator=g) * 0.02).to(BF16)),
+                    "tailing_text_hidden": encode_tensor((torch.randn(3, d.hidden, generator=g) * 0.02).to(BF16))}
+            pending.append(Request(request_id=f"r{i}", num_prompt_tokens=n, prompt_token_ids=[d.codec_pad_id] * n, sampling_params=sp,
+                                   additional_information=info, ignore_eos=True))
+        for r in pending[:60]:
+            core.add_request(r)
+        pending = pending[60:]
+        streams, codes, hid, kvlen, steps, handles = {}, {}, {}, {}, 0, 0
+        while (pending or core.has_work()) and steps < 400:
+            if steps % 3 == 2 and pending:
+                core.add_request(pending.pop(0))
+            for o in core.step():
+                streams.setdefault(o.request_id, []).extend(o.new_token_ids)
+                if o.pooling_output is not None and o.new_token_ids:
+                    codes.setdefault(o.request_id, []).append(o.pooling_output["audio_codes"].clone())
+                    hid.setdefault(o.request_id, []).append(o.pooling_output["hidden"].clone())
+                if o.finished and o.kv_transfer_params:
+                    kvlen[o.request_id] = o.kv_transfer_params["kv_metadata"]["seq_len"]
+            handles += sum(isinstance(h, AsyncStepOutput) for _, h in core.inflight)
+            steps += 1
+        core.step()
+        chains = int(wk.engine.status[2])
+        rows, free = list(wk.model_runner.rows), sched.pool.num_free
+        wk.shutdown()
+        return streams, codes, hid, kvlen, handles, rows, free, chains
+
+    s0, c0, h0, k0, n0, rows0, free0, _ = run_once(False)
+    s1, c1, h1, k1, n1, rows1, free1, _ = run_once(True)
+    assert n0 == 0 and n1 > 0, "the async loop keeps AsyncStepOutput handles in flight"
+    assert len(s0) == 72 and s0 == s1, "token streams"
+    assert k0 == k1 and len(k0) == 72
+    for k in s0:
+        assert len(c0[k]) == len(c1[k]) and all(torch.equal(a, b) for a, b in zip(c0[k], c1[k])), f"{k}: code frames"
+        assert all(torch.equal(a, b) for a, b in zip(h0[k], h1[k])), f"{k}: hidden states"
+    assert rows0 == rows1 == [] and free0 == free1 == nb - 1
+
+
 def test_omni_request_prompt_built_on_device_then_decodes_with_queued_text_steps():
     """A Qwen3-Omni style request carries the thinker's outputs, not ready talker embeddings: the runner's prompt builder
     (prompt_builder_omni = the reference's talker_preprocess_prefill) makes the prompt and the text-step queue on the
@@ -384,15 +451,15 @@ def test_engine_core_soak_with_request_churn():
     bs, nb = 16, 40
     dflt = SamplingParams(temperature=0.9, top_k=20, repetition_penalty=1.05, seed=5)
 
-    def run_once():
+    def run_once(async_on=False):
         cfg = make_config(d, kv_cache_dtype="fp8", block_size=bs, max_num_seqs=8, num_gpu_blocks_override=nb, weights=w,
-                          enforce_eager=False, default_sampling_params=dflt)
+                          enforce_eager=False, default_sampling_params=dflt, async_scheduling=async_on)
         wk = MI355XARWorker(cfg, local_rank=0, rank=0)
         wk.init_device(); wk.load_model(); wk.initialize_from_config(None)
         wk.engine.set_sampling(cp_greedy=0, cp_temperature=0.9, cp_top_k=20)
         wk.compile_or_warm_up_model()
         sched = MI355XARScheduler(num_blocks=nb, block_size=bs, max_num_seqs=8, max_num_batched_tokens=64,
-                                  max_model_len=d.max_model_len, need_send_cache=False)
+                                  max_model_len=d.max_model_len, need_send_cache=False, async_scheduling=async_on)
         core = TalkerStageEngine(wk, sched)
         g = torch.Generator().manual_seed(77)
         want = {}
@@ -408,7 +475,7 @@ def test_engine_core_soak_with_request_churn():
                                    additional_information=info, ignore_eos=True))
             want[f"r{i}"] = m
         streams, finished, steps = {}, {}, 0
-        while (pending or sched.has_unfinished_requests()) and steps < 4000:
+        while (pending or core.has_work()) and steps < 4000:
             for _ in range(2):                                   # requests keep arriving while others decode
                 if pending:
                     core.add_request(pending.pop(0))
@@ -430,6 +497,12 @@ def test_engine_core_soak_with_request_churn():
     assert stats["replays"] > 0
     _, streams2, *_ = run_once()
     assert streams2 == streams, "same workload, same seeds -> same token streams"
+    # async scheduling (stage_configs/qwen3_tts.yaml:16): every step is dispatched before its predecessor's outputs are read; the
+    # arrival pattern relative to the steps shifts (outputs come one loop turn later), the requests' streams do not
+    want3, streams3, finished3, _, stats3, free3, rows3 = run_once(async_on=True)
+    assert set(finished3) == set(want) and all(r == "length" for r in finished3.values())
+    assert streams3 == streams, "async scheduling changes no request's token stream"
+    assert free3 == nb - 1 and rows3 == [] and stats3["replays"] > 0
 
 
 def test_chunk_streamer_fed_by_the_real_runner_ships_the_oracles_frames():
