@@ -50,7 +50,9 @@ struct ChainPrefetch {           // N = loads per wave that F issues
 // ONEPASS: more than 6 tiles still combine in ONE pass (the caller's LDS holds CH_WAVES * NT * MT KB of slots): one barrier
 // instead of three and twice the epilogue threads at work; same order of additions.
 // PS: rows per sum(r^2) slab (64; 128 for the code predictor's two-position pass, whose stream holds 128 rows)
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false, int PS = 64>
+// WAUX: cache policy of the WEIGHT loads (0 default, OMNI_AUX_NT = non-temporal: MI355X_MICROARCH "nt-weights" -- for slices that exactly
+// one workgroup reads once per launch; round 5 A/B, profiles/r05_ab_table.txt)
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false, int PS = 64, int WAUX = 0>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -97,7 +99,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #endif
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), 0);
+                Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), WAUX);
         }
         if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
     }
@@ -131,7 +133,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         if (WRING) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                Wq[d % G][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + wave + d * CH_WAVES) * 1024), 0);
+                Wq[d % G][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + wave + d * CH_WAVES) * 1024), WAUX);
         }
         if (NORM && !NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, (wave + d * CH_WAVES) * 64, 0);
 #ifdef OMNI_DEBUG_HOOKS

@@ -15,6 +15,7 @@
 #include "gemm_frag.cuh"
 
 #define OMNI_AUX_SC1 16        // cache-policy bit of the raw buffer builtins: sc1 on gfx940+
+#define OMNI_AUX_NT 2          // ... and nt (non-temporal: streamed bytes that nobody re-reads)
 
 // The flag words are kept in OMNI_FLAG_REPLICAS copies, OMNI_FLAG_STRIDE words apart (lines of different memory channels): a
 // workgroup publishes to every copy with ONE store instruction (one lane per copy) and polls only the copy of its XCD

@@ -402,6 +402,7 @@ class TalkerEngine:
         al = lambda n: (n + 255) // 256 * 256  # noqa: E731
         self._rec_off = (0, al((Bm + 4) * 4), al((Bm + 4) * 4) + al(Bm * Q * 8))
         self.out_record = z(self._rec_off[2] + Bm * H * 2, dt=torch.uint8)
+        self._op_handle = None                  # torch_ops.register_engine(self), on first use
         self.ids_status, self.audio_codes, self.last_hidden = self.split_out_record(self.out_record)
         self.input_ids = self.ids_status[:Bm]
         self.status = self.ids_status[Bm:]
@@ -509,7 +510,15 @@ class TalkerEngine:
         return io
 
     def decode_step(self, B: int, advance: bool = True) -> None:
-        """One talker decode step for rows [0, B) on torch's current stream (capturable)."""
+        """One talker decode step for rows [0, B) on torch's current stream (capturable): `torch.ops.mi355x_omni.decode_step_`
+        over omni_talker_decode_step -- host code calling HIP through a PyTorch-ROCm custom op, for the one call that matters."""
+        if self._op_handle is None:
+            from . import torch_ops
+            self._op_handle = torch_ops.register_engine(self)
+        torch.ops.mi355x_omni.decode_step_(self._op_handle, self.out_record, self.positions, self.seq_lens, self.seen, self.steps,
+                                           self.kv_caches, self.text_step, self.block_table, self.num_live, int(B), bool(advance))
+
+    def _decode_step_native(self, B: int, advance: bool = True) -> None:
         st = L.current_stream()
         if self.n_sub > 1 and B > self.sub_rows:
             # fork: one branch per row range (works eagerly and under stream capture -> parallel graph branches)

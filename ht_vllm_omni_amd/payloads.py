@@ -27,6 +27,7 @@ class SamplingParams:
     seed: int | None = 42
     max_tokens: int = 4096
     stop_token_ids: tuple[int, ...] = (2150,)
+    logprobs: int | None = None        # vLLM: the sampled token's log-probability + this many top alternatives per generated token
 
     @property
     def greedy(self) -> bool:
@@ -64,6 +65,21 @@ class OmniSchedulerOutput:
     preempted_req_ids: set[str] = field(default_factory=set)
     # omni: {req_id: {"seq_len": int, "block_ids": [...], "custom_metadata": {...}?}}  (output.py:73-77)
     finished_requests_needing_kv_transfer: dict[str, dict] = field(default_factory=dict)
+
+
+@dataclass
+class LogprobsLists:
+    """vLLM ``v1.outputs.LogprobsLists``: one entry per OUTPUT ROW of the step (index = req_id_to_index), each covering the tokens
+    that row sampled this step (0 or 1 here): ids / log-probabilities of [sampled token, top-1, top-2, ...] and the sampled token's
+    rank (1 = it was the most probable)."""
+    logprob_token_ids: list[list[int]]
+    logprobs: list[list[float]]
+    sampled_token_ranks: list[int]
+
+    def slice_request(self, req_index: int, num_tokens: int = 1, num_logprobs: int | None = None) -> "LogprobsLists":
+        n = None if num_logprobs is None else num_logprobs + 1
+        return LogprobsLists([self.logprob_token_ids[req_index][:n]] if num_tokens else [], [self.logprobs[req_index][:n]] if num_tokens else [],
+                             [self.sampled_token_ranks[req_index]] if num_tokens else [])
 
 
 @dataclass

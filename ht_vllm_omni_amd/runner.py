@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from .connectors import OmniKVTransferManager
-from .payloads import (EMPTY_MODEL_RUNNER_OUTPUT, OmniModelRunnerOutput, OmniSchedulerOutput, SamplingParams,
+from .payloads import (EMPTY_MODEL_RUNNER_OUTPUT, LogprobsLists, OmniModelRunnerOutput, OmniSchedulerOutput, SamplingParams,
                        decode_additional_information)
 
 logger = logging.getLogger("ht_vllm_omni_amd.runner")
@@ -98,6 +98,9 @@ class _StepState:
     # reads this snapshot, never `self.rows`
     sched_rows: list = field(default_factory=list)
     n_rows: int = 0
+    # requested log-probabilities (SamplingParams.logprobs; gpu_ar_model_runner.py:516-519,631-636): row -> device tensors
+    # (token ids [k + 1], logprobs [k + 1], rank, NaNs in the row's logits), filled at dispatch from the step's own logits
+    logprobs: dict = field(default_factory=dict)
 
 
 @dataclass
@@ -109,6 +112,7 @@ class _HostRecord:
     codes: torch.Tensor | None                  # [nd, Q] int64
     spans: dict[int, torch.Tensor]              # row -> hidden [n, H] of its prefill span
     dropped: set = field(default_factory=set)   # rows whose decode output of this step does not exist (redo: they had left)
+    logprobs: dict = field(default_factory=dict)   # row -> (ids list, logprobs list, rank, nans)
 
 
 class AsyncStepOutput:
@@ -180,6 +184,10 @@ class MI355XARModelRunner:
         self._pin: dict[str, list] = {}                 # pinned host rings for the dispatch-side H2D copies (async, never blocking)
         self._pin_i = 0
         self.chain_fallbacks = 0
+        # after a fall-back the chains come back once `_rearm_after` launch-path steps went by clean (doubling after every fall-back:
+        # a GPU that is shared for good settles on the launch path, a passing neighbour costs one redo) -- ADVICE r4
+        self._rearm_after, self._clean_steps, self._chains_parked = 512, 0, False
+        self._num_live = -1                             # what engine.num_live holds (device word rewritten only when it changes)
         # Qwen3-Omni requests arrive with the thinker's outputs instead of ready talker_prompt_embeds: the builder
         # (prompt_builder_omni.OmniTalkerPromptBuilder = the reference's talker_preprocess_prefill) turns them into the
         # prompt embeddings + the queue of text steps on the device
@@ -226,7 +234,7 @@ class MI355XARModelRunner:
         if perm == list(range(n)):
             return
         self._tt_flush()
-        idx = torch.as_tensor(perm, device=self.engine.input_ids.device)
+        idx = self._h2d("perm", np.asarray(perm, np.int64), torch.int64)
         for name in _ROW_BUFFERS + ("rope_delta",):
             buf = getattr(self.engine, name, None)
             if buf is None:
@@ -322,8 +330,8 @@ class MI355XARModelRunner:
             st = RequestState(req_id=nr.req_id, prompt_embeds=pe.to(BF16).cpu().contiguous(),
                               block_ids=list(nr.block_ids[0]), sampling=nr.sampling_params or self.default_sampling,
                               num_computed=int(nr.num_computed_tokens),
-                              tail=None if tail is None else tail.to(device=dev, dtype=BF16).reshape(-1, self.d.hidden),
-                              tts_pad=pad.to(device=dev, dtype=BF16).reshape(-1), info=info)
+                              tail=None if tail is None else self._up(tail, BF16).reshape(-1, self.d.hidden),
+                              tts_pad=self._up(pad, BF16).reshape(-1), info=info)
             mp = getattr(nr, "mrope_positions", None)
             mp = info.get("mrope_positions") if mp is None else mp
             if mp is not None:
@@ -338,7 +346,9 @@ class MI355XARModelRunner:
                 # emit (an id outside the table read device memory out of bounds)
                 rows = int(getattr(e, "rope_rows", 0) or self.d.max_model_len)
                 # last sequence index the request can reach: the scheduler stops it at max_model_len whatever max_tokens says
-                end = min(st.prompt_len + int(getattr(st.sampling, "max_tokens", 0) or 0), int(self.d.max_model_len)) - 1
+                # (max_tokens None / 0 = vLLM's "no cap": the bound is then max_model_len itself -- ADVICE r4)
+                mt = int(getattr(st.sampling, "max_tokens", 0) or 0)
+                end = (min(st.prompt_len + mt, int(self.d.max_model_len)) if mt > 0 else int(self.d.max_model_len)) - 1
                 lo = min([st.prompt_len + md, end + md] + ([int(mp.min())] if mp.numel() else []))
                 hi = max([st.prompt_len + md, end + md] + ([int(mp.max())] if mp.numel() else []))
                 if lo < 0 or hi >= rows:
@@ -356,10 +366,11 @@ class MI355XARModelRunner:
             self.rows.append(nr.req_id)
             self._reset_row(r)
             e.set_row_sampling(r, **row_sampling)
-            e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=dev)
+            e.block_table[r, :len(st.block_ids)] = self._up(st.block_ids, torch.int32)
         # cached requests: new blocks (block_table.append_row, gpu_model_runner.py:489); vLLM's own scheduler brings a
         # preempted request back HERE, flagged resumed_from_preemption, with its complete new block list (:470-489)
         c = so.scheduled_cached_reqs
+        upd_at, upd_val = [], []
         for i, rid in enumerate(c.req_ids):
             resumed = i < len(c.resumed_from_preemption) and c.resumed_from_preemption[i]
             if resumed and rid in self.preempted:
@@ -371,9 +382,15 @@ class MI355XARModelRunner:
             if nb:
                 new = list(nb[0])
                 r = self.rows.index(rid)
-                dev = e.block_table.device
-                e.block_table[r, len(st.block_ids):len(st.block_ids) + len(new)] = torch.as_tensor(new, dtype=torch.int32, device=dev)
+                base = r * int(e.block_table.shape[1]) + len(st.block_ids)
+                upd_at.extend(range(base, base + len(new)))
+                upd_val.extend(new)
                 st.block_ids.extend(new)
+        if upd_at:
+            # the step's new blocks of ALL rows in one pinned upload + one scatter (a pageable copy per row would hold the host
+            # until the step in flight had drained: profiles/r05_pinned_read_probe.txt)
+            t = self._h2d("bt_upd", np.asarray([upd_at, upd_val], np.int64), torch.int64)
+            e.block_table.view(-1).index_put_((t[0],), t[1].to(torch.int32))
 
     def _update_intermediate_buffer(self, req_id: str, upd: dict) -> None:
         """Merge a per-request update into ``model_intermediate_buffer`` (V/worker/gpu_model_runner.py:1330-1353, known answers
@@ -464,7 +481,7 @@ class MI355XARModelRunner:
         self.rows.append(rid)
         self._reset_row(r)
         e.set_row_sampling(r, **self._row_sampling(rid, st.sampling))
-        e.block_table[r, :len(st.block_ids)] = torch.as_tensor(st.block_ids, dtype=torch.int32, device=e.block_table.device)
+        e.block_table[r, :len(st.block_ids)] = self._up(st.block_ids, torch.int32)
 
     def _restore_decode_row(self, r: int, st: RequestState, hidden_last: torch.Tensor, position: int | None = None) -> None:
         e, d = self.engine, self.d
@@ -479,7 +496,7 @@ class MI355XARModelRunner:
         e.steps[r] = L
         e.seen[r].zero_()
         ids = [d.codec_pad_id] + [t for t in st.output_ids if 0 <= t < d.vocab]
-        e.seen[r, torch.as_tensor(ids, dtype=torch.long, device=e.seen.device)] = 1
+        e.seen[r, self._up(ids, torch.long)] = 1
 
     # ------------------------------------------------------------------ phase 1
     @torch.inference_mode()
@@ -548,14 +565,13 @@ class MI355XARModelRunner:
             meta.append((r, s0, n))
             rope.append(st.rope_ids(s0, n))
             any_mrope = any_mrope or st.mrope_positions is not None or st.mrope_delta != 0
-        sampled = None
+        sampled, lp_pre = None, None
         if xs:
             dev = e.input_ids.device
-            x = torch.cat(xs, 0).to(dev)
-            hid = e.prefill(x, torch.as_tensor(np.concatenate(pos), dtype=torch.int32, device=dev),
-                            torch.as_tensor(np.concatenate(req), dtype=torch.int32, device=dev),
-                            torch.as_tensor(np.concatenate(slots), dtype=torch.int64, device=dev),
-                            **({"rope_positions": torch.cat(rope, 1).to(device=dev, dtype=torch.int32)} if any_mrope else {}))
+            x = self._up(torch.cat(xs, 0))
+            hid = e.prefill(x, self._up(np.concatenate(pos), torch.int32), self._up(np.concatenate(req), torch.int32),
+                            self._up(np.concatenate(slots), torch.int64),
+                            **({"rope_positions": self._up(torch.cat(rope, 1), torch.int32)} if any_mrope else {}))
             o = 0
             for r, s0, n in meta:
                 st = self.requests[self.rows[r]]
@@ -572,6 +588,9 @@ class MI355XARModelRunner:
                 hl = torch.stack([prefill_done[r] for r in rows_done])
                 logits = e.compute_logits(hl)
                 sampled = self._sample_prefill(rows_done, logits)
+                kk = self._wants_logprobs([self.requests[self.rows[r]] for r in rows_done])
+                if kk >= 0:
+                    lp_pre = (rows_done, self._logprob_rows(logits, sampled, kk))
                 for j, r in enumerate(rows_done):
                     st = self.requests[self.rows[r]]
                     e.last_hidden[r] = hl[j]
@@ -579,7 +598,7 @@ class MI355XARModelRunner:
                     e.seq_lens[r] = st.prompt_len + 1
                     if getattr(e, "rope_delta", None) is not None:
                         e.rope_delta[r] = st.mrope_delta
-                e.input_ids[torch.as_tensor(rows_done, device=dev)] = sampled
+                e.input_ids[self._up(rows_done, torch.long)] = sampled
 
         # ---- decode rows: text-step queue pop (talker.py:618-629), then the native step
         if nd:
@@ -592,6 +611,13 @@ class MI355XARModelRunner:
             torch.index_select(self._tt, 0, self._h2d("tt_idx", idx, torch.int64), out=e.text_step[:nd])
             with _Range("gpu_model_runner: forward"):      # the native step: talker_mtp, backbone, compute_logits AND the sampler
                 self._run_decode(nd)
+        lp_rows: dict = {}
+        if lp_pre is not None:
+            lp_rows["pre"] = lp_pre
+        if nd:
+            kk = self._wants_logprobs([self.requests[self.rows[r]] for r in range(nd)])
+            if kk >= 0:        # behind the step, from the logits its lm_head left and the ids its sampler drew (device, stream-ordered)
+                lp_rows["dec"] = (list(range(nd)), self._logprob_rows(e.logits[:nd], e.input_ids[:nd], kk))
         # host counters move at DISPATCH (the scheduler advances num_computed_tokens when it schedules, too): the next
         # execute_model may run before this step's ids have been read
         sched_rows = []
@@ -605,8 +631,36 @@ class MI355XARModelRunner:
             elif r in prefill_done:
                 st.n_sampled += 1
             sched_rows.append((r, rid, st))
-        self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans, sched_rows, len(self.rows))
+        self.execute_model_state = _StepState(scheduler_output, list(range(nd)), prefill_done, sampled, spans, sched_rows, len(self.rows),
+                                              lp_rows)
         return None
+
+    def _logprob_rows(self, logits: torch.Tensor, ids: torch.Tensor, k: int):
+        """vLLM Sampler.gather_logprobs on the step's own (masked, raw: before temperature / penalties -- vLLM's default
+        `raw_logprobs` mode) logits: per row the sampled token's log-probability, the top-k alternatives, the sampled token's rank
+        (1 + how many tokens are more probable) and the NaN count of the row (num_nans_in_logits).  Device tensors; no sync."""
+        lg = logits.float()
+        lp = torch.log_softmax(lg, -1)
+        sel = lp.gather(1, ids.long().reshape(-1, 1))
+        topv, topi = lp.topk(k, -1) if k > 0 else (lp[:, :0], ids.long().reshape(-1, 1)[:, :0])
+        rank = (lp > sel).sum(-1) + 1
+        return (torch.cat([ids.long().reshape(-1, 1), topi], 1), torch.cat([sel, topv], 1), rank, torch.isnan(lg).sum(-1))
+
+    def _wants_logprobs(self, rows) -> int:
+        """-1: nobody asked; else the widest request's top-k (every sampled row of the step gets that many: vLLM's max_num_logprobs)."""
+        ks = [int(st.sampling.logprobs) for st in rows if getattr(st.sampling, "logprobs", None) is not None]
+        return max(ks) if ks else -1
+
+    def _up(self, t, dtype=None) -> torch.Tensor:
+        """Any host tensor / list / array onto the device through pinned memory (admission-time uploads: prompt embeddings, index
+        lists): never a pageable copy, which would hold the host until the step in flight has finished."""
+        dev = self.engine.input_ids.device
+        t = t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))
+        if dtype is not None:
+            t = t.to(dtype)
+        if dev.type != "cuda" or t.device.type == "cuda":
+            return t.to(dev)
+        return t.contiguous().pin_memory().to(dev, non_blocking=True)
 
     def _h2d(self, key: str, values, dtype) -> torch.Tensor:
         """A small host array onto the device WITHOUT stalling the host: a pageable source makes the copy wait until the stream
@@ -631,7 +685,7 @@ class MI355XARModelRunner:
         """First token of the requests whose prompt completed this step, each with ITS request's sampling parameters
         (the per-row device arrays the decode sampler reads)."""
         e = self.engine
-        idx = torch.as_tensor(rows, device=logits.device)
+        idx = self._up(rows, torch.long)
         seen = e.seen.index_select(0, idx)
         seen[:, self.d.codec_pad_id] = 1       # prompt ids are codec_pad placeholders (talker.py:603-605)
         steps = torch.zeros(len(rows), dtype=torch.int32, device=logits.device)
@@ -682,8 +736,11 @@ class MI355XARModelRunner:
             self.graphs.clear()
             if self.use_graphs and sizes:
                 e.num_live.fill_(0)             # the capture's eager warm-up pass must not touch live rows
+                self._num_live = 0
                 self.capture_graphs(sizes)
             self.chain_fallbacks += 1
+            self._chains_parked, self._clean_steps = hasattr(e, "set_chains"), 0
+            self._rearm_after *= 2
         dec = [(r, rid, st) for r, rid, st in stt.sched_rows if r < len(stt.decode_rows)]
         live = [(r, rid, st) for r, rid, st in dec if self.requests.get(rid) is st and rid in self.rows]
         rec.dropped = {r for r, _, _ in dec} - {r for r, _, _ in live}
@@ -722,11 +779,22 @@ class MI355XARModelRunner:
             rec.hidden[r] = hid_cpu[k]
             rec.codes[r] = codes_cpu[k]
         rec.status = [0, status[1], status[2], 0]
+        if any(r in rec.logprobs for r, _, _ in live):
+            kk = max(len(rec.logprobs[r][0]) for r, _, _ in live if r in rec.logprobs) - 1
+            tid, lp, rank, nans = (t.cpu().tolist() for t in self._logprob_rows(e.logits[:nd], e.input_ids[:nd], kk))
+            for k, (r, _, _) in enumerate(live):
+                rec.logprobs[r] = (tid[k], lp[k], int(rank[k]), int(nans[k]))
 
     def _run_decode(self, nd: int) -> None:
         # rows [nd, bucket) of the padded graph may be live PREFILL rows of the persistent batch (decode-first order):
         # the device-side live count keeps the step off their KV blocks, ids, hidden state and counters
-        self.engine.num_live.fill_(nd)
+        if self._chains_parked:
+            self._clean_steps += 1
+            if self._clean_steps >= self._rearm_after and not self._inflight_dirty():
+                self._rearm_chains()
+        if self._num_live != nd:
+            self.engine.num_live.fill_(nd)
+            self._num_live = nd
         g = self.graphs.get(self._bucket(nd)) if self.use_graphs else None
         if g is not None:
             g.replay()
@@ -734,6 +802,24 @@ class MI355XARModelRunner:
         else:
             self.engine.decode_step(nd)
             self.cudagraph_stats["eager_steps"] += 1
+
+    def _inflight_dirty(self) -> bool:
+        return any(h.record is not None for h in self._inflight)
+
+    def _rearm_chains(self) -> None:
+        """Give the persistent chains another try after a long clean stretch on the launch path (same bits either way)."""
+        e = self.engine
+        logger.info("persistent chains re-armed after %d clean launch-path steps (fall-backs so far: %d)", self._clean_steps, self.chain_fallbacks)
+        if e.input_ids.device.type == "cuda":
+            torch.cuda.synchronize()
+        e.set_chains(True)
+        sizes = sorted(self.graphs)
+        self.graphs.clear()
+        if self.use_graphs and sizes:
+            e.num_live.fill_(0)
+            self._num_live = 0
+            self.capture_graphs(sizes)
+        self._chains_parked, self._clean_steps = False, 0
 
     # ------------------------------------------------------------------ phase 2
     def _snapshot(self, stt: _StepState):
@@ -776,22 +862,33 @@ class MI355XARModelRunner:
             hid = e.last_hidden[:n].to("cpu", copy=True)          # a copy of its own: requests keep views of it
             codes = e.audio_codes[:nd].cpu() if nd else None
             spans = {r: h.cpu() for r, (_, _, h) in stt.prefill_spans.items()}
-            return _HostRecord(ids, status, hid, codes, spans)
+            return _HostRecord(ids, status, hid, codes, spans, logprobs=self._logprobs_host(stt))
         if pending[0] == "host":
             _, buf, hid, codes, sp = pending
             has_status = getattr(e, "ids_status", None) is not None
             ids = buf[:n].tolist()
             status = buf[-4:].tolist() if (has_status and nd) else [0, 0, 0, 0]
-            return _HostRecord(ids, status, hid, codes, {r: h.cpu() for r, (_, _, h) in sp.items()})
+            return _HostRecord(ids, status, hid, codes, {r: h.cpu() for r, (_, _, h) in sp.items()}, logprobs=self._logprobs_host(stt))
         _, slot, ev, sp = pending
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ev)
             host = slot.cpu()                        # blocks on the side stream alone: the step after this one keeps running
             spans = {r: h.cpu() for r, (_, _, h) in sp.items()}
+            lps = self._logprobs_host(stt)
         ids_all, codes_all, hid_all = e.split_out_record(host)
         ids = ids_all[:n].tolist()
         status = ids_all[-4:].tolist() if nd else [0, 0, 0, 0]
-        return _HostRecord(ids, status, hid_all[:n], codes_all[:nd] if nd else None, spans)
+        return _HostRecord(ids, status, hid_all[:n], codes_all[:nd] if nd else None, spans, logprobs=lps)
+
+    @staticmethod
+    def _logprobs_host(stt: _StepState) -> dict:
+        """row -> (token ids, logprobs, rank, NaN count) on the host (tensors computed at dispatch, behind the step)."""
+        out: dict = {}
+        for rows, (tid, lp, rank, nans) in stt.logprobs.values():
+            tid, lp, rank, nans = tid.cpu().tolist(), lp.cpu().tolist(), rank.cpu().tolist(), nans.cpu().tolist()
+            for j, r in enumerate(rows):
+                out[r] = (tid[j], lp[j], int(rank[j]), int(nans[j]))
+        return out
 
     @torch.inference_mode()
     def sample_tokens(self, grammar_output=None):
@@ -847,6 +944,8 @@ class MI355XARModelRunner:
         with _Range("gpu_model_runner: postprocess"):       # the step's frames as host lists (the request records keep them)
             codes_list = rec.codes.tolist() if nd else []
         req_ids, sampled, pooler = [], [], []
+        want_lp = bool(rec.logprobs)
+        lp_ids, lp_vals, lp_rank, nans = [], [], [], {}
         with _Range("gpu_model_runner: bookkeep"):
             for r, rid, st in stt.sched_rows:
                 payload: dict[str, Any] = {}
@@ -872,8 +971,20 @@ class MI355XARModelRunner:
                         sampled.append([])
                 req_ids.append(rid)
                 pooler.append(payload)
+                if want_lp:
+                    t = rec.logprobs.get(r) if sampled[-1] else None
+                    lp_ids.append(t[0] if t else [])
+                    lp_vals.append(t[1] if t else [])
+                    lp_rank.append(t[2] if t else 0)
+                    if t:
+                        nans[rid] = t[3]
                 st.last_hidden_cpu = rec.hidden[r]       # h[t] of the request's next decode step (a view of this step's host copy)
         return OmniModelRunnerOutput(
             req_ids=req_ids, req_id_to_index={rid: i for i, rid in enumerate(req_ids)}, sampled_token_ids=sampled,
             pooler_output=pooler if self.engine_output_type != "text" else None, kv_extracted_req_ids=kv_extracted,
-            cudagraph_stats=dict(self.cudagraph_stats))
+            # SamplingParams.logprobs (gpu_ar_model_runner.py:516-519,631-636): filled when any request of the step asked
+            logprobs=LogprobsLists(lp_ids, lp_vals, lp_rank) if want_lp else None, num_nans_in_logits=nans if want_lp else None,
+            # which path the step ran on rides with every output (status word 2 of THIS step's record: bit 0 the code predictor's
+            # chain, bit 1 the backbone's), with the fall-backs so far (a fall-back was visible in a log line only)
+            cudagraph_stats=dict(self.cudagraph_stats, chain_fallbacks=self.chain_fallbacks, chains_ran=int(rec.status[2]),
+                                 persistent_chains=bool(getattr(self.engine, "persistent_chains", False))))

@@ -95,6 +95,7 @@ class EngineCoreOutput:
     finish_reason: str | None = None
     stop_reason: int | None = None
     kv_transfer_params: dict | None = None
+    new_logprobs: Any = None           # LogprobsLists slice of the request (omni_ar_scheduler.py:319-321), when it asked
 
     @property
     def finished(self) -> bool:
@@ -361,8 +362,11 @@ class MI355XARScheduler:
                     req.num_computed_tokens -= req.num_output_placeholders
                     req.num_output_placeholders = 0
                 kv_params = self._free_request(req)
+            new_lp = None
+            if kept and runner_output.logprobs is not None and getattr(req.sampling_params, "logprobs", None) is not None:
+                new_lp = runner_output.logprobs.slice_request(idx, len(kept), int(req.sampling_params.logprobs))   # omni_ar_scheduler.py:319-321
             if kept or pooled is not None or stopped:
-                outs.append(EngineCoreOutput(rid, kept, pooled, req.get_finished_reason(), req.stop_reason, kv_params))
+                outs.append(EngineCoreOutput(rid, kept, pooled, req.get_finished_reason(), req.stop_reason, kv_params, new_lp))
             if self.chunk_streamer is not None and pooled is not None and n == 1 and "audio_codes" in pooled:
                 stream_reqs.append(req)
                 stream_rows.append(pooled["audio_codes"].reshape(-1))

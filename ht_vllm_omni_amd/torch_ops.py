@@ -15,6 +15,10 @@ has kernels: a CPU tensor fails loudly with PyTorch's "no kernel for backend" er
   paged_attn_prefill(q, k_cache, v_cache, block_table, req_of_tok, positions, ...) -> Tensor
   topk_sample(logits, seen?, steps?, greedy, temperature, top_k, top_p, rep_penalty, seed, ...) -> Tensor   vLLM Sampler
   allreduce_oneshot_(peers, r_io?, partials?, out?, which, M)          RowParallelLinear's all-reduce (tp_comm.PeerAllReduce)
+  decode_step_(engine, out_record, positions, seq_lens, seen, steps, kv_caches, text_step, block_table, num_live, B, advance)
+        the WHOLE talker decode step -- talker_mtp + code predictor, 28 layers over the paged KV, lm_head, sampler -- as ONE op over
+        `omni_talker_decode_step` (gpu_ar_model_runner.py:93-400 `_model_forward` + :454 `_sample`): the call the product makes
+        every step (engine.TalkerEngine.decode_step routes through it; hipGraph capture records its launches)
 """
 from __future__ import annotations
 
@@ -45,6 +49,9 @@ _lib.define("paged_attn_prefill(Tensor q, Tensor k_cache, Tensor v_cache, Tensor
 _lib.define("topk_sample(Tensor logits, Tensor(a!)? seen, Tensor(b!)? steps, bool greedy, float temperature, int top_k, float top_p, "
             "float rep_penalty, int seed, int step_mul, int step_add, bool inc_steps) -> Tensor")
 _lib.define("allreduce_oneshot_(int peers, Tensor(a!)? r_io, Tensor(b!)? partials, Tensor(c!)? out, int which, int M, bool accumulate) -> ()")
+_lib.define("decode_step_(int engine, Tensor(a!) out_record, Tensor(b!) positions, Tensor(c!) seq_lens, Tensor(d!) seen, Tensor(e!) steps, "
+            "Tensor(f!)[] kv_caches, Tensor text_step, Tensor block_table, Tensor num_live, int B, bool advance) -> ()")
+_ENGINES: dict[int, object] = {}        # decode_step_: handle -> TalkerEngine (weak: the engine unregisters itself)
 
 
 def _impl(name):
@@ -118,6 +125,31 @@ def _allreduce_oneshot_(peers, r_io, partials, out, which, M, accumulate):
     ar.all_reduce(int(which), r_io=r_io, accumulate=bool(accumulate), partials=partials, out=out, M=int(M))
 
 
+@_impl("decode_step_")
+def _decode_step_(engine, out_record, positions, seq_lens, seen, steps, kv_caches, text_step, block_table, num_live, B, advance):
+    eng = _ENGINES.get(int(engine))
+    eng = eng() if eng is not None else None
+    if eng is None:
+        raise L.OmniError(f"decode_step_: unknown engine handle {engine} (register_engine first)")
+    # the native step reads and writes the engine's graph-stable buffers: the tensors named in the schema (what the step mutates,
+    # for the dispatcher's aliasing rules) must BE those buffers
+    for name, t in (("out_record", out_record), ("positions", positions), ("seq_lens", seq_lens), ("seen", seen), ("steps", steps),
+                    ("text_step", text_step), ("block_table", block_table), ("num_live", num_live)):
+        if t.data_ptr() != getattr(eng, name).data_ptr():
+            raise L.OmniError(f"decode_step_: `{name}` is not the engine's own buffer")
+    if len(kv_caches) != len(eng.kv_caches) or any(a.data_ptr() != b.data_ptr() for a, b in zip(kv_caches, eng.kv_caches)):
+        raise L.OmniError("decode_step_: `kv_caches` are not the engine's own cache tensors")
+    eng._decode_step_native(int(B), bool(advance))
+
+
+def register_engine(eng) -> int:
+    """Handle of a TalkerEngine for `decode_step_` (weakly held: an engine that is gone makes the op raise)."""
+    import weakref
+    h = id(eng)
+    _ENGINES[h] = weakref.ref(eng, lambda _r, h=h: _ENGINES.pop(h, None))
+    return h
+
+
 def register_peers(ar) -> int:
     """Handle of a connected tp_comm.PeerAllReduce for `allreduce_oneshot_` (the op schema carries an int, not the object)."""
     h = id(ar)
@@ -126,4 +158,4 @@ def register_peers(ar) -> int:
 
 
 OPS = ("rmsnorm_residual_", "skinny_gemm", "silu_mul", "lmhead_mask", "qknorm_rope_kvwrite_", "paged_attn_decode", "paged_attn_prefill",
-       "topk_sample", "allreduce_oneshot_")
+       "topk_sample", "allreduce_oneshot_", "decode_step_")

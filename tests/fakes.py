@@ -76,6 +76,10 @@ class FakeEngine:
             steps += 1
         return ids
 
+    def set_chains(self, on):
+        self.persistent_chains = bool(on)
+        self.calls.append(("set_chains", bool(on)))
+
     def recover_from_chain_timeout(self):
         self.status.zero_()
         self.persistent_chains = False

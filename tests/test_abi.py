@@ -115,8 +115,14 @@ def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
     import torch
     from ht_vllm_omni_amd import torch_ops as T
     for n in ("rmsnorm_residual_", "qknorm_rope_kvwrite_", "paged_attn_decode", "paged_attn_prefill", "silu_mul", "skinny_gemm",
-              "lmhead_mask", "topk_sample", "allreduce_oneshot_"):
+              "lmhead_mask", "topk_sample", "allreduce_oneshot_", "decode_step_"):
         assert n in T.OPS and hasattr(torch.ops.mi355x_omni, n), n
+    # the whole decode step is an op too: the engine's per-step call goes through it, its schema names what it mutates
+    sch = str(torch.ops.mi355x_omni.decode_step_.default._schema)
+    assert "Tensor(a!) out_record" in sch and "Tensor(f!)[] kv_caches" in sch
+    import inspect
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    assert "torch.ops.mi355x_omni.decode_step_" in inspect.getsource(TalkerEngine.decode_step)
     assert "Tensor(b!) out" in str(torch.ops.mi355x_omni.rmsnorm_residual_.default._schema)      # caller-allocated output: graph-safe
     with pytest.raises(NotImplementedError):
         torch.ops.mi355x_omni.silu_mul(torch.zeros(2, 8, dtype=torch.bfloat16))
