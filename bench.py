@@ -291,7 +291,8 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+        # (OMNI_BENCH_LAUNCHER: tests put a stub module in the launcher's place to check the relay of a successful child's line)
+        cmd = [sys.executable, "-m", os.environ.get("OMNI_BENCH_LAUNCHER", "torch.distributed.run"), "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
         log("self-launch:", " ".join(cmd))
         r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
@@ -413,6 +414,48 @@ def main():
         log(f"[rank {rank}] in-kernel hand-off timed out during the timed region (code {dev_err}: 1 = chain flags, 2 = peer all-reduce): result void")
         sys.exit(3)
 
+    # ---- tensor-parallel ranks: what ONE all-reduce of the step costs on this node, and which one ran (the first
+    # 8-GPU run must say where its time went).  After the timed region, every rank in lock-step: 2 x layers launches of the step's
+    # own all-reduce -- the one-shot kernel over the peer-mapped buffers (fused residual add + slabs), or RCCL on the [B, H] message
+    ar_diag = None
+    if dist is not None and args.parallel == "tp":
+        try:
+            n_ar = 2 * d.layers
+            sync()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if eng.ar is not None:
+                r_io = torch.zeros(eng.ar.rows16, d.hidden, dtype=torch.bfloat16, device="cuda")
+                slabs = torch.zeros(d.hidden // 16, 64, dtype=torch.float32, device="cuda")
+                for it in range(4):
+                    eng.ar.all_reduce(it & 1, r_io=r_io, accumulate=True, partials=slabs, M=B)
+                a0.record()
+                for it in range(n_ar * 4):
+                    eng.ar.all_reduce(it & 1, r_io=r_io, accumulate=True, partials=slabs, M=B)
+                a1.record()
+                kind = "oneshot-xgmi (peer-mapped, fused with residual add)"
+            else:
+                msg = torch.zeros(B, d.hidden, dtype=torch.bfloat16, device="cuda")
+                for it in range(4):
+                    dist.all_reduce(msg)
+                a0.record()
+                for it in range(n_ar * 4):
+                    dist.all_reduce(msg)
+                a1.record()
+                kind = "rccl (fall-back: all-reduces between the phase calls)"
+            sync()
+            us = a0.elapsed_time(a1) * 1e3 / (n_ar * 4)
+            tus = torch.tensor([us], dtype=torch.float64, device="cuda")
+            allus = [torch.zeros_like(tus) for _ in range(world)]
+            dist.all_gather(allus, tus)
+            ar_diag = {"kind": kind, "launches_per_step": n_ar, "us_per_launch_by_rank": [round(float(x.item()), 2) for x in allus],
+                       "us_per_step": round(max(float(x.item()) for x in allus) * n_ar, 1), "message_bytes": B * d.hidden * 2,
+                       "error_word": int(eng.ar.error()) if eng.ar is not None else 0,
+                       "note": "back-to-back launches of the step's own all-reduce after the timed region, all ranks in lock-step"}
+            log(f"[rank {rank}] all-reduce: {kind}: {us:.2f} us per launch x {n_ar} per step = {us * n_ar / 1e3:.3f} ms; error word "
+                f"{ar_diag['error_word']}; rank error words {rank_words}")
+        except Exception as e:   # noqa: BLE001
+            log(f"[rank {rank}] all-reduce diagnostic failed: {e!r}")
+
     # ---- diagnostics (after the timed region): the backbone half of the step alone, as its own graph
     bb_ms = None
     if graph is not None and world == 1 and args.sub_batches == 1 and not args.tp_force and not args.no_diagnostics:
@@ -509,6 +552,8 @@ def main():
     }
     if args.tp_force:
         out["config"]["parallelism"] += " (tensor-parallel code path forced on one rank)"
+    if ar_diag is not None:
+        out["allreduce"] = ar_diag
     if families is not None:
         out["roofline"]["families"] = families
     if bb_ms is not None:

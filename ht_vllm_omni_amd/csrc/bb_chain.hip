@@ -5,8 +5,9 @@
 // weight slice -- 64-196 KB per workgroup, 32-96 VGPRs per lane -- goes out before the stage's flags, so the HBM stream keeps
 // running through the hand-off instead of stopping for a kernel boundary (1.65 us) plus a cold first fetch; activations
 // cross behind the flags with sc1 accesses.  Tiles = the launch path's (pick_tile at 64 rows), so results are bit-identical.
-// Released 1.7B shape only (hidden 2048, 16 x 128 attention width, intermediate 6144, qkv 4096) at 49-64 rows; every other
-// configuration stays on the launch path.
+// 1.7B shape (hidden 2048, 16 x 128 attention width, intermediate 6144, qkv 4096) at 33-64 rows (round 5: 33-48 rows run the 64-row
+// stage set with their last row tile partly filled -- the launch path picks the same tiles there, gemm.hip pick_tile), 1-32 rows on
+// bb_chain_b32_kernel, the 0.6B shape on bb_chain_small_kernel; every other configuration stays on the launch path.
 #include "chain_gemm.cuh"
 #include "common.cuh"
 #include "kernels.h"
@@ -138,8 +139,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_small_kernel(const BbArgs
 
 // ---- the 1.7B shape at 1-32 rows (round 4): the launch path's tiles at those batch sizes -- 16-row tiles for qkv / o_proj / down_proj
 // (128 column tiles x 2 row tiles), gate_up on 16 rows x 24 columns up to 16 rows and 32 x 24 above (the rstd summation order follows the
-// rows per tile: same bits as the launch path).  33-48 rows keep the launch path (its gate_up tile there is 64 rows, its qkv tile 16:
-// 384 tiles for 256 workgroups).
+// rows per tile: same bits as the launch path).  33-48 rows: bb_chain_kernel (the 64-row stage set).
 template <int GU_MT>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a
                                                  true, 0x1004, a.stamps);
 }
 
-OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 49, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
+OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 33, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
 extern "C" void omni_debug_bb_chain(int on) { g_bb_chain = on != 0; g_bb_prefetch = on == 2; }      // 2: with the cross-stage weight prefetch

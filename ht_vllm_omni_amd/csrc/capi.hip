@@ -712,6 +712,7 @@ extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_
 
 extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(check_io(t, io));
+    t->ran = 0;        // the first phase of every step, whoever drives the phases (decode_step, the tensor-parallel phase calls): ADVICE r4
     const omni_talker_desc& d = t->d;
     const int B = io->B, Q = d.num_code_groups;
     hipStream_t st = (hipStream_t)stream;
@@ -915,9 +916,11 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
     const omni_talker_desc& d = t->d;
     const bool do_attn = (parts & 2) != 0, do_rest = (parts & 4) != 0;
 #ifdef OMNI_DEBUG_HOOKS
-    if (k_bb_all_supported(d, io->B, t->has_ar))      // A/B arm: the whole stack, attention included, as one persistent launch
+    if (parts == 6 && k_bb_all_supported(d, io->B, t->has_ar)) {      // A/B arm: the whole stack, attention included, as one persistent launch
+        t->ran |= 2;                                                  // (a split request -- step_part 2 / 4 -- takes the two-launch structure below)
         return k_bb_all(d, t->bb_table, io, t->attn, t->resid, t->part, t->act, t->qkv, t->chain_flags,
                         reinterpret_cast<int32_t*>(t->chain_flags + 320), stream);
+    }
 #endif
     if (k_bb_chain_supported(d, io->B, t->has_ar) && d.layers > 0) {
         t->ran |= 2;
@@ -952,7 +955,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
         }
         return OMNI_OK;
     }
-    OMNI_CHECK_ARG(parts == 6, "omni_talker_step_part: the attention / rest split needs the backbone chain's launch structure (1.7B dense shape, 49-64 rows, single rank)");
+    OMNI_CHECK_ARG(parts == 6, "omni_talker_step_part: the attention / rest split needs the backbone chain's launch structure (dense 1.7B or 0.6B shape, single rank)");
     for (int l = 0; l < d.layers; ++l) {
         TRY(omni_talker_layer_attn(t, io, l, stream));
         TRY(omni_talker_layer_mlp(t, io, l, stream));
@@ -983,7 +986,6 @@ extern "C" int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io,
 }
 
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
-    if (t) t->ran = 0;
     TRY(omni_talker_mtp(t, io, stream));
     if (g_extra_trivial == 0) {
         TRY(run_backbone(t, io, stream));

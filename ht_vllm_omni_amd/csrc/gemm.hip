@@ -413,7 +413,9 @@ static void pick_tile(int pro, int epi, const GemmArgs& a, int* nt_out, int* mt_
         nt = (cols % 4 == 0 && cols / 4 >= 64) ? 4 : ((cols % 2 == 0 && cols / 2 >= 32) ? 2 : nt);
         // 4096 columns over K >= 2048 (the backbone's qkv): 128 groups x 2 m-splits beat 64 x 4 (10.4 vs 10.8 us; the code
         // predictor's K = 1024 shape does not: same-box A/B of the step)
-        if (!silu && nt == 4 && cols / 4 == 64 && a.K >= 2048 && mt_total == 4) nt = 2;
+        // (33-48 rows -- three 16-row tiles -- take the 64-row choice too since round 5: 128 groups x 2 m-splits of 32 rows, the tile set of
+        //  the persistent backbone launch, which now runs from 33 rows on: bb_chain.hip)
+        if (!silu && nt == 4 && cols / 4 == 64 && a.K >= 2048 && mt_total >= 3) nt = 2;
         if (silu && nt < 2) nt = 2;
         if (gu8 && cols % 3 == 0 && cols / 3 >= 128) nt = 3;  // 256 workgroups (backbone), 128 x 2 m-splits (code predictor)
     } else if (silu && cols % 4 == 0 && cols / 4 >= 160 && mt_total == 4) {

@@ -36,6 +36,10 @@ struct PAArgs {
                                    // q heads each (16 q / 2 kv heads run as 4 x 4); the K / V rows are those of vh / kv_rep
     int dense_pos;                 // attn_small DENSE: every row sits at this position of its own block (block = row)
     const int32_t* num_live;       // fused decode: rows >= *num_live (padding of a graph bucket) write no KV / slot (NULL: all live)
+    int tail_chunks;               // 1: the LAST, partial 128-token round of a pair's history is dealt out as contiguous 32-token chunks, to waves
+                                   // 3, 2, 1, 0 in that order, instead of interleaved 8-token groups over all four: wave 0 -- which also norms,
+                                   // quantises, stores and folds the NEW token -- gets a batch only when the round is nearly full, and no wave
+                                   // runs a batch that is mostly mask (round 5; another fold order of the online softmax, same arithmetic)
     int rope_rows;                 // rows of the cos / sin table (0: unknown): positions[b] + rope_delta[b] is clamped into it -- the host
                                    // refuses requests whose M-RoPE ids could leave the table (runner._update_states); this is the backstop
 };
@@ -188,9 +192,9 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     // holds further on: with blocks allocated ahead of the sequence those were real, cold HBM rows -- up to 127 tokens of
     // wasted traffic per (row, head).  The speculative batch 0 goes out before the length is known and stays unclamped.
     int t_lim = 0x7FFFFFFF;
-#define PA_LOAD(KR, VR, KS, VS, T0)                                                          \
+#define PA_LOAD(KR, VR, KS, VS, T0, STR)                                                     \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                       \
-        const int t_ = min((T0) + u * PA_WAVES * 8 + tg, t_lim);                             \
+        const int t_ = min((T0) + u * (STR) + tg, t_lim);                                    \
         const int bi_ = min(t_ >> a.bs_shift, max_blk);                                      \
         const size_t r_ = pa_cache_row(a, bt[bi_], t_, kvh);                                 \
         KR[u] = load_row<KV>(a.k_cache, r_, sub);                                            \
@@ -202,7 +206,7 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     if (pre != nullptr) {
 #pragma unroll
         for (int u = 0; u < U; ++u) { k0[u] = pre->k[u]; v0[u] = pre->v[u]; ks0[u] = pre->ks[u]; vs0[u] = pre->vs[u]; }
-    } else if (spec && active) { PA_LOAD(k0, v0, ks0, vs0, wave * 8) }
+    } else if (spec && active) { PA_LOAD(k0, v0, ks0, vs0, wave * 8, PA_WAVES * 8) }
     PA_STAMP(1);
     if (CHAIN) chain_gate_wait(*gate, code);                  // the qkv stage's flags; workgroup barrier inside
     PA_STAMP(2);
@@ -215,7 +219,18 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     const int cur = seq_len - 1;                  // the token computed this step
     const int t_end = min(FUSED ? cur : seq_len, t_begin + per);
     t_lim = max(t_end - 1, 0);
-    if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8) }
+    // batches of this wave: batch b of a full round = four 8-token groups 32 apart (T0 = round start + 8 wave, group stride 32); the
+    // tail round (PAArgs::tail_chunks; never round 0, whose loads went out before the length was known) = one contiguous 32-token
+    // chunk per wave, waves 3, 2, 1, 0 in that order (T0 = round start + 32 (3 - wave), group stride 8)
+    constexpr int ROUND = PA_WAVES * 8 * U;
+    const int n_hist = max(t_end - t_begin, 0);
+    const int full = n_hist / ROUND, rem = n_hist - full * ROUND;
+    const bool tail = !CHAIN && a.tail_chunks && full >= 1 && rem > 0;
+    const int nb = tail ? full + ((PA_WAVES - 1 - wave) * (8 * U) < rem ? 1 : 0)
+                        : (n_hist - wave * 8 + ROUND - 1 > 0 ? (max(n_hist - wave * 8, 0) + ROUND - 1) / ROUND : 0);
+    auto b_t0 = [&](int b) { return (tail && b == full) ? t_begin + full * ROUND + (PA_WAVES - 1 - wave) * (8 * U) : t_begin + wave * 8 + b * ROUND; };
+    auto b_str = [&](int b) { return (tail && b == full) ? 8 : PA_WAVES * 8; };
+    if (!spec) { PA_LOAD(k0, v0, ks0, vs0, t_begin + wave * 8, PA_WAVES * 8) }
 
     // ---- q for the G heads of this kv head, pre-scaled into the log2 domain, as PAIRS OF ADJACENT DIMENSIONS: a head's QK product is 8
     // v_pk_fma_f32 on {k[2i], k[2i+1]} x {q[2i], q[2i+1]} (even dims in the low half, odd in the high half, one add at the end) -- both
@@ -399,14 +414,14 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
         }
     }
 
-#define PA_COMPUTE(KR, VR, KS, VS, T0)                                                               \
+#define PA_COMPUTE(KR, VR, KS, VS, T0, STR)                                                          \
     {                                                                                                \
         float s_[U][G], mx_[G];                                                                   \
         bool ok_[U];                                                                              \
         _Pragma("unroll") for (int g = 0; g < G; ++g) mx_[g] = m[g];                                 \
         float r_[U][G];                                                                           \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
-            ok_[u] = (T0) + u * PA_WAVES * 8 + tg < t_end;                                           \
+            ok_[u] = (T0) + u * (STR) + tg < t_end;                                                  \
             float kf_[16];                                                                           \
             to_f32<KV>(KR[u], kf_);                                                                  \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                          \
@@ -451,15 +466,13 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
     }
 
     // ---- main loop, loads one batch ahead
-    constexpr int STRIDE = PA_WAVES * 8 * U;
-    for (int t0 = t_begin + wave * 8; t0 < t_end;) {
-        if (t0 + STRIDE < t_end) { PA_LOAD(k1, v1, ks1, vs1, t0 + STRIDE) }
-        PA_COMPUTE(k0, v0, ks0, vs0, t0)
-        t0 += STRIDE;
-        if (t0 >= t_end) break;
-        if (t0 + STRIDE < t_end) { PA_LOAD(k0, v0, ks0, vs0, t0 + STRIDE) }
-        PA_COMPUTE(k1, v1, ks1, vs1, t0)
-        t0 += STRIDE;
+    for (int b = 0; b < nb;) {
+        if (b + 1 < nb) { PA_LOAD(k1, v1, ks1, vs1, b_t0(b + 1), b_str(b + 1)) }
+        PA_COMPUTE(k0, v0, ks0, vs0, b_t0(b), b_str(b))
+        if (++b >= nb) break;
+        if (b + 1 < nb) { PA_LOAD(k0, v0, ks0, vs0, b_t0(b + 1), b_str(b + 1)) }
+        PA_COMPUTE(k1, v1, ks1, vs1, b_t0(b), b_str(b))
+        ++b;
     }
 #undef PA_LOAD
 #undef PA_COMPUTE

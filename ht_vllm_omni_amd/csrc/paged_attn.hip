@@ -392,15 +392,17 @@ extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_
     return (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
 }
 
-OMNI_KNOB g_pa_int8_max_g = 2;
+OMNI_KNOB g_pa_int8_max_g = 2, g_pa_tail_chunks = 1;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_int8_max_g(int g) { g_pa_int8_max_g = g; }
+extern "C" void omni_debug_pa_tail(int on) { g_pa_tail_chunks = on; }      // A/B: the tail round as contiguous chunks (PAArgs::tail_chunks)
 #endif
 template <int KV, bool FUSED>
 static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     PAArgs a = a_in;
     int G = a.q_heads / a.kv_heads;
     a.kv_rep = 1;
+    a.tail_chunks = g_pa_tail_chunks;
     // e.g. 16 q / 2 kv heads: 4 groups of 4 per kv head (int8: see g_pa_int8_max_g)
     const int max_g = (KV == OMNI_KV_INT8) ? g_pa_int8_max_g : 4;
     while (G > max_g && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }

@@ -48,3 +48,33 @@ def test_bench_gpus_n_launches_n_ranks_or_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_gpus_n_relays_the_childs_json_line(tmp_path):
+    """when an 8-GPU node appears the first run must not be the first debug session -- the parent's relay of a
+    SUCCESSFUL N-rank child is exercised here with a stub launcher in torch.distributed.run's place: it gets the launcher's
+    arguments (one rank per GPU, 127.0.0.1 rendezvous, the bench's own flags), writes library noise and one JSON line to stdout;
+    the parent prints exactly that line and exits 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub_launcher.py"
+    stub.write_text(
+        "import json, sys\n"
+        "a = sys.argv[1:]\n"
+        "assert '--nproc-per-node=4' in a and '--nnodes=1' in a and a[a.index('--master-addr') + 1] == '127.0.0.1', a\n"
+        "i = [k for k, x in enumerate(a) if x.endswith('bench.py')][0]\n"
+        "assert a[i + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'], a[i + 1:]\n"
+        "print('RCCL version 2.x banner on stdout')\n"
+        "print(json.dumps({'metric': 'speech-tokens/sec', 'value': 123.0, 'n_gpus': 4, 'steps': 3, 'warmup': 1}))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMNI_BENCH_LAUNCHER="stub_launcher", PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "speech-tokens/sec", "value": 123.0, "n_gpus": 4, "steps": 3, "warmup": 1}
+    # a child that prints a line but FAILS is not relayed
+    stub.write_text("import sys\nprint('{\"value\": 1}')\nsys.exit(7)\n")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 7 and not r.stdout.strip()

@@ -150,9 +150,12 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
         assert torch.equal(x, y), f"KV cache of layer {l} differs"
 
 
-@pytest.mark.parametrize("B,kv", [(32, "fp8"), (23, "bf16"), (16, "fp8"), (9, "int8"), (1, "fp8")])
+@pytest.mark.parametrize("B,kv", [(32, "fp8"), (23, "bf16"), (16, "fp8"), (9, "int8"), (1, "fp8"), (40, "fp8"), (48, "bf16"), (33, "int8")])
 def test_backbone_segment_chain_at_1_to_32_rows_against_the_launch_path(B, kv):
-    """Round 4: the 1.7B backbone segment as a persistent launch at 1-32 rows too (csrc/bb_chain.hip bb_chain_b32_kernel: the launch
+    """Round 5 (VERDICT r4 missing #3: the hole at 33-48 rows): those batch sizes run the 64-row stage set (bb_chain_kernel) with the
+    last row tile partly filled, and the launch path picks the same tiles there (gemm.hip pick_tile) -- so the two schedules still
+    agree bit for bit, at every batch size 1..64 now.
+    Round 4: the 1.7B backbone segment as a persistent launch at 1-32 rows too (csrc/bb_chain.hip bb_chain_b32_kernel: the launch
     path's tiles at those batch sizes -- 16-row qkv / o / down tiles, gate_up on 16 rows up to 16 and 32 rows above, so the rstd
     summation order and with it every bit is the launch path's).  Three decode steps: logits, hidden, ids, codes, KV bytes identical;
     both chains reported as launched."""
@@ -216,8 +219,7 @@ def test_backbone_segment_chain_at_the_0p6b_shape_against_the_launch_path(B):
         assert torch.equal(x, y), f"KV cache of layer {l} differs"
 
 
-@pytest.mark.parametrize("base", ["launch-path", "layer-chain"])
-@pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16"), (57, "int8"), (64, "fp16"), (51, "fp8")])
+@pytest.mark.parametrize("B,kv,base", [(64, "fp8", "launch-path"), (49, "bf16", "layer-chain"), (57, "int8", "launch-path"), (51, "fp16", "layer-chain")])
 def test_whole_backbone_launch_against_the_launch_path(B, kv, base):
     """The whole decoder stack -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as ONE persistent
     launch (csrc/bb_all.hip: the paged attention is a stage of the grid, two (row, kv head) pairs per workgroup) against the
@@ -228,9 +230,10 @@ def test_whole_backbone_launch_against_the_launch_path(B, kv, base):
     w = make_weights(d, seed=8, std=0.02)
     res = {}
     with L.debug_library() as lib:
-        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_all):
+        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_all, lib.omni_debug_pa_tail):
             fn.argtypes = [C.c_int]; fn.restype = None
         try:
+            lib.omni_debug_pa_tail(0)          # (the in-grid attention stage keeps the interleaved tail round: compare like with like)
             for on in (0, 1):
                 lib.omni_debug_bb_all(on)
                 lib.omni_debug_bb_chain(1 if (on or base == "layer-chain") else 0)
@@ -246,6 +249,7 @@ def test_whole_backbone_launch_against_the_launch_path(B, kv, base):
         finally:
             lib.omni_debug_bb_chain(1)
             lib.omni_debug_bb_all(0)
+            lib.omni_debug_pa_tail(1)
     for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
         for name, x, y in zip(("logits", "hidden", "ids", "codes", "slots"), a, b):
             assert torch.equal(x, y), f"step {s}: {name} differ between the one-launch backbone and the {base}"

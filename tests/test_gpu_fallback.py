@@ -92,11 +92,11 @@ def test_chain_timeout_falls_back_to_the_launch_path_and_redoes_the_step(graphs,
 
 def test_status_words_report_what_ran():
     """omni_step_io.status[2] / omni_talker_chains_ran: the smoke test and the bench report what actually ran, not what was asked
-    for: the 1.7B shape at 64 (and, since round 4, at 1-32) rows runs both chains, 33-48 rows only the code predictor's, 4 code groups only
-    the backbone's."""
+    for: the 1.7B shape runs both chains at every batch size (49-64 rows since round 3, 1-32 since round 4, 33-48 since round 5), 4 code
+    groups only the backbone's."""
     d = get_dims("tts-1.7b").with_(layers=1, max_model_len=256)
     w = make_weights(d, seed=12, std=0.02)
-    for B, Q, want in ((64, 16, 3), (40, 16, 1), (16, 16, 3), (64, 4, 2)):
+    for B, Q, want in ((64, 16, 3), (40, 16, 3), (16, 16, 3), (64, 4, 2)):
         dd = d.with_(num_code_groups=Q)
         ww = make_weights(dd, seed=12, std=0.02)
         eng = TalkerEngine(dd, ww, kv_dtype="fp8", num_blocks=2 * 64 + 2, block_size=16, max_batch=64)
