@@ -117,6 +117,10 @@ def cpu_baseline(d, w, args, lens):
     from oracle import talker_oracle as O
     B, bs = args.cpu_batch, 16
     n_steps = args.cpu_steps
+    # the thread count the oracle runs FASTEST at on this class of host (many small torch ops: one thread per core of a 128-core box is
+    # ~10 x slower than 16 threads, profiles/r05_oracle_threads.txt): the fair CPU figure, and `cores` says how many were used
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     lens = lens[:B]
     ctx = [n + getattr(args, "ctx_before_timed", args.warmup) + args.steps // 2 for n in lens]     # the timed window's mean context
     nblk = sum((c + n_steps + bs) // bs for c in ctx) + 1
@@ -143,7 +147,9 @@ def cpu_baseline(d, w, args, lens):
         orc.decode_step(states, bts, greedy=False, sampling=samp, cp_kw=cpk)
     dt = time.perf_counter() - t0
     O.clear_weight_cache()
-    return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads0)
+    return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": used, "kind": "port",
             "sample": f"{n_steps} full decode step(s) of the CPU oracle (re-prefill code predictor as in the reference) on "
                       + (f"all {B} requests of the batch" if B == args.batch else f"the first {B} of the {args.batch} requests")
                       + f" (SURVEY 8d's 64 x 32 steps would be ~25 min of CPU: bounded to {n_steps} step(s), ~{dt:.0f} s), "
@@ -251,7 +257,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--num-blocks", type=int, default=8192)
     ap.add_argument("--ttfa-steps", type=int, default=16, help="initial_chunk_size at full load (chunk_size_utils.py:12-33)")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-oracle leg (its fastest setting on a 128-core host)")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -399,7 +406,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ev_ms = e0.elapsed_time(e1) / args.steps
-    chains_ran = eng.chains_ran()            # what the captured step launched: bit 0 the code-predictor chain, bit 1 the backbone chain
+    chains_ran = int(eng.status[2])          # status word 2 of the LAST REPLAYED step (what it launched: bit 0 the code-predictor chain, bit 1
+                                             # the backbone chain) -- not the last CAPTURED one
     # a timed-out flag wait (peer all-reduce, persistent chains) makes the remaining steps wrong AND faster: void the run
     # on every rank when any rank saw one
     dev_err = int(eng.chain_error() != 0) + 2 * int(eng.ar is not None and eng.ar.error() != 0)

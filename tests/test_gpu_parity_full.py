@@ -190,13 +190,14 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles(calibrat
     x_t = eng.inputs_embeds[:B].cpu()
     dec_h_gpu, dec_lg_gpu, codes_gpu = eng.last_hidden[:B].cpu(), eng.logits[:B].cpu(), eng.audio_codes[:B].cpu()
 
-    # ---- code predictor: all 15 groups
+    # ---- code predictor: all 15 groups (its private cache is bf16: the KV scales do not reach it -- checked in the unit-scale case)
     orc = O.TalkerOracle(d, w, kv_dtype="fp8", num_blocks=nb, block_size=bs)
-    ref_codes, ref_lg = orc.code_predictor(ids0, w["embed"][ids0], hid_gpu[last], do_sample=False, return_logits=True)
     assert torch.equal(codes_gpu[:, 0], ids0), "layer-0 code = the sampled id"
     on_path = torch.ones(B, dtype=torch.bool)
     per_group = []
-    for grp in range(1, d.num_code_groups):
+    if not calibrate:
+        ref_codes, ref_lg = orc.code_predictor(ids0, w["embed"][ids0], hid_gpu[last], do_sample=False, return_logits=True)
+    for grp in range(1, d.num_code_groups if not calibrate else 1):
         same = codes_gpu[:, grp] == ref_codes[:, grp]
         n_on = int(on_path.sum())
         assert n_on >= B // 2, f"group {grp}: only {n_on} of {B} rows still on the oracle's greedy path"
@@ -210,6 +211,8 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles(calibrat
         on_path &= same
     frames = float(on_path.float().mean())
     assert frames >= 0.5, f"only {frames:.2f} of the rows decoded the oracle's whole frame"
+    if calibrate:
+        frames, per_group = None, None
 
     # ---- backbone at 64 rows: three-way accuracy of the decode step the chains computed
     def oracle_run(act_dtype):
@@ -243,19 +246,30 @@ def test_full_depth_b64_persistent_chains_against_bf16_and_fp32_oracles(calibrat
     json.dump(report, open(f"gpurun_out/b64_chain_parity{'_calibrated' if calibrate else ''}.json", "w"), indent=1)
 
 
+_CFG2 = {}
+
+
+def _config2_bf16():
+    """The bf16-cache run of BASELINE config #2, once per session: two tests read it (the GPU suite's time)."""
+    if "rec" not in _CFG2:
+        d = get_dims("tts-0.6b").with_(layers=2, max_model_len=512)
+        w = make_weights(d, seed=77, std=0.02)
+        g = torch.Generator().manual_seed(2)
+        lens = torch.randint(8, 70, (16,), generator=g).tolist()
+        _CFG2.update(d=d, w=w, lens=lens, rec=_scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0))
+    return _CFG2
+
+
 def test_config2_0p6b_decode_bf16_kv_matches_oracle():
     """BASELINE config #2: Qwen3-TTS-0.6B dimensions, bf16 weights, the KV cache in the model dtype (vLLM kv_cache_dtype
     "auto" -- a bf16 model cannot be given an fp16 cache there), TP = 1: 2 backbone layers, the whole 16-group code
     predictor, B = 16, prefill + 3 decode steps against the oracle."""
-    d = get_dims("tts-0.6b").with_(layers=2, max_model_len=512)
-    w = make_weights(d, seed=77, std=0.02)
-    g = torch.Generator().manual_seed(2)
-    lens = torch.randint(8, 70, (16,), generator=g).tolist()
     # the step's inputs are the previous step's outputs (hidden state, 16 summed code embeddings), so the single worst logit
     # of 16 x 3072 logits / 16 x 1024 hidden values widens with the step index: measured 2.9 (hipBLASLt prefill) and 5.2 (tile
     # prefill: other rounding flips, same arithmetic) bf16 ulps at step 2; the MEAN deviation of the step-2 hidden state measured
     # 2.1e-3 / 3.06e-3 with the two prefills (8e-4 of its scale 3.7): bound 4e-3
-    rec = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
+    c = _config2_bf16()
+    rec, w = c["rec"], c["w"]
     _check(rec, mean_tol=4e-3, max_ulps=8.0, weights=w)   # 16 rows x 15 greedy argmaxes per step: near-ties may flip (checked as such)
     assert rec["engine"].kv_caches[0].dtype == torch.bfloat16
 
@@ -264,15 +278,13 @@ def test_config2_with_a_half_kv_cache_as_baseline_words_it():
     """BASELINE config #2 says "bf16 weights / fp16 KV".  OMNI_KV_FP16 stores the model's bf16 K / V as IEEE half (exact inside the
     half range): prefill (MFMA attention, half -> bf16 staging) + 3 decode steps (fused write, half -> fp32 reads) against the
     oracle with a torch.float16 cache, and bit-identical to the bf16-cache engine on the same requests."""
-    d = get_dims("tts-0.6b").with_(layers=2, max_model_len=512)
-    w = make_weights(d, seed=77, std=0.02)
-    g = torch.Generator().manual_seed(2)
-    lens = torch.randint(8, 70, (16,), generator=g).tolist()
+    c = _config2_bf16()
+    d, w, lens = c["d"], c["w"], c["lens"]
     rec16 = _scenario(d, w, "fp16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
     _check(rec16, mean_tol=4e-3, max_ulps=8.0, weights=w)
     e16 = rec16["engine"]
     assert e16.kv_caches[0].dtype == torch.float16
-    recbf = _scenario(d, w, "bf16", prompt_lens=lens, n_steps=3, num_blocks=128, mean_tol=4e-3, max_ulps=8.0)
+    recbf = c["rec"]
     for a, b in zip(rec16["steps"], recbf["steps"]):
         assert torch.equal(a["logits"][0], b["logits"][0]) and torch.equal(a["codes"][0], b["codes"][0]) and torch.equal(a["hidden"][0], b["hidden"][0])
     for l in range(d.layers):
