@@ -152,7 +152,7 @@ def cpu_baseline(d, w, args, lens):
     return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": used, "kind": "port",
             "sample": f"{n_steps} full decode step(s) of the CPU oracle (re-prefill code predictor as in the reference) on "
                       + (f"all {B} requests of the batch" if B == args.batch else f"the first {B} of the {args.batch} requests")
-                      + f" (SURVEY 8d's 64 x 32 steps would be ~25 min of CPU: bounded to {n_steps} step(s), ~{dt:.0f} s), "
+                      + f" (SURVEY 8d's 64 x 32 steps would be ~{32 * dt / n_steps / 60:.1f} min of CPU: bounded to {n_steps} step(s), ~{dt:.0f} s), "
                       f"fp8 KV, mean ctx {int(np.mean(ctx))}, no prefill; {dt / n_steps * 1e3:.0f} ms/step"}
 
 

@@ -48,7 +48,7 @@ def main():
                 rows.append((f"   {name} tile_hint {hint}", th, tb, flops))
     # Code2Wav decoder shapes at a 325-frame window (T4 = 1300 rows after the 2 x 2 upsample)
     T4 = 1300
-    for name, T, Cin, Cout, taps, dil in (("dec.conv7 1024->1536", T4, 1024, 1536, 7, 1), ("blk0 res conv7 768 d3", T4 * 8, 768, 768, 7, 3),
+    for name, T, Cin, Cout, taps, dil in () if os.environ.get("PREFILL_ONLY") == "1" else (("dec.conv7 1024->1536", T4, 1024, 1536, 7, 1), ("blk0 res conv7 768 d3", T4 * 8, 768, 768, 7, 3),
                                           ("blk1 res conv7 384 d9", T4 * 40, 384, 384, 7, 9), ("blk2 res conv7 192 d1", T4 * 160, 192, 192, 7, 1),
                                           ("blk3 res conv7 96 d3", T4 * 480, 96, 96, 7, 3), ("blk3 res conv1 96", T4 * 480, 96, 96, 1, 1),
                                           ("blk0 transconv 1536->768 s8", T4, 1536, 768 * 8, 2, 1), ("blk3 transconv 192->96 s3", T4 * 160, 192, 96 * 3, 2, 1)):
