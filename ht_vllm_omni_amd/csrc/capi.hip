@@ -728,7 +728,7 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
 }
 
 // decode rows: fused norm+qkv, fused rope/kv-write/attention, o_proj
-static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st) {
+static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st, bool with_o = true) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
@@ -743,6 +743,7 @@ static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void
                             l == 0 ? io->slot_mapping : nullptr, t->attn, t->attn_ws, B, hq, hkv, D, d.block_size,
                             d.kv_dtype, d.k_scale, d.v_scale, 1.0f / sqrtf((float)D), d.max_model_len, d.frag_layout, -1, st,
                             io->num_live, io->rope_delta, d.rope_rows > 0 ? d.rope_rows : d.max_model_len, t->kv_scale_dev + 2 * l));
+    if (!with_o) return OMNI_OK;          // the o_proj is the first stage of the layer's persistent launch (moe_chain.hip)
     if (d.fused_norm && t->has_ar) {
         // tensor-parallel rank on the norm-free stream: partial o_proj -> this rank's peer-mapped buffer (fragment-major),
         // then ONE launch sums the ranks' partials, adds into r and writes the sum(r^2) slabs
@@ -903,6 +904,17 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     return OMNI_OK;
 }
 
+// the routed experts + combine of a sparse-MoE layer on the norm-free stream (the tail of omni_talker_layer_mlp's MoE branch): reads the
+// normalised rows, the routing and the shared expert's output, adds into r and writes the slabs
+static int moe_experts_tail(omni_talker* t, int layer, int B, void* stream) {
+    const omni_talker_desc& d = t->d;
+    const omni_layer_weights& w = t->layer[layer];
+    const int El = d.moe_experts_local > 0 ? d.moe_experts_local : d.moe_experts;
+    return omni_moe_experts_resid(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, d.moe_w8 ? w.moe_gate_up_scale : nullptr, w.moe_down,
+                                  d.moe_w8 ? w.moe_down_scale : nullptr, d.moe_shared_inter > 0 ? t->moe_shared : nullptr, w.moe_shared_gate, t->moe_act,
+                                  t->moe_y, t->resid, t->part, nullptr, B, d.hidden, d.moe_inter, El, d.moe_e0, d.moe_top_k, stream);
+}
+
 // diagnostics: append N trivial launches after every layer phase to price a launch inside the real step
 OMNI_KNOB g_extra_trivial = 0;
 __global__ void dbg_nop_kernel(int32_t* p) { if (threadIdx.x == 9999) p[0] = 0; }
@@ -956,7 +968,18 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
         return OMNI_OK;
     }
     OMNI_CHECK_ARG(parts == 6, "omni_talker_step_part: the attention / rest split needs the backbone chain's launch structure (dense 1.7B or 0.6B shape, single rank)");
+    // the Omni talker's sparse-MoE layer: o_proj -> router | shared gate_up -> shared down + routing as ONE persistent launch between the
+    // attention launch and the expert GEMMs (moe_chain.hip, round 5): 10 -> 6 launches per layer, same bits
+    const bool moe_chain = k_moe_chain_supported(d, io->B, t->has_ar);
+    if (moe_chain) t->ran |= 2;
     for (int l = 0; l < d.layers; ++l) {
+        if (moe_chain) {
+            TRY(layer_attn_decode(t, l, io, stream, false));
+            TRY(k_moe_chain(d, t->layer[l], t->attn, t->resid, t->part, t->normed_rm, t->moe_logits, t->act, t->moe_shared, t->moe_idx, t->moe_w, io->B,
+                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
+            TRY(moe_experts_tail(t, l, io->B, stream));
+            continue;
+        }
         TRY(omni_talker_layer_attn(t, io, l, stream));
         TRY(omni_talker_layer_mlp(t, io, l, stream));
     }

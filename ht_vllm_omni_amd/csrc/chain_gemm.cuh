@@ -56,7 +56,9 @@ template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, c
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
-                                           unsigned long long* stamps, const u32x4 (*Wpre)[NT] = nullptr, PF prefetch = PF()) {
+                                           unsigned long long* stamps, const u32x4 (*Wpre)[NT] = nullptr, PF prefetch = PF(),
+                                           uint16_t* normed_out = nullptr /* PRO 2: the normalised rows, row-major [M][K] (plain stores:
+                                           for the NEXT launch), written by the workgroup columns bx < 8 as gemm_skinny_kernel spreads them */) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int G = (XG == 0 || XG > NTW) ? NTW : XG;
     constexpr bool NORM = PRO == 2 || PRO == 3, DEFER = PRO == 3;
@@ -64,8 +66,14 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     constexpr int K = NTW * CH_WAVES * 32;
     constexpr int nsteps = K / 32;
     constexpr bool GU8 = EPI == OMNI_EPI_SILU_MUL_GU8;
+    // OMNI_EPI_SILU_MUL (round 5: the MoE layer's shared expert): W = [gate rows | up rows], n-tiles [0, NT/2) are gate tiles, [NT/2, NT)
+    // the matching up tiles N rows further down (gemm_skinny_kernel's pairing); out = N activation columns
+    constexpr bool SILU2 = EPI == OMNI_EPI_SILU_MUL;
     constexpr bool WRING = WSRC == 1, WFIFO = WSRC == 2;
-    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32_BF16RND || GU8, "chain_gemm: epilogue");
+    static_assert(EPI == OMNI_EPI_BF16 || EPI == OMNI_EPI_RESID || EPI == OMNI_EPI_F32_BF16RND || GU8 || SILU2, "chain_gemm: epilogue");
+    static_assert(!SILU2 || (NT % 2 == 0 && WSRC == 0 && NT * MT <= 6), "chain_gemm: plain SiLU-mul = gate / up tile pairs, whole slice ahead of the flags");
+    // first 16-row tile of W behind n-tile j of this workgroup
+    auto wtile = [&](int j) { return SILU2 ? (j < NT / 2 ? bx * (NT / 2) + j : (N >> 4) + bx * (NT / 2) + (j - NT / 2)) : bx * NT + j; };
     static_assert(EPI != OMNI_EPI_RESID || (NT == 1 && PRO == 0), "chain_gemm: residual epilogue = one n-tile, plain x");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: address parts below stay in SGPRs
@@ -99,7 +107,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #endif
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)(((bx * NT + j) * nsteps + ks) * 1024), WAUX);
+                Wq[d][j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (uint32_t)((wtile(j) * nsteps + ks) * 1024), WAUX);
         }
         if (NW_EARLY) NWq[d % G] = __builtin_amdgcn_raw_buffer_load_b128(nrs, q * 16, ks * 64, 0);
     }
@@ -197,6 +205,15 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #pragma unroll
             for (int j = 0; j < NT; ++j) Wn[j] = Wq[WRING ? d % G : d][j];
         }
+        if (PRO == 2 && normed_out != nullptr && bx < CH_WAVES && wave == bx) {
+            // k-steps bx, bx + 8, ... of the normalised rows leave through workgroup column bx (gemm_skinny_kernel: column x takes k-steps
+            // x + gridDim.x * wave): here wave w owns k-steps w + 8 d, so column bx's wave bx holds exactly those -- the same values
+            const int ks = wave + d * CH_WAVES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (i * 16 + (lane & 15) < Mloc)
+                    *reinterpret_cast<u32x4*>(normed_out + (size_t)(m_base + i * 16 + (lane & 15)) * K + ks * 32 + 8 * q) = Xn[i];
+        }
         if (d + G < NTW) load_x(d + G);                                   // refill the slot just consumed
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -211,7 +228,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     static_assert(NT * MT % PASSES == 0, "chain_gemm: tiles per combine pass");
     f32x4* lds4 = reinterpret_cast<f32x4*>(lds);
     constexpr int LN = GU8 ? 32 : 64;
-    constexpr int ITEMS = TP * LN;
+    constexpr int ITEMS = (SILU2 ? TP / 2 : TP) * LN;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
     if (pass > 0) chain_barrier(g);                                      // the previous pass's readers are done with the slots
@@ -235,6 +252,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         for (int w = 0; w < CH_WAVES; ++w) {
             sum += lds4[(w * TP + tl) * 64 + l];
             if (GU8) sum2 += lds4[(w * TP + tl) * 64 + l + 32];
+            if (SILU2) sum2 += lds4[(w * TP + (NT / 2 + j) * MT + i) * 64 + l];
         }
         if (DEFER) {
             // rstd of this item's row: the eight wave partials of the slab reduction, in wave order (the combine barrier covered them)
@@ -248,7 +266,13 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #ifdef OMNI_DEBUG_HOOKS
         if (g.skip == 3 && sum[0] != 12345.678f) continue;       // timing experiment: no epilogue stores (results garbage)
 #endif
-        if (GU8) {
+        if (SILU2) {
+            const int n = bx * 16 * (NT / 2) + j * 16 + 4 * (l >> 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu_mul_bf16(sum[e], sum2[e]);
+            coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])});
+        } else if (GU8) {
             const int n = (bx * NT + j) * 8 + 4 * (l >> 4);
             float o[4];
 #pragma unroll

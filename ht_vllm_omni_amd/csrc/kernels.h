@@ -91,6 +91,11 @@ bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
 bool k_bb_chain_small(const omni_talker_desc& d);       // the 0.6B shape: the segment on the code predictor's 16-row stage set, any batch
 int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
                int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small = false);
+// the sparse-MoE layer between its attention launch and its expert GEMMs (o_proj -> router | shared gate_up -> shared down + routing) as
+// one persistent launch (moe_chain.hip); supported = the Omni talker's shape on a single rank, <= 64 rows
+bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
+int k_moe_chain(const omni_talker_desc& d, const omni_layer_weights& w, const void* attn, void* resid, float* part, void* normed_rm, void* logits,
+                void* act, void* shared, int32_t* topk_idx, void* topk_w, int B, uint32_t* flags, int32_t* err, void* stream);
 // the WHOLE backbone -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as one persistent launch
 // (bb_all.hip): the layer pointers live in a device table filled at engine creation
 size_t k_bb_all_table_bytes(int layers);
