@@ -728,11 +728,12 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
 }
 
 // decode rows: fused norm+qkv, fused rope/kv-write/attention, o_proj
-static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st, bool with_o = true) {
+static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st, bool with_o = true, bool with_qkv = true) {
     const omni_talker_desc& d = t->d;
     const omni_layer_weights& w = t->layer[l];
     const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
-    if (d.fused_norm)       // slab count: 1 after mtp_finalize, H / 16 after any residual GEMM
+    if (!with_qkv) {}       // the qkv rows were left by the previous layer's persistent tail (moe_chain.hip moe_tail_kernel)
+    else if (d.fused_norm)  // slab count: 1 after mtp_finalize, H / 16 after any residual GEMM
         TRY(xnorm_gemm(t, t->resid, t->part, l == 0 ? 1 : H / 16, w.ln1, nullptr, w.wqkv, t->qkv, B, (hq + 2 * hkv) * D, H,
                        OMNI_EPI_BF16, nullptr, 0, st));
     else
@@ -974,10 +975,22 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
     if (moe_chain) t->ran |= 2;
     for (int l = 0; l < d.layers; ++l) {
         if (moe_chain) {
-            TRY(layer_attn_decode(t, l, io, stream, false));
+            const bool tail = k_moe_tail_enabled();
+            TRY(layer_attn_decode(t, l, io, stream, false, l == 0 || !tail));
             TRY(k_moe_chain(d, t->layer[l], t->attn, t->resid, t->part, t->normed_rm, t->moe_logits, t->act, t->moe_shared, t->moe_idx, t->moe_w, io->B,
                             t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
-            TRY(moe_experts_tail(t, l, io->B, stream));
+            if (tail && l + 1 < d.layers) {
+                // expert GEMMs, then { combine -> the next layer's qkv } as the layer's second persistent launch
+                const omni_layer_weights& w = t->layer[l];
+                const int El = d.moe_experts_local > 0 ? d.moe_experts_local : d.moe_experts;
+                TRY(k_moe_experts_phases(t->normed_rm, t->moe_idx, t->moe_w, w.moe_gate_up, d.moe_w8 ? w.moe_gate_up_scale : nullptr, w.moe_down,
+                                         d.moe_w8 ? w.moe_down_scale : nullptr, t->moe_act, t->moe_y, io->B, d.hidden, d.moe_inter, El, d.moe_e0,
+                                         d.moe_top_k, stream));
+                TRY(k_moe_tail(d, w, t->layer[l + 1], t->moe_y, t->normed_rm, t->moe_shared, t->moe_idx, t->resid, t->part, t->qkv, io->B,
+                               t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
+            } else {
+                TRY(moe_experts_tail(t, l, io->B, stream));
+            }
             continue;
         }
         TRY(omni_talker_layer_attn(t, io, l, stream));

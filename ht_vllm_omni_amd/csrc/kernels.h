@@ -96,6 +96,12 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
 bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
 int k_moe_chain(const omni_talker_desc& d, const omni_layer_weights& w, const void* attn, void* resid, float* part, void* normed_rm, void* logits,
                 void* act, void* shared, int32_t* topk_idx, void* topk_w, int B, uint32_t* flags, int32_t* err, void* stream);
+// ... and its tail: the expert GEMM launches (moe.hip), then { combine into the residual stream -> the NEXT layer's qkv } as one persistent launch
+int k_moe_experts_phases(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up, const void* w_down,
+                         const float* s_down, void* act_ws, void* y_ws, int T, int H, int I, int E_local, int e0, int top_k, void* stream);
+bool k_moe_tail_enabled();
+int k_moe_tail(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights& next, const void* y_ws, const void* normed_rm,
+               const void* shared, const int32_t* topk_idx, void* resid, float* part, void* qkv, int B, uint32_t* flags, int32_t* err, void* stream);
 // the WHOLE backbone -- qkv(0), then attention -> o_proj -> gate_up -> down_proj -> next qkv per layer -- as one persistent launch
 // (bb_all.hip): the layer pointers live in a device table filled at engine creation
 size_t k_bb_all_table_bytes(int layers);

@@ -319,7 +319,7 @@ static int moe_experts_impl(const void* x, const int32_t* topk_idx, const void* 
                             const void* w_down, const float* s_down, const void* shared, const void* w_shared_gate, void* act_ws,
                             void* y_ws, void* out, int T, int H, int I, int E, int e0, int top_k, void* stream, int out_mode = 0,
                             float* part = nullptr) {
-    OMNI_CHECK_ARG(x && topk_idx && topk_w && w_gate_up && w_down && act_ws && y_ws && out, "omni_moe_experts: null pointer");
+    OMNI_CHECK_ARG(x && topk_idx && topk_w && w_gate_up && w_down && act_ws && y_ws && (out || out_mode == 3), "omni_moe_experts: null pointer");
     OMNI_CHECK_ARG(T >= 1 && T <= MOE_MAXT && top_k >= 1 && top_k <= MOE_MAXK && T * top_k <= MOE_THREADS,
                    "omni_moe_experts: T=%d top_k=%d (T <= %d, T * top_k <= %d)", T, top_k, MOE_MAXT, MOE_THREADS);
     OMNI_CHECK_ARG(H % 64 == 0 && I % 32 == 0 && E >= 1 && E <= 65535 && e0 >= 0, "omni_moe_experts: H=%d I=%d E=%d e0=%d (H %% 64, I %% 32)", H, I, E, e0);
@@ -339,6 +339,7 @@ static int moe_experts_impl(const void* x, const int32_t* topk_idx, const void* 
     if (w8) hipLaunchKernelGGL((moe_expert_kernel<2, 4, true>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
     else hipLaunchKernelGGL((moe_expert_kernel<2, 4, false>), dim3(H / 64, E), dim3(MOE_THREADS), MOE_WAVES * 4 * 4 * 64 * sizeof(float), st, a);
     OMNI_CHECK_LAUNCH("omni_moe_experts(down)");
+    if (out_mode == 3) return OMNI_OK;      // the combine is a stage of the caller's persistent launch (moe_chain.hip moe_tail_kernel)
 #define COMBINE(M_)                                                                                                        \
     hipLaunchKernelGGL(moe_combine_kernel<M_>, dim3(T), dim3(256), 0, st, (const uint16_t*)y_ws, topk_idx, (const uint16_t*)x, \
                        (const uint16_t*)w_shared_gate, (const uint16_t*)shared, (uint16_t*)out, part, top_k, H, e0, e0 + E)
@@ -363,6 +364,13 @@ extern "C" int omni_moe_experts_ex(const void* x, const int32_t* topk_idx, const
                                    int E_local, int e0, int top_k, void* stream) {
     return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, s_gate_up, w_down, s_down, shared, w_shared_gate, act_ws, y_ws, out, T, H, I,
                             E_local, e0, top_k, stream);
+}
+
+// the two expert GEMM launches alone: y_ws [T * k, H] holds the weighted expert outputs, the combine is the caller's (moe_chain.hip)
+int k_moe_experts_phases(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up, const float* s_gate_up, const void* w_down,
+                         const float* s_down, void* act_ws, void* y_ws, int T, int H, int I, int E_local, int e0, int top_k, void* stream) {
+    return moe_experts_impl(x, topk_idx, topk_w, w_gate_up, s_gate_up, w_down, s_down, nullptr, nullptr, act_ws, y_ws, nullptr, T, H, I, E_local, e0,
+                            top_k, stream, 3);
 }
 
 extern "C" int omni_moe_experts_resid(const void* x, const int32_t* topk_idx, const void* topk_w, const void* w_gate_up,

@@ -114,10 +114,123 @@ __global__ __launch_bounds__(CH_THREADS) void moe_chain_kernel(const MoeChainArg
     if (t < a.B && !g.dead) mc_route_row(a, t);
 }
 
-OMNI_KNOB g_moe_chain = 1, g_moe_chain_nap = 1;
+// ---- the layer's tail: { combine -> next layer's qkv } behind the two expert GEMM launches.  The combine is moe_combine_kernel<2>'s
+// arithmetic (moe.hip: per token the experts' weighted outputs in ascending expert index, bf16 accumulation, + the sigmoid-gated shared
+// expert, r = bf16(r + delta) on the fragment-major stream, the slabs) on the first 256 threads of workgroup t; the qkv GEMM reads r and
+// the slabs behind the combine's flags (16 rows x 64 columns per workgroup: the launch path's 16 x 32 tile differs in shape only -- a
+// column's dot product, its split over the 8 waves and the combine order do not depend on how many columns a workgroup owns)
+struct MoeTailArgs {
+    const uint16_t *y, *x, *w_sg, *shared; const int32_t* topk_idx;
+    uint16_t* resid; float* part;
+    const uint16_t *ln1_next, *wqkv_next; uint16_t* qkv;
+    int B, top_k, e_lo, e_hi, nap; float eps;
+    uint32_t* flags; int32_t* err;
+};
+
+__device__ __forceinline__ void mc_combine_row(const MoeTailArgs& a, int t, float* lds) {
+    constexpr int H = 1024, MAXK = 8;
+    int* order = reinterpret_cast<int*>(lds);
+    float* red = lds + 8;
+    float* s_gate = lds + 12;
+    const int top_k = a.top_k;
+    const bool worker = threadIdx.x < 256;
+    if (threadIdx.x < (unsigned)top_k) {                  // thread k: rank of expert k among the token's experts
+        const int mine = a.topk_idx[(size_t)t * top_k + threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < top_k; ++j) rank += a.topk_idx[(size_t)t * top_k + j] < mine ? 1 : 0;
+        order[rank] = threadIdx.x;
+    }
+    float gate = 0.f;
+    if (a.shared && worker) {
+        float dsum = 0.f;
+        for (int h = threadIdx.x; h < H; h += 256) dsum = fmaf(bf2f(a.x[(size_t)t * H + h]), bf2f(a.w_sg[h]), dsum);
+        dsum = wave_sum(dsum);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    }
+    __syncthreads();
+    if (a.shared) {
+        if (threadIdx.x == 0) {
+            const float lg = bfround((red[0] + red[1]) + (red[2] + red[3]));
+            *s_gate = bfround(1.0f / (1.0f + expf(-lg)));
+        }
+        __syncthreads();
+        gate = *s_gate;
+    }
+    if (!worker) return;
+    int ord[MAXK];
+    bool loc[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        ord[k] = k < top_k ? order[k] : 0;
+        const int ek = k < top_k ? a.topk_idx[(size_t)t * top_k + ord[k]] : -1;
+        loc[k] = ek >= a.e_lo && ek < a.e_hi;
+    }
+    const coh_rsrc_t rrs = coh_rsrc(a.resid), prs = coh_rsrc(a.part);
+    for (int h = threadIdx.x * 2; h < H; h += 512) {
+        uint32_t yv[MAXK];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            yv[k] = (k < top_k && loc[k]) ? *reinterpret_cast<const uint32_t*>(a.y + ((size_t)t * top_k + ord[k]) * H + h) : 0u;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < top_k && loc[k]) { a0 = bfround(a0 + bf_lo(yv[k])); a1 = bfround(a1 + bf_hi(yv[k])); }
+        if (a.shared) {
+            const uint32_t sv = *reinterpret_cast<const uint32_t*>(a.shared + (size_t)t * H + h);
+            a0 = bfround(a0 + bfround(gate * bf_lo(sv)));
+            a1 = bfround(a1 + bfround(gate * bf_hi(sv)));
+        }
+        const uint32_t off = (uint32_t)frag_off(t, h, H) * 2;
+        const uint32_t ro = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.resid) + off);      // written by an earlier launch
+        const float r0 = bfround(bf_lo(ro) + a0), r1 = bfround(bf_hi(ro) + a1);
+        coh_st4(rrs, off, pack_bf2(r0, r1));
+        float ss = r0 * r0 + r1 * r1;                      // 8 adjacent threads hold the 16 columns of one slab
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        if ((threadIdx.x & 7) == 0) coh_st4(prs, (uint32_t)((h >> 4) * 64 + t) * 4, __float_as_uint(ss));
+    }
+}
+
+__global__ __launch_bounds__(CH_THREADS) void moe_tail_kernel(const MoeTailArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[MC_LDS_FLOATS];
+    ChainGate g;
+    chain_gate_init(g, a.flags, a.err);
+    g.dom = 8;
+    g.nap = a.nap;
+    const int wg = blockIdx.x;
+    constexpr int H = 1024, NQ = 2560;
+    if (wg < a.B) {                      // stage 0x2101: the combine of row wg
+        mc_combine_row(a, wg, lds);
+        chain_gate_arrive(g);
+    } else {
+        chain_gate_skip(g);
+    }
+    if (wg < 160)                        // stage 0x2102: the next layer's qkv, 40 column groups of 64 x 4 row groups
+        chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg % 40, wg / 40, lds, g,
+                                              true, 0x2102, nullptr);
+    else
+        chain_gate_skip(g);
+}
+
+OMNI_KNOB g_moe_chain = 1, g_moe_chain_nap = 1, g_moe_tail = 1;
 #ifdef OMNI_DEBUG_HOOKS
-extern "C" void omni_debug_moe_chain(int on) { g_moe_chain = on != 0; }
+extern "C" void omni_debug_moe_chain(int on) { g_moe_chain = on != 0; g_moe_tail = on != 2; }      // 2: the first chain only (the tail as launches)
 #endif
+bool k_moe_tail_enabled() { return g_moe_tail != 0; }
+
+int k_moe_tail(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights& next, const void* y_ws, const void* normed_rm,
+               const void* shared, const int32_t* topk_idx, void* resid, float* part, void* qkv, int B, uint32_t* flags, int32_t* err, void* stream) {
+    MoeTailArgs a{};
+    a.y = (const uint16_t*)y_ws; a.x = (const uint16_t*)normed_rm; a.w_sg = (const uint16_t*)w.moe_shared_gate; a.shared = (const uint16_t*)shared;
+    a.topk_idx = topk_idx; a.resid = (uint16_t*)resid; a.part = part;
+    a.ln1_next = (const uint16_t*)next.ln1; a.wqkv_next = (const uint16_t*)next.wqkv; a.qkv = (uint16_t*)qkv;
+    a.B = B; a.top_k = d.moe_top_k; a.e_lo = d.moe_e0; a.e_hi = d.moe_e0 + (d.moe_experts_local > 0 ? d.moe_experts_local : d.moe_experts);
+    a.nap = g_moe_chain_nap; a.eps = d.eps; a.flags = flags; a.err = err;
+    hipLaunchKernelGGL(moe_tail_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+    OMNI_CHECK_LAUNCH("moe_tail");
+    return OMNI_OK;
+}
 
 bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
     static int cus = -1;
@@ -128,7 +241,7 @@ bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
     }
     return g_moe_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 128 &&
            (d.moe_experts_local == 0 || d.moe_experts_local == 128) && d.moe_top_k >= 1 && d.moe_top_k <= 8 && d.moe_shared_inter == 768 &&
-           d.hidden == 1024 && d.head_dim == 128 && d.q_heads * 128 == 2048 && B >= 1 && B <= 64;
+           d.hidden == 1024 && d.head_dim == 128 && d.q_heads * 128 == 2048 && d.kv_heads == 2 && B >= 1 && B <= 64;
 }
 
 int k_moe_chain(const omni_talker_desc& d, const omni_layer_weights& w, const void* attn, void* resid, float* part, void* normed_rm, void* logits,
