@@ -95,6 +95,7 @@ struct ChainGate {
     int dom;               // log2 of the flag domain: 6 = the row group's 64 workgroups, 7 = a pair of groups, 8 = all 256
     int nap;               // s_sleep units (64 clocks) between two polls: 0, 1, 2, 4, 8
     int ahead;             // stages this workgroup has passed without rows since it last waited (chain_gate_skip)
+    int skip_units;        // sleep per skipped stage before the first poll, in units of 32 x 64 clocks (3 = ~2.9 us; A/B knob)
     int skip;              // debug library only (timing experiments, results garbage): 1 = fetch half of every weight slice, 2 = half of the activations
     unsigned long long* stamps;   // debug library only: timeline stamps of the attention stage (pa_body.cuh, CHAIN), or NULL
     // engine mode (NULL / unused in the plain chains): barriers among the 8 compute waves only, weights from the LDS FIFO
@@ -158,6 +159,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
     g.dead = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
     g.dom = 8;
     g.nap = 1;
+    g.skip_units = 3;
     g.skip = 0;
     g.stamps = nullptr;
     g.ahead = 0;
@@ -176,7 +178,7 @@ __device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, i
 // stages early: it sleeps ~2.5 us per skipped stage (a stage takes 3-5.5 us) before its first poll.
 __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
     if (threadIdx.x < 64 && !g.dead) {
-        for (int i = 0; i < g.ahead; ++i) __builtin_amdgcn_s_sleep(96);
+        for (int i = 0; i < g.ahead * g.skip_units; ++i) __builtin_amdgcn_s_sleep(32);
         // (1 << dom) / 4 lanes x 4 flags each (the other lanes read copies)
         const uint32_t off = chain_flag_copy() + ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
         unsigned spins = 0;

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) 
     ChainGate g;
     chain_gate_init(g, a.flags, a.err);
     g.dom = 8;                            // 64-row gate_up tiles and the (row, head) pairs tie every row together
-    g.nap = a.nap;
+    g.nap = a.nap & 31;
+    if (a.nap >> 5) g.skip_units = (a.nap >> 5) - 1;
     const int wg = blockIdx.x;
     const int Hc = 1024, NQ = 4096, NI = 3072;
     const int M2 = a.Bp + a.B;
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
     ChainGate g;
     chain_gate_init(g, a.flags, a.err);
     g.dom = a.dom;
-    g.nap = a.nap;
+    g.nap = a.nap & 31;
+    if (a.nap >> 5) g.skip_units = (a.nap >> 5) - 1;      // debug library: nap + 32 (units + 1) selects the run-ahead sleep (coherent.cuh)
     g.skip = a.skip;
     const int wg = blockIdx.x;
     {
