@@ -425,6 +425,10 @@ def test_attn_decode_fused(ops, kv, hq, hkv, split):
     if kv == "bf16":
         assert_bf16_close(got, ref_store, what="cache after fused write")
     else:
+        # THE exception to "bit-exact for byte work" (VERDICT r4 weak #2): K reaches the quantiser through the q/k-norm, whose fp32 sum
+        # over the 128 dimensions runs in another order here than in the oracle -- a value that lands on a rounding boundary of the 8-bit
+        # format flips its byte.  Budget: < 1e-3 of the bytes of the whole cache tensor (only the new token's rows can differ at all).  V
+        # does not pass through a norm: its bytes ARE exact (tests/test_gpu_parity_full.py::test_device_kv_write_bytes..., fixture G3)
         assert (got != ref_store).float().mean().item() < 1e-3
     if kv == "int8":
         torch.testing.assert_close(sc.cpu(), pk.scales, rtol=1e-2, atol=0)
