@@ -196,8 +196,8 @@ int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, cons
         a.stamps = g_bb_stamps;
 #endif
         // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: the launch path's policy (32-row
-        // tiles above 32 rows), so that both schedules produce the same bits
-        if (B > 32) hipLaunchKernelGGL(bb_chain_small_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        // tiles above 48 rows, gemm.hip pick_tile), so that both schedules produce the same bits
+        if (B > 48) hipLaunchKernelGGL(bb_chain_small_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(bb_chain_small_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
         OMNI_CHECK_LAUNCH("bb_chain_small");
         return OMNI_OK;

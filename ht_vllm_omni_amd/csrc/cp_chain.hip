@@ -477,7 +477,9 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
         a.ptab = (const uint16_t*)d.cp_proj_table;
     }
     a.dom = g_chain_dom < 6 ? 6 : (g_chain_dom > 8 ? 8 : g_chain_dom);
-    const bool narrow = g_chain_gu_narrow == 2 || (g_chain_gu_narrow && B > 32);      // 2 (debug): the 32-row tile at any batch size
+    // (32-row gate_up tiles from 49 rows: at 33-48 rows the launch path takes 16-row tiles too since round 5 -- gemm.hip pick_tile -- so
+    //  that the fourth row group has no work in any stage and its workgroups leave at the start of the launch)
+    const bool narrow = g_chain_gu_narrow == 2 || (g_chain_gu_narrow && B > 48);      // 2 (debug): the 32-row tile at any batch size
     if (narrow && a.dom < 7) a.dom = 7;  // the 32-row tile ties two row groups together
     a.skip = g_chain_skip;
     // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: follow the launch path's tile

@@ -425,6 +425,11 @@ static void pick_tile(int pro, int epi, const GemmArgs& a, int* nt_out, int* mt_
     if (g_tile_nt && epi != OMNI_EPI_RESID && (!silu || g_tile_nt >= 2) && (g_tile_nt != 3 || gu8) && cols % g_tile_nt == 0) nt = g_tile_nt;
     const int groups = silu ? a.N / (8 * nt) : a.N / (16 * nt);
     int splits = groups >= 160 ? 1 : (g_gemm_wgs + groups - 1) / groups;
+    // the 1024-wide gate_up (code predictor, 0.6B backbone: 128 groups of 24 columns) at 33-48 rows: three 16-row tiles, not a 32-row pair
+    // with a half-empty partner (round 5) -- the tile set of the persistent chains there, whose fourth row group then has no work in ANY
+    // stage and leaves at once instead of idling through four stages per layer to wake up for this one (B = 40: the predictor phase cost
+    // 0.25 ms MORE than at 64 rows; cp_chain.hip k_cp_chain, bb_chain.hip)
+    if (pro == 2 && gu8 && nt == 3 && groups == 128 && mt_total == 3) splits = 3;
     if (splits > mt_total) splits = mt_total;
     if (splits < 1) splits = 1;
     int mt = (mt_total + splits - 1) / splits;       // 1..4

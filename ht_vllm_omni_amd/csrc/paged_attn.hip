@@ -379,7 +379,10 @@ static int pick_nsplit(int rows, int kv_heads, int max_seq_len) {
     const int wgs = rows * kv_heads;
     if (wgs >= 384) return 1;                         // 1.5+ workgroups per CU already (and: the persistent backbone launch of
                                                       // bb_all.hip never splits -- 48+ rows x 8 heads take the same arithmetic on both paths)
-    int ns = (512 + wgs - 1) / wgs;
+    // as many KV splits as keep the grid within ONE round of the chip (512 workgroups of 4 waves = two per CU): rounding UP put 320
+    // workgroups (40 rows x 8 heads) at 640 -- a second, quarter-filled round plus the merge launch: 0.45 ms per step for the 28 launches
+    // against 0.33 unsplit (round 5, profiles/r05_other_configs.txt)
+    int ns = 512 / wgs;
     const int cap = (max_seq_len + 255) / 256;        // >= 256 tokens per split
     if (ns > cap) ns = cap;
     if (ns > 16) ns = 16;
