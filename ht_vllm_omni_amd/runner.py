@@ -695,9 +695,15 @@ class MI355XARModelRunner:
         return ids
 
     def _bucket(self, n: int) -> int:
-        b = 1
-        while b < n:
-            b *= 2
+        """Padded batch size a step of n live decode rows runs at: 1, 2, 4, 8, then multiples of 8 (vLLM's default cudagraph capture
+        sizes).  Powers of two up to 64 put 33 live rows into the 64-row graph; a step costs 3.13 / 3.23 / 3.43 / 3.48 ms at 12 / 25 / 48 /
+        64 rows (profiles/r05_ab_table.txt), so the finer buckets are worth their eleven captures."""
+        if n <= 8:
+            b = 1
+            while b < n:
+                b *= 2
+        else:
+            b = (n + 7) // 8 * 8
         return min(b, self.max_num_seqs)
 
     def capture_graphs(self, sizes=None) -> None:
