@@ -152,3 +152,46 @@ def test_get_output_is_idempotent_and_ordered():
     assert run.requests["a"].output_ids == o1.sampled_token_ids[0] + o2.sampled_token_ids[0]
     s.update_from_output(so1, o1); s.update_from_output(so2, o2)
     assert s.requests["a"].num_output_placeholders == 0 and s.requests["a"].output_token_ids == run.requests["a"].output_ids
+
+
+def test_async_abort_while_a_step_is_in_flight():
+    """A request aborted between dispatch and get_output: the scheduler frees it at once, the step in flight still carries its row (its
+    output is dropped on arrival: omni_ar_scheduler.py:240-245 `request is None or request.is_finished()`), the runner drops the row with the
+    next scheduler output, the other requests' streams are untouched."""
+    d = get_dims("tiny")
+
+    def run(abort_at):
+        eng = FakeEngine(d, max_batch=4)
+        runr = MI355XARModelRunner(eng, use_graphs=False, async_scheduling=True)
+        s = MI355XARScheduler(num_blocks=64, block_size=16, max_num_seqs=4, max_num_batched_tokens=48, max_model_len=512, async_scheduling=True)
+        core = TalkerStageEngine(_Worker(runr), s)
+        for i in range(3):
+            core.add_request(_request(d, f"r{i}", 6 + i, max_tokens=10, tail=2, seed=i))
+        streams = {}
+        for it in range(60):
+            if it == abort_at:
+                assert core.inflight, "a step must be in flight when the abort arrives"
+                s.abort_request("r1")
+            if not core.has_work():
+                break
+            for o in core.step():
+                streams.setdefault(o.request_id, []).extend(o.new_token_ids)
+        assert not core.has_work() and not runr.requests and not runr._inflight
+        return streams, s
+
+    ref, _ = run(-1)
+    got, s = run(4)
+    assert got["r0"] == ref["r0"] and got["r2"] == ref["r2"]
+    assert len(got["r1"]) < len(ref["r1"]) and got["r1"] == ref["r1"][:len(got["r1"])]
+    assert s.pool.num_free == 63 and not s.requests
+
+
+def test_async_stop_token_of_a_preempted_request_arrives_late():
+    """The step that samples a request's STOP token is in flight when the scheduler preempts that request (pool dry): the token arrives
+    while the request sits in the waiting queue; it is finished there (vLLM's stopped_preempted_reqs), never recomputed, and the
+    synchronous loop's streams are reproduced."""
+    ref = _run(False, num_blocks=8, n_req=6, max_tokens=14)
+    tok = ref["streams"]["r3"][6]
+    a, b = _run(False, num_blocks=8, n_req=6, max_tokens=14, stop=(tok,)), _run(True, num_blocks=8, n_req=6, max_tokens=14, stop=(tok,))
+    assert a["streams"] == b["streams"] and a["finish"] == b["finish"]
+    assert not b["run"].requests and not b["run"].preempted and b["sched"].pool.num_free == a["sched"].pool.num_free
