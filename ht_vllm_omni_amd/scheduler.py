@@ -335,6 +335,11 @@ class MI355XARScheduler:
                 continue
             idx = runner_output.req_id_to_index.get(rid)
             if idx is None:
+                # scheduled, but the runner has nothing for it: a decode row it dropped from a REDONE step (the request had been preempted
+                # before the redo: runner._redo_step).  The token it was to sample never existed: give the placeholder back, or the request
+                # would wait for it forever
+                if req.num_output_placeholders and req.status == RequestStatus.PREEMPTED:
+                    req.num_output_placeholders -= 1
                 continue
             new_ids = list(runner_output.sampled_token_ids[idx]) if runner_output.sampled_token_ids else []
             if req.num_output_placeholders and new_ids:

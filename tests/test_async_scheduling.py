@@ -195,3 +195,24 @@ def test_async_stop_token_of_a_preempted_request_arrives_late():
     a, b = _run(False, num_blocks=8, n_req=6, max_tokens=14, stop=(tok,)), _run(True, num_blocks=8, n_req=6, max_tokens=14, stop=(tok,))
     assert a["streams"] == b["streams"] and a["finish"] == b["finish"]
     assert not b["run"].requests and not b["run"].preempted and b["sched"].pool.num_free == a["sched"].pool.num_free
+
+
+def test_a_dropped_row_gives_its_placeholder_back():
+    """runner._redo_step drops a decode row whose request was preempted before the redo (its token of the redone step never existed): the
+    runner output then lacks a request the step had scheduled.  The scheduler must return that request's placeholder, or the preempted
+    request would never be admitted again."""
+    from ht_vllm_omni_amd.payloads import OmniModelRunnerOutput
+    from ht_vllm_omni_amd.scheduler import RequestStatus
+    d = get_dims("tiny")
+    s = MI355XARScheduler(num_blocks=64, block_size=16, max_num_seqs=4, max_num_batched_tokens=48, max_model_len=512, async_scheduling=True)
+    s.add_request(_request(d, "a", 6, max_tokens=8))
+    so1 = s.schedule()
+    s.update_from_output(so1, OmniModelRunnerOutput(req_ids=["a"], req_id_to_index={"a": 0}, sampled_token_ids=[[5]]))
+    so2 = s.schedule()                                   # a decode step for a, in flight
+    req = s.requests["a"]
+    assert so2.num_scheduled_tokens == {"a": 1} and req.num_output_placeholders == 1
+    s.running.remove(req); s.pool.free_request("a"); req.status = RequestStatus.PREEMPTED; req.num_computed_tokens = 0; s.waiting.appendleft(req)
+    s.update_from_output(so2, OmniModelRunnerOutput(req_ids=[], req_id_to_index={}, sampled_token_ids=[]))      # the runner dropped the row
+    assert req.num_output_placeholders == 0
+    so3 = s.schedule()
+    assert [r.req_id for r in so3.scheduled_new_reqs] == ["a"] and so3.num_scheduled_tokens["a"] == 7      # recomputed: prompt + its one token
