@@ -59,6 +59,125 @@ __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
 
 __device__ __forceinline__ float tg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
+// Epilogue of a tile kernel: `acc[j][i]` = this wave's WN n-tiles x WM m-tiles (D[n][m] fragments), first row mw0, first column nw0; `lds` is dead.
+template <int WN, int WM, bool GU8>
+__device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN][WM], uint8_t* lds, int wave, int lane, int mw0, int nw0) {
+    const int c = lane & 15, q = lane >> 4;
+    // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image in fp32, ONE m-tile
+    // (16 rows x the wave's WN * 16 columns) per pass.  Row side: 8 columns per lane, a row's lanes cover WN * 64 contiguous bytes
+    // of an fp32 output (whole 128-byte lines); + fp32 residual (the pass's residual loads are issued before its image is written:
+    // the epilogue of a residual GEMM is an HBM phase, not a chain of load -> add -> store round trips), then up to three stores of
+    // the SAME fp32 value: fp32 (the residual stream), bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand).
+    constexpr int IPITCH = WN * 64 + 16;                  // bytes per image row
+    constexpr int PER_ROW = GU8 ? WN : WN * 2;            // lane items per image row: a [8 gate | 8 up] tile, or 8 columns
+    constexpr int RIT = (16 * PER_ROW + 63) / 64;         // row-side iterations per pass
+    uint8_t* img = lds + wave * (16 * IPITCH);
+    f32x4 bq[WN], sq[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = nw0 + j * 16 + 4 * q;
+        bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sq[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (n < a.N) {
+            if (a.bias) bq[j] = *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.scale) sq[j] = *reinterpret_cast<const f32x4*>(a.scale + n);
+        }
+    }
+    f32x4 rv[RIT][2];
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass) {
+        const int mp0 = mw0 + pass * 16;
+        if (!GU8 && a.resid) {
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
+                const int m = mp0 + row, n = nw0 + ch * 8;
+                rv[it][0] = rv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < 16 * PER_ROW && m < a.M && n < a.N) {
+                    const float* rp = a.resid + (size_t)m * a.ldr + n;
+                    rv[it][0] = *reinterpret_cast<const f32x4*>(rp);
+                    rv[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[j][pass][e] + bq[j][e];
+                if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
+                v[e] = t * sq[j][e];
+            }
+            *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (GU8) {
+            // tile j of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
+            // torch's F.silu(g) * u on bf16 tensors (omni_silu_mul, oracle silu_mul)
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / PER_ROW, j = idx - row * PER_ROW;
+                const int m = mp0 + row, n = nw0 + j * 16;
+                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
+                const float* gp = reinterpret_cast<const float*>(img + row * IPITCH + j * 64);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g0 = bfround(gp[2 * e]), g1 = bfround(gp[2 * e + 1]);
+                    const float u0 = bfround(gp[8 + 2 * e]), u1 = bfround(gp[8 + 2 * e + 1]);
+                    const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));   // torch: F.silu(bf16) is bf16
+                    o[e] = pack_bf2(s0 * u0, s1 * u1);
+                }
+                *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
+                const int m = mp0 + row, n = nw0 + ch * 8;
+                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
+                f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
+                f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
+                if (a.resid) {
+                    y0 += rv[it][0];
+                    y1 += rv[it][1];
+                }
+                if (a.out_f32) {
+                    float* op = a.out_f32 + (size_t)m * a.ldf + n;
+                    *reinterpret_cast<f32x4*>(op) = y0;
+                    *reinterpret_cast<f32x4*>(op + 4) = y1;
+                }
+                if (a.out) {
+                    u32x4 o;
+                    o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
+                    o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
+                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                }
+                if (a.out2) {
+                    const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
+                    const f32x4 ib0 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n), ib1 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n + 4);
+                    f32x4 z0, z1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s0 = __sinf(y0[e] * al0[e]), s1 = __sinf(y1[e] * al1[e]);
+                        z0[e] = y0[e] + ib0[e] * s0 * s0;
+                        z1[e] = y1[e] + ib1[e] * s1 * s1;
+                    }
+                    u32x4 o;
+                    o[0] = pack_bf2(z0[0], z0[1]); o[1] = pack_bf2(z0[2], z0[3]);
+                    o[2] = pack_bf2(z1[0], z1[1]); o[3] = pack_bf2(z1[2], z1[3]);
+                    *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Geometry of one instantiation: 8 waves (two per SIMD: while one issues its LDS-DMA pieces -- 60 - 180 cycles each -- or waits
 // for fragments, the other feeds the matrix pipe) as WAVES_N x (8 / WAVES_N); a wave owns WN n-tiles x WM m-tiles of 16 x 16
 // (acc = WN * WM * 4 of its 256 registers); BN = WAVES_N * WN * 16, BM = (8 / WAVES_N) * WM * 16.
@@ -223,120 +342,234 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a_
 #undef TG_SLICE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is dead: its tail loads (zeros) landed
 
-    // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image in fp32, ONE m-tile
-    // (16 rows x the wave's WN * 16 columns) per pass.  Row side: 8 columns per lane, a row's lanes cover WN * 64 contiguous bytes
-    // of an fp32 output (whole 128-byte lines); + fp32 residual (the pass's residual loads are issued before its image is written:
-    // the epilogue of a residual GEMM is an HBM phase, not a chain of load -> add -> store round trips), then up to three stores of
-    // the SAME fp32 value: fp32 (the residual stream), bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand).
-    constexpr int IPITCH = WN * 64 + 16;                  // bytes per image row
-    constexpr int PER_ROW = GU8 ? WN : WN * 2;            // lane items per image row: a [8 gate | 8 up] tile, or 8 columns
-    constexpr int RIT = (16 * PER_ROW + 63) / 64;         // row-side iterations per pass
-    uint8_t* img = lds + wave * (16 * IPITCH);
-    const int mw0 = m0 + wm * WM * 16;                    // first row of this wave
-    const int nw0 = n0 + wn * WN * 16;                    // first column of this wave
-    f32x4 bq[WN], sq[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = nw0 + j * 16 + 4 * q;
-        bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sq[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (n < a.N) {
-            if (a.bias) bq[j] = *reinterpret_cast<const f32x4*>(a.bias + n);
-            if (a.scale) sq[j] = *reinterpret_cast<const f32x4*>(a.scale + n);
-        }
+    tile_epilogue<WN, WM, GU8>(a, acc, lds, wave, lane, m0 + wm * WM * 16, n0 + wn * WN * 16);
+}
+
+// ---- the two-group ("ping-pong") form of the 256-column tile.  Same images, same MFMA, same accumulation order as gemm_tile_kernel
+// (bit-identical output); what differs is WHEN a wave does what.  The eight waves are two groups of four, one wave of each group per SIMD:
+// group 0 owns the tile's first MA m-tiles (16 rows each), group 1 the next MB, and wave column wc = wave & 3 owns n-tiles [4 wc, + 4).
+// A K-tile (64 deep: two 32-deep steps) is four phases of [LDS reads + 2 LDS-DMA pieces | barrier | 12 - 16 MFMAs | barrier], one quadrant
+// of the wave's tile per phase, and group 1 runs ONE barrier interval behind group 0: while one wave of a SIMD issues its loads (an LDS-DMA
+// piece costs its issuer 60 - 180 cycles) and waits for its fragments, the other one owns the matrix pipe.  In gemm_tile_kernel both waves
+// of a SIMD load at the same time and then want the pipe at the same time.  The groups need not be equal: BM = 16 (MA + MB) rows comes in
+// steps of 16, so that a grid can be cut to ONE or two full rounds of the 256 CUs (6.4 k tokens x 2048 columns = 248 tiles of 208 rows).
+// Staging: a K-tile's image is four 16 KB half-tiles in the order of their first use (x: the low m-tiles of both groups | W: n-tiles 0-1 of
+// every wave column | W: n-tiles 2-3 | x: the high m-tiles), one half-tile per phase (two pieces per wave; a wave without a real piece
+// loads zeros into a spare KB: uniform vmcnt), SIX half-tiles ahead of the phase that runs; two 64 KB buffers.  Order of a region's life:
+// read in phase p (the reads retire at that wave's lgkmcnt(0) behind the phase's first barrier) -> re-staged no earlier than phase p + 2 ->
+// waited for (counted vmcnt(6) behind every phase's two pieces, before that phase's first barrier: the half-tiles up to three ahead of the
+// phase have landed) -> read from the next phase on, at most two half-tiles ahead of it (the low W fragments of K-tile t + 1 in K-tile t's fourth phase).
+// With the groups one interval apart every one of these edges still has a barrier that BOTH parties passed in between.
+template <int N_> struct PPInt { static constexpr int value = N_; };
+
+// scripts/probes/gemm_pp_stamps.hip compiles this file with -DPP_STAMPS: the shader clock at the section boundaries of K-tiles 8 ... 23 of
+// one workgroup (first wave of each group), kept in LDS behind the ring (a global store would count in vmcnt) and copied out at the end.
+// PP_STAMPS == 2 adds a stamp between the loads and the first barrier (its lgkmcnt(0) moves the wait for the fragments in front of the barrier).
+#ifdef PP_STAMPS
+__device__ unsigned long long g_pp_stamps[2][1024];
+__device__ int g_pp_stamp_wg;
+#define PP_T() do { if (st_on) { st_buf[st_n] = __builtin_amdgcn_s_memtime(); ++st_n; } } while (0)
+#if PP_STAMPS == 2
+#define PP_T1() PP_T()
+#else
+#define PP_T1()
+#endif
+#else
+#define PP_T()
+#define PP_T1()
+#endif
+
+template <int MA, int MB, bool GU8>
+__global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs a_in) {
+    const TileArgs& a = a_in;
+    constexpr int KT_BYTES = 64 * 1024, HALF = 16 * 1024, SPARE = 2 * KT_BYTES;
+    constexpr int LA = (MA + 1) / 2, LB = (MB + 1) / 2, HA = MA - LA, HB = MB - LB;       // low / high m-tiles of each group
+    static_assert(MA >= MB && MA <= 8 && MB >= 2 && LA + LB <= 8 && HA + HB <= 8, "geometry");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int c = lane & 15, q = lane >> 4;
+    int tile;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, per = nwg >> 3, rem = nwg & 7;
+        tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
     }
-    f32x4 rv[RIT][2];
+    int n_blk, m_blk;
+    {
+        const int per_band = a.band * a.nblocks;
+        const int b = tile / per_band, r = tile - b * per_band;
+        const int h = min(a.band, a.mblocks - b * a.band);
+        n_blk = r / h;
+        m_blk = b * a.band + (r - n_blk * h);
+    }
+    const int m0 = m_blk * (16 * (MA + MB)), n0 = n_blk * 256;
+    const int nsteps = a.K >> 5, nkt = (nsteps + 1) >> 1;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(a.x_rows * a.ldx * 2), 0x00020000);
+
+    // staging: piece e (0 / 1) of a half-tile = fragment f = wave + 8 e of its 16 = (slot t = f >> 1, k-step f & 1).  Slot t of an x half is
+    // the t-th m-tile of [group 0's half | group 1's half]; slot t of a W half is n-tile 4 (t >> 1) + (t & 1) (+ 2 in the high half).
+    unsigned wofs[2][2], xofs[2][2];
+    bool xreal[2][2];
 #pragma unroll
-    for (int pass = 0; pass < WM; ++pass) {
-        const int mp0 = mw0 + pass * 16;
-        if (!GU8 && a.resid) {
+    for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-                const int idx = lane + 64 * it;
-                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
-                const int m = mp0 + row, n = nw0 + ch * 8;
-                rv[it][0] = rv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (idx < 16 * PER_ROW && m < a.M && n < a.N) {
-                    const float* rp = a.resid + (size_t)m * a.ldr + n;
-                    rv[it][0] = *reinterpret_cast<const f32x4*>(rp);
-                    rv[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
-                }
-            }
+        for (int e = 0; e < 2; ++e) {
+            const int f = wave + 8 * e, t = f >> 1, ks = f & 1;
+            const int n16 = (n0 >> 4) + 4 * (t >> 1) + (t & 1) + 2 * hi;
+            wofs[hi][e] = n16 * 16 < a.N ? (unsigned)(((size_t)n16 * nsteps + ks) * 1024 + lane * 16) : TG_OOB;
+            const int cnt0 = hi ? HA : LA, cnt = hi ? HA + HB : LA + LB;
+            const int mt = t < cnt0 ? (hi ? LA : 0) + t : MA + (hi ? LB : 0) + (t - cnt0);
+            const int row = m0 + mt * 16 + c;
+            xreal[hi][e] = t < cnt;
+            xofs[hi][e] = (t < cnt && row < a.M && row < a.x_rows) ? (unsigned)(((size_t)row * a.ldx + ks * 32 + 8 * q) * 2) : TG_OOB;
         }
+    auto stage = [&](int kt, int h, int buf) {                // h: 0 x low, 1 W low, 2 W high, 3 x high (order of first use)
+        const bool live = kt < nkt;
+        const bool is_w = h == 1 || h == 2;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[j][pass][e] + bq[j][e];
-                if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
-                v[e] = t * sq[j][e];
-            }
-            *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
+        for (int e = 0; e < 2; ++e) {
+            const unsigned base = is_w ? wofs[h == 2][e] : xofs[h == 3][e];
+            // an odd count of 32-deep steps: the last K-tile's second step lies past the row's K (x: the next row's data; W: the next n-tile's)
+            const bool tail = ((wave + 8 * e) & 1) && 2 * kt + 1 >= nsteps;
+            const unsigned off = (live && !tail && base != TG_OOB) ? base + (unsigned)kt * (is_w ? 2048u : 128u) : TG_OOB;
+            const bool real = is_w || xreal[h == 3][e];
+            uint8_t* dst = real ? lds + buf * KT_BYTES + h * HALF + (wave + 8 * e) * 1024 : lds + SPARE + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(is_w ? rw : rx, (lds_void_t*)dst, 16, off, 0, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (GU8) {
-            // tile j of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
-            // torch's F.silu(g) * u on bf16 tensors (omni_silu_mul, oracle silu_mul)
+    };
+
+    // prologue: K-tile 0 whole, K-tile 1's first two half-tiles
+    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0); stage(1, 0, 1); stage(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    if (grp) asm volatile("s_barrier" ::: "memory");          // group 1 starts one interval late
+
+    auto run = [&](auto mw_tag) {
+        constexpr int MW = decltype(mw_tag)::value;           // m-tiles of this wave
+        constexpr int LO = (MW + 1) / 2, HI = MW - LO;
+        const int t_lo = grp ? LA : 0, t_hi = grp ? HA : 0;   // this group's first slot in the x halves
+        auto lds_x = [&](int buf, int hi, int i, int ks) {
+            return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 3 : 0) * HALF + ((((hi ? t_hi : t_lo) + i) * 2 + ks) * 1024) + lane * 16);
+        };
+        auto lds_w = [&](int buf, int hi, int j, int ks) {
+            return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 2 : 1) * HALF + (((wc * 2 + j) * 2 + ks) * 1024) + lane * 16);
+        };
+        f32x4 acc[4][MW];
 #pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-                const int idx = lane + 64 * it;
-                const int row = idx / PER_ROW, j = idx - row * PER_ROW;
-                const int m = mp0 + row, n = nw0 + j * 16;
-                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
-                const float* gp = reinterpret_cast<const float*>(img + row * IPITCH + j * 64);
-                u32x4 o;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g0 = bfround(gp[2 * e]), g1 = bfround(gp[2 * e + 1]);
-                    const float u0 = bfround(gp[8 + 2 * e]), u1 = bfround(gp[8 + 2 * e + 1]);
-                    const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));   // torch: F.silu(bf16) is bf16
-                    o[e] = pack_bf2(s0 * u0, s1 * u1);
-                }
-                *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
-            }
-        } else {
+            for (int i = 0; i < MW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 xr[LO][2], wl[2][2], wl2[2][2], wh[2][2];
+#ifdef PP_STAMPS
+        unsigned long long* st_buf = reinterpret_cast<unsigned long long*>(lds + SPARE + 8192 + grp * 4096);
+        int st_n = 0;
+        const bool st_wave = (int)blockIdx.x == g_pp_stamp_wg && wc == 0 && lane == 0;
+        bool st_on = false;
+#endif
+
+#define PP_MFMA(WREG, WHI, XCNT, XHI)                                                                                    \
+    PP_T1();                                                                                                             \
+    asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    PP_T();                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < (XCNT); ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+                acc[(WHI) * 2 + j][(XHI) * LO + i] = tg_mfma(WREG[j][ks], xr[i][ks], acc[(WHI) * 2 + j][(XHI) * LO + i]); \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    PP_T();                                                                                                              \
+    asm volatile("s_barrier" ::: "memory");                                                                              \
+    PP_T();
+#define PP_STAGE(K_, H_, B_)                                                                                             \
+    stage(K_, H_, B_);                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* everything up to three half-tiles ahead of this phase has landed */ \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_KTILE(BUF, WL, WLNEXT, S0K, S0H, S0B, S1K, S1H, S1B, S2K, S2H, S2B, S3K, S3H, S3B)                             \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < LO; ++i)                                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) xr[i][ks] = lds_x(BUF, 0, i, ks);                           \
+        PP_STAGE(S0K, S0H, S0B)                                                                                          \
+        PP_MFMA(WL, 0, LO, 0)                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wh[j][ks] = lds_w(BUF, 1, j, ks);                           \
+        PP_STAGE(S1K, S1H, S1B)                                                                                          \
+        PP_MFMA(wh, 1, LO, 0)                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < HI; ++i)                                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) xr[i][ks] = lds_x(BUF, 1, i, ks);                           \
+        PP_STAGE(S2K, S2H, S2B)                                                                                          \
+        PP_MFMA(wh, 1, HI, 1)                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)             /* the NEXT K-tile's low W fragments: the fourth phase has no reads of its own */ \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) WLNEXT[j][ks] = lds_w((BUF) ^ 1, 0, j, ks);                 \
+        PP_STAGE(S3K, S3H, S3B)                                                                                          \
+        PP_MFMA(WL, 0, HI, 1)                                                                                            \
+    }
 #pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-                const int idx = lane + 64 * it;
-                const int row = idx / PER_ROW, ch = idx - row * PER_ROW;
-                const int m = mp0 + row, n = nw0 + ch * 8;
-                if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
-                f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
-                f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
-                if (a.resid) {
-                    y0 += rv[it][0];
-                    y1 += rv[it][1];
-                }
-                if (a.out_f32) {
-                    float* op = a.out_f32 + (size_t)m * a.ldf + n;
-                    *reinterpret_cast<f32x4*>(op) = y0;
-                    *reinterpret_cast<f32x4*>(op + 4) = y1;
-                }
-                if (a.out) {
-                    u32x4 o;
-                    o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
-                    o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
-                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
-                }
-                if (a.out2) {
-                    const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
-                    const f32x4 ib0 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n), ib1 = *reinterpret_cast<const f32x4*>(a.snake_inv_beta + n + 4);
-                    f32x4 z0, z1;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float s0 = __sinf(y0[e] * al0[e]), s1 = __sinf(y1[e] * al1[e]);
-                        z0[e] = y0[e] + ib0[e] * s0 * s0;
-                        z1[e] = y1[e] + ib1[e] * s1 * s1;
-                    }
-                    u32x4 o;
-                    o[0] = pack_bf2(z0[0], z0[1]); o[1] = pack_bf2(z0[2], z0[3]);
-                    o[2] = pack_bf2(z1[0], z1[1]); o[3] = pack_bf2(z1[2], z1[3]);
-                    *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
-                }
-            }
+            for (int ks = 0; ks < 2; ++ks) wl[j][ks] = lds_w(0, 0, j, ks);
+        for (int u = 0; u < nkt; u += 2) {                    // an odd K-tile count runs one K-tile of zeros (staged out of range)
+#ifdef PP_STAMPS
+            st_on = st_wave && u >= 8 && u < 24;
+            if (u == 8) PP_T();
+#endif
+            PP_KTILE(0, wl, wl2, u + 1, 2, 1, u + 1, 3, 1, u + 2, 0, 0, u + 2, 1, 0)
+            PP_KTILE(1, wl2, wl, u + 2, 2, 0, u + 2, 3, 0, u + 3, 0, 1, u + 3, 1, 1)
         }
-        __builtin_amdgcn_wave_barrier();
+#undef PP_STAGE
+#undef PP_KTILE
+#undef PP_MFMA
+        if (!grp) asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PP_STAMPS
+        if (st_wave)
+            for (int i = 0; i < st_n && i < 1023; ++i) g_pp_stamps[grp][1 + i] = st_buf[i];
+        if (st_wave) g_pp_stamps[grp][0] = st_n;
+#endif
+        tile_epilogue<4, MW, GU8>(a, acc, lds, wave, lane, m0 + (grp ? MA * 16 : 0), n0 + wc * 64);
+    };
+    if (MA == MB || !grp) run(PPInt<MA>{});
+    else run(PPInt<MB>{});
+}
+
+template <int MA, int MB, bool GU8>
+static int launch_tile_pp(TileArgs a, hipStream_t st) {
+    constexpr int BM = 16 * (MA + MB);
+    a.mblocks = (a.M + BM - 1) / BM;
+    a.nblocks = a.N / 256;
+    {
+        const int per_xcd = (a.mblocks * a.nblocks + 7) / 8;
+        int band = 1;
+        while (band * band < per_xcd) ++band;
+        a.band = band > a.mblocks ? a.mblocks : band;
+    }
+#ifdef PP_STAMPS
+    constexpr int LDS_BYTES = 128 * 1024 + TG_WAVES * 1024 + 8192 + 8192;
+#else
+    constexpr int LDS_BYTES = 128 * 1024 + TG_WAVES * 1024;
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_pp_kernel<MA, MB, GU8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { omni_set_error("omni_gemm_tile: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tile_pp_kernel<MA, MB, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), LDS_BYTES, st, a);
+    OMNI_CHECK_LAUNCH("omni_gemm_tile");
+    return OMNI_OK;
+}
+
+template <bool GU8>
+static int launch_tile_pp_rows(int bm, const TileArgs& a, hipStream_t st) {
+    switch (bm) {
+    case 256: return launch_tile_pp<8, 8, GU8>(a, st);
+    case 240: return launch_tile_pp<8, 7, GU8>(a, st);
+    case 224: return launch_tile_pp<7, 7, GU8>(a, st);
+    case 208: return launch_tile_pp<7, 6, GU8>(a, st);
+    default: return launch_tile_pp<6, 6, GU8>(a, st);
     }
 }
 
@@ -373,7 +606,7 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
     const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
     OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
-    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 4, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
+    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 9, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
     OMNI_CHECK_ARG(g->tile_hint < 3 || g->N % 256 == 0, "omni_gemm_tile: tile_hint=%d needs N %% 256 == 0", g->tile_hint);
     OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2 && !g->out_f32), "omni_gemm_tile: SiLU-mul takes out only");
     OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
@@ -412,6 +645,12 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     // 256-column tiles come in three heights.  One workgroup per CU (the ring takes most of the LDS), so a grid runs in rounds of
     // 256 tiles and a round costs ~ the tile's rows: 6.4 k prompt tokens x 2048 columns are 208 tiles of 256 rows (one round, 48 CUs
     // idle) or 232 tiles of 224 rows (one round, 12.5 % shorter).  Same accumulation order in every geometry: bit-identical results.
+    const bool pp_ok = N % 256 == 0 && groups == 1 && !g->group_rows && seg_len == g->K && g->row_off == 0;
+    OMNI_CHECK_ARG(g->tile_hint < 5 || pp_ok, "omni_gemm_tile: tile_hint=%d (two-group tile) takes a plain GEMM with N %% 256 == 0", g->tile_hint);
+    if (g->tile_hint >= 5) {                                  // 5 ... 9: 256, 240, 224, 208, 192 rows
+        const int bm = 256 - 16 * (g->tile_hint - 5);
+        return gu8 ? launch_tile_pp_rows<true>(bm, a, st) : launch_tile_pp_rows<false>(bm, a, st);
+    }
     if (N % 256 == 0) {
         int bm = 256;
         if (g->tile_hint == 3) bm = 224;

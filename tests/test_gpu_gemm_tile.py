@@ -27,7 +27,8 @@ def _close(got, ref, mag, what):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 2048), (257, 192, 96), (513, 384, 672), (640, 128, 64),
-                                   (1111, 96, 672), (255, 288, 96), (70, 48, 32), (900, 272, 160), (6400, 2048, 2048)])
+                                   (1111, 96, 672), (255, 288, 96), (70, 48, 32), (900, 272, 160), (6400, 2048, 2048),
+                                   (700, 256, 64), (1300, 768, 96), (515, 256, 32), (2000, 1024, 6144)])
 def test_plain_gemm_every_tile_configuration(M, N, K):
     """tile_hint 1 = the large tiles (256 / 192 / 128 / 96 columns by N), 2 = the 128 x 64 small-M tile, 0 = the dispatch rule."""
     ops, L, frag_shuffle, _ = _ops()
@@ -42,8 +43,8 @@ def test_plain_gemm_every_tile_configuration(M, N, K):
         _close(outs[-1], ref, mag, f"gemm {M}x{N}x{K} hint {hint}")
     assert torch.equal(outs[0], outs[1])      # same k order per output element in both geometries: bit-identical
     assert torch.equal(outs[0], outs[2])
-    if N % 256 == 0:                           # the 224- and 192-row tiles of the 256-column geometry
-        for hint in (3, 4):
+    if N % 256 == 0:                           # the 224- and 192-row tiles of the 256-column geometry; 5 ... 9 = the two-group tile at 256 ... 192 rows
+        for hint in (3, 4, 5, 6, 7, 8, 9):
             assert torch.equal(outs[0], ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), tile_hint=hint)), hint
 
 
@@ -119,6 +120,21 @@ def test_epilogues_gelu_scale_fp32_residual_stream_and_snake_output():
         assert torch.equal(f2, f), hint
 
 
+def test_two_group_tile_with_the_prefills_residual_epilogue():
+    """tile_hints 5 ... 9 (the two-group tile at 256, 240, 224, 208, 192 rows) on the o_proj / down_proj form (fp32 residual in, bf16 out): bit-identical to the 256 x 256 tile of hint 1."""
+    ops, L, frag_shuffle, _ = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1234, 512, 1088
+    x = torch.randn(M, K, generator=g).to(BF16).cuda()
+    w = frag_shuffle((torch.randn(N, K, generator=g) * 0.05).to(BF16)).cuda()
+    r = (torch.randn(M, N, generator=g) * 3).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    for want in ("b", "f"):
+        a1 = ops.gemm_tile(x, w, bias=b, resid=r, want=want, tile_hint=1)
+        for hint in (5, 6, 7, 8, 9):
+            assert torch.equal(a1, ops.gemm_tile(x, w, bias=b, resid=r, want=want, tile_hint=hint)), (want, hint)
+
+
 @pytest.mark.parametrize("M,I,K", [(333, 3072, 1024), (6400, 6144, 2048), (100, 64, 64)])
 def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     """The decode step's gate_up weight as it lies in HBM (gate / up rows interleaved by 8, fragment-major) serves the
@@ -131,7 +147,7 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     assert out.shape == (M, I)
     assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=2))
     if (2 * I) % 256 == 0:
-        for hint in (3, 4):
+        for hint in (3, 4, 5, 6, 7, 8, 9):
             assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)), hint
     gu = (x.double() @ w.double().T)
     ga, up = gu[:, :I].float().to(BF16), gu[:, I:].float().to(BF16)
@@ -145,7 +161,7 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
 
 
 @pytest.mark.parametrize("M,N,K,taps,dil", [(6400, 2048, 2048, 1, 1), (3000, 96, 96, 7, 9), (5000, 192, 192, 7, 3), (700, 1024, 1024, 1, 1),
-                                              (2600, 768, 768, 7, 1)])
+                                              (2600, 768, 768, 7, 1), (6438, 2048, 6144, 1, 1), (6438, 4096, 2048, 1, 1)])
 def test_race_screen_repeated_launches_are_bit_identical(M, N, K, taps, dil):
     """The ring's synchronisation (LDS-DMA retired by counted vmcnt + a barrier one phase before the read; buffers restaged only
     after the barrier that follows their last read) screened the way a hand-scheduled pipeline has to be: 150 back-to-back
@@ -157,7 +173,7 @@ def test_race_screen_repeated_launches_are_bit_identical(M, N, K, taps, dil):
     w = frag_shuffle((torch.randn(N, taps * K, generator=g) * 0.05).to(BF16)).cuda()
     noise = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     first = None
-    for hint in (1, 2):
+    for hint in (1, 2, 5, 8) if (taps == 1 and N % 256 == 0) else (1, 2):  # 5 / 8: the two-group tile (256 / 208 rows), a different synchronisation structure
         outs = []
         for it in range(150):
             outs.append(ops.gemm_tile(x, w, taps=taps, dilation=dil, tile_hint=hint))
