@@ -347,28 +347,35 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a_
 
 // ---- the two-group ("ping-pong") form of the 256-column tile.  Same images, same MFMA, same accumulation order as gemm_tile_kernel
 // (bit-identical output); what differs is WHEN a wave does what.  The eight waves are two groups of four, one wave of each group per SIMD:
-// group 0 owns the tile's first MA m-tiles (16 rows each), group 1 the next MB, and wave column wc = wave & 3 owns n-tiles [4 wc, + 4).
-// A K-tile (64 deep: two 32-deep steps) is four phases of [LDS reads + 2 LDS-DMA pieces | barrier | 12 - 16 MFMAs | barrier], one quadrant
-// of the wave's tile per phase, and group 1 runs ONE barrier interval behind group 0: while one wave of a SIMD issues its loads (an LDS-DMA
-// piece costs its issuer 60 - 180 cycles) and waits for its fragments, the other one owns the matrix pipe.  In gemm_tile_kernel both waves
-// of a SIMD load at the same time and then want the pipe at the same time.  The groups need not be equal: BM = 16 (MA + MB) rows comes in
-// steps of 16, so that a grid can be cut to ONE or two full rounds of the 256 CUs (6.4 k tokens x 2048 columns = 248 tiles of 208 rows).
-// Staging: a K-tile's image is four 16 KB half-tiles in the order of their first use (x: the low m-tiles of both groups | W: n-tiles 0-1 of
-// every wave column | W: n-tiles 2-3 | x: the high m-tiles), one half-tile per phase (two pieces per wave; a wave without a real piece
-// loads zeros into a spare KB: uniform vmcnt), SIX half-tiles ahead of the phase that runs; two 64 KB buffers.  Order of a region's life:
-// read in phase p (the reads retire at that wave's lgkmcnt(0) behind the phase's first barrier) -> re-staged no earlier than phase p + 2 ->
-// waited for (counted vmcnt(6) behind every phase's two pieces, before that phase's first barrier: the half-tiles up to three ahead of the
-// phase have landed) -> read from the next phase on, at most two half-tiles ahead of it (the low W fragments of K-tile t + 1 in K-tile t's fourth phase).
-// With the groups one interval apart every one of these edges still has a barrier that BOTH parties passed in between.
-template <int N_> struct PPInt { static constexpr int value = N_; };
-
-// scripts/probes/gemm_pp_stamps.hip compiles this file with -DPP_STAMPS: the shader clock at the section boundaries of K-tiles 8 ... 23 of
-// one workgroup (first wave of each group), kept in LDS behind the ring (a global store would count in vmcnt) and copied out at the end.
-// PP_STAMPS == 2 adds a stamp between the loads and the first barrier (its lgkmcnt(0) moves the wait for the fragments in front of the barrier).
+// group g owns the tile's m-tiles [MW g, + MW) (16 rows each; BM = 32 MW), wave column wc = wave & 3 owns n-tiles [4 wc, + 4).  A K-tile
+// (64 deep: two 32-deep steps) is two phases of [12 LDS reads + 4 LDS-DMA pieces | barrier | 24 - 32 MFMAs | barrier], and group 1 runs ONE
+// barrier interval behind group 0: while one wave of a SIMD issues its loads (an LDS-DMA piece costs its issuer 60 - 180 cycles) and waits
+// for its fragments, the other one owns the matrix pipe.  In gemm_tile_kernel both waves of a SIMD load at the same time and then want the
+// pipe at the same time.  Phase 2 t: [x low (t), W high (t) | x low (t) x all four n-tiles]; phase 2 t + 1: [x high (t), W low (t + 1) |
+// x high (t) x all four] (the low W fragments live in two register sets).
+// Staging: a K-tile's image is four 16 KB half-tiles (x: the low m-tiles of both groups | W: n-tiles 0-1 of every wave column | W: n-tiles
+// 2-3 | x: the high m-tiles; a wave without a real piece loads zeros into a spare KB: uniform vmcnt), two 64 KB buffers.  Each phase stages
+// the two half-tiles that the phase after the next one reads, and waits -- vmcnt(4) behind its own four pieces, in front of its first
+// barrier -- for the two that the NEXT phase reads.  Order of a region's life: read in phase p (the reads retire at that wave's lgkmcnt(0)
+// behind the phase's first barrier) -> re-staged in phase p + 2 -> waited for in p + 3 -> read in p + 4.  With the groups one interval
+// apart every one of these edges still has a barrier that BOTH parties passed in between.
+// Measured (scripts/probes/gemm_pp_stamps.hip, profiles/r05_gemm_pp_stamps.txt): 2 400 - 2 600 cycles per K-tile against 2 048 of MFMA at
+// full rate (gemm_tile_kernel: ~2 900); four phases of 12 - 16 MFMAs: +1.5 %; the closing barrier 4 or 8 MFMAs before a section's end
+// (both groups on the pipe for a moment): +9 %; unequal groups (240 / 208 rows): slower than the next taller equal pair.
+//
+// -DPP_STAMPS (the probe only): 1 / 2 = the shader clock at the section boundaries of K-tiles 8 ... 23 of one workgroup (first wave of each
+// group; 2 adds a stamp between the loads and the first barrier), kept in LDS behind the ring (a global store would count in vmcnt);
+// 3 = shader clock and the 100 MHz clock at kernel entry, loop start, loop end, kernel end, nothing inside the loop.
 #ifdef PP_STAMPS
 __device__ unsigned long long g_pp_stamps[2][1024];
 __device__ int g_pp_stamp_wg;
+#if PP_STAMPS == 3
+#define PP_T()
+#define PP_C(k) do { if (st_wave) { g_pp_stamps[grp][1 + 2 * (k)] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][2 + 2 * (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
 #define PP_T() do { if (st_on) { st_buf[st_n] = __builtin_amdgcn_s_memtime(); ++st_n; } } while (0)
+#define PP_C(k)
+#endif
 #if PP_STAMPS == 2
 #define PP_T1() PP_T()
 #else
@@ -377,19 +384,24 @@ __device__ int g_pp_stamp_wg;
 #else
 #define PP_T()
 #define PP_T1()
+#define PP_C(k)
 #endif
 
-template <int MA, int MB, bool GU8>
+template <int MW, bool GU8>
 __global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs a_in) {
     const TileArgs& a = a_in;
     constexpr int KT_BYTES = 64 * 1024, HALF = 16 * 1024, SPARE = 2 * KT_BYTES;
-    constexpr int LA = (MA + 1) / 2, LB = (MB + 1) / 2, HA = MA - LA, HB = MB - LB;       // low / high m-tiles of each group
-    static_assert(MA >= MB && MA <= 8 && MB >= 2 && LA + LB <= 8 && HA + HB <= 8, "geometry");
+    constexpr int LO = (MW + 1) / 2, HI = MW - LO;            // low / high m-tiles of a wave
+    static_assert(MW >= 2 && MW <= 8, "geometry");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wc = wave & 3;
     const int c = lane & 15, q = lane >> 4;
+#ifdef PP_STAMPS
+    const bool st_wave = (int)blockIdx.x == g_pp_stamp_wg && wc == 0 && lane == 0;
+#endif
+    PP_C(0);
     int tile;
     {
         const int nwg = gridDim.x, id = blockIdx.x;
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs
         n_blk = r / h;
         m_blk = b * a.band + (r - n_blk * h);
     }
-    const int m0 = m_blk * (16 * (MA + MB)), n0 = n_blk * 256;
+    const int m0 = m_blk * (32 * MW), n0 = n_blk * 256;
     const int nsteps = a.K >> 5, nkt = (nsteps + 1) >> 1;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(a.x_rows * a.ldx * 2), 0x00020000);
@@ -420,13 +432,13 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs
             const int f = wave + 8 * e, t = f >> 1, ks = f & 1;
             const int n16 = (n0 >> 4) + 4 * (t >> 1) + (t & 1) + 2 * hi;
             wofs[hi][e] = n16 * 16 < a.N ? (unsigned)(((size_t)n16 * nsteps + ks) * 1024 + lane * 16) : TG_OOB;
-            const int cnt0 = hi ? HA : LA, cnt = hi ? HA + HB : LA + LB;
-            const int mt = t < cnt0 ? (hi ? LA : 0) + t : MA + (hi ? LB : 0) + (t - cnt0);
+            const int cnt = hi ? HI : LO;                     // per group
+            const int mt = (t < cnt ? 0 : MW) + (hi ? LO : 0) + (t < cnt ? t : t - cnt);
             const int row = m0 + mt * 16 + c;
-            xreal[hi][e] = t < cnt;
-            xofs[hi][e] = (t < cnt && row < a.M && row < a.x_rows) ? (unsigned)(((size_t)row * a.ldx + ks * 32 + 8 * q) * 2) : TG_OOB;
+            xreal[hi][e] = t < 2 * cnt;
+            xofs[hi][e] = (t < 2 * cnt && row < a.M && row < a.x_rows) ? (unsigned)(((size_t)row * a.ldx + ks * 32 + 8 * q) * 2) : TG_OOB;
         }
-    auto stage = [&](int kt, int h, int buf) {                // h: 0 x low, 1 W low, 2 W high, 3 x high (order of first use)
+    auto stage = [&](int kt, int h, int buf) {                // h: 0 x low, 1 W low, 2 W high, 3 x high
         const bool live = kt < nkt;
         const bool is_w = h == 1 || h == 2;
 #pragma unroll
@@ -440,104 +452,103 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs
             __builtin_amdgcn_raw_ptr_buffer_load_lds(is_w ? rw : rx, (lds_void_t*)dst, 16, off, 0, 0, 0);
         }
     };
+    const int t_lo = grp ? LO : 0, t_hi = grp ? HI : 0;       // this group's first slot in the x halves
+    auto lds_x = [&](int buf, int hi, int i, int ks) {
+        return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 3 : 0) * HALF + ((((hi ? t_hi : t_lo) + i) * 2 + ks) * 1024) + lane * 16);
+    };
+    auto lds_w = [&](int buf, int hi, int j, int ks) {
+        return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 2 : 1) * HALF + (((wc * 2 + j) * 2 + ks) * 1024) + lane * 16);
+    };
 
-    // prologue: K-tile 0 whole, K-tile 1's first two half-tiles
-    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0); stage(1, 0, 1); stage(1, 1, 1);
+    // prologue: K-tile 0 whole and K-tile 1's low W -- what phase 0 expects to be in flight behind what it reads
+    stage(0, 1, 0); stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     if (grp) asm volatile("s_barrier" ::: "memory");          // group 1 starts one interval late
 
-    auto run = [&](auto mw_tag) {
-        constexpr int MW = decltype(mw_tag)::value;           // m-tiles of this wave
-        constexpr int LO = (MW + 1) / 2, HI = MW - LO;
-        const int t_lo = grp ? LA : 0, t_hi = grp ? HA : 0;   // this group's first slot in the x halves
-        auto lds_x = [&](int buf, int hi, int i, int ks) {
-            return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 3 : 0) * HALF + ((((hi ? t_hi : t_lo) + i) * 2 + ks) * 1024) + lane * 16);
-        };
-        auto lds_w = [&](int buf, int hi, int j, int ks) {
-            return *reinterpret_cast<const u32x4*>(lds + buf * KT_BYTES + (hi ? 2 : 1) * HALF + (((wc * 2 + j) * 2 + ks) * 1024) + lane * 16);
-        };
-        f32x4 acc[4][MW];
+    f32x4 acc[4][MW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < MW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 xr[LO][2], wl[2][2], wl2[2][2], wh[2][2];
+        for (int i = 0; i < MW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 xr[LO][2], wl[2][2], wl2[2][2], wh[2][2];
 #ifdef PP_STAMPS
-        unsigned long long* st_buf = reinterpret_cast<unsigned long long*>(lds + SPARE + 8192 + grp * 4096);
-        int st_n = 0;
-        const bool st_wave = (int)blockIdx.x == g_pp_stamp_wg && wc == 0 && lane == 0;
-        bool st_on = false;
+    unsigned long long* st_buf = reinterpret_cast<unsigned long long*>(lds + SPARE + 8192 + grp * 4096);
+    int st_n = 0;
+    bool st_on = false;
 #endif
 
-#define PP_MFMA(WREG, WHI, XCNT, XHI)                                                                                    \
+#define PP_MFMA(WL, XCNT, XHI)                                                                                           \
     PP_T1();                                                                                                             \
     asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     PP_T();                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
-        _Pragma("unroll") for (int i = 0; i < (XCNT); ++i)                                                               \
+        _Pragma("unroll") for (int i = 0; i < (XCNT); ++i) {                                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-                acc[(WHI) * 2 + j][(XHI) * LO + i] = tg_mfma(WREG[j][ks], xr[i][ks], acc[(WHI) * 2 + j][(XHI) * LO + i]); \
+                acc[j][(XHI) * LO + i] = tg_mfma(WL[j][ks], xr[i][ks], acc[j][(XHI) * LO + i]);                          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+                acc[2 + j][(XHI) * LO + i] = tg_mfma(wh[j][ks], xr[i][ks], acc[2 + j][(XHI) * LO + i]);                  \
+        }                                                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     PP_T();                                                                                                              \
     asm volatile("s_barrier" ::: "memory");                                                                              \
     PP_T();
-#define PP_STAGE(K_, H_, B_)                                                                                             \
-    stage(K_, H_, B_);                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* everything up to three half-tiles ahead of this phase has landed */ \
-    __builtin_amdgcn_sched_barrier(0);
-#define PP_KTILE(BUF, WL, WLNEXT, S0K, S0H, S0B, S1K, S1H, S1B, S2K, S2H, S2B, S3K, S3H, S3B)                             \
+#define PP_KTILE(KT, BUF, WL, WLNEXT)                                                                                    \
     {                                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < LO; ++i)                                                                   \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) xr[i][ks] = lds_x(BUF, 0, i, ks);                           \
-        PP_STAGE(S0K, S0H, S0B)                                                                                          \
-        PP_MFMA(WL, 0, LO, 0)                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wh[j][ks] = lds_w(BUF, 1, j, ks);                           \
-        PP_STAGE(S1K, S1H, S1B)                                                                                          \
-        PP_MFMA(wh, 1, LO, 0)                                                                                            \
+        stage((KT) + 1, 0, (BUF) ^ 1);                                                                                   \
+        stage((KT) + 1, 2, (BUF) ^ 1);                                                                                   \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        PP_MFMA(WL, LO, 0)                                                                                               \
         _Pragma("unroll") for (int i = 0; i < HI; ++i)                                                                   \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) xr[i][ks] = lds_x(BUF, 1, i, ks);                           \
-        PP_STAGE(S2K, S2H, S2B)                                                                                          \
-        PP_MFMA(wh, 1, HI, 1)                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)             /* the NEXT K-tile's low W fragments: the fourth phase has no reads of its own */ \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) WLNEXT[j][ks] = lds_w((BUF) ^ 1, 0, j, ks);                 \
-        PP_STAGE(S3K, S3H, S3B)                                                                                          \
-        PP_MFMA(WL, 0, HI, 1)                                                                                            \
+        stage((KT) + 1, 3, (BUF) ^ 1);                                                                                   \
+        stage((KT) + 2, 1, BUF);                                                                                         \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        PP_MFMA(WL, HI, 1)                                                                                               \
     }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wl[j][ks] = lds_w(0, 0, j, ks);
-        for (int u = 0; u < nkt; u += 2) {                    // an odd K-tile count runs one K-tile of zeros (staged out of range)
+        for (int ks = 0; ks < 2; ++ks) wl[j][ks] = lds_w(0, 0, j, ks);
+    PP_C(1);
+    for (int u = 0; u < nkt; u += 2) {                        // an odd K-tile count runs one K-tile of zeros (staged out of range)
 #ifdef PP_STAMPS
-            st_on = st_wave && u >= 8 && u < 24;
-            if (u == 8) PP_T();
+        st_on = st_wave && u >= 8 && u < 24;
+        if (u == 8) PP_T();
 #endif
-            PP_KTILE(0, wl, wl2, u + 1, 2, 1, u + 1, 3, 1, u + 2, 0, 0, u + 2, 1, 0)
-            PP_KTILE(1, wl2, wl, u + 2, 2, 0, u + 2, 3, 0, u + 3, 0, 1, u + 3, 1, 1)
-        }
-#undef PP_STAGE
+        PP_KTILE(u, 0, wl, wl2)
+        PP_KTILE(u + 1, 1, wl2, wl)
+    }
 #undef PP_KTILE
 #undef PP_MFMA
-        if (!grp) asm volatile("s_barrier" ::: "memory");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef PP_STAMPS
-        if (st_wave)
-            for (int i = 0; i < st_n && i < 1023; ++i) g_pp_stamps[grp][1 + i] = st_buf[i];
-        if (st_wave) g_pp_stamps[grp][0] = st_n;
+    PP_C(2);
+    if (!grp) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if defined(PP_STAMPS) && PP_STAMPS != 3
+    if (st_wave)
+        for (int i = 0; i < st_n && i < 1023; ++i) g_pp_stamps[grp][1 + i] = st_buf[i];
+    if (st_wave) g_pp_stamps[grp][0] = st_n;
 #endif
-        tile_epilogue<4, MW, GU8>(a, acc, lds, wave, lane, m0 + (grp ? MA * 16 : 0), n0 + wc * 64);
-    };
-    if (MA == MB || !grp) run(PPInt<MA>{});
-    else run(PPInt<MB>{});
+    tile_epilogue<4, MW, GU8>(a, acc, lds, wave, lane, m0 + grp * MW * 16, n0 + wc * 64);
+#if defined(PP_STAMPS) && PP_STAMPS == 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_C(3);
+#endif
 }
 
-template <int MA, int MB, bool GU8>
+template <int MW, bool GU8>
 static int launch_tile_pp(TileArgs a, hipStream_t st) {
-    constexpr int BM = 16 * (MA + MB);
+    constexpr int BM = 32 * MW;
     a.mblocks = (a.M + BM - 1) / BM;
     a.nblocks = a.N / 256;
     {
@@ -553,24 +564,20 @@ static int launch_tile_pp(TileArgs a, hipStream_t st) {
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_pp_kernel<MA, MB, GU8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_pp_kernel<MW, GU8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { omni_set_error("omni_gemm_tile: LDS attribute: %s", hipGetErrorString(e)); return OMNI_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tile_pp_kernel<MA, MB, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_tile_pp_kernel<MW, GU8>), dim3(a.mblocks * a.nblocks), dim3(TG_THREADS), LDS_BYTES, st, a);
     OMNI_CHECK_LAUNCH("omni_gemm_tile");
     return OMNI_OK;
 }
 
 template <bool GU8>
 static int launch_tile_pp_rows(int bm, const TileArgs& a, hipStream_t st) {
-    switch (bm) {
-    case 256: return launch_tile_pp<8, 8, GU8>(a, st);
-    case 240: return launch_tile_pp<8, 7, GU8>(a, st);
-    case 224: return launch_tile_pp<7, 7, GU8>(a, st);
-    case 208: return launch_tile_pp<7, 6, GU8>(a, st);
-    default: return launch_tile_pp<6, 6, GU8>(a, st);
-    }
+    if (bm == 256) return launch_tile_pp<8, GU8>(a, st);
+    if (bm == 224) return launch_tile_pp<7, GU8>(a, st);
+    return launch_tile_pp<6, GU8>(a, st);
 }
 
 template <int WAVES_N, int WN, int WM, bool GU8>
@@ -606,7 +613,7 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     OMNI_CHECK_ARG((int64_t)g->N * g->K * 2 < (int64_t)TG_OOB, "omni_gemm_tile: W exceeds the 2 GB descriptor");
     const bool gu8 = g->act == OMNI_TILE_ACT_SILU_MUL_GU8;
     OMNI_CHECK_ARG(g->act == OMNI_TILE_ACT_NONE || g->act == OMNI_TILE_ACT_GELU || gu8, "omni_gemm_tile: act=%d", g->act);
-    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 9, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
+    OMNI_CHECK_ARG(g->tile_hint >= 0 && g->tile_hint <= 7, "omni_gemm_tile: tile_hint=%d", g->tile_hint);
     OMNI_CHECK_ARG(g->tile_hint < 3 || g->N % 256 == 0, "omni_gemm_tile: tile_hint=%d needs N %% 256 == 0", g->tile_hint);
     OMNI_CHECK_ARG(!gu8 || (g->out && !g->resid && !g->out2 && !g->out_f32), "omni_gemm_tile: SiLU-mul takes out only");
     OMNI_CHECK_ARG(!g->out2 || (g->snake_alpha && g->snake_inv_beta), "omni_gemm_tile: out2 needs the snake parameters");
@@ -645,16 +652,13 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
     // 256-column tiles come in three heights.  One workgroup per CU (the ring takes most of the LDS), so a grid runs in rounds of
     // 256 tiles and a round costs ~ the tile's rows: 6.4 k prompt tokens x 2048 columns are 208 tiles of 256 rows (one round, 48 CUs
     // idle) or 232 tiles of 224 rows (one round, 12.5 % shorter).  Same accumulation order in every geometry: bit-identical results.
-    const bool pp_ok = N % 256 == 0 && groups == 1 && !g->group_rows && seg_len == g->K && g->row_off == 0;
-    OMNI_CHECK_ARG(g->tile_hint < 5 || pp_ok, "omni_gemm_tile: tile_hint=%d (two-group tile) takes a plain GEMM with N %% 256 == 0", g->tile_hint);
-    if (g->tile_hint >= 5) {                                  // 5 ... 9: 256, 240, 224, 208, 192 rows
-        const int bm = 256 - 16 * (g->tile_hint - 5);
-        return gu8 ? launch_tile_pp_rows<true>(bm, a, st) : launch_tile_pp_rows<false>(bm, a, st);
-    }
+    // A plain GEMM (no conv window, no groups) runs them in the two-group form (gemm_tile_pp_kernel: 5 - 8 % faster at every height).
     if (N % 256 == 0) {
+        const bool pp_ok = groups == 1 && !g->group_rows && seg_len == g->K && g->row_off == 0;
+        OMNI_CHECK_ARG(g->tile_hint < 5 || pp_ok, "omni_gemm_tile: tile_hint=%d (two-group tile) takes a plain GEMM", g->tile_hint);
         int bm = 256;
-        if (g->tile_hint == 3) bm = 224;
-        else if (g->tile_hint == 4) bm = 192;
+        if (g->tile_hint == 3 || g->tile_hint == 6) bm = 224;
+        else if (g->tile_hint == 4 || g->tile_hint == 7) bm = 192;
         else if (g->tile_hint == 0 && groups == 1) {
             long long best = -1;
             for (int cand : {256, 224, 192}) {
@@ -663,6 +667,7 @@ extern "C" int omni_gemm_tile(const omni_tile_gemm* g, void* stream) {
                 if (best < 0 || cost < best) { best = cost; bm = cand; }
             }
         }
+        if (g->tile_hint >= 5 || (g->tile_hint == 0 && pp_ok)) return gu8 ? launch_tile_pp_rows<true>(bm, a, st) : launch_tile_pp_rows<false>(bm, a, st);
         if (bm == 224) return gu8 ? launch_tile<4, 4, 7, true>(a, st, groups) : launch_tile<4, 4, 7, false>(a, st, groups);
         if (bm == 192) return gu8 ? launch_tile<4, 4, 6, true>(a, st, groups) : launch_tile<4, 4, 6, false>(a, st, groups);
         return gu8 ? launch_tile<2, 8, 4, true>(a, st, groups) : launch_tile<2, 8, 4, false>(a, st, groups);

@@ -167,8 +167,8 @@ typedef struct omni_tile_gemm {
     void* out2; int ldo2; const float* snake_alpha; const float* snake_inv_beta;
     int M, N, K;
     int tile_hint;   /* 0: automatic; 1: the large output tiles (256 x 256 ...); 2: the 128 x 64 tile of small-M problems;
-                        3 / 4: 256 columns x 224 / 192 rows (N % 256 == 0); 5 ... 9: the two-group form of the 256-column tile at
-                        256, 240, 224, 208, 192 rows (plain GEMM, N % 256 == 0; same results) */
+                        3 / 4: 256 columns x 224 / 192 rows (N % 256 == 0); 5 / 6 / 7: the two-group form of the 256-column tile at
+                        256 / 224 / 192 rows (plain GEMMs only; what 0 picks for them; same results) */
     /* grouped (batched) launch, groups > 1: group g computes out rows [g * out_group_rows, + M) from x rows [g * x_group_rows, + M)
      * and the matrix w + g * w_group_elems (elements) -- the expert-sorted [E, cap, H] batch of the MoE prefill against the
      * decode step's per-expert fragment-major weights (replaces the batched GEMMs vLLM's FusedMoE issues under

@@ -40,8 +40,8 @@ def main():
             ta.append(timed(a, 20)); tb.append(timed(b, 20))
         ta, tb = min(ta), min(tb)
         rows.append((f"prefill {name} M={M} N={N} K={K}", ta, tb, flops))
-        if os.environ.get("HINTS", "0") == "1":            # each tile height of the 256-column geometry (1: 256, 3: 224 rows; 5 ... 9: the two-group tile at 256, 240, 224, 208, 192 rows)
-            for hint in (1, 3, 5, 6, 7, 8, 9):
+        if os.environ.get("HINTS", "0") == "1":            # each tile height of the 256-column geometry (1: 256, 3: 224 rows, the lockstep kernel; 5 / 6 / 7: the two-group kernel at 256 / 224 / 192 rows)
+            for hint in (1, 3, 5, 6, 7):
                 h = (lambda hint=hint: ops.gemm_tile(x, wf, act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)) if gu else \
                     (lambda hint=hint: ops.gemm_tile(x, wf, tile_hint=hint))
                 th = min(timed(h, 20) for _ in range(5))

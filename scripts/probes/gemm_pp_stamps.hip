@@ -1,10 +1,10 @@
 // Probe (round 5): where does a K-tile of the two-group prefill GEMM tile (gemm_prefill.hip, gemm_tile_pp_kernel) spend its cycles?
 // Compiles the product source with -DPP_STAMPS: one workgroup keeps the shader clock at every section boundary of K-tiles 8 ... 23 for the
-// first wave of each group.  Per phase: [loads + 2 LDS-DMA pieces | barrier + lgkmcnt(0)] -> stamp b -> [MFMAs issued] -> stamp c ->
+// first wave of each group.  Per phase: [loads + 4 LDS-DMA pieces | barrier + lgkmcnt(0)] -> stamp b -> [MFMAs issued] -> stamp c ->
 // [closing barrier] -> stamp d.  d(prev) -> b = own loads, the wait for the fragments and for the OTHER group's MFMA section;
 // b -> c = this wave's MFMA issue; c -> d = the wait for the other group's loads.  PP_STAMPS=2 adds stamp a in front of the first barrier.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPP_STAMPS=1 -Iinclude -Iht_vllm_omni_amd/csrc -o /tmp/gemm_pp_stamps scripts/probes/gemm_pp_stamps.hip
-//   /tmp/gemm_pp_stamps [tile_hint 5..9] [M] [N] [K]
+//   /tmp/gemm_pp_stamps [tile_hint 5 | 6 | 7 = 256 | 224 | 192 rows] [M] [N] [K]
 #include "../../ht_vllm_omni_amd/csrc/gemm_prefill.hip"
 #include <cstdarg>
 #include <cstdio>
@@ -45,17 +45,28 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         static unsigned long long st[2][1024];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pp_stamps), sizeof(st)));
-        const int per = PP_STAMPS == 2 ? 4 : 3;
+#if PP_STAMPS == 3
+        printf("tile_hint %d  M %d N %d K %d: %.1f us per launch; workgroup %d\n", hint, M, N, K, ms * 50, wg);
+        for (int grp = 0; grp < 2; ++grp) {
+            const unsigned long long* t = &st[grp][1];       // (shader clock, 100 MHz clock) x {entry, loop start, loop end, end}
+            const int nkt = (K / 32 + 1) / 2, nkt2 = (nkt + 1) & ~1;
+            const double ghz = (double)(t[4] - t[2]) / ((double)(t[5] - t[3]) * 10.0);
+            printf("  group %d: prologue %llu cycles, K loop %llu = %.0f per K-tile (%d K-tiles run) at %.2f GHz (ideal 2048), epilogue %llu; "
+                   "entry -> end %.1f us\n", grp, t[2] - t[0], t[4] - t[2], (double)(t[4] - t[2]) / nkt2, nkt2, ghz, t[6] - t[4], (t[7] - t[1]) / 100.0);
+        }
+        continue;
+#endif
+        const int per = PP_STAMPS == 2 ? 4 : 3, phases = 2;
         printf("tile_hint %d  M %d N %d K %d: %.1f us per launch (stamped build); workgroup %d, K-tiles 8-23, shader cycles (median over the 16 K-tiles)\n", hint, M, N, K, ms * 50, wg);
         for (int grp = 0; grp < 2; ++grp) {
             const int n = (int)st[grp][0];
             const unsigned long long* t = &st[grp][1];
-            const int ktiles = (n - 1) / (4 * per);
+            const int ktiles = (n - 1) / (phases * per);
             printf("  group %d (%d stamps, %d K-tiles): total per K-tile %llu\n", grp, n, ktiles, ktiles ? (t[n - 1] - t[0]) / ktiles : 0ull);
-            for (int ph = 0; ph < 4; ++ph) {
+            for (int ph = 0; ph < phases; ++ph) {
                 std::vector<long long> seg[4];
                 for (int kt = 0; kt < ktiles; ++kt) {
-                    const int base = (kt * 4 + ph) * per;       // t[base] = the previous closing barrier passed
+                    const int base = (kt * phases + ph) * per;       // t[base] = the previous closing barrier passed
                     for (int s2 = 0; s2 < per; ++s2) seg[s2].push_back((long long)(t[base + s2 + 1] - t[base + s2]));
                 }
                 printf("    phase %d:", ph + 1);

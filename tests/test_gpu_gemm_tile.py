@@ -30,7 +30,8 @@ def _close(got, ref, mag, what):
                                    (1111, 96, 672), (255, 288, 96), (70, 48, 32), (900, 272, 160), (6400, 2048, 2048),
                                    (700, 256, 64), (1300, 768, 96), (515, 256, 32), (2000, 1024, 6144)])
 def test_plain_gemm_every_tile_configuration(M, N, K):
-    """tile_hint 1 = the large tiles (256 / 192 / 128 / 96 columns by N), 2 = the 128 x 64 small-M tile, 0 = the dispatch rule."""
+    """tile_hint 1 = the large tiles (256 / 192 / 128 / 96 columns by N; the lockstep kernel), 2 = the 128 x 64 small-M tile, 0 = the
+    dispatch rule (plain GEMMs with N % 256 == 0: the two-group kernel)."""
     ops, L, frag_shuffle, _ = _ops()
     g = torch.Generator().manual_seed(M * 7 + N)
     x = torch.randn(M, K, generator=g).to(BF16)
@@ -43,8 +44,8 @@ def test_plain_gemm_every_tile_configuration(M, N, K):
         _close(outs[-1], ref, mag, f"gemm {M}x{N}x{K} hint {hint}")
     assert torch.equal(outs[0], outs[1])      # same k order per output element in both geometries: bit-identical
     assert torch.equal(outs[0], outs[2])
-    if N % 256 == 0:                           # the 224- and 192-row tiles of the 256-column geometry; 5 ... 9 = the two-group tile at 256 ... 192 rows
-        for hint in (3, 4, 5, 6, 7, 8, 9):
+    if N % 256 == 0:                           # the 224- and 192-row tiles of the 256-column geometry; 5 / 6 / 7 = the two-group tile at 256 / 224 / 192 rows
+        for hint in (3, 4, 5, 6, 7):
             assert torch.equal(outs[0], ops.gemm_tile(x.cuda(), frag_shuffle(w).cuda(), tile_hint=hint)), hint
 
 
@@ -121,7 +122,7 @@ def test_epilogues_gelu_scale_fp32_residual_stream_and_snake_output():
 
 
 def test_two_group_tile_with_the_prefills_residual_epilogue():
-    """tile_hints 5 ... 9 (the two-group tile at 256, 240, 224, 208, 192 rows) on the o_proj / down_proj form (fp32 residual in, bf16 out): bit-identical to the 256 x 256 tile of hint 1."""
+    """tile_hints 5 / 6 / 7 (the two-group tile at 256 / 224 / 192 rows) on the o_proj / down_proj form (fp32 residual in, bf16 out): bit-identical to the 256 x 256 tile of hint 1."""
     ops, L, frag_shuffle, _ = _ops()
     g = torch.Generator().manual_seed(11)
     M, N, K = 1234, 512, 1088
@@ -131,7 +132,7 @@ def test_two_group_tile_with_the_prefills_residual_epilogue():
     b = torch.randn(N, generator=g).cuda()
     for want in ("b", "f"):
         a1 = ops.gemm_tile(x, w, bias=b, resid=r, want=want, tile_hint=1)
-        for hint in (5, 6, 7, 8, 9):
+        for hint in (5, 6, 7):
             assert torch.equal(a1, ops.gemm_tile(x, w, bias=b, resid=r, want=want, tile_hint=hint)), (want, hint)
 
 
@@ -147,7 +148,7 @@ def test_interleaved_gate_up_with_fused_silu_mul(M, I, K):
     assert out.shape == (M, I)
     assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=2))
     if (2 * I) % 256 == 0:
-        for hint in (3, 4, 5, 6, 7, 8, 9):
+        for hint in (3, 4, 5, 6, 7):
             assert torch.equal(out, ops.gemm_tile(x.cuda(), gu8_shuffle(w).cuda(), act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)), hint
     gu = (x.double() @ w.double().T)
     ga, up = gu[:, :I].float().to(BF16), gu[:, I:].float().to(BF16)
@@ -173,7 +174,7 @@ def test_race_screen_repeated_launches_are_bit_identical(M, N, K, taps, dil):
     w = frag_shuffle((torch.randn(N, taps * K, generator=g) * 0.05).to(BF16)).cuda()
     noise = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     first = None
-    for hint in (1, 2, 5, 8) if (taps == 1 and N % 256 == 0) else (1, 2):  # 5 / 8: the two-group tile (256 / 208 rows), a different synchronisation structure
+    for hint in (1, 2, 5, 6, 7) if (taps == 1 and N % 256 == 0) else (1, 2):  # 5 / 6 / 7: the two-group tile, a synchronisation structure of its own
         outs = []
         for it in range(150):
             outs.append(ops.gemm_tile(x, w, taps=taps, dilation=dil, tile_hint=hint))
