@@ -42,7 +42,12 @@ void omni_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (bf16_t)f); }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// one v_cvt_pk_bf16_f32 (the scalar form costs two conversions, a shift and an or; same round-to-nearest-even values)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 

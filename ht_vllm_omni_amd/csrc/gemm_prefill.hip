@@ -59,8 +59,19 @@ __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
 
 __device__ __forceinline__ float tg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
+#ifdef TG_EPI_NT                     // probe arm: the bf16 output as non-temporal stores
+#define TG_STORE_OUT(p, v) __builtin_nontemporal_store((v), reinterpret_cast<u32x4*>(p))
+#else
+#define TG_STORE_OUT(p, v) (*reinterpret_cast<u32x4*>(p) = (v))
+#endif
 // Epilogue of a tile kernel: `acc[j][i]` = this wave's WN n-tiles x WM m-tiles (D[n][m] fragments), first row mw0, first column nw0; `lds` is dead.
-template <int WN, int WM, bool GU8>
+__device__ __forceinline__ bool tile_plain(const TileArgs& a) {
+    return !a.bias && !a.scale && a.act != OMNI_TILE_ACT_GELU && !a.resid && !a.out_f32 && !a.out2 && a.out;
+}
+
+// PLAIN = no bias, scale, GELU, residual, fp32 or snake output (the talker prefill's four GEMMs): the same values (acc + 0 and * 1 change
+// nothing) without ~20 wave-uniform branches per pass -- they, not the stores, were most of an 11 k-cycle epilogue (profiles/r05_gemm_pp_stamps.txt).
+template <int WN, int WM, bool GU8, bool PLAIN>
 __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN][WM], uint8_t* lds, int wave, int lane, int mw0, int nw0) {
     const int c = lane & 15, q = lane >> 4;
     // ---- epilogue.  Register side: y = act(acc + bias) * scale in fp32, transposed through this wave's LDS image in fp32, ONE m-tile
@@ -68,6 +79,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
     // of an fp32 output (whole 128-byte lines); + fp32 residual (the pass's residual loads are issued before its image is written:
     // the epilogue of a residual GEMM is an HBM phase, not a chain of load -> add -> store round trips), then up to three stores of
     // the SAME fp32 value: fp32 (the residual stream), bf16 (the next GEMM's operand), bf16(snake(y)) (the next conv's operand).
+    // (Two images per wave, pass p + 1's written before pass p's is read back, measured SLOWER: 5.9 k -> 8.5 k cycles per epilogue.)
     constexpr int IPITCH = WN * 64 + 16;                  // bytes per image row
     constexpr int PER_ROW = GU8 ? WN : WN * 2;            // lane items per image row: a [8 gate | 8 up] tile, or 8 columns
     constexpr int RIT = (16 * PER_ROW + 63) / 64;         // row-side iterations per pass
@@ -78,16 +90,39 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
         const int n = nw0 + j * 16 + 4 * q;
         bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         sq[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (n < a.N) {
+        if (!PLAIN && n < a.N) {
             if (a.bias) bq[j] = *reinterpret_cast<const f32x4*>(a.bias + n);
             if (a.scale) sq[j] = *reinterpret_cast<const f32x4*>(a.scale + n);
         }
     }
+    const bool gelu = !PLAIN && a.act == OMNI_TILE_ACT_GELU;
+    auto write_image = [&](const int pass) {
+        if (PLAIN) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = acc[j][pass];
+        } else if (gelu) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tg_gelu(acc[j][pass][e] + bq[j][e]) * sq[j][e];
+                *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (acc[j][pass][e] + bq[j][e]) * sq[j][e];
+                *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
+            }
+        }
+    };
     f32x4 rv[RIT][2];
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
         const int mp0 = mw0 + pass * 16;
-        if (!GU8 && a.resid) {
+        if (!PLAIN && !GU8 && a.resid) {
 #pragma unroll
             for (int it = 0; it < RIT; ++it) {
                 const int idx = lane + 64 * it;
@@ -101,17 +136,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[j][pass][e] + bq[j][e];
-                if (a.act == OMNI_TILE_ACT_GELU) t = tg_gelu(t);
-                v[e] = t * sq[j][e];
-            }
-            *reinterpret_cast<f32x4*>(img + c * IPITCH + (j * 16 + 4 * q) * 4) = v;
-        }
+        write_image(pass);
         __builtin_amdgcn_wave_barrier();
         if (GU8) {
             // tile j of a row = [8 gate | 8 up] -> 8 act columns at n / 2: bf16(bf16(SiLU(bf16 gate)) * bf16 up), the rounding points of
@@ -131,7 +156,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                     const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));   // torch: F.silu(bf16) is bf16
                     o[e] = pack_bf2(s0 * u0, s1 * u1);
                 }
-                *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
+                TG_STORE_OUT(a.out + (size_t)m * a.ldo + (n >> 1), o);
             }
         } else {
 #pragma unroll
@@ -142,6 +167,13 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                 if (idx >= 16 * PER_ROW || m >= a.M || n >= a.N) continue;
                 f32x4 y0 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32);
                 f32x4 y1 = *reinterpret_cast<const f32x4*>(img + row * IPITCH + ch * 32 + 16);
+                if (PLAIN) {
+                    u32x4 o;
+                    o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
+                    o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
+                    TG_STORE_OUT(a.out + (size_t)m * a.ldo + n, o);
+                    continue;
+                }
                 if (a.resid) {
                     y0 += rv[it][0];
                     y1 += rv[it][1];
@@ -155,7 +187,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                     u32x4 o;
                     o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
                     o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
-                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                    TG_STORE_OUT(a.out + (size_t)m * a.ldo + n, o);
                 }
                 if (a.out2) {
                     const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
@@ -342,7 +374,8 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_kernel(const TileArgs a_
 #undef TG_SLICE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is dead: its tail loads (zeros) landed
 
-    tile_epilogue<WN, WM, GU8>(a, acc, lds, wave, lane, m0 + wm * WM * 16, n0 + wn * WN * 16);
+    if (tile_plain(a)) tile_epilogue<WN, WM, GU8, true>(a, acc, lds, wave, lane, m0 + wm * WM * 16, n0 + wn * WN * 16);
+    else tile_epilogue<WN, WM, GU8, false>(a, acc, lds, wave, lane, m0 + wm * WM * 16, n0 + wn * WN * 16);
 }
 
 // ---- the two-group ("ping-pong") form of the 256-column tile.  Same images, same MFMA, same accumulation order as gemm_tile_kernel
@@ -539,7 +572,8 @@ __global__ __launch_bounds__(TG_THREADS) void gemm_tile_pp_kernel(const TileArgs
         for (int i = 0; i < st_n && i < 1023; ++i) g_pp_stamps[grp][1 + i] = st_buf[i];
     if (st_wave) g_pp_stamps[grp][0] = st_n;
 #endif
-    tile_epilogue<4, MW, GU8>(a, acc, lds, wave, lane, m0 + grp * MW * 16, n0 + wc * 64);
+    if (tile_plain(a)) tile_epilogue<4, MW, GU8, true>(a, acc, lds, wave, lane, m0 + grp * MW * 16, n0 + wc * 64);
+    else tile_epilogue<4, MW, GU8, false>(a, acc, lds, wave, lane, m0 + grp * MW * 16, n0 + wc * 64);
 #if defined(PP_STAMPS) && PP_STAMPS == 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_C(3);
