@@ -28,6 +28,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PF_BN 32          // keys per LDS tile (two 16-key MFMA tiles)
 #define PF_ROWB 264       // LDS row pitch in bytes: 128 bf16 + 8 B (4 qk groups x 4 keys apart -> banks 0-7, 8-15, ...)
 #define PF_LOG2E 1.4426950408889634f
+// waves per SIMD asked of the register allocator (left alone it takes 177 registers = 2 waves: the kernel is latency-bound, two barriers per
+// 32-key tile): 4 (<= 128 registers) for the fp8 cache, 3 for the formats whose staging registers would spill at 4
+#define PF_WAVES_PER_EU(KV, G) ((G) < 2 ? 1 : ((KV) == OMNI_KV_FP8 ? 4 : 3))
 
 struct PFArgs {
     const uint16_t* q;             // bf16 [T, Hq, 128] (normed + roped)
@@ -41,21 +44,24 @@ __device__ __forceinline__ f32x4 pf_mfma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// 16 cache bytes -> bf16 values in LDS (fp8 e4m3fn and int8 are exact in bf16; scales are applied to scores / P)
+// 16 cache bytes: loaded raw (pf_load), then written to LDS as bf16 values (pf_store; fp8 e4m3fn and int8 are exact in bf16; scales are
+// applied to scores / P).  Two steps so that the NEXT tile's bytes travel while the current tile is computed on.
 template <int KV>
-__device__ __forceinline__ void pf_stage(unsigned char* dst_row, const void* cache, size_t row, int ch) {
+__device__ __forceinline__ u32x4 pf_load(const void* cache, size_t row, int ch) {
+    if (OMNI_KV_IS16(KV)) return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(cache) + row * 128 + ch * 8);
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(cache) + row * 128 + ch * 16);
+}
+template <int KV>
+__device__ __forceinline__ void pf_store(unsigned char* dst_row, const u32x4 v, int ch) {
     if (KV == OMNI_KV_BF16) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(cache) + row * 128 + ch * 8);
         *reinterpret_cast<u32x4*>(dst_row + ch * 16) = v;
     } else if (KV == OMNI_KV_FP16) {
         // half -> bf16: exact for the values a bf16 model writes (a bf16 number inside the half range keeps its 8 significant bits)
-        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(cache) + row * 128 + ch * 8);
         u32x4 o;
 #pragma unroll
         for (int w = 0; w < 4; ++w) o[w] = pack_bf2(h_lo(v[w]), h_hi(v[w]));
         *reinterpret_cast<u32x4*>(dst_row + ch * 16) = o;
     } else {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(cache) + row * 128 + ch * 16);
         uint32_t o[8];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -75,7 +81,7 @@ __device__ __forceinline__ void pf_stage(unsigned char* dst_row, const void* cac
 }
 
 template <int KV, int G>
-__global__ __launch_bounds__(64 * G) void paged_attn_prefill_mfma_kernel(const PFArgs a) {
+__global__ __launch_bounds__(64 * G, PF_WAVES_PER_EU(KV, G)) void paged_attn_prefill_mfma_kernel(const PFArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char sK[PF_BN * PF_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char sV[PF_BN * PF_ROWB];
     __shared__ float sKs[PF_BN], sVs[PF_BN];
@@ -115,17 +121,36 @@ __global__ __launch_bounds__(64 * G) void paged_attn_prefill_mfma_kernel(const P
         nkeys = __shfl(nkeys, 0, 64);                    // rows replicate over the 4 qk groups: lane 0 has the max
         const int32_t* bt = a.block_table + (size_t)rq * a.bt_stride;
 
-        for (int k0 = 0; k0 < nkeys; k0 += PF_BN) {
-            __syncthreads();                             // the previous tile has been consumed by every wave
-            constexpr int CH = OMNI_KV_IS16(KV) ? 16 : 8;          // 16-B chunks per cache row
-            for (int it = threadIdx.x; it < PF_BN * CH; it += NT) {
+        constexpr int CH = OMNI_KV_IS16(KV) ? 16 : 8;              // 16-B chunks per cache row
+        constexpr int ITERS = (PF_BN * CH + NT - 1) / NT;          // (key, chunk) items per thread and tile
+        u32x4 rk[ITERS], rv[ITERS];
+        float rks[ITERS], rvs[ITERS];
+        auto fetch = [&](int k0) {                                 // tile k0's cache bytes -> registers
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int it = threadIdx.x + i * NT;
+                if (PF_BN * CH % NT != 0 && it >= PF_BN * CH) continue;
                 const int kk = it / CH, ch = it - kk * CH;
                 const int key = min(k0 + kk, nkeys - 1);           // tail keys: valid address, masked below
                 const size_t row = (((size_t)bt[key >> a.bs_shift] << a.bs_shift) + (key & (a.bs - 1))) * a.kv_heads + kvh;
-                pf_stage<KV>(sK + kk * PF_ROWB, a.k_cache, row, ch);
-                pf_stage<KV>(sV + kk * PF_ROWB, a.v_cache, row, ch);
-                if (KV == OMNI_KV_INT8 && ch == 0) { sKs[kk] = a.k_scales[row]; sVs[kk] = a.v_scales[row]; }
+                rk[i] = pf_load<KV>(a.k_cache, row, ch);
+                rv[i] = pf_load<KV>(a.v_cache, row, ch);
+                if (KV == OMNI_KV_INT8 && ch == 0) { rks[i] = a.k_scales[row]; rvs[i] = a.v_scales[row]; }
             }
+        };
+        if (nkeys > 0) fetch(0);
+        for (int k0 = 0; k0 < nkeys; k0 += PF_BN) {
+            __syncthreads();                             // the previous tile has been consumed by every wave
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int it = threadIdx.x + i * NT;
+                if (PF_BN * CH % NT != 0 && it >= PF_BN * CH) continue;
+                const int kk = it / CH, ch = it - kk * CH;
+                pf_store<KV>(sK + kk * PF_ROWB, rk[i], ch);
+                pf_store<KV>(sV + kk * PF_ROWB, rv[i], ch);
+                if (KV == OMNI_KV_INT8 && ch == 0) { sKs[kk] = rks[i]; sVs[kk] = rvs[i]; }
+            }
+            if (k0 + PF_BN < nkeys) fetch(k0 + PF_BN);   // the next tile travels while this one is computed on
             __syncthreads();
 
             // ---- S^T = K . Q^T for two 16-key tiles
