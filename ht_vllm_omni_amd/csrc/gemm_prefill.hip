@@ -59,16 +59,11 @@ __device__ __forceinline__ f32x4 tg_mfma(u32x4 a, u32x4 b, f32x4 c) {
 
 __device__ __forceinline__ float tg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
-#ifdef TG_EPI_NT                     // probe arm: the bf16 output as non-temporal stores
-#define TG_STORE_OUT(p, v) __builtin_nontemporal_store((v), reinterpret_cast<u32x4*>(p))
-#else
-#define TG_STORE_OUT(p, v) (*reinterpret_cast<u32x4*>(p) = (v))
-#endif
-// Epilogue of a tile kernel: `acc[j][i]` = this wave's WN n-tiles x WM m-tiles (D[n][m] fragments), first row mw0, first column nw0; `lds` is dead.
 __device__ __forceinline__ bool tile_plain(const TileArgs& a) {
     return !a.bias && !a.scale && a.act != OMNI_TILE_ACT_GELU && !a.resid && !a.out_f32 && !a.out2 && a.out;
 }
 
+// Epilogue of a tile kernel: `acc[j][i]` = this wave's WN n-tiles x WM m-tiles (D[n][m] fragments), first row mw0, first column nw0; `lds` is dead.
 // PLAIN = no bias, scale, GELU, residual, fp32 or snake output (the talker prefill's four GEMMs): the same values (acc + 0 and * 1 change
 // nothing) without ~20 wave-uniform branches per pass -- they, not the stores, were most of an 11 k-cycle epilogue (profiles/r05_gemm_pp_stamps.txt).
 template <int WN, int WM, bool GU8, bool PLAIN>
@@ -156,7 +151,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                     const float s0 = bfround(g0 / (1.0f + expf(-g0))), s1 = bfround(g1 / (1.0f + expf(-g1)));   // torch: F.silu(bf16) is bf16
                     o[e] = pack_bf2(s0 * u0, s1 * u1);
                 }
-                TG_STORE_OUT(a.out + (size_t)m * a.ldo + (n >> 1), o);
+                *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + (n >> 1)) = o;
             }
         } else {
 #pragma unroll
@@ -171,7 +166,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                     u32x4 o;
                     o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
                     o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
-                    TG_STORE_OUT(a.out + (size_t)m * a.ldo + n, o);
+                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
                     continue;
                 }
                 if (a.resid) {
@@ -187,7 +182,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, f32x4 (&acc)[WN
                     u32x4 o;
                     o[0] = pack_bf2(y0[0], y0[1]); o[1] = pack_bf2(y0[2], y0[3]);
                     o[2] = pack_bf2(y1[0], y1[1]); o[3] = pack_bf2(y1[2], y1[3]);
-                    TG_STORE_OUT(a.out + (size_t)m * a.ldo + n, o);
+                    *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.ldo + n) = o;
                 }
                 if (a.out2) {
                     const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n), al1 = *reinterpret_cast<const f32x4*>(a.snake_alpha + n + 4);
