@@ -13,6 +13,7 @@
 // ---- in-kernel timeline of a stage (libomni_talker_debug.so only; scripts/chain_timeline.py): wave 0 of every workgroup
 // stamps the constant 100 MHz counter at fixed points.  Product builds compile the macro away.
 #define CH_NSTAMP 8
+#define CH_STAMP_PASS (40 * CH_NSTAMP * OMNI_CHAIN_WGS)      // stamp words of one predictor pass (cp_chain.hip: block `pass` of the buffer)
 #ifdef OMNI_DEBUG_HOOKS
 #define CH_STAMP(buf, sidx, k)                                                                                          \
     do {                                                                                                                \
@@ -100,7 +101,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         const int ks = wave + d * CH_WAVES;
         if (WSRC == 0) {
 #ifdef OMNI_DEBUG_HOOKS
-            if (g.skip == 1 && d >= (NTW + 1) / 2) {       // ingest experiment: the second half of the slice is not fetched
+            if ((g.skip == 1 && d >= (NTW + 1) / 2) ||     // ingest experiment: the second half of the slice is not fetched
+                (g.skip == 4 && wave == 0) || g.skip == 5) {   // round 6: the POLLING wave fetches no weights (4) / no wave does (5): what the polls lose behind them
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Wq[d][j] = (u32x4){0u, 0u, 0u, 0u};
             } else

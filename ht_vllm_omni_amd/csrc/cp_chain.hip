@@ -57,9 +57,9 @@ struct ChainArgs {
 
 // ---- attention stage at buffer position pos <= 15 (dense private cache: row b owns block b): one wave per (row, q head),
 // the work layout of attn_tiny_dense_kernel (paged_attn.hip).  Waves 0-3 of workgroup w take pairs 4 w .. 4 w + 3.
-__device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, int pos, float* lds, ChainGate& g, int code) {
+__device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer& L, int pos, float* lds, ChainGate& g, int code,
+                                           unsigned long long* stamps) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
-    unsigned long long* stamps = a.stamps;
     CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
@@ -164,8 +164,7 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
 // head GEMM's logits and, unless this was the last group, gathers the folded embedding -> projection row of the drawn code
 // into the residual stream as the next pass's input (slab 0 = its sum of squares).  sample_kernel's arithmetic (sampler_body.cuh):
 // waves 0-3 are the row's 256 threads, waves 4-7 only keep the barriers.
-__device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* lds, ChainGate& gate, int code) {
-    unsigned long long* stamps = a.stamps;
+__device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* lds, ChainGate& gate, int code, unsigned long long* stamps) {
     const int sidx = 26;
     CH_STAMP(stamps, sidx, 0);
     const int rows_per_dom = 16 << (gate.dom - 6);
@@ -181,7 +180,64 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
     CH_STAMP(stamps, sidx, 1);
     chain_gate_wait(gate, code);
     CH_STAMP(stamps, sidx, 2);
-    if (has_row) {
+    // the pick is wave 0's alone, without a workgroup barrier (sampler_body.cuh smp_pick_wave: round 6, 8.4 -> ~2.5 us per pass); rows that ask
+    // for top-p keep the 4-wave pick.  Workgroup-uniform: kernel arguments only
+    const bool wave_path = a.greedy || !(a.top_p > 0.f && a.top_p < 1.f);
+    if (wave_path) {
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const SmpLds S = smp_carve<8>(lds);
+            const coh_rsrc_t lrs = coh_rsrc(a.logits);
+            const int V = a.codebook;
+            const uint32_t base = (uint32_t)b * a.logits_ld + (uint32_t)(g - 1) * a.logits_pass;
+            // a moderate temperature keeps the head GEMM's bf16-exact logits strictly ordered under the division: select first, divide the kept
+            const bool late = !a.greedy && a.temperature >= 1.0f / 64 && a.temperature <= 64.0f;
+            float xr[32];
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const u32x4 v4 = coh_ld16(lrs, (base + j8 * 256 + 4 * lane) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xr[j8 * 4 + c] = __uint_as_float(v4[c]);
+            }
+            // (both fix-ups behind wave-uniform branches the optimiser cannot turn into 32 selects: as straight-line code they were 32 IEEE
+            //  divisions on every pick)
+            if (V < 2048) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 32; ++e)
+                    if ((e >> 2) * 256 + 4 * lane + (e & 3) >= V) xr[e] = -INFINITY;
+            }
+            if (!a.greedy && !late) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 32; ++e) xr[e] = xr[e] / a.temperature;
+            }
+            const uint32_t seed = a.row_seed ? a.row_seed[b] : a.seed;
+            const uint32_t step = (uint32_t)(a.steps ? a.steps[b] * a.Q + g : g);
+            const int pick = smp_pick_wave<32>(xr, V, a.greedy, a.top_k, late, a.temperature, seed, step, S.ckey);
+            CH_STAMP(stamps, sidx, 4);
+            if (more) {
+                // the folded embedding -> projection row of the drawn code: lane l moves 16-byte pieces l and l + 64 of the 2 KB row; the
+                // slab value in sample_kernel's order of additions (piece sums, one wave_sum per 64 pieces, then the two halves)
+                const int Hc = 1024;
+                const uint16_t* tab = a.ptab + ((size_t)(g - 1) * a.codebook + pick) * Hc;
+                const coh_rsrc_t rrs = coh_rsrc(a.resid);
+                float ss2[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int v = lane + 64 * h2;
+                    const u32x4 w4 = ld16(tab + v * 8);
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ss += bf_lo(w4[j]) * bf_lo(w4[j]) + bf_hi(w4[j]) * bf_hi(w4[j]);
+                    coh_st16(rrs, (uint32_t)frag_off(b, v * 8, Hc) * 2, w4);
+                    ss2[h2] = wave_sum(ss);
+                }
+                if (lane == 0) coh_st4(coh_rsrc(a.part), (uint32_t)b * 4, __float_as_uint(((ss2[0] + ss2[1]) + 0.f) + 0.f));
+            }
+            if (lane == 0) coh_st4(coh_rsrc(a.codes), ((uint32_t)b * a.Q + g) * 4, (uint32_t)pick);
+        }
+    } else {
         constexpr int NPT = 8;
         const SmpLds S = smp_carve<NPT>(lds);
         const coh_rsrc_t lrs = coh_rsrc(a.logits);
@@ -200,7 +256,7 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
         }
         const uint32_t seed = a.row_seed ? a.row_seed[b] : a.seed;
         const uint32_t step = (uint32_t)(a.steps ? a.steps[b] * a.Q + g : g);
-        const int pick = smp_pick<NPT>(xr, V, a.greedy, a.top_k, a.top_p, seed, step, S, live);
+        const int pick = smp_pick<NPT>(xr, V, a.greedy, a.top_k, a.top_p, seed, step, S, live, stamps);
         CH_STAMP(stamps, sidx, 4);
         if (more) {
             const int Hc = 1024;
@@ -240,7 +296,10 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
 // The pair attention: one wave per (row, q head) as attn_pair01_kernel (paged_attn.hip) -- position 0 attends to itself (output = its
 // V row), position 1 to both; q / k / v cross from the qkv stage with sc1 dword loads (elements 2 l, 2 l + 1 per lane: V needs no
 // other layout; the (l, l + 64) pairing of the norm + RoPE is restored through LDS), K / V of both positions go to the private cache.
-__device__ __forceinline__ void chain_attn_pair(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code) {
+__device__ __forceinline__ void chain_attn_pair(const ChainArgs& a, const ChainLayer& L, float* lds, ChainGate& g, int code,
+                                                unsigned long long* stamps) {
+    const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
+    CH_STAMP(stamps, sidx, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q_heads = a.q_heads, kv_heads = a.kv_heads, bs = a.bs;
     if ((int)blockIdx.x * 4 >= a.B * q_heads) {
@@ -253,7 +312,9 @@ __device__ __forceinline__ void chain_attn_pair(const ChainArgs& a, const ChainL
     const int ratio = q_heads / kv_heads, kvh = h / ratio;
     const int nslots = q_heads + 2 * kv_heads;
     const coh_rsrc_t krs = coh_rsrc(L.kc), vrs = coh_rsrc(L.vc), qrs = coh_rsrc(a.qkv), ars = coh_rsrc(a.attn);
+    CH_STAMP(stamps, sidx, 1);
     chain_gate_wait(g, code);
+    CH_STAMP(stamps, sidx, 2);
     if (active) {
         const uint32_t r0 = (uint32_t)row * nslots * 128, r1 = (uint32_t)(a.Bp + row) * nslots * 128;
         const uint32_t ko = (uint32_t)(q_heads + kvh) * 128, vo = (uint32_t)(q_heads + kv_heads + kvh) * 128;
@@ -293,7 +354,9 @@ __device__ __forceinline__ void chain_attn_pair(const ChainArgs& a, const ChainL
         coh_st4(ars, (uint32_t)frag_off(a.Bp + row, col, width) * 2,
                 pack_bf2(fmaf(p1, bf_lo(v1w), p0 * bf_lo(v0w)) * inv, fmaf(p1, bf_hi(v1w), p0 * bf_hi(v0w)) * inv));
     }
+    CH_STAMP(stamps, sidx, 6);
     chain_gate_arrive(g);
+    CH_STAMP(stamps, sidx, 7);
 }
 
 __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) {
@@ -310,21 +373,21 @@ __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) 
     for (int l = 0; l < a.layers; ++l) {
         const ChainLayer& L = a.layer[l];
         chain_gemm<2, 4, 4, 2, OMNI_EPI_BF16, 0, 0, ChainNoPrefetch, false, 128>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, M2, NQ, a.eps, wg & 63,
-                                                                                 wg >> 6, lds, g, l > 0, 0x0100 | (16 * l + 1), nullptr);
-        chain_attn_pair(a, L, lds, g, 0x0100 | (16 * l + 2));
+                                                                                 wg >> 6, lds, g, l > 0, 0x0100 | (16 * l + 1), a.stamps);
+        chain_attn_pair(a, L, lds, g, 0x0100 | (16 * l + 2), a.stamps);
         chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps, wg & 63,
-                                                                                  wg >> 6, lds, g, true, 0x0100 | (16 * l + 3), nullptr);
+                                                                                  wg >> 6, lds, g, true, 0x0100 | (16 * l + 3), a.stamps);
         np = Hc / 16;
         chain_gemm<4, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8, 0, 0, ChainNoPrefetch, false, 128>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, M2, NI, a.eps,
-                                                                                         wg & 127, wg >> 7, lds, g, true, 0x0100 | (16 * l + 4), nullptr);
+                                                                                         wg & 127, wg >> 7, lds, g, true, 0x0100 | (16 * l + 4), a.stamps);
         chain_gemm<2, 1, 12, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps,
-                                                                                   wg & 63, wg >> 6, lds, g, true, 0x0100 | (16 * l + 5), nullptr);
+                                                                                   wg & 63, wg >> 6, lds, g, true, 0x0100 | (16 * l + 5), a.stamps);
     }
     // group 1: head GEMM on the position-1 rows (fragment-major tiles Bp / 16 onwards; their slabs start at row Bp), then the sampler
     chain_gemm<1, 2, 4, 2, OMNI_EPI_F32_BF16RND, 0, 0, ChainNoPrefetch, false, 128>(a.lm_head, a.cp_norm, a.resid + (size_t)a.Bp * Hc, a.part + a.Bp, np,
                                                                                     a.logits, a.logits_ld, nullptr, a.B, a.codebook, a.eps, wg & 63, wg >> 6,
-                                                                                    lds, g, true, 0x0156, nullptr);
-    chain_sample(a, 1, lds, g, 0x01F2);
+                                                                                    lds, g, true, 0x0156, a.stamps);
+    chain_sample(a, 1, lds, g, 0x01F2, a.stamps);
 }
 
 // DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm: its
@@ -357,29 +420,37 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
     const int Hc = 1024, NQ = 4096, NI = 3072;
     for (int pass = a.g0; pass < a.g1; ++pass) {
         const int pc = pass << 8;            // error-word stage codes: (pass << 8) | (16 * layer + stage + 1); head 0xF1, sampler 0xF2
+        // debug library: every pass stamps its own block of CH_STAMP_PASS words (round 6: the cold tail of the passes in the real step)
+        unsigned long long* const st = a.stamps ? a.stamps + (size_t)pass * CH_STAMP_PASS : nullptr;
         for (int l = 0; l < a.layers; ++l) {
             const ChainLayer& L = a.layer[l];
+            // the workgroup index, opaque per layer: hipcc otherwise hoists every tile / k-step offset of every stage (they depend on
+            // blockIdx only) out of both loops and parks ~450 of them in VGPR lanes for the whole launch (v_writelane / v_readlane)
+            int wg = blockIdx.x;
+            asm volatile("" : "+s"(wg));
             chain_gemm<1, 4, 4, DEFER ? 3 : 2, OMNI_EPI_BF16>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 63, wg >> 6, lds, g,
-                                                              l > 0 || pass > a.g0, pc | (16 * l + 1), a.stamps);
-            chain_attn(a, L, pass, lds, g, pc | (16 * l + 2));
+                                                              l > 0 || pass > a.g0, pc | (16 * l + 1), st);
+            chain_attn(a, L, pass, lds, g, pc | (16 * l + 2), st);
             chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                                   true, pc | (16 * l + 3), a.stamps);
+                                                   true, pc | (16 * l + 3), st);
             np = Hc / 16;
             if (GU_NARROW)
                 chain_gemm<2, 3, 4, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 127, wg >> 7,
-                                                                          lds, g, true, pc | (16 * l + 4), a.stamps);
+                                                                          lds, g, true, pc | (16 * l + 4), st);
             else   // 16 rows x 48 act columns: half the in-register RMSNorm per workgroup, a weight slice twice as wide (prefetched)
                 chain_gemm<1, 6, 4, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, a.B, NI, a.eps, wg & 63, wg >> 6,
-                                                                          lds, g, true, pc | (16 * l + 4), a.stamps);
+                                                                          lds, g, true, pc | (16 * l + 4), st);
             chain_gemm<1, 1, 12, 0, OMNI_EPI_RESID>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, Hc, a.eps, wg & 63, wg >> 6, lds, g,
-                                                    true, pc | (16 * l + 5), a.stamps);
+                                                    true, pc | (16 * l + 5), st);
         }
         if (!a.with_head) continue;
+        int wg = blockIdx.x;
+        asm volatile("" : "+s"(wg));
         // group `pass`: final norm folded into the head GEMM (2048 logits per row), then one workgroup per row samples
         chain_gemm<1, 2, 4, 2, OMNI_EPI_F32_BF16RND>(a.lm_head + (size_t)(pass - 1) * a.codebook * Hc, a.cp_norm, a.resid, a.part, np,
                                                      a.logits + (size_t)(pass - 1) * a.logits_pass, a.logits_ld, nullptr, a.B, a.codebook, a.eps,
-                                                     wg & 63, wg >> 6, lds, g, true, pc | 0x56, a.stamps);
-        chain_sample(a, pass, lds, g, pc | 0xF2);
+                                                     wg & 63, wg >> 6, lds, g, true, pc | 0x56, st);
+        chain_sample(a, pass, lds, g, pc | 0xF2, st);
         np = 1;
     }
 }
@@ -394,7 +465,8 @@ extern "C" void omni_debug_chain_pair(int on) { g_chain_pair = on; }            
 static unsigned long long* g_chain_stamps = nullptr;
 // 0: launch per op; 1: one persistent launch per pass (layer stack only); 2: one persistent launch for all passes incl. heads + samplers
 extern "C" void omni_debug_cp_chain(int on) { g_cp_chain = on != 0; g_chain_span = on; }
-// device buffer of 40 * CH_NSTAMP * 256 uint64 that every following chain launch overwrites (NULL: off)
+// device buffer of 16 blocks (one per predictor pass; block 0: the pair kernel) of 40 * CH_NSTAMP * 256 uint64 that every following chain
+// launch overwrites (NULL: off)
 extern "C" void omni_debug_chain_stamps(void* buf) { g_chain_stamps = (unsigned long long*)buf; }
 #endif
 
@@ -446,6 +518,9 @@ int k_cp_pair(const omni_talker_desc& d, const omni_layer_weights* layers, uint1
     a.steps = head->steps; a.row_seed = head->row_seed; a.codes = head->codes;
     a.ptab = (const uint16_t*)d.cp_proj_table;
     a.dom = 8; a.nap = g_chain_nap;
+#ifdef OMNI_DEBUG_HOOKS
+    a.stamps = g_chain_stamps;            // block 0 of the stamp buffer (the chain's passes 2 .. 15 stamp blocks 2 .. 15)
+#endif
     hipLaunchKernelGGL(cp_pair_kernel, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     OMNI_CHECK_LAUNCH("cp_pair");
     return OMNI_OK;

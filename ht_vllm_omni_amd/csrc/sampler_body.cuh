@@ -6,6 +6,16 @@
 #pragma once
 #include "common.cuh"
 
+// debug library: in-kernel timeline of the pick (cp_chain.hip's stamp buffer, stage slot 27; scripts/step_timeline.py)
+#ifdef OMNI_DEBUG_HOOKS
+#define SMP_STAMP(buf, k)                                                                                   \
+    do {                                                                                                    \
+        if ((buf) != nullptr && threadIdx.x == 0) (buf)[((size_t)27 * 8 + (k)) * 256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define SMP_STAMP(buf, k) do { (void)(buf); } while (0)
+#endif
+
 #define SMP_THREADS 256            // LIVE threads of a row
 #define SMP_WAVES (SMP_THREADS / 64)
 #define SMP_MAXW 8                 // waves that may reach the barriers (live + passive)
@@ -76,8 +86,9 @@ __device__ __forceinline__ int block_argmax(float v, int idx, float* sval, int* 
 // (workgroup barriers inside, under workgroup-uniform conditions only).
 template <int NPT>
 __device__ __forceinline__ int smp_pick(float (&xr)[NPT], int V, int greedy, int top_k, float top_p, uint32_t seed, uint32_t step,
-                                        const SmpLds& S, bool live) {
+                                        const SmpLds& S, bool live, unsigned long long* stamps = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SMP_STAMP(stamps, 0);
     float* row = S.row;
     uint32_t (*hist)[256] = reinterpret_cast<uint32_t (*)[256]>(S.hist);
     float* sval = S.sval; int* sidx = S.sidx; uint32_t* sel_prefix = S.sel_prefix; uint32_t* sel_k = S.sel_k;
@@ -214,10 +225,12 @@ __device__ __forceinline__ int smp_pick(float (&xr)[NPT], int V, int greedy, int
                 __syncthreads();
                 mx = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
                 L = fminf(fminf(wq[0], wq[1]), fminf(wq[2], wq[3]));
+                SMP_STAMP(stamps, 1);
             }
             if (fast) {
                 n = compact(L);
                 if (n > SMP_PCAP) fast = false;                      // uniform: every thread sees the same total
+                SMP_STAMP(stamps, 2);
             }
             if (!fast) {
                 kth = radix_kth();
@@ -255,6 +268,7 @@ __device__ __forceinline__ int smp_pick(float (&xr)[NPT], int V, int greedy, int
                 if (fast) {
                     __syncthreads();
                     kth = *S.kth_s;                                   // -inf when fewer than top_k finite values exist
+                    SMP_STAMP(stamps, 3);
                 }
                 if (want_p) {
                     // partition sum over the kept candidates {x >= kth}; candidate c stays iff the mass before it is < top_p
@@ -299,7 +313,174 @@ __device__ __forceinline__ int smp_pick(float (&xr)[NPT], int V, int greedy, int
             }
         }
         if (bi == 0x7FFFFFFF) bi = 0;
+        SMP_STAMP(stamps, 4);
         pick = block_argmax(bv, bi, sval, sidx);
+        SMP_STAMP(stamps, 5);
+#ifdef OMNI_DEBUG_HOOKS
+        if (stamps != nullptr && threadIdx.x == 0) stamps[((size_t)27 * 8 + 6) * 256 + blockIdx.x] = (unsigned long long)n;      // candidates ranked
+#endif
     }
     return pick;
+}
+
+// ---- Round 6: the pick of one row by ONE wave, no workgroup barrier (the code-predictor chain's sampler stage: 8.4 us of its 11.4 were the
+// 4-wave pick above -- 6 barriers, a 64-step readlane rank loop, two LDS compaction passes; profiles/r06_step_timeline.txt).  Same function
+// of the row as smp_pick without top-p (top-k with ties kept -> Gumbel-max with the counter RNG, smallest index on equal scores; greedy =
+// first argmax), so both paths pick the same id bit for bit (tests/test_gpu_chain.py: chain == launch path).
+//   lane l holds EPL elements: x[e] = element (e >> 2) * 256 + 4 l + (e & 3)  (16-byte loads), -inf past V
+//   late_temp: x is BEFORE the temperature and bf16-exact (the chain's head GEMM rounds its logits to bf16): dividing by a moderate T > 0
+//     keeps such values strictly ordered, so the k-th largest is found on the raw values and only the kept candidates are divided (2 instead
+//     of EPL IEEE divisions per lane); otherwise x is final.
+//   1  two group maxima per lane; L = largest 16-bit key prefix with >= k of the 128 group maxima at or above it (16 ballot-count
+//      bisection steps): at least k elements are >= L
+//   2  candidates {x >= L, x > -inf}: wave prefix scan, 64-bit sort keys (value key << 32 | ~index) into LDS, read back two per lane
+//   3  exact k-th largest key among them by the same bisection (16 steps when every key is bf16-exact, else 32); ties kept
+//   4  Gumbel scores of the kept candidates, wave argmax
+// Rows that do not fit (no top-k; more than 128 candidates: massive ties) take the same steps over all EPL registers of every lane (slow,
+// exact, still without a barrier).
+#define SMP_WAVE_CAND 128
+__device__ __forceinline__ int smp_count_ge(uint32_t a, uint32_t b, uint32_t t) {
+    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(a >= t)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(b >= t));
+}
+template <int EPL>
+__device__ __forceinline__ int smp_pick_wave(const float (&x)[EPL], int V, int greedy, int top_k, bool late_temp, float temperature,
+                                             uint32_t seed, uint32_t step, unsigned long long* cand /* LDS [SMP_WAVE_CAND + 64] */) {
+    static_assert(EPL % 8 == 0, "smp_pick_wave: elements per lane");
+    int lane = threadIdx.x & 63;
+    // opaque to the optimiser: inside a persistent kernel's pass loop hipcc otherwise hoists the EPL per-element index values out of the
+    // loop and keeps them in scratch for the whole launch (128 spilled VGPRs in cp_chain_kernel)
+    asm volatile("" : "+v"(lane));
+    auto index_of = [&](int e) { return (e >> 2) * 256 + 4 * lane + (e & 3); };
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    if (greedy) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (x[e] > bv) { bv = x[e]; bi = index_of(e); }        // a lane's indices ascend with e: its first maximum wins
+        if (bi == 0x7FFFFFFF) bi = 4 * lane < V ? 4 * lane : 0x7FFFFFFE;
+        wave_argmax(bv, bi);
+        return bi >= V ? 0 : bi;
+    }
+    const bool want_k = top_k > 0 && top_k < V;
+    int n = 0, cnt = 0, inc = 0;
+    float L = -INFINITY;
+    bool bounded = false;
+    if (want_k) {
+        // 1: lower bound of the k-th largest value
+        float g0 = -INFINITY, g1 = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < EPL / 2; ++e) { g0 = fmaxf(g0, x[e]); g1 = fmaxf(g1, x[EPL / 2 + e]); }
+        const uint32_t k0 = ord_key(g0) >> 16, k1 = ord_key(g1) >> 16;
+        uint32_t t = 0;
+#pragma unroll
+        for (int bit = 15; bit >= 0; --bit) {
+            const uint32_t c = t | (1u << bit);
+            if (smp_count_ge(k0, k1, c) >= top_k) t = c;
+        }
+        // a FINITE bound (key prefix above -inf's 0x007F) or none: fewer than k finite group maxima take the slow form below
+        bounded = t >= 0x0080u;
+        L = key_val(t << 16);
+    }
+    if (bounded) {
+        // 2: compaction (x >= L implies x > -inf)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cnt += x[e] >= L ? 1 : 0;
+        // inclusive prefix over the 64 lanes: 4 DPP row shifts, then the totals of the rows below (lanes 15 / 31 / 47)
+        int v = cnt;
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+        const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+        const int row = lane >> 4;
+        inc = v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+        n = __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (!bounded || n > SMP_WAVE_CAND) {
+        // no top-k, or massive ties: every register of every lane competes.  The exact k-th largest key by bisection over all of them
+        // (32 steps x EPL ballots); fewer than k finite values: kth stays 0 = everything finite
+        float kt = -INFINITY;
+        if (want_k) {
+            uint32_t kth = 0;
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t c = kth | (1u << bit);
+                int ge = 0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+                    ge += __builtin_popcountll(__builtin_amdgcn_ballot_w64(x[e] > -INFINITY && ord_key(x[e]) >= c));
+                if (ge >= top_k) kth = c;
+            }
+            const float kth_f = kth ? key_val(kth) : -INFINITY;
+            kt = late_temp ? kth_f / temperature : kth_f;
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {          // (fully unrolled: a dynamic register index would put x[] into scratch)
+            const float xt = late_temp ? x[e] / temperature : x[e];
+            if (xt >= kt && x[e] > -INFINITY) {
+                const int i = index_of(e);
+                const float sc = xt - logf(-logf(hash_uniform(seed, step, (uint32_t)i)));
+                if (sc > bv || (sc == bv && i < bi)) { bv = sc; bi = i; }
+            }
+        }
+    } else {
+        // branch-free: every element is written as (value bits, ~index), the ones below L to this lane's dump slot behind the list (an
+        // exec-masked store per element cost 17 instructions each, 544 of the pick's ~1500); byte offsets, sort keys built after the read-back
+        char* const cb = reinterpret_cast<char*>(cand);
+        const int dump = (SMP_WAVE_CAND + lane) * 8;
+        int o8 = (inc - cnt) * 8;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const bool c = x[e] >= L;
+            *reinterpret_cast<uint2*>(cb + (c ? o8 : dump)) = make_uint2(__float_as_uint(x[e]), ~(uint32_t)index_of(e));
+            o8 += c ? 8 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint2 w0 = *reinterpret_cast<const uint2*>(cb + lane * 8), w1 = *reinterpret_cast<const uint2*>(cb + (lane + 64) * 8);
+        // (slots past n hold stale bytes: key 0 sorts after everything)
+        const uint32_t q0 = lane < n ? ord_key(__uint_as_float(w0.x)) : 0u, q1 = lane + 64 < n ? ord_key(__uint_as_float(w1.x)) : 0u;
+        const unsigned long long c0 = ((unsigned long long)q0 << 32) | w0.y, c1 = ((unsigned long long)q1 << 32) | w1.y;
+        // 3: the exact k-th largest key (ties kept); fewer than k candidates = fewer than k finite values: keep them all
+        uint32_t kth = 0;
+        if (n >= top_k) {
+            // bf16-exact values (their float bits end in 16 zeros; the key of a negative one then ends in 16 ones): 16 steps on the key
+            // prefixes; anything else: all 32 bits
+            const bool wide = __builtin_amdgcn_ballot_w64((((lane < n ? w0.x : 0u) | (lane + 64 < n ? w1.x : 0u)) & 0xFFFFu) != 0) != 0;
+            if (wide) {
+#pragma unroll 1
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t c = kth | (1u << bit);
+                    if (smp_count_ge(q0, q1, c) >= top_k) kth = c;
+                }
+            } else {
+                const uint32_t h0 = q0 >> 16, h1 = q1 >> 16;
+                uint32_t t16 = 0;
+#pragma unroll
+                for (int bit = 15; bit >= 0; --bit) {
+                    const uint32_t c = t16 | (1u << bit);
+                    if (smp_count_ge(h0, h1, c) >= top_k) t16 = c;
+                }
+                kth = (t16 << 16) | ((t16 & 0x8000u) ? 0u : 0xFFFFu);
+            }
+        }
+        // 4: Gumbel scores of the kept candidates (value >= kth by FLOAT compare of the final values, as smp_pick keeps them)
+        const float kth_f = n >= top_k ? key_val(kth) : -INFINITY;
+        const float kt = late_temp ? kth_f / temperature : kth_f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned long long me = s2 ? c1 : c0;
+            if ((uint32_t)(me >> 32) != 0u) {
+                const float xv = key_val((uint32_t)(me >> 32));
+                const int i = (int)(~(uint32_t)me);
+                const float xt = late_temp ? xv / temperature : xv;
+                if (xt >= kt) {
+                    const float sc = xt - logf(-logf(hash_uniform(seed, step, (uint32_t)i)));
+                    if (sc > bv || (sc == bv && i < bi)) { bv = sc; bi = i; }
+                }
+            }
+        }
+    }
+    wave_argmax(bv, bi);
+    return bi == 0x7FFFFFFF ? 0 : bi;
 }

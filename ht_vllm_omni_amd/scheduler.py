@@ -146,7 +146,10 @@ class MI355XARScheduler:
         elif req in self.waiting:
             self.waiting.remove(req)
         req.status = RequestStatus.FINISHED_ABORTED
-        req.num_output_placeholders = 0          # whatever is still in flight for it is dropped on arrival (request finished)
+        # whatever is still in flight for it is dropped on arrival (request finished); as on the stop path, the positions of the dropped
+        # tokens do not count as computed -- a KV hand-off of the aborted request ships the synchronous loop's length
+        req.num_computed_tokens -= req.num_output_placeholders
+        req.num_output_placeholders = 0
         self._free_request(req)
 
     def has_unfinished_requests(self) -> bool:
@@ -272,7 +275,9 @@ class MI355XARScheduler:
         if not c or req.request_id in self.waiting_for_transfer_free or req.request_id in self.transfer_triggered_requests:
             return False
         if c.get("type") == "prefill_finished":
-            if req.num_computed_tokens >= req.num_prompt_tokens:
+            # SETTLED tokens, not scheduled ones: with async scheduling num_computed_tokens already counts the prompt's final chunk while
+            # that chunk is still in flight, and the shipped length (settled) would be P - 1 one step early
+            if self._settled_tokens(req) >= req.num_prompt_tokens:
                 self.transfer_triggered_requests.add(req.request_id)
                 self._mark_request_for_kv_transfer(req.request_id, self._settled_tokens(req))
         elif c.get("type") == "special_token":

@@ -216,3 +216,65 @@ def test_a_dropped_row_gives_its_placeholder_back():
     assert req.num_output_placeholders == 0
     so3 = s.schedule()
     assert [r.req_id for r in so3.scheduled_new_reqs] == ["a"] and so3.num_scheduled_tokens["a"] == 7      # recomputed: prompt + its one token
+
+
+def _sched_only_loop(async_on, *, prompt=20, budget=8, criteria=None, steps=12, abort_at=None, need_send_cache=False):
+    """The scheduler alone under the engine loop's call order (depth-2 queue when async): every scheduled decode row samples token 7."""
+    from ht_vllm_omni_amd.payloads import OmniModelRunnerOutput
+    s = MI355XARScheduler(num_blocks=64, block_size=16, max_num_seqs=4, max_num_batched_tokens=budget, max_model_len=512,
+                          async_scheduling=async_on, kv_transfer_criteria=criteria, need_send_cache=need_send_cache)
+    s.add_request(Request(request_id="a", num_prompt_tokens=prompt, prompt_token_ids=[1] * prompt,
+                          sampling_params=SamplingParams(temperature=0.0, max_tokens=6)))
+    shipped, inflight = {}, []
+
+    def runner_output(so):
+        ids, toks = [], []
+        for rid, n in so.num_scheduled_tokens.items():
+            r = s.requests.get(rid)
+            ids.append(rid)
+            # the step samples iff it computes the request's last known token (prompt end or a decode row)
+            samples = r is not None and so_computed[id(so)][rid] + n >= r.num_prompt_tokens
+            toks.append([7] if samples else [])
+        return OmniModelRunnerOutput(req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)}, sampled_token_ids=toks,
+                                     pooler_output=None, kv_extracted_req_ids=list(so.finished_requests_needing_kv_transfer))
+
+    so_computed = {}
+    for it in range(steps):
+        if abort_at is not None and it == abort_at:
+            shipped["seen_at_abort"] = len(s.requests["a"].output_token_ids)
+            s.abort_request("a")
+        before = {rid: r.num_computed_tokens for rid, r in s.requests.items()}
+        so = s.schedule()
+        so_computed[id(so)] = before
+        for rid, meta in so.finished_requests_needing_kv_transfer.items():
+            shipped.setdefault(rid, []).append((it, meta["seq_len"]))
+        if so.total_num_scheduled_tokens or so.finished_requests_needing_kv_transfer:
+            inflight.append(so)
+        if async_on and len(inflight) < 2 and so.total_num_scheduled_tokens:
+            continue
+        if inflight:
+            so0 = inflight.pop(0)
+            s.update_from_output(so0, runner_output(so0))
+    return shipped, s
+
+
+def test_async_prefill_finished_handoff_of_a_chunked_prompt_ships_the_whole_prompt():
+    """with async scheduling and a prompt chunked by the token budget (P = 20, budget 8), the `prefill_finished` KV hand-off must
+    fire when the final chunk has SETTLED and ship seq_len = P, as the synchronous loop does -- not one step early with P - 1."""
+    crit = {"type": "prefill_finished"}
+    a, _ = _sched_only_loop(False, criteria=crit)
+    b, _ = _sched_only_loop(True, criteria=crit)
+    assert [n for _, n in a["a"]] == [20], a
+    assert [n for _, n in b["a"]] == [20], b
+
+
+def test_async_abort_ships_no_positions_of_dropped_tokens():
+    """an aborted request that must ship its KV (need_send_cache) ships the tokens that SETTLED -- the placeholders of the steps in
+    flight are taken back from num_computed_tokens as on the stop path."""
+    a, sa = _sched_only_loop(False, prompt=9, budget=48, need_send_cache=True, abort_at=4, steps=8)
+    b, sb = _sched_only_loop(True, prompt=9, budget=48, need_send_cache=True, abort_at=4, steps=8)
+    # a decode step computes one position and samples one token: settled positions = P + tokens seen - 1, in both modes (before the fix
+    # the async scheduler shipped up to two positions more: those of the dropped tokens)
+    for r in (a, b):
+        assert r["seen_at_abort"] >= 1 and [n for _, n in r["a"]] == [9 + r["seen_at_abort"] - 1], r
+    assert b["seen_at_abort"] <= a["seen_at_abort"]

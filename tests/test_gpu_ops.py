@@ -669,6 +669,61 @@ def test_sampler_candidate_filter_edges(ops, V, top_k, top_p):
             assert outg[b].item() == int(torch.argmax(logits[b])), b
 
 
+@pytest.mark.parametrize("V,top_k,temperature", [(2048, 50, 0.9), (2048, 50, 1.3), (3072, 50, 0.9), (2048, 64, 1.0 / 128), (2048, 3, 0.9),
+                                                 (1000, 50, 0.9), (2048, 130, 0.9), (3072, 0, 0.9), (2048, 2048, 0.7)])
+def test_sampler_one_wave_pick_matches_the_four_wave_pick(V, top_k, temperature):
+    """Round 6: rows without top-p are picked by ONE wave (sampler_body.cuh smp_pick_wave: lower bound by ballot bisection, LDS
+    compaction, exact k-th key by bisection, Gumbel-max) -- the same function of the row as the 4-wave pick.  Both kernels on the same
+    rows (debug library: omni_debug_sample_wave 0 / 1): identical ids on EVERY row -- bf16-exact logits (the code predictor's: temperature
+    applied late, to the kept candidates only), fp32 logits (divided first), negative top-k sets, ties across the threshold, rows with
+    fewer finite values than top_k, constant rows (> 128 candidates: the exact slow form), +inf, temperatures outside the late range,
+    top_k > 128 (more kept values than list slots), no top-k; greedy too.  And against the oracle where its margin allows."""
+    import ctypes as C
+    from ht_vllm_omni_amd import _lib as L
+    from ht_vllm_omni_amd import ops as _ops
+    g = torch.Generator().manual_seed(V * 31 + top_k)
+    B = 24
+    logits = torch.randn(B, V, generator=g) * 2
+    logits[:12] = logits[:12].to(BF16).float()                     # the chain's head GEMM output: bf16-exact
+    logits[1] = -logits[1].abs() - 3.0                             # every value negative (keys end in ones)
+    logits[2] = 0.25                                               # constant row
+    logits[3] = float("-inf"); logits[3, 5:25] = torch.randn(20, generator=g).to(BF16).float()     # fewer finite values than top_k = 50
+    logits[4, : V // 2] = 1.0                                      # half the row tied
+    logits[5] = (logits[5] * 4).round() / 4                        # coarse grid: duplicates everywhere, ties at the threshold
+    logits[6, 7] = float("inf")
+    logits[7, V // 3:] = float("-inf")                             # masked tail
+    logits[13] = (logits[13] * 4).round() / 4
+    logits[14] = float("-inf")                                     # nothing finite: index 0
+    logits[15, ::2] = float("-inf")
+    steps = torch.arange(B, dtype=torch.int32).cuda()
+    seen = torch.zeros(B, V, dtype=torch.uint8)
+    seen[16:, : V // 4] = 1                                        # repetition penalty on some rows of the fp32 half
+    kw = dict(temperature=temperature, top_k=top_k, seed=1234)
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_sample_wave.argtypes = [C.c_int]; lib.omni_debug_sample_wave.restype = None
+        for mode in (0, 1):
+            lib.omni_debug_sample_wave(mode)
+            sn = seen.clone().cuda()
+            a = _ops.sample(logits.cuda(), greedy=False, steps=steps, step_mul=16, step_add=3, rep_penalty=1.3, seen=sn, **kw).cpu()
+            gr = _ops.sample(logits.cuda(), greedy=True).cpu()
+            res[mode] = (a, gr, sn.cpu())
+        lib.omni_debug_sample_wave(1)
+    assert torch.equal(res[0][0], res[1][0]), f"sampled ids differ between the 4-wave and the one-wave pick in rows {(res[0][0] != res[1][0]).nonzero().flatten().tolist()}"
+    assert torch.equal(res[0][1], res[1][1]), "greedy ids differ between the two picks"
+    assert torch.equal(res[0][2], res[1][2]), "seen marks differ"
+    assert res[1][0][6].item() == 7 and res[1][0][14].item() == 0
+    n_checked = 0
+    for b in range(B):
+        sl = seen[b].nonzero().flatten().tolist()
+        okw = dict(greedy=False, step=b * 16 + 3, rep_penalty=1.3, seen_ids=sl, **kw)
+        if b in (6, 14) or b >= 16 or O.sample_row_margin(logits[b], **okw) < 1e-4:       # (the margin helper knows no penalty: rows 16+ are
+            continue                                                                        #  checked between the two kernels only)
+        assert res[1][0][b].item() == O.sample_row(logits[b], **okw), b
+        n_checked += 1
+    assert n_checked >= 10
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_snake_beta(ops, golden_dir, dtype):
     """SnakeBeta of the Code2Wav decoder (the reference's Triton kernel -> HIP): golden vectors minted from the
