@@ -22,7 +22,7 @@ LIB_DEBUG = os.path.join(HERE, "libomni_talker_debug.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm_prefill.hip", "norm.hip", "rope_kv.hip", "paged_attn.hip", "prefill_attn.hip", "moe.hip",
            "sampler.hip", "cp_chain.hip", "bb_chain.hip", "moe_chain.hip", "allreduce.hip", "codec.hip", "conv_unit.hip"]
 # debug library only: the probes, and the losing A/B arms of the backbone chain (rounds 3 and 4; no product knob reaches them)
-DEBUG_ONLY = ["debug.hip", "bb_xw.hip", "bb_pp.hip", "bb_engine.hip", "bb_all.hip"]
+DEBUG_ONLY = ["debug.hip", "bb_engine.hip", "bb_all.hip"]
 # per-file extra flags
 EXTRA = {"debug.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -126,10 +126,10 @@ __global__ __launch_bounds__(CH_THREADS) void bb_all_kernel(const BbAllArgs a) {
         const BbLayerDev Ly = bba_layer(a.layers, 0);
         set_layer(Ly, 0);
         if (PRE)
-            chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 4, 0>(Ly.wqkv, Ly.ln1, a.resid, a.part, 1, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
+            chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 4, 0>(Ly.wqkv, Ly.ln1, a.resid, a.part, 1, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
                                                         false, 0x20001, a.stamp_layer == 0 ? a.stamps : nullptr, nullptr, pf);
         else
-            chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 4>(Ly.wqkv, Ly.ln1, a.resid, a.part, 1, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
+            chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 4>(Ly.wqkv, Ly.ln1, a.resid, a.part, 1, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
                                                      false, 0x20001, a.stamp_layer == 0 ? a.stamps : nullptr);
     }
     for (int l = 0; l < a.L; ++l) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_all_kernel(const BbAllArgs a) {
                                           PRE ? &pre : nullptr);
         chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0>(Ly.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                   true, lc | 3, st);
-        chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, 2, 1, ChainNoPrefetch, true>(Ly.wgu, Ly.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps,
+        chain_gemm<4, 3, 8, 3, OMNI_EPI_SILU_MUL_GU8, 2, 1, ChainNoPrefetch, true>(Ly.wgu, Ly.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps,
                                                                                    wg, 0, lds, g, true, lc | 4, st);
         chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, 4>(Ly.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                    true, lc | 5, st);
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(CH_THREADS) void bb_all_kernel(const BbAllArgs a) {
             const BbLayerDev Ln = bba_layer(a.layers, l + 1);
             set_layer(Ln, l + 1);
             if (PRE)
-                chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 4, 0>(Ln.wqkv, Ln.ln1, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7,
+                chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 4, 0>(Ln.wqkv, Ln.ln1, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7,
                                                             lds, g, true, lc | 1, a.stamp_layer == l + 1 ? a.stamps : nullptr, nullptr, pf);
             else
-                chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 4>(Ln.wqkv, Ln.ln1, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7,
+                chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 4>(Ln.wqkv, Ln.ln1, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7,
                                                          lds, g, true, lc | 1, a.stamp_layer == l + 1 ? a.stamps : nullptr);
         }
     }

@@ -149,14 +149,14 @@ __global__ __launch_bounds__(ENG_THREADS) void bb_engine_kernel(const EngArgs a)
     chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 2>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                  false, 0x2001, a.stamps);
     g.piece_base += 8 * 8 * 1;
-    chain_gemm<4, 3, 8, 2, OMNI_EPI_SILU_MUL_GU8, 4, 2>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
+    chain_gemm<4, 3, 8, 3, OMNI_EPI_SILU_MUL_GU8, 4, 2>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
                                                         true, 0x2002, a.stamps);
     g.piece_base += 8 * 8 * 3;
     chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, 8, 2>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                   true, 0x2003, a.stamps);
     g.piece_base += 24 * 8 * 1;
     if (a.wqkv_next)
-        chain_gemm<2, 2, 8, 2, OMNI_EPI_BF16, 0, 2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127,
+        chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 0, 2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127,
                                                     wg >> 7, lds, g, true, 0x2004, a.stamps);
     // a bounded LDS wait that ran out goes into the global error word the host reads
     if (threadIdx.x == 0 && __hip_atomic_load(&es->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) atomicCAS(a.err, 0, 0x2fff);

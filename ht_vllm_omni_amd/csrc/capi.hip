@@ -955,12 +955,6 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
             if (k_bb_engine_enabled())
                 TRY(k_bb_engine(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                                 t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
-            else if (k_bb_xw_enabled())
-                TRY(k_bb_xw(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
-                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
-            else if (k_bb_pp_enabled())
-                TRY(k_bb_pp(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
-                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
             else
 #endif
             TRY(k_bb_chain(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,

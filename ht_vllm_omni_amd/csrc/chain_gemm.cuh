@@ -24,7 +24,8 @@
 #define CH_STAMP(buf, sidx, k) do { (void)(buf); (void)(sidx); } while (0)
 #endif
 
-// PRO 3 (round 4; an A/B arm): the RMSNorm's rstd OFF the critical path.  PRO 2 needs rstd before the first MFMA
+// PRO 3 (round 4: an A/B arm; round 6: the product form of every norm-fused stage whose normalised rows are nobody's output -- qkv, gate_up --
+// in the chains and, with the same arithmetic, in gemm_skinny_kernel): the RMSNorm's rstd OFF the critical path.  PRO 2 needs rstd before the first MFMA
 // (x = w * bf16(r * rstd)): slab loads -> LDS reduction -> barrier sit between the flags and the arithmetic.  PRO 3 feeds the MFMAs
 // bf16(w * r) -- no rstd -- and scales the fp32 sums by rstd[row] in the epilogue: the slab reduction shares the combine barrier.
 // One rounding point moves (bf16(w * bf16(r * rstd)) -> rstd * sum(W * bf16(w * r))): NOT the reference's bits; gated on the accuracy
@@ -126,14 +127,15 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     CH_STAMP(stamps, sidx, 2);                                           // 2: flags seen, barrier passed
 
     // ---- behind the flags: the slabs (first: they return first) and the activation fragments, all in one round trip
-    constexpr int XROWS = MT * 16, NCH = CH_THREADS / XROWS, PE = 128 / NCH;
-    float pv[PE];
+    constexpr int XROWS = MT * 16;
+    typedef SlabOrder<XROWS> SO;             // the canonical slab order (gemm_frag.cuh): the launch path's, whatever row tile it picked
+    float pv[SO::PE];
     if (NORM) {
         const coh_rsrc_t prs = coh_rsrc(part_in);
-        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+        const int row = lane % XROWS, sub = lane / XROWS;
 #pragma unroll
-        for (int e = 0; e < PE; ++e) {
-            const int p = ch + e * NCH;
+        for (int e = 0; e < SO::PE; ++e) {
+            const int p = SO::index(wave, sub, e);
             pv[e] = coh_ldf(prs, (uint32_t)(min(p, np_in - 1) * PS + m_base + row) * 4);
             if (p >= np_in) pv[e] = 0.f;
         }
@@ -165,11 +167,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     float* red = lds + CH_WAVES * ((NT * MT > 6 && !ONEPASS) ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
     if (NORM) {
         // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
-        float s_ = 0.f;
-#pragma unroll
-        for (int e = 0; e < PE; ++e) s_ += pv[e];
-        if (XROWS <= 32) s_ = xor32_sum(s_);
-        if (XROWS <= 16) s_ = xor16_sum(s_);
+        const float s_ = SO::reduce(pv);
         red[wave * 64 + lane] = s_;
     }
     if (PRO == 2) {
@@ -263,7 +261,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             for (int w = 0; w < CH_WAVES; ++w) tsum += red[w * 64 + ml];
             const float rl = 1.0f / sqrtf(tsum / (float)K + eps);
             sum *= rl;
-            if (GU8) sum2 *= rl;
+            if (GU8 || SILU2) sum2 *= rl;
         }
 #ifdef OMNI_DEBUG_HOOKS
         if (g.skip == 3 && sum[0] != 12345.678f) continue;       // timing experiment: no epilogue stores (results garbage)

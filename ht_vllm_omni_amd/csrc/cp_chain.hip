@@ -372,13 +372,13 @@ __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) 
     int np = a.np_in;
     for (int l = 0; l < a.layers; ++l) {
         const ChainLayer& L = a.layer[l];
-        chain_gemm<2, 4, 4, 2, OMNI_EPI_BF16, 0, 0, ChainNoPrefetch, false, 128>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, M2, NQ, a.eps, wg & 63,
+        chain_gemm<2, 4, 4, 3, OMNI_EPI_BF16, 0, 0, ChainNoPrefetch, false, 128>(L.wqkv, L.ln1, a.resid, a.part, np, a.qkv, NQ, nullptr, M2, NQ, a.eps, wg & 63,
                                                                                  wg >> 6, lds, g, l > 0, 0x0100 | (16 * l + 1), a.stamps);
         chain_attn_pair(a, L, lds, g, 0x0100 | (16 * l + 2), a.stamps);
         chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps, wg & 63,
                                                                                   wg >> 6, lds, g, true, 0x0100 | (16 * l + 3), a.stamps);
         np = Hc / 16;
-        chain_gemm<4, 3, 4, 2, OMNI_EPI_SILU_MUL_GU8, 0, 0, ChainNoPrefetch, false, 128>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, M2, NI, a.eps,
+        chain_gemm<4, 3, 4, 3, OMNI_EPI_SILU_MUL_GU8, 0, 0, ChainNoPrefetch, false, 128>(L.wgu, L.ln2, a.resid, a.part, np, a.act, 0, nullptr, M2, NI, a.eps,
                                                                                          wg & 127, wg >> 7, lds, g, true, 0x0100 | (16 * l + 4), a.stamps);
         chain_gemm<2, 1, 12, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 128>(L.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, M2, Hc, a.eps,
                                                                                    wg & 63, wg >> 6, lds, g, true, 0x0100 | (16 * l + 5), a.stamps);
@@ -390,9 +390,10 @@ __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) 
     chain_sample(a, 1, lds, g, 0x01F2, a.stamps);
 }
 
-// DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm: its
-// normalised rows are an output) -- round 4's A/B arm of VERDICT r3 item 1b
-template <bool GU_NARROW, bool DEFER = false>
+// DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm) -- round 4's
+// A/B arm of VERDICT r3 item 1b, the product form since round 6 (the launch path's gemm_skinny_kernel takes it for the same GEMMs: same bits);
+// <.., false> = round 5's exact-rstd stages, debug library only
+template <bool GU_NARROW, bool DEFER = true>
 __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
     static_assert(CH_LDS_FLOATS * 4 >= SMP_LDS_BYTES(8), "sampler working set must fit the chain's LDS");
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
 }
 
 // ---- host
-OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0, g_chain_defer = 0, g_chain_pair = 1;
+OMNI_KNOB g_cp_chain = 1, g_chain_dom = 7, g_chain_gu_narrow = 1, g_chain_nap = 1, g_chain_span = 2, g_chain_skip = 0, g_chain_defer = 1, g_chain_pair = 1;
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_chain_mode(int dom, int gu_narrow, int nap) { g_chain_dom = dom; g_chain_gu_narrow = gu_narrow; g_chain_nap = nap; }
 extern "C" void omni_debug_chain_skip(int mode) { g_chain_skip = mode; }
@@ -565,10 +566,10 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
     a.stamps = g_chain_stamps;
 #endif
 #ifdef OMNI_DEBUG_HOOKS
-    if (g_chain_defer) {
-        if (a.gu_narrow) hipLaunchKernelGGL((cp_chain_kernel<true, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((cp_chain_kernel<false, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
-        OMNI_CHECK_LAUNCH("cp_chain(deferred rstd)");
+    if (!g_chain_defer) {      // timing arm: round 5's exact rstd (its bits are no longer the launch path's)
+        if (a.gu_narrow) hipLaunchKernelGGL((cp_chain_kernel<true, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((cp_chain_kernel<false, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
+        OMNI_CHECK_LAUNCH("cp_chain(exact rstd)");
         return OMNI_OK;
     }
 #endif

@@ -103,19 +103,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
     // NCH-th slab; slabs are [n group][64 rows], so a wave-level load is contiguous) -- issued BEFORE the W ring so that
     // it returns first (loads complete in order) and the reduction overlaps the W latency.  Loads are unconditional
     // (clamped slab index): a predicated load would force hipcc to drain every outstanding load at each wait.
-    constexpr int XROWS = MT * 16, NCH = GEMM_THREADS / XROWS, PE = 128 / NCH;    // PE slabs per thread cover np <= 128
-    float pv[PE];
+    // PRO 3 (round 6; the chains' DEFER form, chain_gemm.cuh): the row's rstd is NOT folded into the operand fragments -- x = bf16(w * r)
+    // -- but multiplies the fp32 sums in the epilogue: the slab reduction leaves the critical path between the operand loads and the first
+    // MFMA (one LDS round trip + a workgroup barrier per norm-fused GEMM).  One rounding point moves: rstd * sum(W * bf16(w r)) instead of
+    // sum(W * bf16(w * bf16(r rstd))) -- one bf16 rounding per element instead of two; gated on the accuracy tests (tests/test_gpu_parity_full.py
+    // three-way statement), not on the oracle's bits.  Taken for the GEMMs whose normalised rows are nobody's output (qkv, gate_up).
+    constexpr bool NORM = PRO == 2 || PRO == 3, DEFER = PRO == 3;
+    constexpr int XROWS = MT * 16, NCH = GEMM_THREADS / XROWS;
+    typedef SlabOrder<XROWS> SO;                                                  // canonical slab order (gemm_frag.cuh): SO::PE slabs per thread cover np <= 128
+    float pv[SO::PE];
     float psum = 0.f;
-    if (PRO == 2) {
-        const int row = threadIdx.x % XROWS, ch = threadIdx.x / XROWS;
+    if (NORM) {
+        const int row = lane % XROWS, sub = lane / XROWS, ch = threadIdx.x / XROWS;
         const float* pp = a.part_in + m_base + row;
 #pragma unroll
-        for (int e = 0; e < PE; ++e) {
-            const int p = ch + e * NCH;
+        for (int e = 0; e < SO::PE; ++e) {
+            const int p = SO::index(wave, sub, e);
             pv[e] = pp[(size_t)min(p, a.np_in - 1) * a.pstride];
             if (p >= a.np_in) pv[e] = 0.f;
         }
-        for (int p = ch + PE * NCH; p < a.np_in; p += NCH) psum += pp[(size_t)p * a.pstride];      // hidden > 2048 only
+        for (int p = ch + 128; p < a.np_in; p += NCH) psum += pp[(size_t)p * a.pstride];      // hidden > 2048 only (no chain there)
     }
     // EPI_RESID: the old residual values this thread will add into (one epilogue item per thread), fetched up front
     uint2 r_old = make_uint2(0, 0);
@@ -131,13 +138,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         // part 2 (after the W ring is in flight): fixed-order reduction -> rstd of this workgroup's rows.  row = lane % XROWS:
         // fold the channels that share a wave by shuffles, the 8 waves through a private LDS area past the epilogue's
         // (ONE barrier; every wave then holds all row sums and picks its MFMA rows by shuffle)
-        float s_ = psum;
-#pragma unroll
-        for (int e = 0; e < PE; ++e) s_ += pv[e];
-        if (XROWS <= 32) s_ = xor32_sum(s_);
-        if (XROWS <= 16) s_ = xor16_sum(s_);
+        float s_ = SO::reduce(pv);
+        if (a.np_in > 128) {                                   // the slabs past the canonical 128: folded over the row's channels as before
+            if (XROWS <= 32) psum = xor32_sum(psum);
+            if (XROWS <= 16) psum = xor16_sum(psum);
+            s_ += psum;
+        }
         float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;      // past the combine slots
         red[wave * 64 + lane] = s_;
+        if (DEFER) return;                                     // read behind the combine barrier, by the epilogue
         __syncthreads();
         float t = 0.f;
 #pragma unroll
@@ -160,7 +169,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         for (int i = 0; i < MT; ++i) {
             int m = i * 16 + r;
             m = m_base + (m < Mloc ? m : Mloc - 1);   // rows past M: valid address, result discarded
-            xrow[i] = a.xshuf ? a.x + ((size_t)((m_base >> 4) + i) * nsteps) * 512 + lane * 8
+            // (fragment-major x holds ceil(M / 16) row tiles: a workgroup tile that reaches past them -- 3 row tiles run as MT = 4 -- re-reads the
+            //  last one, results discarded; until round 6 it read 16 rows past the end of the caller's buffer)
+            const int xt = min((m_base >> 4) + i, ((a.M + 15) >> 4) - 1);
+            xrow[i] = a.xshuf ? a.x + ((size_t)xt * nsteps) * 512 + lane * 8
                               : a.x + (size_t)m * a.ldx + 8 * q;
         }
         // k-steps of W AND x in flight per wave on the counted path.  Same-box A/B of the whole step (scripts/ab.sh):
@@ -182,16 +194,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 for (int j = 0; j < NT; ++j) Wq[d][j] = NTL ? ld16_nt(wrow[j] + ks * wstep) : ld16(wrow[j] + ks * wstep);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) Xq[d][i] = ld16(xrow[i] + ks * xstep);
-                if (PRO == 2) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
+                if (NORM) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
             }
-            if (PRO == 2) xnorm_rstd();
+            if (NORM) xnorm_rstd();
             const int G = ntw / P;
             for (int g = 0; g + 1 < G; ++g) {
 #pragma unroll
                 for (int d = 0; d < P; ++d) {
-                    if (PRO == 2) {
+                    if (NORM) {
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
+                        for (int i = 0; i < MT; ++i) Xq[d][i] = DEFER ? xw_frag(Xq[d][i], NWq[d]) : xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
                     }
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
@@ -202,14 +214,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     for (int j = 0; j < NT; ++j) Wq[d][j] = NTL ? ld16_nt(wrow[j] + ks * wstep) : ld16(wrow[j] + ks * wstep);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) Xq[d][i] = ld16(xrow[i] + ks * xstep);
-                    if (PRO == 2) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
+                    if (NORM) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
                 }
             }
 #pragma unroll
             for (int d = 0; d < P; ++d) {
-                if (PRO == 2) {
+                if (NORM) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) Xq[d][i] = xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
+                    for (int i = 0; i < MT; ++i) Xq[d][i] = DEFER ? xw_frag(Xq[d][i], NWq[d]) : xnorm_frag(Xq[d][i], NWq[d], rstd[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -230,9 +242,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         if (ntw > 0) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + wave * xstep);
-            if (PRO == 2) NW[0] = ld16(a.norm_w + wave * 32 + 8 * q);
+            if (NORM) NW[0] = ld16(a.norm_w + wave * 32 + 8 * q);
         }
-        if (PRO == 2) xnorm_rstd();
+        if (NORM) xnorm_rstd();
         for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -242,11 +254,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                         const int k1 = (wave + (t + 1) * GEMM_WAVES) * xstep;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) X[(d + 1) & 1][i] = ld16(xrow[i] + k1);
-                        if (PRO == 2) NW[(d + 1) & 1] = ld16(a.norm_w + (wave + (t + 1) * GEMM_WAVES) * 32 + 8 * q);
+                        if (NORM) NW[(d + 1) & 1] = ld16(a.norm_w + (wave + (t + 1) * GEMM_WAVES) * 32 + 8 * q);
                     }
-                    if (PRO == 2) {
+                    if (NORM) {
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) X[d & 1][i] = xnorm_frag(X[d & 1][i], NW[d & 1], rstd[i]);
+                        for (int i = 0; i < MT; ++i) X[d & 1][i] = DEFER ? xw_frag(X[d & 1][i], NW[d & 1]) : xnorm_frag(X[d & 1][i], NW[d & 1], rstd[i]);
                     }
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
@@ -315,6 +327,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 if (EPI == OMNI_EPI_SILU_MUL) sum2 += lds4[(w * (NT * MT) + (NT / 2 + j) * MT + i) * 64 + l];
                 if (GU8) sum2 += lds4[(w * (NT * MT) + j * MT + i) * 64 + l + 32];
             }
+            if (DEFER) {
+                // rstd of this item's row: the eight wave partials of the slab reduction, in wave order (the combine barrier covered them)
+                const float* red = lds + GEMM_WAVES * NT * MT * 4 * 64;
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < GEMM_WAVES; ++w) tsum += red[w * 64 + ml];
+                const float rl = 1.0f / sqrtf(tsum / (float)K + a.eps);
+                sum *= rl;
+                if (SILU) sum2 *= rl;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) { v[g] = sum[g]; v2[g] = sum2[g]; }
         }
@@ -372,8 +394,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
 }
 
 
-OMNI_KNOB g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1, g_gemm_stage = 0;
+OMNI_KNOB g_gemm_nt = 1, g_gemm_wgs = 256, g_tile_nt = 0, g_tile_mt = 0, g_gemm_counted = 1, g_gemm_stage = 0, g_gemm_defer = 1;
 #ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_gemm_defer(int on) { g_gemm_defer = on; }          // 0: round 5's exact rstd in every norm-fused GEMM of the launch path (the chains have their own knobs)
 extern "C" void omni_debug_gemm_stage(int stage) { g_gemm_stage = stage; }   // leave every GEMM kernel after stage N (timing only: results are garbage)
 extern "C" void omni_debug_set(int nt, int rn, int wgs) { g_gemm_counted = rn ? 0 : 1; g_gemm_nt = nt & 1; g_gemm_wgs = wgs; }   // rn != 0: generic schedule
 extern "C" void omni_debug_tile(int nt, int mt) { g_tile_nt = nt; g_tile_mt = mt; }   // 0 = policy default
@@ -384,7 +407,7 @@ static int launch_gemm(const GemmArgs& a_in, int m_splits, hipStream_t st) {
     GemmArgs a = a_in;
     a.dbg_stage = g_gemm_stage;
     const int groups = (EPI == OMNI_EPI_SILU_MUL || EPI == OMNI_EPI_SILU_MUL_GU8) ? a.N / (8 * NT) : a.N / (16 * NT);
-    size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float) + (PRO == 2 ? GEMM_WAVES * 64 * sizeof(float) : 0);
+    size_t lds = (size_t)GEMM_WAVES * NT * MT * 4 * 64 * sizeof(float) + (PRO >= 2 ? GEMM_WAVES * 64 * sizeof(float) : 0);
     if (lds > 65536) {   // NT = 4, MT = 4: 128 KB of the CU's 160 KB (one workgroup per CU)
         static bool done_t = false, done_f = false;
         if (!done_t) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT, NT, PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); done_t = true; }
@@ -442,7 +465,7 @@ static void pick_tile(int pro, int epi, const GemmArgs& a, int* nt_out, int* mt_
 template <int PRO, int EPI>
 static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
     int nt, mt, splits;
-    pick_tile(PRO, EPI, a, &nt, &mt, &splits);
+    pick_tile(PRO == 3 ? 2 : PRO, EPI, a, &nt, &mt, &splits);      // the deferred-rstd form takes the norm-fused tiles
 #define TILE(N_, M_) if (nt == N_ && mt == M_) return launch_gemm<M_, N_, PRO, EPI>(a, splits, st);
 #define TILE_M(N_) TILE(N_, 1) TILE(N_, 2) TILE(N_, 4)
     if constexpr (EPI == OMNI_EPI_SILU_MUL) { TILE_M(2) TILE_M(4) }
@@ -480,7 +503,8 @@ static int dispatch_epi(const GemmArgs& a, int epilogue, hipStream_t st) {
             if constexpr (PRO == 0) return dispatch_tile<0, OMNI_EPI_F32>(a, st);
             break;
         case OMNI_EPI_F32_BF16RND:
-            return dispatch_tile<PRO, OMNI_EPI_F32_BF16RND>(a, st);
+            if constexpr (PRO != 3) return dispatch_tile<PRO, OMNI_EPI_F32_BF16RND>(a, st);
+            break;
         case OMNI_EPI_RESID:
             if constexpr (PRO == 0) return dispatch_tile<0, OMNI_EPI_RESID>(a, st);
             break;
@@ -576,6 +600,9 @@ int k_gemm_xnorm(const void* r, const float* partials, int nparts, const void* n
                    epilogue == OMNI_EPI_F32_BF16RND, "omni_gemm_xnorm: epilogue %d unsupported", epilogue);
     OMNI_CHECK_ARG(!a.oshuf || (epilogue != OMNI_EPI_F32_BF16RND && N % 32 == 0),
                    "omni_gemm_xnorm: fragment-major output needs a bf16 epilogue and N %% 32 == 0");
+    // deferred rstd (PRO 3) where the normalised rows are nobody's output and the epilogue is a bf16 one: qkv, gate_up -- the rule of the
+    // persistent chains (cp_chain.hip, bb_chain.hip, moe_chain.hip), so that both schedules produce the same bits
+    if (g_gemm_defer && normed_out == nullptr && epilogue != OMNI_EPI_F32_BF16RND) return dispatch_epi<3>(a, epilogue, (hipStream_t)stream);
     return dispatch_epi<2>(a, epilogue, (hipStream_t)stream);
 }
 extern "C" int omni_gemm_xnorm(const void* r, const float* partials, int nparts, const void* norm_w, float eps,

@@ -46,6 +46,29 @@ __device__ __forceinline__ u32x4 xw_frag(u32x4 v, u32x4 nw) {
     return v;
 }
 
+// ---- the sum(r^2) slabs of a row -> one wave partial, in an order that does NOT depend on the rows per tile (round 6: with the rstd applied to
+// the fp32 sums -- PRO 3 -- a last-bit difference of rstd between two tile shapes shows in the outputs; the chains and the launch path may
+// pick different row tiles for the same GEMM, e.g. the pair pass below 64 rows).  Canonical order for np <= 128 slabs: wave w owns slabs
+// w + 8 k (k < 16); quarter j of them (k = j + 4 i) is summed in ascending i; the wave's partial is (q0 + q1) + (q2 + q3); the row total is the
+// eight wave partials in wave order.  A wave holds CPW = 64 / XROWS sub-channels per row (lane / XROWS): each sums 4 / CPW quarters, the
+// butterfly steps (lane ^ 32, lane ^ 16) pair them as the formula does.
+template <int XROWS>
+struct SlabOrder {
+    static_assert(XROWS == 16 || XROWS == 32 || XROWS == 64, "slab reduction: 16-, 32- or 64-row tiles");
+    static constexpr int CPW = 64 / XROWS, QPS = 4 / CPW, PE = 4 * QPS;
+    // slab index of entry e of sub-channel `sub` of wave `wave`
+    static __device__ __forceinline__ int index(int wave, int sub, int e) { return wave + 8 * ((sub * QPS + e / 4) + 4 * (e % 4)); }
+    static __device__ __forceinline__ float reduce(const float (&pv)[PE]) {
+        float q[QPS];
+#pragma unroll
+        for (int j = 0; j < QPS; ++j) q[j] = ((pv[4 * j] + pv[4 * j + 1]) + pv[4 * j + 2]) + pv[4 * j + 3];
+        float s_ = QPS == 4 ? (q[0] + q[1]) + (q[QPS - 2] + q[QPS - 1]) : (QPS == 2 ? q[0] + q[QPS - 1] : q[0]);
+        if (CPW == 4) s_ = xor16_sum(s_);        // sub-channels 0 | 1 and 2 | 3 first: (q0 + q1), (q2 + q3)
+        if (CPW >= 2) s_ = xor32_sum(s_);        // ... then the two halves of the wave
+        return s_;
+    }
+};
+
 // SiLU(gate) * up with the bf16 rounding points of HF's bf16 modules (each op rounds)
 __device__ __forceinline__ float silu_mul_bf16(float gate_acc, float up_acc) {
     const float gt = bfround(gate_acc);

@@ -111,16 +111,6 @@ int k_bb_all_set_scales(void* table_dev, int layers, const float* k, const float
 bool k_bb_all_supported(const omni_talker_desc& d, int B, bool has_ar);
 int k_bb_all(const omni_talker_desc& d, const void* table_dev, const omni_step_io* io, void* attn, void* resid, float* part, void* act, void* qkv,
              uint32_t* flags, int32_t* err, void* stream);
-// the same segment with the operand streams on different waves (bb_xw.hip): 8 compute waves stream weights into registers, 4 service
-// waves poll, fetch + normalise the activations into an LDS ring, combine, store and publish
-bool k_bb_xw_enabled();
-int k_bb_xw(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-            int B, float eps, uint32_t* flags, int32_t* err, void* stream);
-// the same segment with its stages dealt to two alternating 4-wave groups of a workgroup (bb_pp.hip): one group's weight stream
-// covers the other group's hand-off
-bool k_bb_pp_enabled();
-int k_bb_pp(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-            int B, float eps, uint32_t* flags, int32_t* err, void* stream);
 // the same segment as a loader / consumer engine (bb_engine.hip): 4 extra waves stream the weights into an LDS FIFO by LDS-DMA
 bool k_bb_engine_enabled();
 int k_bb_engine(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,

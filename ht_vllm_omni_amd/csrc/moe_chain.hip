@@ -99,7 +99,7 @@ __global__ __launch_bounds__(CH_THREADS) void moe_chain_kernel(const MoeChainArg
     chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 63, wg >> 6, lds, g, false, 0x2001,
                                            nullptr);
     if (wg < 192)            // shared expert gate_up: 48 column groups of 16 activation columns x 4 row groups
-        chain_gemm<1, 2, 4, 2, OMNI_EPI_SILU_MUL>(a.sgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, IS, a.eps, wg % 48, wg / 48, lds, g, true,
+        chain_gemm<1, 2, 4, 3, OMNI_EPI_SILU_MUL>(a.sgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, IS, a.eps, wg % 48, wg / 48, lds, g, true,
                                                   0x2002, nullptr);
     else if (wg < 224)       // router: 8 column groups x 4 row groups; column group x also writes k-steps x, x + 8, ... of the normalised rows
         chain_gemm<1, 1, 4, 2, OMNI_EPI_BF16>(a.router, a.ln2, a.resid, a.part, H / 16, a.logits, E, nullptr, a.B, E, a.eps, (wg - 192) & 7, (wg - 192) >> 3,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(CH_THREADS) void moe_tail_kernel(const MoeTailArgs 
         chain_gate_skip(g);
     }
     if (wg < 160)                        // stage 0x2102: the next layer's qkv, 40 column groups of 64 x 4 row groups
-        chain_gemm<1, 4, 4, 2, OMNI_EPI_BF16>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg % 40, wg / 40, lds, g,
+        chain_gemm<1, 4, 4, 3, OMNI_EPI_BF16>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg % 40, wg / 40, lds, g,
                                               true, 0x2102, nullptr);
     else
         chain_gate_skip(g);

@@ -76,6 +76,35 @@ def make_weights(d: TalkerDims, seed: int = 1234, std: float = 0.02, norm_noise:
     return w
 
 
+def peak_predictor_heads(d: TalkerDims, w: dict[str, torch.Tensor], gamma: float = 2.0, stream_gain: float = 20.0,
+                         seed: int = 99) -> dict[str, torch.Tensor]:
+    """A copy of `w` whose code-predictor heads have a CLEAR greedy winner for every input (N(0, std) heads give flat
+    logits -- a quarter of all 15-group frames leave the oracle's greedy path at a <= 3-ulp tie, and a kernel bug that only moves
+    low-margin picks would hide there).  Head g (the group-g logits, read at buffer position g) gets, on row perm_g[c], `gamma` times the unit
+    direction of the projected INPUT embedding of code c at that position -- embed[c] for g = 1, cp.embed[g - 2][c] after that -- on top of
+    its N(0, std) row, and the input projection is scaled by `stream_gain` so that the input's own direction is still a quarter of the
+    residual stream behind the five layers (unscaled, the first sub-layer's output is 30 x the input and the direction is gone): the winner
+    of group g is perm_g[code of group g - 1] with a margin of tens of bf16 ulps (measured on the oracle: >= 19 at 64 rows x 15 groups),
+    still a function of the row's input, still through every stage of every pass, the layers still three quarters of what the head reads.
+    Values stay bf16-exact (rounded once here); everything else is shared with `w`."""
+    if not d.has_cp_projection:
+        raise ValueError("peak_predictor_heads: built for predictors with an input projection (cp_hidden != hidden)")
+    g = torch.Generator().manual_seed(seed)
+    out = dict(w)
+    out["cp.proj_w"] = (w["cp.proj_w"].float() * stream_gain).to(torch.bfloat16)
+    head = w["cp.lm_head"].float().clone()
+    for grp in range(1, d.num_code_groups):
+        tab = (w["embed"][: d.codebook] if grp == 1 else w["cp.embed"][grp - 2]).float()
+        # the code's OWN direction: the projection's bias and the table's mean are common to every code
+        x = tab @ out["cp.proj_w"].float().T
+        x = x - x.mean(dim=0, keepdim=True)
+        x = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        perm = torch.randperm(d.codebook, generator=g)
+        head[grp - 1, perm] += gamma * x
+    out["cp.lm_head"] = head.to(torch.bfloat16)
+    return out
+
+
 def weight_bytes(d: TalkerDims) -> dict[str, int]:
     """Algorithmic weight bytes read once per talker step."""
     if d.moe_experts > 0:      # every expert counted once (T * k = 512 assignments over 128 experts hit ~98 % of them) + shared + router

@@ -21,17 +21,15 @@ void omni_debug_bb_all_stamps(void* buf, int layer);       /* uint64 [8][8][256]
 void omni_debug_chain_defer(int on);                       /* code-predictor chain A/B arm: RMSNorm rstd applied in the qkv / gate_up epilogues (another rounding point than the reference's; timing + accuracy experiments) */
 void omni_debug_chain_pair(int on);                        /* code predictor: positions 0 / 1 + group 1's head and sampler as one persistent launch (cp_pair_kernel) */
 void omni_debug_chain_skip(int mode);                      /* code-predictor chain timing experiment: 1 = fetch half of every weight slice, 2 = half of the activations, 4 = the polling wave fetches no weights, 5 = no wave does (garbage results) */
-void omni_debug_bb_xw(int on);                             /* backbone segment with weights and activations on different waves (bb_xw.hip) */
 void omni_debug_bb_min_rows(int rows);                     /* backbone chain: smallest batch the 64-row stage set takes (33 since round 5; 49: round 4's policy, 33-48 rows launch per op) */
 void omni_debug_moe_chain(int on);                         /* sparse-MoE layer: o_proj -> router | shared gate_up -> shared down + routing as one persistent launch (moe_chain.hip) */
 void omni_debug_pa_tail(int on);                           /* decode attention: the last, partial 128-token round as contiguous 32-token chunks per wave (0: interleaved groups) */
 void omni_debug_bb_deep(int mode);                         /* backbone chain arms: 1-3 deeper rings, 4 two-pass gate_up combine, 5 gate_up weights ahead of the flags, 6 rstd in the epilogue, 7-9 nt weight loads (gate_up / o+down+qkv / all) */
 void omni_debug_sample_wave(int on);                       /* row sampler: 1 = one wave per row (smp_pick_wave, round 6) where eligible, 0 = always the 4-wave sample_kernel */
-void omni_debug_bb_pp(int on);                             /* backbone segment on two alternating wave groups (bb_pp.hip); 0 = the plain chain */
-void omni_debug_pp_stamps(void* buf);                      /* int64 [4][8][256] timeline stamps of the two-group chain (scripts/bb_timeline.py) */
 void omni_debug_bb_engine(int on);                         /* backbone segment as the loader / consumer engine (bb_engine.hip) instead of the plain chain */
 void omni_debug_eng_stamps(void* buf);                     /* stage stamps of the engine's compute wave 0 */
 void omni_debug_bb_stamps(void* buf);                      /* as omni_debug_chain_stamps for the backbone segment launches */
+void omni_debug_gemm_defer(int on);                         /* launch path: 1 = rstd of the qkv / gate_up GEMMs applied in the epilogue (round 6 default, the chains' arithmetic), 0 = round 5's exact form */
 void omni_debug_gemm_stage(int stage);                      /* leave every GEMM kernel after stage 1..4 (timing attribution only) */
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
 void omni_debug_small_tiny(int on);                         /* code-predictor attention: the (token, quarter) / readlane kernel */

@@ -523,8 +523,10 @@ class TalkerOracle:
             codes[:, g] = nxt
             if g < Q - 1:
                 buf[:, g + 1] = self.cp_project(w["cp.embed"][g - 1][nxt])
+        # (test infrastructure: the group logits of the last call, for the near-tie check of a forked greedy frame)
+        self.last_cp_logits = torch.stack(all_logits, 1) if all_logits else None
         if return_logits:
-            return codes, torch.stack(all_logits, 1)
+            return codes, self.last_cp_logits
         return codes
 
     def talker_mtp(self, input_ids: torch.Tensor, input_embeds: torch.Tensor, last_hidden: torch.Tensor,

@@ -12,9 +12,8 @@ torch.cuda.set_device(0)
 d, w, eng = bench.build_engine(args, 0, 1)
 lib = eng.lib
 _mode = os.environ.get("BB_STAMPS", "eng")
-for _k, _v in (("bb_engine", int(_mode == "eng")), ("bb_pp", int(_mode == "pp"))):
-    _f = getattr(lib, "omni_debug_" + _k); _f.argtypes = [C.c_int]; _f.restype = None
-    _f(_v)
+_f = lib.omni_debug_bb_engine; _f.argtypes = [C.c_int]; _f.restype = None      # BB_STAMPS=bb: the plain chain, eng: the loader / consumer engine
+_f(int(_mode == "eng"))
 eng.set_sampling(greedy=0, temperature=0.9, top_k=50, rep_penalty=1.05, seed=42, cp_greedy=0, cp_temperature=0.9, cp_top_k=50)
 bench.setup_requests(d, eng, args)
 B = 64

@@ -57,8 +57,11 @@ def test_chain_is_bit_identical_to_the_launch_chain(model, B, mode):
             lib.omni_debug_cp_chain(2)
             lib.omni_debug_chain_mode(7, 1, 1)
     if mode[2] == 0 and B > 32:          # other summation order of the norm statistics: equal to rounding, not to the bit
-        assert_e2e_close(res[1][1], res[0][1], mean_tol=2e-3, max_ulps=3, what="wide gate_up tile vs launch chain")
-        assert (res[1][0] == res[0][0]).all(dim=1).float().mean().item() >= 0.8
+        # (rows whose greedy codes forked at a near-tie read other inputs from that group on: the logits are compared on the rows that stayed
+        #  together -- until round 6 no row of this seed forked and the comparison silently covered all of them)
+        same = (res[1][0] == res[0][0]).all(dim=1)
+        assert same.float().mean().item() >= 0.8
+        assert_e2e_close(res[1][1][same], res[0][1][same], mean_tol=2e-3, max_ulps=3, what="wide gate_up tile vs launch chain")
         return
     bad = (res[1][0] != res[0][0]).any(dim=1).nonzero().flatten().tolist()
     assert torch.equal(res[1][0], res[0][0]), f"greedy codes differ between the persistent chain and the launch chain in rows {bad}: first differing group per row {[int((res[1][0][b] != res[0][0][b]).nonzero()[0]) for b in bad]}"
@@ -96,27 +99,24 @@ def _decode_engine(d, w, B, kv="fp8"):
     return eng
 
 
-@pytest.mark.parametrize("mode", ["engine", "plain-chain", "ping-pong", "split-roles", "deep-rings"])
+@pytest.mark.parametrize("mode", ["engine", "plain-chain", "deep-rings"])
 @pytest.mark.parametrize("B,kv", [(64, "fp8"), (49, "bf16")])
 def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
     """o_proj -> gate_up -> down_proj -> next qkv as one persistent launch per layer against the launch-per-op backbone of the
     same library at the 1.7B shape.  The plain chain (csrc/bb_chain.hip) and the loader / consumer engine (bb_engine.hip) keep
     the launch path's tiles and summation order: logits, hidden state, sampled ids, codes and every KV byte of three decode
-    steps are identical.  The two-group chain (bb_pp.hip, an A/B arm, off by default) sums its K-partials over 4 waves instead of 8: first
-    step within accumulation-order rounding of the launch path, the same sampled ids in nearly every row.  No flag wait
-    times out in any mode."""
+    steps are identical.  (Rounds 3's two-group and split-role arms -- bb_pp.hip, bb_xw.hip: both lost -- left the tree in round 6, when
+    the deferred rstd became the product arithmetic; NOTEBOOK "Round 3" keeps their measurements.)  No flag wait times out in any mode."""
     d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
     w = make_weights(d, seed=8, std=0.02)
     res = {}
     with L.debug_library() as lib:
-        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_engine, lib.omni_debug_bb_pp, lib.omni_debug_bb_xw, lib.omni_debug_bb_deep):
+        for fn in (lib.omni_debug_bb_chain, lib.omni_debug_bb_engine, lib.omni_debug_bb_deep):
             fn.argtypes = [C.c_int]; fn.restype = None
         try:
             for on in (0, 1):
                 lib.omni_debug_bb_chain(on)
                 lib.omni_debug_bb_engine(int(mode == "engine"))
-                lib.omni_debug_bb_pp(int(mode == "ping-pong"))
-                lib.omni_debug_bb_xw(int(mode == "split-roles"))
                 lib.omni_debug_bb_deep(int(mode == "deep-rings"))
                 eng = _decode_engine(d, w, B, kv)
                 outs = []
@@ -129,20 +129,7 @@ def test_backbone_segment_chain_against_the_launch_path(B, kv, mode):
         finally:
             lib.omni_debug_bb_chain(1)
             lib.omni_debug_bb_engine(0)
-            lib.omni_debug_bb_pp(0)
-            lib.omni_debug_bb_xw(0)
             lib.omni_debug_bb_deep(0)
-    if mode == "ping-pong":
-        (lg1, h1, ids1, _), (lg0, h0, ids0, _) = res[1][0][0], res[0][0][0]
-        # (the two 32-row groups run the attention with KV splits, the 64-row launch path without: another order of additions.  The
-        #  bound is on rounding-level agreement, widened from 3 to 4 ulps when the QK product went to dimension pairs in round 4)
-        assert_e2e_close(h1.cpu(), h0.cpu(), mean_tol=3e-3, max_ulps=4, what="two-group chain vs launch path: hidden, step 0")
-        fin = torch.isfinite(lg0.cpu()).all(0)
-        assert_e2e_close(lg1.cpu()[:, fin], lg0.cpu()[:, fin], mean_tol=3e-3, max_ulps=8, what="two-group chain vs launch path: logits, step 0")
-        assert (ids1 == ids0).float().mean().item() >= 0.9
-        for l, (x, y) in enumerate(zip(res[1][1], res[0][1])):
-            assert (x != y).float().mean().item() < 0.02, f"KV cache of layer {l}: more than rounding-level differences"
-        return
     for s, (a, b) in enumerate(zip(res[1][0], res[0][0])):
         for name, x, y in zip(("logits", "hidden", "ids", "codes"), a, b):
             assert torch.equal(x, y), f"step {s}: {name} differ between the backbone chain and the launch path"
