@@ -165,12 +165,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 
     float rstd[MT];
     float* red = lds + CH_WAVES * ((NT * MT > 6 && !ONEPASS) ? NT * MT / 2 : NT * MT) * 4 * 64;      // behind the combine slots
-    if (NORM) {
-        // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
-        const float s_ = SO::reduce(pv);
-        red[wave * 64 + lane] = s_;
-    }
     if (PRO == 2) {
+        // fixed-order reduction of the slabs -> rstd of this workgroup's rows (gemm.hip xnorm_rstd, same order of additions)
+        red[wave * 64 + lane] = SO::reduce(pv);
         chain_barrier(g);
         float t = 0.f;
 #pragma unroll
@@ -179,6 +176,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
 #pragma unroll
         for (int i = 0; i < MT; ++i) rstd[i] = __shfl(rl, i * 16 + (lane & 15), 64);
     }
+    // (PRO 3: the slab loads went out ahead of the activation loads and returned ahead of them; their reduction waits behind the MFMA loop,
+    //  where nothing is stalled on it -- written there, not left to the scheduler: the register pins of SlabOrder::reduce fix its place)
 
     CH_STAMP(stamps, sidx, 3);                                           // 3: rstd known (slabs arrived, reduced)
     f32x4 acc[NT][MT];
@@ -222,6 +221,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         if (WFIFO) eng_release(g, wave, g.piece_base + (unsigned)(d + 1) * (8 * NT));      // the MFMAs above hold the fragments: the pieces are free
     }
 
+    if (DEFER) red[wave * 64 + lane] = SO::reduce(pv);      // the row statistics: read behind the combine barrier, by the epilogue
     // ---- combine the 8 K-partials through LDS (wave order 0..7), epilogue with write-through stores.  More than 6 tiles (the
     // backbone's gate_up: 12) go through the combine area in two passes of NT * MT / 2 tiles, so that it stays at 48 KB
     constexpr int PASSES = (NT * MT > 6 && !ONEPASS) ? 2 : 1, TP = NT * MT / PASSES;

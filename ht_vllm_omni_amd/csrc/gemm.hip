@@ -196,7 +196,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                 for (int i = 0; i < MT; ++i) Xq[d][i] = ld16(xrow[i] + ks * xstep);
                 if (NORM) NWq[d] = ld16(a.norm_w + ks * 32 + 8 * q);
             }
-            if (NORM) xnorm_rstd();
+            if (PRO == 2) xnorm_rstd();
             const int G = ntw / P;
             for (int g = 0; g + 1 < G; ++g) {
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
             for (int i = 0; i < MT; ++i) X[0][i] = ld16(xrow[i] + wave * xstep);
             if (NORM) NW[0] = ld16(a.norm_w + wave * 32 + 8 * q);
         }
-        if (NORM) xnorm_rstd();
+        if (PRO == 2) xnorm_rstd();
         for (int t0 = 0; t0 < ntw; t0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
         }
     }
 
+    if (DEFER) xnorm_rstd();      // PRO 3: the slab reduction behind the MFMA loop (its loads returned ahead of the operands'); read by the epilogue
     DBG_STAGE(3);                                                  // 3: + main loop (operand loads, normalisation, MFMA)
     // the normalised rows themselves (h[t+1] of the final norm) leave row-major, spread over the n groups: workgroup column x
     // re-reads the (L2-hot) fragments of k-steps x, x + gridDim.x, ... of its rows -- a second pass kept out of the main loop so

@@ -298,19 +298,7 @@ class TalkerEngine:
                 setattr(self._cp_layers[i], n, lw[n].data_ptr())
 
         # ---- paged KV cache, one tensor per layer: [2, num_blocks, block_size, Hkv_local, D]
-        store = {"bf16": BF16, "auto": BF16, "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8, "fp16": torch.float16,
-                 "float16": torch.float16, "half": torch.float16}[kv_dtype]
-        shape = (2, num_blocks, block_size, self.hkv_l, d.head_dim)
-        self.kv_caches = [torch.zeros(shape, dtype=store, device=dev) for _ in range(d.layers)]
-        self.kv_scales = ([torch.zeros(shape[:-1], dtype=torch.float32, device=dev) for _ in range(d.layers)]
-                          if self.kv_code == L.KV_INT8 else None)
-        self._kc = (C.c_void_p * d.layers)(*[c[0].data_ptr() for c in self.kv_caches])
-        self._vc = (C.c_void_p * d.layers)(*[c[1].data_ptr() for c in self.kv_caches])
-        if self.kv_scales is not None:
-            self._ks = (C.c_void_p * d.layers)(*[s[0].data_ptr() for s in self.kv_scales])
-            self._vs = (C.c_void_p * d.layers)(*[s[1].data_ptr() for s in self.kv_scales])
-        else:
-            self._ks = self._vs = None
+        self._alloc_kv(num_blocks)
 
         # ---- descriptor + scratch + native engine
         desc = L.TalkerDesc()
@@ -345,6 +333,7 @@ class TalkerEngine:
         # V/worker/gpu_ar_model_runner.py:122,269-275): the FIRST prefill pass of this engine sets k = max|k| / 200, v = max|v| / 100 per
         # layer from its own tokens, before its cache write (oracle: talker_oracle.TalkerOracle(calculate_kv_scales=True))
         self.k_scale_l, self.v_scale_l = [float(k_scale)] * d.layers, [float(v_scale)] * d.layers
+        self._calibrate_requested = bool(calculate_kv_scales)
         self.calibrate_pending = bool(calculate_kv_scales) and self.kv_code == L.KV_FP8
         desc.masked_logit = float(masked_logit)      # 0: -inf (TTS); -1e9: the Omni talker's finite suppression value
         desc.embed, desc.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
@@ -435,6 +424,78 @@ class TalkerEngine:
                              cp_temperature=0.9, cp_top_k=50, cp_top_p=1.0)
         self._attn_out = self._scratch_view(self.lib.omni_talker_attn_out(self.handle), Bm * H).view(Bm, H)
         self._mlp_out = self._scratch_view(self.lib.omni_talker_mlp_out(self.handle), Bm * H).view(Bm, H)
+
+    def _alloc_kv(self, num_blocks: int) -> None:
+        d, dev = self.d, self.device
+        store = {"bf16": BF16, "auto": BF16, "fp8": torch.uint8, "fp8_e4m3": torch.uint8, "int8": torch.int8, "fp16": torch.float16,
+                 "float16": torch.float16, "half": torch.float16}[self.kv_dtype]
+        shape = (2, num_blocks, self.block_size, self.hkv_l, d.head_dim)
+        self.num_blocks = num_blocks
+        self.kv_caches = [torch.zeros(shape, dtype=store, device=dev) for _ in range(d.layers)]
+        self.kv_scales = ([torch.zeros(shape[:-1], dtype=torch.float32, device=dev) for _ in range(d.layers)]
+                          if self.kv_code == L.KV_INT8 else None)
+        self._kc = (C.c_void_p * d.layers)(*[c[0].data_ptr() for c in self.kv_caches])
+        self._vc = (C.c_void_p * d.layers)(*[c[1].data_ptr() for c in self.kv_caches])
+        if self.kv_scales is not None:
+            self._ks = (C.c_void_p * d.layers)(*[s[0].data_ptr() for s in self.kv_scales])
+            self._vs = (C.c_void_p * d.layers)(*[s[1].data_ptr() for s in self.kv_scales])
+        else:
+            self._ks = self._vs = None
+
+    def kv_cache_bytes(self) -> int:
+        return sum(c.numel() * c.element_size() for c in self.kv_caches) + sum(s.numel() * 4 for s in (self.kv_scales or []))
+
+    def resize_kv_cache(self, num_blocks: int) -> None:
+        """Replace the paged KV cache by one of `num_blocks` blocks, keeping weights, scratch and every per-step buffer: the worker
+        measures the process's footprint on a probe cache first (worker.determine_available_memory), then sizes the real one.  The native
+        engine is re-created on the same descriptor (its cache pointers are creation-time constants); call before any graph capture."""
+        if self.n_sub > 1:
+            raise L.OmniError("resize_kv_cache: single-handle engines only")
+        self.lib.omni_talker_destroy(self.handle)
+        self.handle = None
+        self.kv_caches = self.kv_scales = None
+        torch.cuda.empty_cache()
+        self._alloc_kv(int(num_blocks))
+        pvp = C.POINTER(C.c_void_p)
+        self._desc.k_cache, self._desc.v_cache = C.cast(self._kc, pvp), C.cast(self._vc, pvp)
+        if self._ks is not None:
+            self._desc.k_scales, self._desc.v_scales = C.cast(self._ks, pvp), C.cast(self._vs, pvp)
+        self.scratch.zero_()
+        self.handle = self.lib.omni_talker_create(C.byref(self._desc))
+        if not self.handle:
+            raise L.OmniError("omni_talker_create: " + self.lib.omni_last_error().decode())
+        self._op_handle = None
+        self.calibrate_pending = bool(getattr(self, "_calibrate_requested", False)) and self.kv_code == L.KV_FP8
+
+    def profile_run(self, num_tokens: int, batch: int) -> None:
+        """The worker's memory probe (V/worker/base.py:118-123 `profile_run`): one prefill of `num_tokens` synthetic prompt tokens spread
+        over `batch` requests and one decode step at `batch` rows, so that every workspace, code object and allocator pool the steps
+        need exists when the footprint is read.  The probe cache must hold the tokens; its contents are garbage afterwards."""
+        d, bs = self.d, self.block_size
+        batch = max(1, min(batch, self.max_batch))
+        per = max(1, min(num_tokens // batch, d.max_model_len - 2, (self.num_blocks - 1) // batch * bs - 1))
+        lens = [per] * batch
+        bt = torch.zeros(self.max_batch, self.bt_stride, dtype=torch.int32)
+        nxt = 1
+        for r, n in enumerate(lens):
+            need = (n + 1 + bs - 1) // bs
+            bt[r, :need] = torch.arange(nxt, nxt + need, dtype=torch.int32)
+            nxt += need
+        self.block_table.copy_(bt)
+        T = sum(lens)
+        x = torch.zeros(T, d.hidden, dtype=BF16, device=self.device)
+        pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32)
+        req = torch.cat([torch.full((n,), r) for r, n in enumerate(lens)]).to(torch.int32)
+        slots = torch.tensor([int(bt[int(req[t]), int(pos[t]) // bs]) * bs + int(pos[t]) % bs for t in range(T)])
+        cal, self.calibrate_pending = self.calibrate_pending, False          # the probe must not fix the fp8 scales
+        self.prefill(x, pos.to(self.device), req.to(self.device), slots.to(self.device))
+        self.positions[:batch] = per
+        self.seq_lens[:batch] = per + 1
+        self.decode_step(batch)
+        torch.cuda.synchronize(self.device)
+        self.calibrate_pending = cal
+        for t in (self.positions, self.seq_lens, self.steps, self.seen, self.block_table, self.input_ids):
+            t.zero_()
 
     def split_out_record(self, rec: torch.Tensor):
         """(ids + 4 status words [Bm + 4] int32, audio codes [Bm, Q] int64, h [Bm, H] bf16) as views of an output record --

@@ -172,12 +172,47 @@ class MI355XARWorker:
             check_against_dims(w, self.dims)
         self._weights = w if w is not None else make_weights(self.dims, seed=getattr(self.vllm_config, "seed", 1234))
 
-    # ---- memory (base.py:78-156): bytes available for the KV cache after weights and step scratch
+    # ---- memory (base.py:78-156): bytes available for the KV cache after weights and step scratch -- MEASURED, per process
     def determine_available_memory(self) -> int:
-        wb = weight_bytes(self.dims)
-        resident = wb["backbone"] // self.tp_size + wb["lm_head"] + 2 * wb["code_predictor"] + (1 << 30)
-        budget = int(self.init_total * float(getattr(self.vllm_config, "gpu_memory_utilization", 0.9)))
-        return max(budget - resident - (self.init_total - self.init_free), 0)
+        """requested = total * gpu_memory_utilization; available = requested - what THIS process holds once the model is resident and a
+        profile run (one full prefill chunk + one decode step at max_num_seqs: every workspace, code object and allocator pool) has gone
+        through -- the reference's algorithm (V/worker/base.py:78-156: `memory_profiling` around `profile_run`, then per-PID memory, so that
+        stages initialising concurrently on one device do not book each other's bytes; gpu_memory_utils.py:69-124).  Per-PID bytes come
+        from the KFD's counters (gpu_memory.process_gpu_memory); where they are not readable, from the hipMemGetInfo delta against the
+        init_device snapshot (counts other processes' allocations in between too: conservative).  The engine is built here on a probe
+        cache just large enough for the profile run and keeps its weights; initialize_from_config resizes the cache (engine.resize_kv_cache).
+        `kv_cache_memory_bytes` in the config short-cuts the arithmetic, not the profile run (base.py:103-110)."""
+        from .gpu_memory import kv_cache_budget, process_gpu_memory
+        cfg = self.vllm_config
+        if self.engine is None:
+            tokens = int(getattr(cfg, "max_num_batched_tokens", 8192) or 8192)
+            probe_blocks = (tokens + cfg.block_size - 1) // cfg.block_size + 2 * int(cfg.max_num_seqs) + 2
+            self._build_engine(probe_blocks)
+            self.engine.profile_run(tokens, int(cfg.max_num_seqs))
+        probe_kv = self.engine.kv_cache_bytes()
+        explicit = getattr(cfg, "kv_cache_memory_bytes", None)
+        if explicit:
+            self.available_kv_cache_memory_bytes = int(explicit)
+            return int(explicit)
+        free_now, _ = self._mem_get_info()
+        proc = self._process_memory()
+        self.memory_accounting = "process-scoped (KFD)" if proc is not None else "snapshot delta"
+        if proc is None:
+            proc = max(self.init_free - free_now, 0)
+        self.process_memory_bytes = int(proc)
+        self.available_kv_cache_memory_bytes = kv_cache_budget(self.init_total, float(getattr(cfg, "gpu_memory_utilization", 0.9)), int(proc), probe_kv)
+        logger.info("KV cache budget: %.2f GiB (%s: this process holds %.2f GiB, of it %.2f GiB probe cache; total %.2f GiB)",
+                    self.available_kv_cache_memory_bytes / 2 ** 30, self.memory_accounting, proc / 2 ** 30, probe_kv / 2 ** 30,
+                    self.init_total / 2 ** 30)
+        return int(self.available_kv_cache_memory_bytes)
+
+    def _mem_get_info(self):
+        return torch.cuda.mem_get_info(self.device)
+
+    def _process_memory(self):
+        from .gpu_memory import process_gpu_memory
+        torch.cuda.synchronize(self.device)
+        return process_gpu_memory()
 
     # ---- KV cache spec (vLLM Worker.get_kv_cache_spec -> {layer name: KVCacheSpec}; the executor sizes the cache from the
     # specs' page sizes and hands the result back as a KVCacheConfig, V/worker/base.py:78-156, gpu_ar_model_runner.py:118-124)
@@ -193,8 +228,25 @@ class MI355XARWorker:
     def kv_bytes_per_block(self) -> int:
         return sum(s.page_size_bytes for s in self.get_kv_cache_spec().values())
 
-    def initialize_from_config(self, kv_cache_config: Any = None) -> None:
+    def _build_engine(self, num_blocks: int) -> None:
         from .engine import TalkerEngine
+        cfg = self.vllm_config
+        # tensor-parallel ranks: the all-reduce of the step is a kernel of the step (peer-mapped buffers over hipIpc, fused with
+        # the residual add: tp_comm.py) -- checked against RCCL on random data first, every rank falls back to RCCL
+        # all-reduces between the phase calls if any rank disagrees (the reference's group: gpu_ar_worker.py:69-75)
+        self.peer_allreduce = None
+        if self.tp_size > 1:       # dense and sparse-MoE backbones alike (MoE: omni_moe_experts_resid leaves the rank's partial)
+            from .tp_comm import setup_peer_allreduce
+            self.peer_allreduce = setup_peer_allreduce(self.dims.hidden, min(cfg.max_num_seqs, 64), self.rank, self.tp_size,
+                                                       log=logger.info)
+        self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(num_blocks),
+                                   block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
+                                   tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce,
+                                   calculate_kv_scales=bool(getattr(cfg, "calculate_kv_scales", False)))
+        self._embed_table = self._weights["embed"]
+        self._weights = None
+
+    def initialize_from_config(self, kv_cache_config: Any = None) -> None:
         from .runner import MI355XARModelRunner
         cfg = self.vllm_config
         # a KVCacheConfig-shaped object: .num_blocks, or .kv_cache_tensors = [{size, shared_by: [layer names]}] (one per layer in
@@ -211,20 +263,11 @@ class MI355XARWorker:
             nb = min(per)
         if nb is None:
             nb = max(self.determine_available_memory() // self.kv_bytes_per_block(), 2)
-        # tensor-parallel ranks: the all-reduce of the step is a kernel of the step (peer-mapped buffers over hipIpc, fused with
-        # the residual add: tp_comm.py) -- checked against RCCL on random data first, every rank falls back to RCCL
-        # all-reduces between the phase calls if any rank disagrees (the reference's group: gpu_ar_worker.py:69-75)
-        self.peer_allreduce = None
-        if self.tp_size > 1:       # dense and sparse-MoE backbones alike (MoE: omni_moe_experts_resid leaves the rank's partial)
-            from .tp_comm import setup_peer_allreduce
-            self.peer_allreduce = setup_peer_allreduce(self.dims.hidden, min(cfg.max_num_seqs, 64), self.rank, self.tp_size,
-                                                       log=logger.info)
-        self.engine = TalkerEngine(self.dims, self._weights, kv_dtype=cfg.kv_cache_dtype, num_blocks=int(nb),
-                                   block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
-                                   tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce,
-                                   calculate_kv_scales=bool(getattr(cfg, "calculate_kv_scales", False)))
-        embed_table = self._weights["embed"]
-        self._weights = None
+        if self.engine is not None:          # built (and measured) by determine_available_memory on a probe cache: give it the real one
+            self.engine.resize_kv_cache(int(nb))
+        else:
+            self._build_engine(int(nb))
+        embed_table = self._embed_table
         conn = OmniConnectorFactory.create_connector(cfg.connector) if getattr(cfg, "connector", None) else None
         # Qwen3-Omni talker: config.prompt_builder = {"weights": {text, hidden, codec_embed}, "ids": OmniPromptIds | dict}
         pb_cfg, builder = getattr(cfg, "prompt_builder", None), None

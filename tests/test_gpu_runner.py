@@ -28,8 +28,13 @@ def test_worker_runner_matches_oracle(graphs):
                       enforce_eager=not graphs, default_sampling_params=sp)
     wk = MI355XARWorker(cfg, local_rank=0, rank=0)
     wk.init_device(); wk.load_model()
-    assert wk.determine_available_memory() > 0
+    # measured, per process (round 6): the engine is built on a probe cache and profiled here, resized -- not rebuilt -- below
+    budget = wk.determine_available_memory()
+    probe_engine, probe_blocks = wk.engine, wk.engine.num_blocks
+    assert budget > 0 and wk.memory_accounting in ("process-scoped (KFD)", "snapshot delta") and wk.process_memory_bytes > wk.engine.kv_cache_bytes()
+    assert budget <= wk.init_total and probe_blocks >= 8192 // bs
     wk.initialize_from_config(None)
+    assert wk.engine is probe_engine and wk.engine.num_blocks == nb and wk.engine.kv_caches[0].shape[1] == nb
     conn = InProcConnector()
     wk.model_runner.kv_transfer_manager = OmniKVTransferManager(conn)
     wk.engine.set_sampling(cp_greedy=1)

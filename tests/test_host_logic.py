@@ -637,3 +637,63 @@ def test_kv_transfer_payload_resolved_id_int8_scales_and_tp_slices():
                                              tp_rank=1, tp_size=2)
     obj, _ = c.get("0", "1", "omni_0_to_1_kv_cache_r_tp1")
     assert obj["metadata"]["tp_rank"] == 1 and obj["metadata"]["tp_size"] == 2
+
+
+def test_kv_cache_budget_is_measured_per_process(tmp_path):
+    """the worker's KV budget = total * gpu_memory_utilization - what THIS process holds after the model is resident and a
+    profile run went through (V/worker/base.py:78-156, gpu_memory_utils.py:69-124), not an analytic estimate.  Host logic on fakes: the
+    KFD's per-process counters when they are readable (a neighbour stage's allocations do not shrink the budget), the hipMemGetInfo
+    snapshot delta when they are not (conservative: they do), the probe cache given back, an explicit kv_cache_memory_bytes honoured, the
+    profiled engine resized -- not rebuilt -- by initialize_from_config."""
+    from ht_vllm_omni_amd import gpu_memory as GM
+    from ht_vllm_omni_amd.worker import MI355XARWorker, make_config
+    GiB = 1 << 30
+    # the KFD's per-process files: one per GPU node, summed
+    proc = tmp_path / "proc" / "4242"
+    proc.mkdir(parents=True)
+    (proc / "vram_1001").write_text(f"{7 * GiB}\n")
+    (proc / "vram_1002").write_text("0\n")
+    (proc / "pasid").write_text("32769\n")
+    assert GM.process_gpu_memory(4242, root=str(tmp_path / "proc")) == 7 * GiB
+    assert GM.process_gpu_memory(1, root=str(tmp_path / "proc")) is None
+    assert GM.kv_cache_budget(288 * GiB, 0.9, 7 * GiB, 1 * GiB) == int(288 * GiB * 0.9) - 6 * GiB
+    assert GM.kv_cache_budget(10 * GiB, 0.5, 9 * GiB, 0) == 0
+
+    class _Eng:
+        def __init__(self, nb):
+            self.nb, self.profiled, self.resized = nb, None, None
+        def kv_cache_bytes(self):
+            return self.nb * 1000
+        def profile_run(self, tokens, batch):
+            self.profiled = (tokens, batch)
+        def resize_kv_cache(self, nb):
+            self.resized = nb
+
+    def worker(process_bytes, free_now, **cfg_kw):
+        cfg = make_config("tiny", max_num_seqs=8, gpu_memory_utilization=0.5)
+        for k, v in cfg_kw.items():
+            setattr(cfg, k, v)
+        w = MI355XARWorker(cfg)
+        w.init_free, w.init_total = 90 * GiB, 100 * GiB            # another stage already held 10 GiB when this one started
+        built = []
+        w._build_engine = lambda nb: (built.append(nb), setattr(w, "engine", _Eng(nb)))
+        w._mem_get_info = lambda: (free_now, 100 * GiB)
+        w._process_memory = lambda: process_bytes
+        return w, built
+
+    # per-process counters: this process holds 6 GiB (incl. the probe cache); the neighbour grew by 20 GiB meanwhile -- not ours
+    w, built = worker(6 * GiB, 64 * GiB)
+    got = w.determine_available_memory()
+    probe = built[0] * 1000
+    assert got == 50 * GiB - (6 * GiB - probe) and w.memory_accounting.startswith("process-scoped")
+    assert w.engine.profiled == (8192, 8) and built == [8192 // 16 + 2 * 8 + 2]
+    # no counters: the snapshot delta (26 GiB: ours AND the neighbour's growth) -- smaller, never larger
+    w2, _ = worker(None, 64 * GiB)
+    assert w2.determine_available_memory() == 50 * GiB - (26 * GiB - probe) and w2.memory_accounting == "snapshot delta"
+    # explicit kv_cache_memory_bytes: honoured, the profile run still happens
+    w3, _ = worker(6 * GiB, 64 * GiB, kv_cache_memory_bytes=3 * GiB)
+    assert w3.determine_available_memory() == 3 * GiB and w3.engine.profiled is not None
+    # a second call does not rebuild or re-profile
+    eng = w.engine
+    w.determine_available_memory()
+    assert w.engine is eng and len(built) == 1
