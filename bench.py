@@ -149,7 +149,7 @@ def cpu_baseline(d, w, args, lens):
     O.clear_weight_cache()
     used = torch.get_num_threads()
     torch.set_num_threads(threads0)
-    return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": used, "kind": "port",
+    return {"value": B * n_steps / dt, "unit": "speech-tokens/s", "cores": used, "cores_host": os.cpu_count(), "kind": "port",
             "sample": f"{n_steps} full decode step(s) of the CPU oracle (re-prefill code predictor as in the reference) on "
                       + (f"all {B} requests of the batch" if B == args.batch else f"the first {B} of the {args.batch} requests")
                       + f" (SURVEY 8d's 64 x 32 steps would be ~{32 * dt / n_steps / 60:.1f} min of CPU: bounded to {n_steps} step(s), ~{dt:.0f} s), "
@@ -431,9 +431,24 @@ def main():
             n_ar = 2 * d.layers
             sync()
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # every rank agrees that its buffers exist BEFORE the first lock-step collective: a rank-local failure (an allocation, a bad
+            # error word) must not leave the other ranks waiting in a collective until the RCCL time-out with the measured line lost
+            ok, r_io, slabs, msg = 1, None, None, None
+            try:
+                if eng.ar is not None:
+                    r_io = torch.zeros(eng.ar.rows16, d.hidden, dtype=torch.bfloat16, device="cuda")
+                    slabs = torch.zeros(d.hidden // 16, 64, dtype=torch.float32, device="cuda")
+                    ok = int(eng.ar.error() == 0)
+                else:
+                    msg = torch.zeros(B, d.hidden, dtype=torch.bfloat16, device="cuda")
+            except Exception as e:   # noqa: BLE001
+                log(f"[rank {rank}] all-reduce diagnostic: set-up failed on this rank: {e!r}")
+                ok = 0
+            okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                raise RuntimeError("a rank could not set the diagnostic up: skipped on every rank")
             if eng.ar is not None:
-                r_io = torch.zeros(eng.ar.rows16, d.hidden, dtype=torch.bfloat16, device="cuda")
-                slabs = torch.zeros(d.hidden // 16, 64, dtype=torch.float32, device="cuda")
                 for it in range(4):
                     eng.ar.all_reduce(it & 1, r_io=r_io, accumulate=True, partials=slabs, M=B)
                 a0.record()
@@ -442,7 +457,6 @@ def main():
                 a1.record()
                 kind = "oneshot-xgmi (peer-mapped, fused with residual add)"
             else:
-                msg = torch.zeros(B, d.hidden, dtype=torch.bfloat16, device="cuda")
                 for it in range(4):
                     dist.all_reduce(msg)
                 a0.record()
@@ -630,6 +644,7 @@ def main():
                     out["roofline"]["traffic"] = tj["traffic_bytes_per_step"]
                     out["roofline"]["traffic_ctx"] = tctx
                     out["roofline"]["traffic_note"] = f"bytes/step, PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command ({rel})"
+                    out["roofline"]["traffic_source"] = {"file": rel, "mean_ctx": tctx, "measured_by": "the builder, separate rocprofv3 --pmc passes of this command; not re-measured in this run"}
                 else:
                     out["roofline"]["traffic_other_ctx"] = {"bytes_per_step": tj["traffic_bytes_per_step"], "mean_ctx": tctx, "source": rel}
                 break

@@ -182,7 +182,7 @@ class MI355XARModelRunner:
         self._stage_i = 0
         self._copy_stream = None
         self._pin: dict[str, list] = {}                 # pinned host rings for the dispatch-side H2D copies (async, never blocking)
-        self._pin_i = 0
+        self._pin_i: dict[str, int] = {}          # ring position per call-site key (_h2d)
         self.chain_fallbacks = 0
         # after a fall-back the chains come back once `_rearm_after` launch-path steps went by clean (doubling after every fall-back:
         # a GPU that is shared for good settles on the launch path, a passing neighbour costs one redo) -- ADVICE r4
@@ -665,8 +665,9 @@ class MI355XARModelRunner:
     def _h2d(self, key: str, values, dtype) -> torch.Tensor:
         """A small host array onto the device WITHOUT stalling the host: a pageable source makes the copy wait until the stream
         has drained (measured: profiles/r05_pinned_read_probe.txt -- the host would sit out the step in flight instead of running
-        ahead of it); a pinned source is queued behind it.  One ring of pinned buffers per call site: a buffer is rewritten
-        eight calls later, long after its copy ran (at most two steps are in flight)."""
+        ahead of it); a pinned source is queued behind it.  One ring of pinned buffers AND one ring position per call site (a
+        single shared counter made a key's reuse distance depend on how often the OTHER keys were used): a key's buffer is rewritten
+        eight calls OF THAT KEY later, long after its copy ran (at most two steps are in flight, a key is used at most twice per step)."""
         dev = self.engine.input_ids.device
         arr = np.ascontiguousarray(values)
         if dev.type != "cuda":
@@ -676,8 +677,8 @@ class MI355XARModelRunner:
         if ring is None or ring[0].numel() < n or ring[0].dtype != dtype:
             cap = max(64, 1 << (max(n, 1) - 1).bit_length())
             ring = self._pin[key] = [torch.empty(cap, dtype=dtype).pin_memory() for _ in range(8)]
-        self._pin_i += 1
-        buf = ring[self._pin_i % len(ring)]
+        i = self._pin_i[key] = self._pin_i.get(key, -1) + 1
+        buf = ring[i % len(ring)]
         buf[:n].copy_(torch.from_numpy(arr.reshape(-1)).to(dtype))
         return buf[:n].to(dev, non_blocking=True).reshape(arr.shape)
 

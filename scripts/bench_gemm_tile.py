@@ -35,11 +35,15 @@ def main():
         else:
             a = lambda: ops.gemm_tile(x, wf)
             b = lambda: F.linear(x, w)
+        # (round 6, VERDICT r5 item 8: the DISPATCH line is the one DESIGN quotes -- it used to be timed first, on clocks and caches the later
+        #  tile_hint lines no longer had; every variant of a shape now gets the same discarded warm-up rounds before any of them is timed)
+        for _ in range(3):
+            timed(a, 20); timed(b, 20)
         ta, tb = [], []
         for _ in range(5):
             ta.append(timed(a, 20)); tb.append(timed(b, 20))
         ta, tb = min(ta), min(tb)
-        rows.append((f"prefill {name} M={M} N={N} K={K}", ta, tb, flops))
+        rows.append((f"prefill {name} M={M} N={N} K={K} (dispatch rule)", ta, tb, flops))
         if os.environ.get("HINTS", "0") == "1":            # each tile height of the 256-column geometry (1: 256, 3: 224 rows, the lockstep kernel; 5 / 6 / 7: the two-group kernel at 256 / 224 / 192 rows)
             for hint in (1, 3, 5, 6, 7):
                 h = (lambda hint=hint: ops.gemm_tile(x, wf, act=L.TILE_ACT_SILU_MUL_GU8, tile_hint=hint)) if gu else \
