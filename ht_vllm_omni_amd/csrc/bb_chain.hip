@@ -5,9 +5,15 @@
 // weight slice -- 64-196 KB per workgroup, 32-96 VGPRs per lane -- goes out before the stage's flags, so the HBM stream keeps
 // running through the hand-off instead of stopping for a kernel boundary (1.65 us) plus a cold first fetch; activations
 // cross behind the flags with sc1 accesses.  Tiles = the launch path's (pick_tile at 64 rows), so results are bit-identical.
-// 1.7B shape (hidden 2048, 16 x 128 attention width, intermediate 6144, qkv 4096) at 33-64 rows (round 5: 33-48 rows run the 64-row
-// stage set with their last row tile partly filled -- the launch path picks the same tiles there, gemm.hip pick_tile), 1-32 rows on
-// bb_chain_b32_kernel, the 0.6B shape on bb_chain_small_kernel; every other configuration stays on the launch path.
+// Shapes (round 6: parameters, not literals -- the checkpoint decides them, configuration_qwen3_tts.py:192-216): the stage set is a template
+// on the k-steps per wave of its three reduction widths -- KO = q_heads * 128 / 256 (o_proj), KH = hidden / 256 (gate_up, qkv), KI =
+// intermediate / 256 (down_proj) -- and reads the output widths (hidden, intermediate, qkv) from its arguments; BB_SHAPES lists the
+// instantiated triples: the released 1.7B shape (8, 8, 24) and (6, 6, 18) = hidden 1536 / intermediate 4608 / 12 q heads, a shape no released
+// checkpoint has (tests/test_gpu_chain.py).  A shape runs here when its triple is listed and every stage's tile grid fits the 256
+// workgroups (k_bb_chain_supported); since the rstd moved into the epilogues (PRO 3) and the slab order is canonical (gemm_frag.cuh) the
+// bits no longer depend on which row tiles the launch path picks for the same GEMM.  33-64 rows: bb_chain_kernel (33-48 rows run the 64-row
+// stage set with their last row tile partly filled), 1-32 rows: bb_chain_b32_kernel, the 0.6B shape (hidden 1024 = the code predictor's
+// layer dimensions, 16-row tiles): bb_chain_small_kernel; every other configuration stays on the launch path.
 #include "chain_gemm.cuh"
 #include "common.cuh"
 #include "kernels.h"
@@ -20,7 +26,8 @@ struct BbArgs {
     const uint16_t* attn;               // fragment-major [64][2048]: the attention launch's output
     uint16_t* resid; float* part;       // fragment-major residual stream [64][2048] + sum(r^2) slabs [128][64]
     uint16_t* act;                      // fragment-major [64][6144]
-    uint16_t* qkv;                      // row-major [B][4096]
+    uint16_t* qkv;                      // row-major [B][NQ]
+    int H, I, NQ;                       // output widths: hidden, intermediate, (q_heads + 2 kv_heads) * 128
     int B, nap; float eps;
     uint32_t* flags; int32_t* err;
     unsigned long long* stamps;
@@ -37,7 +44,7 @@ struct BbArgs {
 // round 6 (gemm_skinny_kernel takes it for the same GEMMs); false = round 5's exact-rstd stages, debug library only
 // WNT: bit 0 = non-temporal weight loads in gate_up (every byte read by exactly ONE workgroup), bit 1 = in o_proj / down_proj / qkv (each slice
 // read by the two workgroups of a column tile's row halves) -- round 5 A/B arm (MI355X_MICROARCH "nt-weights")
-template <int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0>
+template <int KO, int KH, int KI, int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -45,39 +52,43 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     g.dom = 8;                          // gate_up's 64-row tiles tie every row group together
     g.nap = a.nap;
     const int wg = blockIdx.x;
-    constexpr int H = 2048, I = 6144, NQ = 4096;
+    const int H = a.H, I = a.I, NQ = a.NQ;
+    // workgroup -> tile: o_proj / down_proj 16 columns x 32 rows, gate_up 24 activation columns x 64 rows, qkv 32 columns x 32 rows; a
+    // workgroup past a stage's grid (column tiles x row tiles < 256 at widths below the 1.7B shape's) publishes the stage and runs ahead
+    const int nc_h = H >> 4, nc_gu = I / 24, nc_q = NQ >> 5;
     // stage codes (error word): 0x1001 .. 0x1004.  Weight registers of the stage AFTER the current one are filled by the current
     // stage (chain_gemm WSRC 3): gate_up's 96 registers during o_proj, down_proj's 96 during gate_up (the allocator reuses
     // gate_up's as its k-steps retire), the next qkv's 64 during down_proj.
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lane16 = lane * 16;
-    u32x4 Wg[8][3], Wd[24][1], Wk[8][2];
-    auto pf_g_ = [&]() {
-        const coh_rsrc_t rs = coh_rsrc(a.wgu);
-#pragma unroll
-        for (int d = 0; d < 8; ++d)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                Wg[d][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)(((wg * 3 + j) * 64 + wave + d * CH_WAVES) * 1024), 0);
-    };
-    auto pf_d_ = [&]() {
-        const coh_rsrc_t rs = coh_rsrc(a.wdown);
-#pragma unroll
-        for (int d = 0; d < 24; ++d) Wd[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)(((wg & 127) * 192 + wave + d * CH_WAVES) * 1024), 0);
-    };
-    auto pf_k_ = [&]() {
-        if (a.wqkv_next == nullptr) return;
-        const coh_rsrc_t rs = coh_rsrc(a.wqkv_next);
-#pragma unroll
-        for (int d = 0; d < 8; ++d)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                Wk[d][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)((((wg & 127) * 2 + j) * 64 + wave + d * CH_WAVES) * 1024), 0);
-    };
-    ChainPrefetch<24, decltype(pf_g_)> pf_g{pf_g_};
-    ChainPrefetch<24, decltype(pf_d_)> pf_d{pf_d_};
-    ChainPrefetch<16, decltype(pf_k_)> pf_k{pf_k_};
     if constexpr (PF) {
+        static_assert(!PF || (KO == 8 && KH == 8 && KI == 24), "the cross-stage prefetch arm (debug library) is built for the 1.7B shape");
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t lane16 = lane * 16;
+        u32x4 Wg[8][3], Wd[24][1], Wk[8][2];
+        auto pf_g_ = [&]() {
+            const coh_rsrc_t rs = coh_rsrc(a.wgu);
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Wg[d][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)(((wg * 3 + j) * 64 + wave + d * CH_WAVES) * 1024), 0);
+        };
+        auto pf_d_ = [&]() {
+            const coh_rsrc_t rs = coh_rsrc(a.wdown);
+#pragma unroll
+            for (int d = 0; d < 24; ++d) Wd[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)(((wg & 127) * 192 + wave + d * CH_WAVES) * 1024), 0);
+        };
+        auto pf_k_ = [&]() {
+            if (a.wqkv_next == nullptr) return;
+            const coh_rsrc_t rs = coh_rsrc(a.wqkv_next);
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    Wk[d][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (uint32_t)((((wg & 127) * 2 + j) * 64 + wave + d * CH_WAVES) * 1024), 0);
+        };
+        ChainPrefetch<24, decltype(pf_g_)> pf_g{pf_g_};
+        ChainPrefetch<24, decltype(pf_d_)> pf_d{pf_d_};
+        ChainPrefetch<16, decltype(pf_k_)> pf_k{pf_k_};
         chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g,
                                                      false, 0x1001, a.stamps, nullptr, pf_g);
         chain_gemm<4, 3, 8, 3, OMNI_EPI_SILU_MUL_GU8, 2, 3>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g,
@@ -88,19 +99,23 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
             chain_gemm<2, 2, 8, 3, OMNI_EPI_BF16, 4, 3>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps,
                                                         wg & 127, wg >> 7, lds, g, true, 0x1004, a.stamps, Wk);
         return;
-    }
+    } else {
     constexpr int NT1 = (WNT & 1) ? OMNI_AUX_NT : 0, NT2 = (WNT & 2) ? OMNI_AUX_NT : 0;
-    chain_gemm<2, 1, 8, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 64, NT2>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127,
-                                                                                  wg >> 7, lds, g, false, 0x1001, a.stamps);
-    chain_gemm<4, 3, 8, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8, GU_G, GUW0 ? 0 : 1, ChainNoPrefetch, GU1P, 64, NT1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0,
-                                                                                                                  nullptr, a.B, I, a.eps, wg, 0, lds, g, true,
-                                                                                                                  0x1002, a.stamps);
-    chain_gemm<2, 1, 24, 0, OMNI_EPI_RESID, DN_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps,
-                                                                                      wg & 127, wg >> 7, lds, g, true, 0x1003, a.stamps);
+    chain_gemm<2, 1, KO, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 64, NT2>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg % nc_h,
+                                                                                   wg / nc_h, lds, g, false, 0x1001, a.stamps);
+    if (wg < nc_gu)
+        chain_gemm<4, 3, KH, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8, GU_G, GUW0 ? 0 : 1, ChainNoPrefetch, GU1P, 64, NT1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0,
+                                                                                                                       nullptr, a.B, I, a.eps, wg, 0, lds, g, true,
+                                                                                                                       0x1002, a.stamps);
+    else
+        chain_gate_skip(g);
+    chain_gemm<2, 1, KI, 0, OMNI_EPI_RESID, DN_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps,
+                                                                                      wg % nc_h, wg / nc_h, lds, g, true, 0x1003, a.stamps);
     if (a.wqkv_next)
-        chain_gemm<2, 2, 8, DEFER ? 3 : 2, OMNI_EPI_BF16, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ,
-                                                                                                    nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g, true,
-                                                                                                    0x1004, a.stamps);
+        chain_gemm<2, 2, KH, DEFER ? 3 : 2, OMNI_EPI_BF16, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ,
+                                                                                                     nullptr, a.B, NQ, a.eps, wg % nc_q, wg / nc_q, lds, g, true,
+                                                                                                     0x1004, a.stamps);
+    }
 }
 
 // ---- the 0.6B backbone shape (hidden 1024, 16 x 128 attention width over 8 kv heads, intermediate 3072: BASELINE config #2) --
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_small_kernel(const BbArgs
 // ---- the 1.7B shape at 1-32 rows (round 4): the launch path's tiles at those batch sizes -- 16-row tiles for qkv / o_proj / down_proj
 // (128 column tiles x 2 row tiles), gate_up on 16 rows x 24 columns up to 16 rows and 32 x 24 above (the rstd summation order follows the
 // rows per tile: same bits as the launch path).  33-48 rows: bb_chain_kernel (the 64-row stage set).
-template <int GU_MT>
+template <int KO, int KH, int KI, int GU_MT>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -149,16 +164,20 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a
     g.dom = 8;
     g.nap = a.nap;
     const int wg = blockIdx.x;
-    constexpr int H = 2048, I = 6144, NQ = 4096;
-    chain_gemm<1, 1, 8, 0, OMNI_EPI_RESID, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g, false, 0x1001,
-                                              a.stamps);
-    chain_gemm<GU_MT, 3, 8, 3, OMNI_EPI_SILU_MUL_GU8, 2, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g, true, 0x1002,
-                                                            a.stamps);
-    chain_gemm<1, 1, 24, 0, OMNI_EPI_RESID, 4>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg & 127, wg >> 7, lds, g, true, 0x1003,
+    const int H = a.H, I = a.I, NQ = a.NQ;
+    const int nc_h = H >> 4, nc_gu = I / 24, nc_q = NQ >> 5;        // 16-row tiles: two row tiles of each column tile cover the 32 rows
+    chain_gemm<1, 1, KO, 0, OMNI_EPI_RESID, 0>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg % nc_h, wg / nc_h, lds, g, false, 0x1001,
+                                               a.stamps);
+    if (wg < nc_gu)
+        chain_gemm<GU_MT, 3, KH, 3, OMNI_EPI_SILU_MUL_GU8, 2, 1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, wg, 0, lds, g, true, 0x1002,
+                                                                 a.stamps);
+    else
+        chain_gate_skip(g);
+    chain_gemm<1, 1, KI, 0, OMNI_EPI_RESID, 4>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg % nc_h, wg / nc_h, lds, g, true, 0x1003,
                                                a.stamps);
     if (a.wqkv_next)
-        chain_gemm<1, 2, 8, 3, OMNI_EPI_BF16, 4>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg & 127, wg >> 7, lds, g,
-                                                 true, 0x1004, a.stamps);
+        chain_gemm<1, 2, KH, 3, OMNI_EPI_BF16, 4>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg % nc_q, wg / nc_q, lds, g,
+                                                  true, 0x1004, a.stamps);
 }
 
 OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 33, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
@@ -170,6 +189,10 @@ extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }
 extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; g_bb_b32 = rows <= 49; }                          // smallest batch the backbone chain takes                                  // deeper activation / weight rings
 #endif
 
+// the instantiated shape triples (KO, KH, KI) = (q_heads * 128, hidden, intermediate) / 256: the released 1.7B shape and one no released
+// checkpoint has (hidden 1536, intermediate 4608, 12 q heads: tests/test_gpu_chain.py, tests/test_gpu_engine.py); a new width = one more line
+#define BB_SHAPES(X) X(8, 8, 24) X(6, 6, 18)
+
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
     static int cus = -1;
     if (cus < 0) {
@@ -178,81 +201,102 @@ bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
     }
     const bool common = g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
-                        d.head_dim == 128 && d.q_heads * 128 == 2048 && (d.q_heads + 2 * d.kv_heads) * 128 == 4096 && B <= 64;
+                        d.head_dim == 128 && B <= 64;
     if (common && k_bb_chain_small(d)) return B >= 1;                          // 0.6B shape: 16-row tiles, every batch size
-    return common && d.hidden == 2048 && d.inter == 6144 && (B >= g_bb_min_rows || (g_bb_b32 && B <= 32));    // 1.7B shape: the launch path's tiles
+    const int H = d.hidden, I = d.inter, KOW = d.q_heads * 128, NQ = (d.q_heads + 2 * d.kv_heads) * 128;
+    bool listed = false;
+#define X(KO_, KH_, KI_) listed = listed || (KOW == KO_ * 256 && H == KH_ * 256 && I == KI_ * 256);
+    BB_SHAPES(X)
+#undef X
+    // every stage's tile grid inside the 256 workgroups: o_proj / down_proj 16 columns x 2 row tiles, gate_up 24 activation columns, qkv 32 x 2
+    const bool grids = I % 24 == 0 && NQ % 32 == 0 && (H / 16) * 2 <= OMNI_CHAIN_WGS && I / 24 <= OMNI_CHAIN_WGS && (NQ / 32) * 2 <= OMNI_CHAIN_WGS;
+    return common && listed && grids && (B >= g_bb_min_rows || (g_bb_b32 && B <= 32));
 }
-bool k_bb_chain_small(const omni_talker_desc& d) { return d.hidden == 1024 && d.inter == 3072; }
+bool k_bb_chain_small(const omni_talker_desc& d) {
+    return d.hidden == 1024 && d.inter == 3072 && d.q_heads * 128 == 2048 && (d.q_heads + 2 * d.kv_heads) * 128 == 4096;
+}
 
-int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-               int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small) {
-    if (small) {
-        BbArgs a{};
-        a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
-        a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
-        a.wqkv_next = next ? (const uint16_t*)next->wqkv : nullptr;
-        a.attn = (const uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
-        a.B = B; a.nap = g_bb_nap; a.eps = eps; a.flags = flags; a.err = err;
+// one shape's launches: the 64-row stage set (33-64 rows) or the 16-row one (1-32 rows); the debug library's A/B arms exist for the 1.7B triple
+template <int KO, int KH, int KI>
+static int bb_launch_shape(const BbArgs& a, int B, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        attr = true;
+    }
+    if (B <= 32) {
+        if (B <= 16) hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 1>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 2>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        OMNI_CHECK_LAUNCH("bb_chain_b32");
+        return OMNI_OK;
+    }
+    hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+    OMNI_CHECK_LAUNCH("bb_chain");
+    return OMNI_OK;
+}
+
+int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part,
+               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small) {
+    BbArgs a{};
+    a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
+    a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
+    a.wqkv_next = next ? (const uint16_t*)next->wqkv : nullptr;
+    a.attn = (const uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
+    a.H = d.hidden; a.I = d.inter; a.NQ = (d.q_heads + 2 * d.kv_heads) * 128;
+    a.B = B; a.nap = g_bb_nap; a.eps = eps; a.flags = flags; a.err = err;
 #ifdef OMNI_DEBUG_HOOKS
-        a.stamps = g_bb_stamps;
+    a.stamps = g_bb_stamps;
 #endif
-        // gate_up's RMSNorm statistics are summed in an order that depends on the rows per tile: the launch path's policy (32-row
-        // tiles above 48 rows, gemm.hip pick_tile), so that both schedules produce the same bits
+    if (small) {
+        // (gate_up on 32-row tiles above 48 rows, on 16-row tiles below: the row group without rows then leaves at launch start -- round 5;
+        //  the bits do not depend on the choice since round 6)
         if (B > 48) hipLaunchKernelGGL(bb_chain_small_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(bb_chain_small_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
         OMNI_CHECK_LAUNCH("bb_chain_small");
         return OMNI_OK;
     }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<4, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<3, 6, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 8, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-#ifdef OMNI_DEBUG_HOOKS
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<2, 4, 4, false, true, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-#endif
-        attr = true;
-    }
-    BbArgs a{};
-    a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
-    a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
-    a.wqkv_next = next ? (const uint16_t*)next->wqkv : nullptr;
+    const int ko = d.q_heads * 128 / 256, kh = d.hidden / 256, ki = d.inter / 256;
+#ifdef OMNI_DEBUG_HOOKS      // the A/B arms of rounds 3-5 (1.7B triple only)
     a.pf = g_bb_prefetch;
-    a.attn = (const uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
-    a.B = B; a.nap = g_bb_nap; a.eps = eps; a.flags = flags; a.err = err;
-#ifdef OMNI_DEBUG_HOOKS
-    a.stamps = g_bb_stamps;
-#endif
-#define BB_LAUNCH(...) hipLaunchKernelGGL((bb_chain_kernel<__VA_ARGS__>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a)
-    if (B <= 32) {
-        if (B <= 16) hipLaunchKernelGGL((bb_chain_b32_kernel<1>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((bb_chain_b32_kernel<2>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a);
-        OMNI_CHECK_LAUNCH("bb_chain_b32");
+    if (ko == 8 && kh == 8 && ki == 24 && B > 32 && (a.pf || g_bb_deep)) {
+        static bool attr = false;
+#define BB_ARM(...) bb_chain_kernel<8, 8, 24, __VA_ARGS__>
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(4, 8, 8, false), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(3, 6, 8, false), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 8, 8, false), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, false), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, true, true), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, true, false, false), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, true, false, true, 1), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, true, false, true, 2), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)BB_ARM(2, 4, 4, false, true, false, true, 3), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+            attr = true;
+        }
+#define BB_LAUNCH(...) hipLaunchKernelGGL((BB_ARM(__VA_ARGS__)), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, (hipStream_t)stream, a)
+        if (a.pf) BB_LAUNCH(2, 4, 4, true);
+        else if (g_bb_deep == 1) BB_LAUNCH(4, 8, 8, false);
+        else if (g_bb_deep == 2) BB_LAUNCH(3, 6, 8, false);
+        else if (g_bb_deep == 3) BB_LAUNCH(2, 8, 8, false);
+        else if (g_bb_deep == 4) BB_LAUNCH(2, 4, 4, false, false);             // round 3's two-pass gate_up combine
+        else if (g_bb_deep == 5) BB_LAUNCH(2, 4, 4, false, true, true);        // gate_up weights ahead of the flags
+        else if (g_bb_deep == 6) BB_LAUNCH(2, 4, 4, false, true, false, false); // round 5's exact rstd (timing arm: no longer the launch path's bits)
+        else if (g_bb_deep == 7) BB_LAUNCH(2, 4, 4, false, true, false, true, 1);   // nt weight loads: gate_up only
+        else if (g_bb_deep == 8) BB_LAUNCH(2, 4, 4, false, true, false, true, 2);   // nt: o_proj / down_proj / qkv
+        else if (g_bb_deep == 9) BB_LAUNCH(2, 4, 4, false, true, false, true, 3);   // nt: every weight load of the launch
+        else BB_LAUNCH(2, 4, 4, false);
+#undef BB_LAUNCH
+#undef BB_ARM
+        OMNI_CHECK_LAUNCH("bb_chain(arm)");
         return OMNI_OK;
     }
-    if (a.pf) BB_LAUNCH(2, 4, 4, true);
-    else if (g_bb_deep == 1) BB_LAUNCH(4, 8, 8, false);
-    else if (g_bb_deep == 2) BB_LAUNCH(3, 6, 8, false);
-    else if (g_bb_deep == 3) BB_LAUNCH(2, 8, 8, false);
-    else if (g_bb_deep == 4) BB_LAUNCH(2, 4, 4, false, false);             // round 3's two-pass gate_up combine
-    else if (g_bb_deep == 5) BB_LAUNCH(2, 4, 4, false, true, true);        // gate_up weights ahead of the flags
-    else if (g_bb_deep == 6) BB_LAUNCH(2, 4, 4, false, true, false, false); // round 5's exact rstd (timing arm: no longer the launch path's bits)
-#ifdef OMNI_DEBUG_HOOKS
-    else if (g_bb_deep == 7) BB_LAUNCH(2, 4, 4, false, true, false, true, 1);   // nt weight loads: gate_up only
-    else if (g_bb_deep == 8) BB_LAUNCH(2, 4, 4, false, true, false, true, 2);   // nt: o_proj / down_proj / qkv
-    else if (g_bb_deep == 9) BB_LAUNCH(2, 4, 4, false, true, false, true, 3);   // nt: every weight load of the launch
 #endif
-    else BB_LAUNCH(2, 4, 4, false);
-#undef BB_LAUNCH
-    OMNI_CHECK_LAUNCH("bb_chain");
-    return OMNI_OK;
+#define X(KO_, KH_, KI_) if (ko == KO_ && kh == KH_ && ki == KI_) return bb_launch_shape<KO_, KH_, KI_>(a, B, (hipStream_t)stream);
+    BB_SHAPES(X)
+#undef X
+    omni_set_error("bb_chain: no stage set for (q width, hidden, intermediate) = (%d, %d, %d)", d.q_heads * 128, d.hidden, d.inter);
+    return OMNI_EINVAL;
 }

@@ -957,7 +957,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
                                 t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
             else
 #endif
-            TRY(k_bb_chain(w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
+            TRY(k_bb_chain(d, w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                            t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, k_bb_chain_small(d)));
         }
         return OMNI_OK;

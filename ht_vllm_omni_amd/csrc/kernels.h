@@ -86,11 +86,12 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
                int g0, int g1, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
                int32_t* err, const omni_chain_head* head, void* stream);
 // the backbone between two attention launches (o_proj -> gate_up -> down_proj -> next layer's qkv) as one persistent launch
-// (bb_chain.hip); supported = the 1.7B dense shape at 49-64 rows on a single rank
+// (bb_chain.hip); supported = a dense shape whose (q width, hidden, intermediate) triple is instantiated there (BB_SHAPES) and whose tile
+// grids fit 256 workgroups, at 1-64 rows on a single rank; or the 0.6B shape (bb_chain_small_kernel)
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
 bool k_bb_chain_small(const omni_talker_desc& d);       // the 0.6B shape: the segment on the code predictor's 16-row stage set, any batch
-int k_bb_chain(const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part, void* act, void* qkv,
-               int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small = false);
+int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part,
+               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small = false);
 // the sparse-MoE layer between its attention launch and its expert GEMMs (o_proj -> router | shared gate_up -> shared down + routing) as
 // one persistent launch (moe_chain.hip); supported = the Omni talker's shape on a single rank, <= 64 rows
 bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar);

@@ -250,7 +250,7 @@ def _scenario(d, w, kv, prompt_lens, n_steps, *, B_pad=None, sampling=None, num_
     return rec
 
 
-def _codes_equal_up_to_near_ties(rec, i, w, tie_ulps=3.0):
+def _codes_equal_up_to_near_ties(rec, i, w, tie_ulps=4.0):      # (3.0 while the step replayed the oracle's rounding points: tests/util.py)
     """Audio codes of step i: bit-exact, except that a row may leave the oracle's greedy path at a group whose two best
     (bf16-rounded) code-predictor logits are within `tie_ulps` bf16 ulps of each other -- after 5 predictor layers the two
     pipelines' logits differ by 1-2 ulp, so an argmax over values that close is decided by the summation order; everything
@@ -448,6 +448,21 @@ def test_real_dims_one_layer():
     lens = torch.randint(4, 40, (64,), generator=g).tolist()
     rec = _scenario(d, w, "fp8", prompt_lens=lens, n_steps=2, num_blocks=300, mean_tol=1e-3)
     _check(rec, mean_tol=1e-3)      # BASELINE weight scale: logits within 1e-3 in the mean, 1-2 bf16 ulp max
+
+
+def test_unreleased_width_runs_both_chains_and_matches_oracle():
+    """a width NO released checkpoint has -- hidden 1536, intermediate 4608, 12 q / 6 kv heads (the dimensions are the
+    checkpoint's to decide: configuration_qwen3_tts.py:192-216) -- takes the persistent chains too (csrc/bb_chain.hip BB_SHAPES: the stage
+    set is instantiated from the shape), reported by the native step (chains_ran == 3), against the oracle: prefill + 2 decode steps at 64
+    rows, 2 backbone layers, the full 5-layer / 16-group predictor."""
+    d = get_dims("tts-1.7b").with_(layers=2, max_model_len=256, hidden=1536, inter=4608, q_heads=12, kv_heads=6)
+    w = make_weights(d, seed=19, std=0.02)
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(4, 40, (64,), generator=g).tolist()
+    rec = _scenario(d, w, "fp8", prompt_lens=lens, n_steps=2, num_blocks=300, mean_tol=2e-3, max_ulps=3)
+    _check(rec, mean_tol=2e-3, max_ulps=3)
+    eng = rec["engine"]
+    assert eng.persistent_chains and eng.chains_ran() == 3 and eng.chain_error() == 0, eng.chains_ran()
 
 
 def test_prefill_wide_paths_match_chunked_native_and_oracle():

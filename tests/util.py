@@ -66,10 +66,11 @@ def assert_e2e_close(got: torch.Tensor, ref: torch.Tensor, *, mean_tol: float = 
     assert d.mean().item() <= mean_tol, f"{what}: mean diff {d.mean().item():.4g} > {mean_tol:.4g}"
 
 
-def codes_on_the_oracles_frame(got: torch.Tensor, ref: torch.Tensor, cp_logits: torch.Tensor, *, tie_ulps: float = 3.0, what: str = "") -> torch.Tensor:
+def codes_on_the_oracles_frame(got: torch.Tensor, ref: torch.Tensor, cp_logits: torch.Tensor, *, tie_ulps: float = 4.0, what: str = "") -> torch.Tensor:
     """Greedy audio codes [B, Q] against the oracle's: bit-exact, except that a row may leave the oracle's greedy path at a group whose two
     best (bf16-rounded) predictor logits -- `cp_logits` [B, Q - 1, V], the ORACLE's -- are within `tie_ulps` bf16 ulps of each other: two bf16
-    pipelines differ by about a rounding there, and an argmax over values that close is decided by it; what follows in that row reads
+    pipelines differ by about a rounding there -- each of the two logits by up to ~2 ulps behind five layers -- and an argmax over values that
+    close is decided by it (4 ulps; 3 while the HIP path replayed the oracle's rounding points); what follows in that row reads
     another input and is not compared.  Returns the mask of the rows still on the oracle's frame; raises on any fork that is no near-tie.
     (Rounds 1-5 replayed the oracle's rounding points and tiny configurations agreed bit for bit; since round 6 -- rstd applied to the fp32
     sums, see above -- they fork where the full-size ones always did.)"""
