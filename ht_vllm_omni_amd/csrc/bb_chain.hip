@@ -28,6 +28,9 @@ struct BbArgs {
     uint16_t* act;                      // fragment-major [64][6144]
     uint16_t* qkv;                      // row-major [B][NQ]
     int H, I, NQ;                       // output widths: hidden, intermediate, (q_heads + 2 kv_heads) * 128
+    // the LAST layer's launch (no next qkv) may end in the talker's own head instead (round 6): final norm folded into the lm_head GEMM, its
+    // normalised rows = h[t + 1] (row-major, rows below *num_live), logits fp32 [B][V] holding bf16-rounded values, the codec mask applied
+    const uint16_t *lm_head, *final_norm; float* logits; uint16_t* last_hidden; const uint8_t* mask; const int32_t* num_live; float mask_fill; int V;
     int B, nap; float eps;
     uint32_t* flags; int32_t* err;
     unsigned long long* stamps;
@@ -44,7 +47,9 @@ struct BbArgs {
 // round 6 (gemm_skinny_kernel takes it for the same GEMMs); false = round 5's exact-rstd stages, debug library only
 // WNT: bit 0 = non-temporal weight loads in gate_up (every byte read by exactly ONE workgroup), bit 1 = in o_proj / down_proj / qkv (each slice
 // read by the two workgroups of a column tile's row halves) -- round 5 A/B arm (MI355X_MICROARCH "nt-weights")
-template <int KO, int KH, int KI, int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0>
+// HEAD: the instantiation the LAST layer launches when the step's head rides along (its own code object entry: the other 27 launches keep the
+// leaner kernel -- with the head stage compiled into every launch the segment cost 0.9 us more per layer, register allocation of the shared stages)
+template <int KO, int KH, int KI, int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0, bool HEAD = false>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -115,6 +120,15 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
         chain_gemm<2, 2, KH, DEFER ? 3 : 2, OMNI_EPI_BF16, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ,
                                                                                                      nullptr, a.B, NQ, a.eps, wg % nc_q, wg / nc_q, lds, g, true,
                                                                                                      0x1004, a.stamps);
+    else if (HEAD && a.lm_head) {
+        // the step's head as the last stage of its last backbone launch (one launch and one cold start less: 9.8 us + a boundary -> a stage):
+        // gemm_skinny_kernel<2, 2, PRO 2, F32_BF16RND>'s tile and arithmetic (exact norm: its normalised rows are h[t + 1])
+        const int nc_v = a.V >> 5;
+        chain_gemm<2, 2, KH, 2, OMNI_EPI_F32_BF16RND, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.lm_head, a.final_norm, a.resid, a.part, H / 16, a.logits, a.V,
+                                                                                                nullptr, a.B, a.V, a.eps, wg % nc_v, wg / nc_v, lds, g, true, 0x1005,
+                                                                                                a.stamps, nullptr, ChainNoPrefetch(), a.last_hidden, a.mask,
+                                                                                                a.mask_fill, a.num_live);
+    }
     }
 }
 
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_small_kernel(const BbArgs
 // ---- the 1.7B shape at 1-32 rows (round 4): the launch path's tiles at those batch sizes -- 16-row tiles for qkv / o_proj / down_proj
 // (128 column tiles x 2 row tiles), gate_up on 16 rows x 24 columns up to 16 rows and 32 x 24 above (the rstd summation order follows the
 // rows per tile: same bits as the launch path).  33-48 rows: bb_chain_kernel (the 64-row stage set).
-template <int KO, int KH, int KI, int GU_MT>
+template <int KO, int KH, int KI, int GU_MT, bool HEAD = false>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ChainGate g;
@@ -178,6 +192,12 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a
     if (a.wqkv_next)
         chain_gemm<1, 2, KH, 3, OMNI_EPI_BF16, 4>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ, nullptr, a.B, NQ, a.eps, wg % nc_q, wg / nc_q, lds, g,
                                                   true, 0x1004, a.stamps);
+    else if (HEAD && a.lm_head) {
+        const int nc_v = a.V >> 5;
+        chain_gemm<1, 2, KH, 2, OMNI_EPI_F32_BF16RND, 4>(a.lm_head, a.final_norm, a.resid, a.part, H / 16, a.logits, a.V, nullptr, a.B, a.V, a.eps, wg % nc_v,
+                                                         wg / nc_v, lds, g, true, 0x1005, a.stamps, nullptr, ChainNoPrefetch(), a.last_hidden, a.mask,
+                                                         a.mask_fill, a.num_live);
+    }
 }
 
 OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 33, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
@@ -223,22 +243,37 @@ static int bb_launch_shape(const BbArgs& a, int B, hipStream_t stream) {
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_b32_kernel<KO, KH, KI, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         attr = true;
     }
+    const bool head = a.lm_head != nullptr;
     if (B <= 32) {
-        if (B <= 16) hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 1>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 2>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        if (B <= 16) {
+            if (head) hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 1, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+            else hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 1>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        } else {
+            if (head) hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 2, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+            else hipLaunchKernelGGL((bb_chain_b32_kernel<KO, KH, KI, 2>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        }
         OMNI_CHECK_LAUNCH("bb_chain_b32");
         return OMNI_OK;
     }
-    hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+    if (head) hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, true>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
     OMNI_CHECK_LAUNCH("bb_chain");
     return OMNI_OK;
 }
 
+bool k_bb_chain_head_supported(const omni_talker_desc& d) {      // the lm_head stage's tile grid: 32 columns x 2 row tiles inside 256 workgroups
+    return !k_bb_chain_small(d) && d.vocab % 32 == 0 && (d.vocab / 32) * 2 <= OMNI_CHAIN_WGS && d.lm_head != nullptr &&
+           !g_bb_prefetch && !g_bb_deep;      // (the debug library's A/B arms keep the head as its own launch)
+}
+
 int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part,
-               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small) {
+               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small, const omni_bb_head* head) {
     BbArgs a{};
     a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
     a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
@@ -246,6 +281,10 @@ int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omn
     a.attn = (const uint16_t*)attn; a.resid = (uint16_t*)resid; a.part = part; a.act = (uint16_t*)act; a.qkv = (uint16_t*)qkv;
     a.H = d.hidden; a.I = d.inter; a.NQ = (d.q_heads + 2 * d.kv_heads) * 128;
     a.B = B; a.nap = g_bb_nap; a.eps = eps; a.flags = flags; a.err = err;
+    if (head != nullptr && next == nullptr && !small) {
+        a.lm_head = (const uint16_t*)d.lm_head; a.final_norm = (const uint16_t*)d.final_norm; a.logits = head->logits; a.V = d.vocab;
+        a.last_hidden = (uint16_t*)head->last_hidden; a.mask = (const uint8_t*)d.allowed_mask; a.mask_fill = head->mask_fill; a.num_live = head->num_live;
+    }
 #ifdef OMNI_DEBUG_HOOKS
     a.stamps = g_bb_stamps;
 #endif
@@ -260,7 +299,7 @@ int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omn
     const int ko = d.q_heads * 128 / 256, kh = d.hidden / 256, ki = d.inter / 256;
 #ifdef OMNI_DEBUG_HOOKS      // the A/B arms of rounds 3-5 (1.7B triple only)
     a.pf = g_bb_prefetch;
-    if (ko == 8 && kh == 8 && ki == 24 && B > 32 && (a.pf || g_bb_deep)) {
+    if (ko == 8 && kh == 8 && ki == 24 && B > 32 && (a.pf || g_bb_deep) && a.lm_head == nullptr) {
         static bool attr = false;
 #define BB_ARM(...) bb_chain_kernel<8, 8, 24, __VA_ARGS__>
         if (!attr) {

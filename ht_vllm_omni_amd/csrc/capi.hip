@@ -119,6 +119,7 @@ struct omni_talker {
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
     int ran;                            // persistent chains launched by the decode-step call in progress / last made (bit 0 cp, bit 1 bb)
+    bool head_fused = false;            // the last backbone launch of the step in progress computed logits + h[t + 1] (run_backbone fuse_head)
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -889,7 +890,8 @@ extern "C" int omni_talker_finish(omni_talker* t, const omni_step_io* io, void* 
     const int B = io->B;
     // final norm fused into the lm_head GEMM; the normalised rows ARE h[t+1] and go straight to last_hidden
     // (postprocess, qwen3_tts_talker.py:649-655): nothing else reads last_hidden after the mtp phase of this step
-    if (d.fused_norm)
+    if (t->head_fused) t->head_fused = false;      // logits and h[t + 1] left by the last backbone launch (run_backbone fuse_head)
+    else if (d.fused_norm)
         TRY(xnorm_gemm(t, t->resid, t->part, d.layers > 0 ? d.hidden / 16 : 1, d.final_norm, io->last_hidden, d.lm_head, io->logits,
                        B, d.vocab, d.hidden, OMNI_EPI_F32_BF16RND, d.allowed_mask, 0, stream, io->num_live));
     else
@@ -917,17 +919,21 @@ static int moe_experts_tail(omni_talker* t, int layer, int B, void* stream) {
 }
 
 // diagnostics: append N trivial launches after every layer phase to price a launch inside the real step
-OMNI_KNOB g_extra_trivial = 0;
+OMNI_KNOB g_extra_trivial = 0, g_bb_head = 1;      // g_bb_head: the lm_head as the last stage of the last backbone launch (0: its own launch, round 5)
 __global__ void dbg_nop_kernel(int32_t* p) { if (threadIdx.x == 9999) p[0] = 0; }
 #ifdef OMNI_DEBUG_HOOKS
 extern "C" void omni_debug_extra_trivial(int n) { g_extra_trivial = n; }
+extern "C" void omni_debug_bb_head(int on) { g_bb_head = on; }
 #endif
 
 // the backbone of one decode step (every layer; the residual stream in t->resid on entry, final residual on exit)
 // parts (timing attribution, omni_talker_step_part): 2 = the attention launches, 4 = everything else of the stack; both = the stack
-static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, int parts = 6) {
+// fuse_head: the talker's head (final norm + lm_head) rides as the last stage of the last layer's persistent launch (bb_chain.hip, round 6) --
+// omni_talker_finish then launches the sampler only (t->head_fused)
+static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, int parts = 6, bool fuse_head = false) {
     const omni_talker_desc& d = t->d;
     const bool do_attn = (parts & 2) != 0, do_rest = (parts & 4) != 0;
+    t->head_fused = false;
 #ifdef OMNI_DEBUG_HOOKS
     if (parts == 6 && k_bb_all_supported(d, io->B, t->has_ar)) {      // A/B arm: the whole stack, attention included, as one persistent launch
         t->ran |= 2;                                                  // (a split request -- step_part 2 / 4 -- takes the two-launch structure below)
@@ -957,8 +963,14 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
                                 t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream));
             else
 #endif
-            TRY(k_bb_chain(d, w, l + 1 < d.layers ? &t->layer[l + 1] : nullptr, t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
-                           t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, k_bb_chain_small(d)));
+            {
+                const bool last = l + 1 == d.layers;
+                const omni_bb_head hd{io->logits, io->last_hidden, io->num_live, mask_fill(t)};
+                const bool with_head = last && fuse_head && g_bb_head && k_bb_chain_head_supported(d);
+                TRY(k_bb_chain(d, w, last ? nullptr : &t->layer[l + 1], t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
+                               t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, k_bb_chain_small(d), with_head ? &hd : nullptr));
+                if (with_head) t->head_fused = true;
+            }
         }
         return OMNI_OK;
     }
@@ -1002,7 +1014,8 @@ extern "C" int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int
     OMNI_CHECK_ARG(parts > 0 && parts < 16, "omni_talker_step_part: parts=%d", parts);
     t->ran = 0;
     if (parts & 1) TRY(omni_talker_mtp(t, io, stream));
-    if (parts & 6) TRY(run_backbone(t, io, stream, parts & 6));
+    if (parts & 6) TRY(run_backbone(t, io, stream, parts & 6, (parts & 12) == 12));
+    else t->head_fused = false;
     if (parts & 8) TRY(omni_talker_finish(t, io, stream));
     return OMNI_OK;
 }
@@ -1011,14 +1024,14 @@ extern "C" int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int
 extern "C" int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(check_io(t, io));
     t->ran = 0;
-    TRY(run_backbone(t, io, stream));
+    TRY(run_backbone(t, io, stream, 6, true));
     return omni_talker_finish(t, io, stream);
 }
 
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(omni_talker_mtp(t, io, stream));
     if (g_extra_trivial == 0) {
-        TRY(run_backbone(t, io, stream));
+        TRY(run_backbone(t, io, stream, 6, true));
         return omni_talker_finish(t, io, stream);
     }
     for (int l = 0; l < t->d.layers; ++l) {

@@ -60,7 +60,9 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
                                            unsigned long long* stamps, const u32x4 (*Wpre)[NT] = nullptr, PF prefetch = PF(),
                                            uint16_t* normed_out = nullptr /* PRO 2: the normalised rows, row-major [M][K] (plain stores:
-                                           for the NEXT launch), written by the workgroup columns bx < 8 as gemm_skinny_kernel spreads them */) {
+                                           for the NEXT launch), written by the workgroup columns bx < 8 as gemm_skinny_kernel spreads them */,
+                                           const uint8_t* mask = nullptr /* EPI_F32_BF16RND: logit n is `mask_fill` where mask[n] == 0 (the codec mask) */,
+                                           float mask_fill = 0.f, const int32_t* nlive_ptr = nullptr /* normed_out: rows >= *nlive_ptr are not written */) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int G = (XG == 0 || XG > NTW) ? NTW : XG;
     constexpr bool NORM = PRO == 2 || PRO == 3, DEFER = PRO == 3;
@@ -208,9 +210,10 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             // k-steps bx, bx + 8, ... of the normalised rows leave through workgroup column bx (gemm_skinny_kernel: column x takes k-steps
             // x + gridDim.x * wave): here wave w owns k-steps w + 8 d, so column bx's wave bx holds exactly those -- the same values
             const int ks = wave + d * CH_WAVES;
+            const int nlive = nlive_ptr ? min(*nlive_ptr, M) - m_base : Mloc;      // h[t+1] of a padded bucket's rows stays untouched
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                if (i * 16 + (lane & 15) < Mloc)
+                if (i * 16 + (lane & 15) < min(Mloc, nlive))
                     *reinterpret_cast<u32x4*>(normed_out + (size_t)(m_base + i * 16 + (lane & 15)) * K + ks * 32 + 8 * q) = Xn[i];
         }
         if (d + G < NTW) load_x(d + G);                                   // refill the slot just consumed
@@ -292,9 +295,14 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
         } else if (EPI == OMNI_EPI_F32_BF16RND) {
             // logits: fp32 cells holding bf16-rounded values (the reference's bf16 head output), row-major
             const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = bfround(sum[e]);
+                if (mask != nullptr && !mask[n + e]) y[e] = mask_fill;
+            }
             coh_st16(ors, (uint32_t)((size_t)m * ldo + n) * 4,
-                     (u32x4){__float_as_uint(bfround(sum[0])), __float_as_uint(bfround(sum[1])), __float_as_uint(bfround(sum[2])),
-                             __float_as_uint(bfround(sum[3]))});
+                     (u32x4){__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])});
         } else {
             const int n = (bx * NT + j) * 16 + 4 * (l >> 4);
             coh_st8(ors, (uint32_t)((size_t)m * ldo + n) * 2, (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])});

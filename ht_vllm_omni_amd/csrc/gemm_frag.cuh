@@ -68,12 +68,12 @@ struct SlabOrder {
 #pragma unroll
         for (int j = 0; j < QPS; ++j) asm volatile("" : "+v"(q[j]));
         float s_ = q[0];
-        if (QPS == 4) {
-            float lo = q[0] + q[1], hi = q[QPS - 2] + q[QPS - 1];
+        if constexpr (QPS == 4) {
+            float lo = q[0] + q[1], hi = q[2] + q[3];
             asm volatile("" : "+v"(lo), "+v"(hi));
             s_ = lo + hi;
-        } else if (QPS == 2) {
-            s_ = q[0] + q[QPS - 1];
+        } else if constexpr (QPS == 2) {
+            s_ = q[0] + q[1];
         }
         if (CPW == 4) s_ = xor16_sum(s_);        // sub-channels 0 | 1 and 2 | 3 first: (q0 + q1), (q2 + q3)
         if (CPW >= 2) s_ = xor32_sum(s_);        // ... then the two halves of the wave

@@ -34,6 +34,7 @@ void omni_debug_gemm_stage(int stage);                      /* leave every GEMM 
 void omni_debug_small_splitq(int on);                       /* small attention: one wave per (row, q head)            */
 void omni_debug_small_tiny(int on);                         /* code-predictor attention: the (token, quarter) / readlane kernel */
 void omni_debug_prefill_mfma(int on);                       /* prefill attention on MFMA (off: per-token VALU path)   */
+void omni_debug_bb_head(int on);                            /* 1 (default): the talker's lm_head rides as the last stage of the last backbone launch; 0: its own launch (round 5) */
 void omni_debug_extra_trivial(int n);                       /* append n no-op launches per layer phase                */
 int omni_debug_launch(int mode, int blocks, int threads, void* p0, void* p1, int arg, int reps, void* stream);
 int omni_debug_mix(int pattern, float* small, const void* big, size_t big_bytes, int reps, void* stream);
