@@ -120,6 +120,7 @@ struct omni_talker {
     bool has_ar;
     int ran;                            // persistent chains launched by the decode-step call in progress / last made (bit 0 cp, bit 1 bb)
     bool head_fused = false;            // the last backbone launch of the step in progress computed logits + h[t + 1] (run_backbone fuse_head)
+    bool tail_fused = false;            // the predictor's all-pass launch of the step in progress assembled the backbone's input and computed layer 0's qkv
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -548,7 +549,9 @@ static int cp_project(omni_talker* t, const void* rows /*bf16 [B,H]*/, int B, vo
 // layer0_ids != NULL and d.cp_e0_table: position-1 input is gathered from the folded table instead of projected.
 static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const void* layer0_embed, const void* last_hidden,
                               int B, int greedy, float temperature, int top_k, float top_p, uint32_t seed, int32_t* steps,
-                              float* cp_logits_out, void* st, const uint32_t* row_seed = nullptr) {
+                              float* cp_logits_out, void* st, const uint32_t* row_seed = nullptr,
+                              const omni_chain_tail* tail = nullptr /* the step's input assembly + first qkv ride with the all-pass launch; t->tail_fused says whether they did */) {
+    t->tail_fused = false;
     const omni_talker_desc& d = t->d;
     const int Q = d.num_code_groups, Hc = d.cp_hidden;
     if (Q <= 1) return OMNI_OK;
@@ -622,9 +625,11 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 hd.logits_pass = cp_logits_out ? d.codebook : 0;
                 hd.greedy = greedy; hd.top_k = top_k; hd.temperature = temperature; hd.top_p = top_p; hd.seed = seed;
                 hd.steps = steps; hd.row_seed = row_seed; hd.codes = t->codes;
+                hd.tail = (tail && k_cp_chain_tail_supported(d, B)) ? tail : nullptr;
                 TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, Q, np, t->cp_resid, t->cp_part, t->cp_qkv,
                                t->cp_attn, t->cp_act, cflags, cerr, &hd, st));
                 t->ran |= 1;
+                t->tail_fused = hd.tail != nullptr;
                 break;
             }
             if (!in_pair) {
@@ -711,7 +716,9 @@ extern "C" int omni_talker_code_predictor(omni_talker* t, const int32_t* layer0_
     return OMNI_OK;
 }
 
-extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* stream) {
+// fuse_tail (the full-step callers): the input assembly below and layer 0's qkv ride as the tail of the predictor's all-pass launch where that
+// launch runs and the backbone takes the chain's launch structure (t->tail_fused; run_backbone then skips its first qkv launch)
+static int mtp_phase(omni_talker* t, const omni_step_io* io, void* stream, bool fuse_tail) {
     TRY(check_io(t, io));
     t->ran = 0;        // the first phase of every step, whoever drives the phases (decode_step, the tensor-parallel phase calls): ADVICE r4
     const omni_talker_desc& d = t->d;
@@ -719,14 +726,19 @@ extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* str
     hipStream_t st = (hipStream_t)stream;
     // e0 = codec_embedding(last sampled id)  (qwen3_tts_talker.py:637-640): gathered only when no folded table
     if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
+    const omni_chain_tail tl{io->input_ids, d.embed, d.vocab, d.cp_embed, io->text_step, io->inputs_embeds, t->resid, t->part, io->audio_codes, d.hidden,
+                             d.layers > 0 ? t->layer[0].wqkv : nullptr, d.layers > 0 ? t->layer[0].ln1 : nullptr, t->qkv, (d.q_heads + 2 * d.kv_heads) * d.head_dim};
+    const bool want_tail = fuse_tail && d.layers > 0 && k_bb_chain_supported(d, B, t->has_ar) && !k_bb_chain_small(d);
     TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->cp_top_p,
-                           io->seed, io->steps, nullptr, stream, io->rows.seed));
+                           io->seed, io->steps, nullptr, stream, io->rows.seed, want_tail ? &tl : nullptr));
+    if (t->tail_fused) return OMNI_OK;
     hipLaunchKernelGGL(mtp_finalize_kernel, dim3(B), dim3(256), 0, st, io->input_ids, t->codes, (const uint16_t*)d.embed,
                        d.vocab, (const uint16_t*)d.cp_embed, (const uint16_t*)io->text_step, (uint16_t*)io->inputs_embeds,
                        t->resid, d.fused_norm ? t->part : nullptr, io->audio_codes, d.hidden, Q, d.codebook);
     OMNI_CHECK_LAUNCH("mtp_finalize");
     return OMNI_OK;
 }
+extern "C" int omni_talker_mtp(omni_talker* t, const omni_step_io* io, void* stream) { return mtp_phase(t, io, stream, false); }
 
 // decode rows: fused norm+qkv, fused rope/kv-write/attention, o_proj
 static int layer_attn_decode(omni_talker* t, int l, const omni_step_io* io, void* st, bool with_o = true, bool with_qkv = true) {
@@ -945,9 +957,10 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
         t->ran |= 2;
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
         const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
-        if (do_rest)
+        if (do_rest && !t->tail_fused)      // (tail_fused: layer 0's qkv rows were left by the predictor's all-pass launch, cp_chain.hip tail)
         TRY(xnorm_gemm(t, t->resid, t->part, 1, t->layer[0].ln1, nullptr, t->layer[0].wqkv, t->qkv, B, (hq + 2 * hkv) * D, H, OMNI_EPI_BF16,
                        nullptr, 0, stream));
+        t->tail_fused = false;
         for (int l = 0; l < d.layers; ++l) {
             const omni_layer_weights& w = t->layer[l];
             if (do_attn)
@@ -1013,7 +1026,8 @@ extern "C" int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int
     TRY(check_io(t, io));
     OMNI_CHECK_ARG(parts > 0 && parts < 16, "omni_talker_step_part: parts=%d", parts);
     t->ran = 0;
-    if (parts & 1) TRY(omni_talker_mtp(t, io, stream));
+    if (parts & 1) TRY(mtp_phase(t, io, stream, (parts & 5) == 5));
+    else t->tail_fused = false;
     if (parts & 6) TRY(run_backbone(t, io, stream, parts & 6, (parts & 12) == 12));
     else t->head_fused = false;
     if (parts & 8) TRY(omni_talker_finish(t, io, stream));
@@ -1024,12 +1038,13 @@ extern "C" int omni_talker_step_part(omni_talker* t, const omni_step_io* io, int
 extern "C" int omni_talker_backbone_step(omni_talker* t, const omni_step_io* io, void* stream) {
     TRY(check_io(t, io));
     t->ran = 0;
+    t->tail_fused = false;
     TRY(run_backbone(t, io, stream, 6, true));
     return omni_talker_finish(t, io, stream);
 }
 
 extern "C" int omni_talker_decode_step(omni_talker* t, const omni_step_io* io, void* stream) {
-    TRY(omni_talker_mtp(t, io, stream));
+    TRY(mtp_phase(t, io, stream, g_extra_trivial == 0));
     if (g_extra_trivial == 0) {
         TRY(run_backbone(t, io, stream, 6, true));
         return omni_talker_finish(t, io, stream);

@@ -49,6 +49,13 @@ struct ChainArgs {
     const uint16_t* ptab;                 // folded projection tables [Q - 1][codebook][Hc]: pass g < Q - 1 gathers row `code` of table g - 1
     uint32_t* flags;
     int32_t* err;
+    // tail of the all-pass launch (round 6): input assembly of the backbone by the last sampler stage's row owners, then layer 0's qkv
+    struct Tail {
+        const int32_t* input_ids; const uint16_t* embed; int vocab; const uint16_t* cp_embed; const uint16_t* text_step;
+        uint16_t* x_out; uint16_t* resid; float* part; int64_t* audio_codes; int H;
+        const uint16_t* wqkv; const uint16_t* ln1; uint16_t* qkv; int NQ;
+        int enabled;
+    } tail;
     int Bp;                               // pair kernel: rows of position 1 start at Bp (B rounded up to 16) in the 128-row stream
     int skip;                             // debug library: ingest experiment (coherent.cuh ChainGate::skip)
     int dom, gu_narrow, nap;              // policy (run-time knobs in the debug library): flag domain (coherent.cuh), gate_up on the launch path's 32 x 24 tile, poll pause
@@ -160,12 +167,69 @@ __device__ __forceinline__ void chain_attn(const ChainArgs& a, const ChainLayer&
     CH_STAMP(stamps, sidx, 7);
 }
 
+// ---- the backbone's input row of batch row b (mtp_finalize_kernel, capi.hip: x[t+1] = bf16(bf16(sum_fp32(e0, emb_1 .. emb_{Q-1})) + text_step), an
+// invalid layer-0 id -> a frame of zeros; qwen3_tts_talker.py:1630-1641) by the workgroup that just drew the row's last code: the same 256 threads,
+// the same order of additions, the same slab value.  Row-major copy (inputs_embeds: the step's output) by plain stores, the residual stream and its
+// slab by write-through stores (the qkv stage behind the flags reads them)
+// (a real call, not inlined: compiled into the sampler stage its code changed the register allocation of the whole pass loop -- the all-pass
+//  launch ran 4.5 us per pass slower with the tail inlined, profiles/r06 NOTEBOOK)
+struct ChainFinArgs { ChainArgs::Tail T; const int32_t* codes; int Q, codebook; };
+__device__ __attribute__((noinline)) void chain_finalize_row(const ChainFinArgs fa, int b, int last_code, float* lds) {
+    const ChainArgs::Tail& T = fa.T;
+    struct { const int32_t* codes; int Q, codebook; } a{fa.codes, fa.Q, fa.codebook};
+    const int Q = a.Q, H = T.H, tid = threadIdx.x;
+    int* cg = reinterpret_cast<int*>(lds + CH_LDS_FLOATS - 128);          // [64] codes of the row | [4] wave sums (past the sampler's carve)
+    float* red = lds + CH_LDS_FLOATS - 64;
+    const int c0 = T.input_ids[b];
+    const bool invalid0 = c0 < 0 || c0 >= a.codebook;
+    if (tid < Q) {
+        int c = tid == 0 ? c0 : (tid == Q - 1 ? last_code : (int)coh_ld4(coh_rsrc(a.codes), ((uint32_t)b * Q + tid) * 4));
+        if (invalid0) c = 0;
+        cg[tid] = c;
+        T.audio_codes[(size_t)b * Q + tid] = (int64_t)c;
+    }
+    __syncthreads();
+    float ss = 0.f;
+    if (tid < 256) {
+        const coh_rsrc_t rrs = coh_rsrc(T.resid);
+        for (int v = tid; v < H / 8; v += 256) {
+            float s[8];
+            {
+                const bool ok = c0 >= 0 && c0 < T.vocab;
+                const u32x4 e = ok ? ld16(T.embed + (size_t)c0 * H + v * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[2 * j] = bf_lo(e[j]); s[2 * j + 1] = bf_hi(e[j]); }
+            }
+#pragma unroll 4
+            for (int g = 1; g < Q; ++g) {
+                const u32x4 e = ld16(T.cp_embed + ((size_t)(g - 1) * a.codebook + cg[g]) * H + v * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[2 * j] += bf_lo(e[j]); s[2 * j + 1] += bf_hi(e[j]); }
+            }
+            const u32x4 tx = ld16(T.text_step + (size_t)b * H + v * 8);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bfround(s[2 * j]) + bf_lo(tx[j]), bfround(s[2 * j + 1]) + bf_hi(tx[j]));
+            *reinterpret_cast<u32x4*>(T.x_out + (size_t)b * H + v * 8) = o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += bf_lo(o[j]) * bf_lo(o[j]) + bf_hi(o[j]) * bf_hi(o[j]);
+            coh_st16(rrs, (uint32_t)frag_off(b, v * 8, H) * 2, o);
+        }
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+    }
+    __syncthreads();
+    if (tid == 0) coh_st4(coh_rsrc(T.part), (uint32_t)b * 4, __float_as_uint(red[0] + red[1] + red[2] + red[3]));
+}
+
 // ---- sampler stage of pass g: the workgroup that owns batch row b (inside b's flag domain) draws code g of row b from the
 // head GEMM's logits and, unless this was the last group, gathers the folded embedding -> projection row of the drawn code
 // into the residual stream as the next pass's input (slab 0 = its sum of squares).  sample_kernel's arithmetic (sampler_body.cuh):
 // waves 0-3 are the row's 256 threads, waves 4-7 only keep the barriers.
+template <bool TAIL = false>
 __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* lds, ChainGate& gate, int code, unsigned long long* stamps) {
     const int sidx = 26;
+    int* const last_code = reinterpret_cast<int*>(lds + CH_LDS_FLOATS - 136);      // the drawn code, for the whole workgroup (tail: chain_finalize_row)
     CH_STAMP(stamps, sidx, 0);
     const int rows_per_dom = 16 << (gate.dom - 6);
     const int wi = blockIdx.x & ((1 << gate.dom) - 1);
@@ -236,6 +300,7 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
                 if (lane == 0) coh_st4(coh_rsrc(a.part), (uint32_t)b * 4, __float_as_uint(((ss2[0] + ss2[1]) + 0.f) + 0.f));
             }
             if (lane == 0) coh_st4(coh_rsrc(a.codes), ((uint32_t)b * a.Q + g) * 4, (uint32_t)pick);
+            if (lane == 0) last_code[0] = pick;
         }
     } else {
         constexpr int NPT = 8;
@@ -282,6 +347,12 @@ __device__ __forceinline__ void chain_sample(const ChainArgs& a, int g, float* l
             }
         }
         if (threadIdx.x == 0) coh_st4(coh_rsrc(a.codes), ((uint32_t)b * a.Q + g) * 4, (uint32_t)pick);
+        if (threadIdx.x == 0) last_code[0] = pick;
+    }
+    if (TAIL && g == a.Q - 1 && a.tail.enabled) {
+        // the row's frame is complete: its owner assembles the backbone's input row right here (no hand-off: the last code is its own)
+        __syncthreads();
+        chain_finalize_row(ChainFinArgs{a.tail, a.codes, a.Q, a.codebook}, b, last_code[0], lds);
     }
     CH_STAMP(stamps, sidx, 6);
     chain_gate_arrive(gate);
@@ -393,7 +464,17 @@ __global__ __launch_bounds__(CH_THREADS) void cp_pair_kernel(const ChainArgs a) 
 // DEFER: rstd of the qkv / gate_up stages applied in their epilogues (chain_gemm PRO 3; the head GEMM keeps the exact norm) -- round 4's
 // A/B arm of VERDICT r3 item 1b, the product form since round 6 (the launch path's gemm_skinny_kernel takes it for the same GEMMs: same bits);
 // <.., false> = round 5's exact-rstd stages, debug library only
-template <bool GU_NARROW, bool DEFER = true>
+// the tail's qkv stage as a real call on a copy of the gate (the launch ends behind it: nothing reads the gate afterwards)
+template <int KHT>
+__device__ __attribute__((noinline)) void chain_tail_qkv(const ChainArgs::Tail T, int B, float eps, float* lds, ChainGate g, int code) {
+    g.dom = 8;
+    const int nc_q = T.NQ >> 5;
+    chain_gemm<2, 2, KHT, 3, OMNI_EPI_BF16, 4>(T.wqkv, T.ln1, T.resid, T.part, 1, T.qkv, T.NQ, nullptr, B, T.NQ, eps, blockIdx.x % nc_q, blockIdx.x / nc_q, lds, g,
+                                               true, code, nullptr);
+}
+
+// KHT: 0, or hidden / 256 of the backbone whose first qkv stage closes the launch (the tail: round 6)
+template <bool GU_NARROW, bool DEFER = true, int KHT = 0>
 __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CH_LDS_FLOATS];
     static_assert(CH_LDS_FLOATS * 4 >= SMP_LDS_BYTES(8), "sampler working set must fit the chain's LDS");
@@ -412,7 +493,7 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
         const bool gemm16 = (wg >> 6) * 16 < a.B, gemm32 = GU_NARROW && (wg >> 7) * 32 < a.B, attn_ = wg * 4 < a.B * a.q_heads;
         const bool smp = a.with_head && wi < rows_per_dom && (wg >> a.dom) * rows_per_dom + wi < a.B;
         if (!(gemm16 || gemm32 || attn_ || smp)) {
-            const uint32_t total = (uint32_t)(a.g1 - a.g0) * (uint32_t)(a.layers * 5 + (a.with_head ? 2 : 0));
+            const uint32_t total = (uint32_t)(a.g1 - a.g0) * (uint32_t)(a.layers * 5 + (a.with_head ? 2 : 0)) + ((KHT > 0 && a.tail.enabled) ? 1u : 0u);
             if (threadIdx.x < 64) chain_flag_publish(g.frs, wg, g.epoch + total);
             return;
         }
@@ -451,8 +532,15 @@ __global__ __launch_bounds__(CH_THREADS) void cp_chain_kernel(const ChainArgs a)
         chain_gemm<1, 2, 4, 2, OMNI_EPI_F32_BF16RND>(a.lm_head + (size_t)(pass - 1) * a.codebook * Hc, a.cp_norm, a.resid, a.part, np,
                                                      a.logits + (size_t)(pass - 1) * a.logits_pass, a.logits_ld, nullptr, a.B, a.codebook, a.eps,
                                                      wg & 63, wg >> 6, lds, g, true, pc | 0x56, st);
-        chain_sample(a, pass, lds, g, pc | 0xF2, st);
+        chain_sample<(KHT > 0)>(a, pass, lds, g, pc | 0xF2, st);
         np = 1;
+    }
+    if constexpr (KHT > 0) {
+        if (a.tail.enabled) {
+            // layer 0's qkv rows of the backbone, behind EVERY row's input assembly (flag domain: all 256 workgroups); gemm_skinny_kernel's
+            // norm-fused arithmetic on 32 x 32 tiles (the bits do not depend on the tile shape: gemm_frag.cuh SlabOrder)
+            chain_tail_qkv<KHT>(a.tail, a.B, a.eps, lds, g, ((a.g1 - 1) << 8) | 0x62);
+        }
     }
 }
 
@@ -527,6 +615,24 @@ int k_cp_pair(const omni_talker_desc& d, const omni_layer_weights* layers, uint1
     return OMNI_OK;
 }
 
+// backbone widths (hidden / 256) the tail's qkv stage is instantiated for: those of bb_chain.hip's BB_SHAPES
+#define CP_TAIL_WIDTHS(X) X(8) X(6)
+OMNI_KNOB g_chain_tail = 1;
+#ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_chain_tail(int on) { g_chain_tail = on; }      // 0: mtp_finalize and the first qkv as launches of their own (round 5)
+#endif
+bool k_cp_chain_tail_supported(const omni_talker_desc& d, int B) {
+    bool listed = false;
+#define X(KH_) listed = listed || d.hidden == KH_ * 256;
+    CP_TAIL_WIDTHS(X)
+#undef X
+    const int NQ = (d.q_heads + 2 * d.kv_heads) * 128;
+    // every row group live (B > 48: no workgroup leaves at launch start, all of them own a qkv tile with rows), the norm-free stream, the
+    // qkv stage's 32 x 32 tile grid inside the 256 workgroups
+    return g_chain_tail && g_chain_defer && g_chain_gu_narrow && g_cp_chain && g_chain_span >= 2 && listed && B > 48 && B <= 64 && d.fused_norm && d.frag_layout && d.moe_experts == 0 && d.head_dim == 128 &&
+           NQ % 32 == 0 && (NQ / 32) * 2 <= OMNI_CHAIN_WGS && d.hidden % 8 == 0;
+}
+
 int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B,
                int g0, int g1, int np_in, uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags,
                int32_t* err, const omni_chain_head* head, void* stream) {
@@ -573,6 +679,16 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
         return OMNI_OK;
     }
 #endif
+    if (head && head->tail && g1 == d.num_code_groups && a.gu_narrow && k_cp_chain_tail_supported(d, B)) {
+        // the launch ends in the step's input assembly + layer 0's qkv (instantiated per backbone width: CP_TAIL_WIDTHS)
+        const omni_chain_tail& T = *head->tail;
+        a.tail = ChainArgs::Tail{T.input_ids, (const uint16_t*)T.embed, T.vocab, (const uint16_t*)T.cp_embed, (const uint16_t*)T.text_step,
+                                 (uint16_t*)T.x_out, (uint16_t*)T.resid, T.part, T.audio_codes, T.H,
+                                 (const uint16_t*)T.wqkv, (const uint16_t*)T.ln1, (uint16_t*)T.qkv, T.NQ, 1};
+#define X(KH_) if (d.hidden == KH_ * 256) { hipLaunchKernelGGL((cp_chain_kernel<true, true, KH_>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a); OMNI_CHECK_LAUNCH("cp_chain(tail)"); return OMNI_OK; }
+        CP_TAIL_WIDTHS(X)
+#undef X
+    }
     if (a.gu_narrow) hipLaunchKernelGGL(cp_chain_kernel<true>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cp_chain_kernel<false>, dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     OMNI_CHECK_LAUNCH("cp_chain");

@@ -75,7 +75,18 @@ struct omni_chain_head {
     int greedy, top_k; float temperature, top_p; uint32_t seed;
     const int32_t* steps; const uint32_t* row_seed;
     int32_t* codes;                                 // [B][Q]
+    // round 6: the step's input assembly and the backbone's first qkv as the TAIL of the all-pass launch (cp_chain.hip): the row owner of the
+    // last sampler stage sums the 16 code embeddings + the text step into the backbone's residual stream (mtp_finalize_kernel's arithmetic),
+    // then one more stage computes layer 0's qkv rows.  NULL: both stay launches of their own
+    const struct omni_chain_tail* tail;
 };
+struct omni_chain_tail {
+    const int32_t* input_ids; const void* embed; int vocab; const void* cp_embed; const void* text_step;
+    void* x_out; void* resid; float* part; int64_t* audio_codes; int H;
+    const void* wqkv; const void* ln1; void* qkv; int NQ;
+};
+// the tail's qkv stage is instantiated for the backbone widths of bb_chain.hip's BB_SHAPES; every row group must be live (B > 48)
+bool k_cp_chain_tail_supported(const omni_talker_desc& d, int B);
 bool k_cp_pair_supported(const omni_talker_desc& d, int B, int greedy, int top_k, float top_p);
 int k_cp_pair(const omni_talker_desc& d, const omni_layer_weights* layers, uint16_t* const* k_cache, uint16_t* const* v_cache, int B, int np_in,
               uint16_t* resid, float* part, uint16_t* qkv, uint16_t* attn, uint16_t* act, uint32_t* flags, int32_t* err, const omni_chain_head* head,

@@ -20,6 +20,7 @@ void omni_debug_bb_all(int on);                            /* backbone: the whol
 void omni_debug_bb_all_stamps(void* buf, int layer);       /* uint64 [8][8][256] timeline stamps of one layer's stages of that launch (NULL: off) */
 void omni_debug_chain_defer(int on);                       /* code-predictor chain A/B arm: RMSNorm rstd applied in the qkv / gate_up epilogues (another rounding point than the reference's; timing + accuracy experiments) */
 void omni_debug_chain_pair(int on);                        /* code predictor: positions 0 / 1 + group 1's head and sampler as one persistent launch (cp_pair_kernel) */
+void omni_debug_chain_tail(int on);                         /* 1 (default): the step's input assembly + layer 0's qkv as the tail of the predictor's all-pass launch; 0: launches of their own (round 5) */
 void omni_debug_chain_skip(int mode);                      /* code-predictor chain timing experiment: 1 = fetch half of every weight slice, 2 = half of the activations, 4 = the polling wave fetches no weights, 5 = no wave does (garbage results) */
 void omni_debug_bb_min_rows(int rows);                     /* backbone chain: smallest batch the 64-row stage set takes (33 since round 5; 49: round 4's policy, 33-48 rows launch per op) */
 void omni_debug_moe_chain(int on);                         /* sparse-MoE layer: o_proj -> router | shared gate_up -> shared down + routing as one persistent launch (moe_chain.hip) */
