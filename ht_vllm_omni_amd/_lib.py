@@ -37,7 +37,7 @@ class LayerWeights(C.Structure):
 
 class ArPeers(C.Structure):
     """omni_ar_peers: peer-mapped partial buffers + flag words of a tensor-parallel group."""
-    _fields_ = [("world", i32), ("rank", i32), ("data", vp * 8), ("flags", vp * 8), ("epoch", vp), ("error", vp)]
+    _fields_ = [("world", i32), ("rank", i32), ("data", vp * 8), ("flags", vp * 8), ("epoch", vp), ("error", vp), ("tile_flags", vp * 8)]
 
 
 class TileGemm(C.Structure):

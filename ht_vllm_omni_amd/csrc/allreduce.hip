@@ -94,16 +94,19 @@ __global__ __launch_bounds__(256) void allreduce_resid_kernel(const ArArgs a) {
         u32x4 old = (u32x4){0, 0, 0, 0};
         if (a.r_io && a.accumulate) old = *reinterpret_cast<const u32x4*>(a.r_io + off);
         u32x4 o, s;
-        float ss = 0.f;
+        float rr[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s0 = bfround(acc[2 * j]), s1 = bfround(acc[2 * j + 1]);          // the all-reduced delta, bf16
             s[j] = pack_bf2(s0, s1);
-            const float r0 = a.accumulate ? bfround(bf_lo(old[j]) + s0) : s0;
-            const float r1 = a.accumulate ? bfround(bf_hi(old[j]) + s1) : s1;
-            o[j] = pack_bf2(r0, r1);
-            ss += r0 * r0 + r1 * r1;
+            rr[2 * j] = a.accumulate ? bfround(bf_lo(old[j]) + s0) : s0;
+            rr[2 * j + 1] = a.accumulate ? bfround(bf_hi(old[j]) + s1) : s1;
+            o[j] = pack_bf2(rr[2 * j], rr[2 * j + 1]);
         }
+        // sum(r^2) of the slab's 16 columns in the order of the chains' residual epilogue (chain_gemm.cuh, gemm.hip RESID: four columns left
+        // to right, then groups 0 + 1 and 2 + 3, then the halves) -- so that the all-reduce inside a backbone chain stage (round 6) and this
+        // launch write the same slab bits
+        float ss = sq4_sum(rr[0], rr[1], rr[2], rr[3]) + sq4_sum(rr[4], rr[5], rr[6], rr[7]);
         if (a.r_io) *reinterpret_cast<u32x4*>(a.r_io + off) = o;
         if (a.out_rm && row < a.M) *reinterpret_cast<u32x4*>(a.out_rm + (size_t)row * a.H + blockIdx.x * 32 + kc * 8) = s;
         if (a.part) {

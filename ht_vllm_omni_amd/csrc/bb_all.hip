@@ -203,7 +203,7 @@ int k_bb_all_set_scales(void* table_dev, int layers, const float* k, const float
 }
 
 bool k_bb_all_supported(const omni_talker_desc& d, int B, bool has_ar) {
-    return g_bb_all && k_bb_chain_supported(d, B, has_ar) && d.hidden == 2048 && d.kv_heads == 8 && d.layers >= 1 &&
+    return g_bb_all && !has_ar && k_bb_chain_supported(d, B) && d.hidden == 2048 && d.kv_heads == 8 && d.layers >= 1 &&
            (d.kv_dtype == OMNI_KV_FP8 || d.kv_dtype == OMNI_KV_BF16 || d.kv_dtype == OMNI_KV_FP16 || d.kv_dtype == OMNI_KV_INT8);
 }
 

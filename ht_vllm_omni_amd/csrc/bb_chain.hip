@@ -34,6 +34,10 @@ struct BbArgs {
     int B, nap; float eps;
     uint32_t* flags; int32_t* err;
     unsigned long long* stamps;
+    // tensor-parallel rank (round 6): o_proj and down_proj are row-parallel partials; their all-reduce rides in the two residual epilogues
+    // (chain_gemm AR).  ar_epoch = allreduce.hip's epoch / ticket words: this launch makes calls epoch + 1 (o_proj) and epoch + 2 (down_proj)
+    ChainAr ar_o, ar_dn;
+    uint32_t* ar_epoch;
 };
 
 // (Round 3 also tried a ninth wave that warms the XCD's L2 with the next stage's slice -- one dword per 64 bytes, nothing
@@ -49,9 +53,17 @@ struct BbArgs {
 // read by the two workgroups of a column tile's row halves) -- round 5 A/B arm (MI355X_MICROARCH "nt-weights")
 // HEAD: the instantiation the LAST layer launches when the step's head rides along (its own code object entry: the other 27 launches keep the
 // leaner kernel -- with the head stage compiled into every launch the segment cost 0.9 us more per layer, register allocation of the shared stages)
-template <int KO, int KH, int KI, int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0, bool HEAD = false>
+// AR: the instantiation of a tensor-parallel rank (the all-reduces inside the o_proj / down_proj stages); HALF: 128 workgroups play the 256 of the
+// stage grid, two VIRTUAL workgroups each, stage by stage (a virtual workgroup's stage needs only stages that every physical workgroup has
+// already run or will run before it waits again: no cycle) -- two such launches of two processes fit the chip side by side, which is how the
+// cross-process exchange is tested on one GPU (tests/test_gpu_tp.py) and how a co-located second engine keeps its backbone chain
+template <int KO, int KH, int KI, int GU_G, int DN_G, int QK_G, bool PF, bool GU1P = true, bool GUW0 = false, bool DEFER = true, int WNT = 0, bool HEAD = false,
+          bool AR = false, bool HALF = false>
 __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(!PF || (!AR && !HALF), "the cross-stage prefetch arm is a single-rank, full-grid experiment");
+    uint32_t e0 = 0;
+    if constexpr (AR) e0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ar_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     ChainGate g;
     chain_gate_init(g, a.flags, a.err);
     g.dom = 8;                          // gate_up's 64-row tiles tie every row group together
@@ -106,20 +118,45 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
         return;
     } else {
     constexpr int NT1 = (WNT & 1) ? OMNI_AUX_NT : 0, NT2 = (WNT & 2) ? OMNI_AUX_NT : 0;
-    chain_gemm<2, 1, KO, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 64, NT2>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps, wg % nc_h,
-                                                                                   wg / nc_h, lds, g, false, 0x1001, a.stamps);
-    if (wg < nc_gu)
-        chain_gemm<4, 3, KH, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8, GU_G, GUW0 ? 0 : 1, ChainNoPrefetch, GU1P, 64, NT1>(a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0,
-                                                                                                                       nullptr, a.B, I, a.eps, wg, 0, lds, g, true,
-                                                                                                                       0x1002, a.stamps);
-    else
-        chain_gate_skip(g);
-    chain_gemm<2, 1, KI, 0, OMNI_EPI_RESID, DN_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps,
-                                                                                      wg % nc_h, wg / nc_h, lds, g, true, 0x1003, a.stamps);
+    // the four stages of (virtual) workgroup WG_ behind gate G_
+#define BB_O(WG_, G_)                                                                                                                                   \
+    chain_gemm<2, 1, KO, 0, OMNI_EPI_RESID, 0, 0, ChainNoPrefetch, false, 64, NT2, AR>(a.wo, nullptr, a.attn, nullptr, 0, a.resid, 0, a.part, a.B, H, a.eps,    \
+                                                                                       (WG_) % nc_h, (WG_) / nc_h, lds, G_, false, 0x1001, a.stamps, nullptr,  \
+                                                                                       ChainNoPrefetch(), nullptr, nullptr, 0.f, nullptr, &a.ar_o, e0 + 1u)
+#define BB_GU(WG_, G_)                                                                                                                                  \
+    do {                                                                                                                                                \
+        if ((WG_) < nc_gu)                                                                                                                              \
+            chain_gemm<4, 3, KH, DEFER ? 3 : 2, OMNI_EPI_SILU_MUL_GU8, GU_G, GUW0 ? 0 : 1, ChainNoPrefetch, GU1P, 64, NT1>(                              \
+                a.wgu, a.ln2, a.resid, a.part, H / 16, a.act, 0, nullptr, a.B, I, a.eps, WG_, 0, lds, G_, true, 0x1002, a.stamps);                        \
+        else                                                                                                                                            \
+            chain_gate_skip(G_);                                                                                                                        \
+    } while (0)
+#define BB_DN(WG_, G_)                                                                                                                                  \
+    chain_gemm<2, 1, KI, 0, OMNI_EPI_RESID, DN_G, 0, ChainNoPrefetch, false, 64, NT2, AR>(a.wdown, nullptr, a.act, nullptr, 0, a.resid, 0, a.part, a.B, H,       \
+                                                                                          a.eps, (WG_) % nc_h, (WG_) / nc_h, lds, G_, true, 0x1003, a.stamps,   \
+                                                                                          nullptr, ChainNoPrefetch(), nullptr, nullptr, 0.f, nullptr, &a.ar_dn,  \
+                                                                                          e0 + 2u)
+#define BB_QK(WG_, G_)                                                                                                                                  \
+    chain_gemm<2, 2, KH, DEFER ? 3 : 2, OMNI_EPI_BF16, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ,    \
+                                                                                                 nullptr, a.B, NQ, a.eps, (WG_) % nc_q, (WG_) / nc_q, lds, G_,   \
+                                                                                                 true, 0x1004, a.stamps)
+    if constexpr (HALF) {
+        static_assert(!HALF || !HEAD, "the half grid has no head stage (a tensor-parallel rank's lm_head stays its own launch)");
+        ChainGate g2;
+        chain_gate_init(g2, a.flags, a.err, wg + OMNI_CHAIN_WGS / 2);
+        g2.dom = 8;
+        g2.nap = a.nap;
+        const int wg2 = wg + OMNI_CHAIN_WGS / 2;
+        BB_O(wg, g); BB_O(wg2, g2);
+        BB_GU(wg, g); BB_GU(wg2, g2);
+        BB_DN(wg, g); BB_DN(wg2, g2);
+        if (a.wqkv_next) { BB_QK(wg, g); BB_QK(wg2, g2); }
+    } else {
+    BB_O(wg, g);
+    BB_GU(wg, g);
+    BB_DN(wg, g);
     if (a.wqkv_next)
-        chain_gemm<2, 2, KH, DEFER ? 3 : 2, OMNI_EPI_BF16, QK_G, 0, ChainNoPrefetch, false, 64, NT2>(a.wqkv_next, a.ln1_next, a.resid, a.part, H / 16, a.qkv, NQ,
-                                                                                                     nullptr, a.B, NQ, a.eps, wg % nc_q, wg / nc_q, lds, g, true,
-                                                                                                     0x1004, a.stamps);
+        BB_QK(wg, g);
     else if (HEAD && a.lm_head) {
         // the step's head as the last stage of its last backbone launch (one launch and one cold start less: 9.8 us + a boundary -> a stage):
         // gemm_skinny_kernel<2, 2, PRO 2, F32_BF16RND>'s tile and arithmetic (exact norm: its normalised rows are h[t + 1])
@@ -128,6 +165,22 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_kernel(const BbArgs a) {
                                                                                                 nullptr, a.B, a.V, a.eps, wg % nc_v, wg / nc_v, lds, g, true, 0x1005,
                                                                                                 a.stamps, nullptr, ChainNoPrefetch(), a.last_hidden, a.mask,
                                                                                                 a.mask_fill, a.num_live);
+    }
+    }
+#undef BB_O
+#undef BB_GU
+#undef BB_DN
+#undef BB_QK
+    if constexpr (AR) {
+        // the last workgroup out closes the launch's two all-reduce calls (allreduce.hip's epoch word: every workgroup read it at its start)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = atomicAdd(a.ar_epoch + 1, 1u);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(a.ar_epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ar_epoch, e0 + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     }
 }
@@ -200,34 +253,47 @@ __global__ __launch_bounds__(CH_THREADS) void bb_chain_b32_kernel(const BbArgs a
     }
 }
 
-OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 33, g_bb_b32 = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
+OMNI_KNOB g_bb_chain = 1, g_bb_nap = 1, g_bb_prefetch = 0, g_bb_deep = 0, g_bb_min_rows = 33, g_bb_b32 = 1, g_bb_ar = 1;      // cross-stage prefetch: measured +0.4 ms per step, off
 #ifdef OMNI_DEBUG_HOOKS
 static unsigned long long* g_bb_stamps = nullptr;
 extern "C" void omni_debug_bb_chain(int on) { g_bb_chain = on != 0; g_bb_prefetch = on == 2; }      // 2: with the cross-stage weight prefetch
 extern "C" void omni_debug_bb_stamps(void* buf) { g_bb_stamps = (unsigned long long*)buf; }
 extern "C" void omni_debug_bb_deep(int mode) { g_bb_deep = mode; }
+extern "C" void omni_debug_bb_ar(int on) { g_bb_ar = on; }                  // 0: tensor-parallel ranks keep the launch-per-op backbone (round 5)
 extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; g_bb_b32 = rows <= 49; }                          // smallest batch the backbone chain takes                                  // deeper activation / weight rings
 #endif
 
 // the instantiated shape triples (KO, KH, KI) = (q_heads * 128, hidden, intermediate) / 256: the released 1.7B shape and one no released
 // checkpoint has (hidden 1536, intermediate 4608, 12 q heads: tests/test_gpu_chain.py, tests/test_gpu_engine.py); a new width = one more line
 #define BB_SHAPES(X) X(8, 8, 24) X(6, 6, 18)
+// ... and the triples of a tensor-parallel RANK (the all-reduce instantiations, full and half grid): the 1.7B shape whole (a one-rank group:
+// bench.py --tp-force), over 2 ranks (BASELINE config #4: 8 q / 4 kv heads, intermediate 3072) and over 4
+#define BB_AR_SHAPES(X) X(8, 8, 24) X(4, 8, 12) X(2, 8, 6)
 
-bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar) {
+// ar: the rank's peer table (NULL = not tensor parallel); half: the 128-workgroup grid (omni_talker_set_chains(t, 2))
+bool k_bb_chain_supported(const omni_talker_desc& d, int B, const omni_ar_peers* ar, bool half) {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0;
         hipDeviceProp_t p;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
     }
-    const bool common = g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && !has_ar && d.moe_experts == 0 &&
+    const bool has_ar = ar != nullptr;
+    // a tensor-parallel rank: every peer's tile flags mapped (omni_ar_peers::tile_flags; a one-rank group exchanges nothing)
+    bool ar_ok = has_ar && g_bb_ar;
+    if (has_ar)
+        for (int p = 0; p < ar->world; ++p) ar_ok = ar_ok && (ar->world == 1 || ar->tile_flags[p] != nullptr);
+    const bool common = g_bb_chain && d.cp_chain && cus >= OMNI_CHAIN_WGS && d.fused_norm && d.frag_layout && (!has_ar || ar_ok) && d.moe_experts == 0 &&
                         d.head_dim == 128 && B <= 64;
-    if (common && k_bb_chain_small(d)) return B >= 1;                          // 0.6B shape: 16-row tiles, every batch size
+    if (common && !has_ar && !half && k_bb_chain_small(d)) return B >= 1;      // 0.6B shape: 16-row tiles, every batch size
     const int H = d.hidden, I = d.inter, KOW = d.q_heads * 128, NQ = (d.q_heads + 2 * d.kv_heads) * 128;
     bool listed = false;
 #define X(KO_, KH_, KI_) listed = listed || (KOW == KO_ * 256 && H == KH_ * 256 && I == KI_ * 256);
-    BB_SHAPES(X)
+    if (has_ar) { BB_AR_SHAPES(X) }
+    else if (half) { X(8, 8, 24) }
+    else { BB_SHAPES(X) }
 #undef X
+    if (has_ar || half) return common && listed && I % 24 == 0 && NQ % 32 == 0 && B >= 33;      // the 64-row stage set only
     // every stage's tile grid inside the 256 workgroups: o_proj / down_proj 16 columns x 2 row tiles, gate_up 24 activation columns, qkv 32 x 2
     const bool grids = I % 24 == 0 && NQ % 32 == 0 && (H / 16) * 2 <= OMNI_CHAIN_WGS && I / 24 <= OMNI_CHAIN_WGS && (NQ / 32) * 2 <= OMNI_CHAIN_WGS;
     return common && listed && grids && (B >= g_bb_min_rows || (g_bb_b32 && B <= 32));
@@ -267,13 +333,39 @@ static int bb_launch_shape(const BbArgs& a, int B, hipStream_t stream) {
     return OMNI_OK;
 }
 
+// the all-reduce / half-grid instantiations of one triple (64-row stage set)
+template <int KO, int KH, int KI, bool AR>
+static int bb_launch_ar(const BbArgs& a, bool half, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        attr = true;
+    }
+    if (half) hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, true>), dim3(OMNI_CHAIN_WGS / 2), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+    OMNI_CHECK_LAUNCH("bb_chain(all-reduce / half grid)");
+    return OMNI_OK;
+}
+
+static void bb_fill_ar(ChainAr& c, const omni_ar_peers& p) {
+    c.world = p.world; c.rank = p.rank;
+    const ptrdiff_t eoff = p.error - reinterpret_cast<int32_t*>(p.flags[p.rank]);      // the error word sits at the same offset in every rank's control block
+    for (int r = 0; r < CH_AR_MAX_WORLD; ++r) {
+        c.data[r] = r < p.world ? (const uint16_t*)p.data[r] : nullptr;
+        c.tflags[r] = r < p.world ? p.tile_flags[r] : nullptr;
+        c.error[r] = r < p.world ? (p.flags[r] ? reinterpret_cast<int32_t*>(p.flags[r]) + eoff : p.error) : nullptr;
+    }
+}
+
 bool k_bb_chain_head_supported(const omni_talker_desc& d) {      // the lm_head stage's tile grid: 32 columns x 2 row tiles inside 256 workgroups
     return !k_bb_chain_small(d) && d.vocab % 32 == 0 && (d.vocab / 32) * 2 <= OMNI_CHAIN_WGS && d.lm_head != nullptr &&
            !g_bb_prefetch && !g_bb_deep;      // (the debug library's A/B arms keep the head as its own launch)
 }
 
 int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part,
-               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small, const omni_bb_head* head) {
+               void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small, const omni_bb_head* head,
+               const omni_bb_ar* ar, bool half) {
     BbArgs a{};
     a.wo = (const uint16_t*)w.wo; a.ln2 = (const uint16_t*)w.ln2; a.wgu = (const uint16_t*)w.wgu; a.wdown = (const uint16_t*)w.wdown;
     a.ln1_next = next ? (const uint16_t*)next->ln1 : nullptr;
@@ -297,6 +389,22 @@ int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omn
         return OMNI_OK;
     }
     const int ko = d.q_heads * 128 / 256, kh = d.hidden / 256, ki = d.inter / 256;
+    if (ar != nullptr || half) {
+        OMNI_CHECK_ARG(!small && B > 32 && a.lm_head == nullptr, "bb_chain: the all-reduce / half-grid launches are the 64-row stage set without a head stage");
+        if (ar != nullptr) {
+            OMNI_CHECK_ARG(ar->attn && ar->mlp && ar->attn->epoch == ar->mlp->epoch, "bb_chain: the two all-reduces share one epoch word");
+            bb_fill_ar(a.ar_o, *ar->attn);
+            bb_fill_ar(a.ar_dn, *ar->mlp);
+            a.ar_epoch = ar->attn->epoch;
+#define X(KO_, KH_, KI_) if (ko == KO_ && kh == KH_ && ki == KI_) return bb_launch_ar<KO_, KH_, KI_, true>(a, half, (hipStream_t)stream);
+            BB_AR_SHAPES(X)
+#undef X
+        } else if (ko == 8 && kh == 8 && ki == 24) {
+            return bb_launch_ar<8, 8, 24, false>(a, true, (hipStream_t)stream);
+        }
+        omni_set_error("bb_chain: no all-reduce / half-grid stage set for (q width, hidden, intermediate) = (%d, %d, %d)", d.q_heads * 128, d.hidden, d.inter);
+        return OMNI_EINVAL;
+    }
 #ifdef OMNI_DEBUG_HOOKS      // the A/B arms of rounds 3-5 (1.7B triple only)
     a.pf = g_bb_prefetch;
     if (ko == 8 && kh == 8 && ki == 24 && B > 32 && (a.pf || g_bb_deep) && a.lm_head == nullptr) {

@@ -19,7 +19,7 @@ void omni_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* omni_last_error(void) { return g_err; }
-extern "C" int omni_abi_version(void) { return 4; }
+extern "C" int omni_abi_version(void) { return 5; }
 
 #define TRY(expr)                    \
     do {                             \
@@ -118,6 +118,7 @@ struct omni_talker {
     uint32_t* chain_flags;              // stage flags of the persistent chains: OMNI_FLAG_REPLICAS copies of [256] (coherent.cuh) + the error word at [320]
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
+    bool chain_half;                    // omni_talker_set_chains(t, 2): the backbone chain on 128 workgroups, the predictor on the launch path
     int ran;                            // persistent chains launched by the decode-step call in progress / last made (bit 0 cp, bit 1 bb)
     bool head_fused = false;            // the last backbone launch of the step in progress computed logits + h[t + 1] (run_backbone fuse_head)
     bool tail_fused = false;            // the predictor's all-pass launch of the step in progress assembled the backbone's input and computed layer 0's qkv
@@ -350,6 +351,7 @@ extern "C" int omni_talker_chain_error(omni_talker* t, int reset) {
 extern "C" int omni_talker_set_chains(omni_talker* t, int on) {
     if (!t) return OMNI_EINVAL;
     t->d.cp_chain = on != 0;            // k_cp_chain_supported / k_bb_chain_supported read it per call
+    t->chain_half = on == 2;
     return OMNI_OK;
 }
 extern "C" int omni_talker_chains_ran(const omni_talker* t) { return t ? t->ran : 0; }
@@ -587,7 +589,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 else
                     TRY(k_gather_frag(nullptr, 0, layer0_embed, r1, part1, B, d.hidden, 0, st, 1, 128));
             }
-            if (d.cp_chain && k_cp_pair_supported(d, B, greedy, top_k, top_p)) {
+            if (d.cp_chain && !t->chain_half && k_cp_pair_supported(d, B, greedy, top_k, top_p)) {
                 // positions 0 / 1 (25 stages) + group 1's head GEMM and sampler as ONE persistent launch (cp_chain.hip cp_pair_kernel)
                 omni_chain_head hd{};
                 hd.logits = cp_logits_out ? cp_logits_out : t->cp_logits;
@@ -633,7 +635,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
                 break;
             }
             if (!in_pair) {
-                if (d.cp_chain && k_cp_chain_supported(d, g)) {
+                if (d.cp_chain && !t->chain_half && k_cp_chain_supported(d, g)) {
                     // the layer stack of this pass as one persistent launch: 25 stages behind flag hand-offs
                     TRY(k_cp_chain(d, t->cp_layer.data(), t->cp_k.data(), t->cp_v.data(), B, g, g + 1, np, t->cp_resid, t->cp_part, t->cp_qkv,
                                    t->cp_attn, t->cp_act, cflags, cerr, nullptr, st));
@@ -728,7 +730,7 @@ static int mtp_phase(omni_talker* t, const omni_step_io* io, void* stream, bool 
     if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
     const omni_chain_tail tl{io->input_ids, d.embed, d.vocab, d.cp_embed, io->text_step, io->inputs_embeds, t->resid, t->part, io->audio_codes, d.hidden,
                              d.layers > 0 ? t->layer[0].wqkv : nullptr, d.layers > 0 ? t->layer[0].ln1 : nullptr, t->qkv, (d.q_heads + 2 * d.kv_heads) * d.head_dim};
-    const bool want_tail = fuse_tail && d.layers > 0 && k_bb_chain_supported(d, B, t->has_ar) && !k_bb_chain_small(d);
+    const bool want_tail = fuse_tail && d.layers > 0 && !t->has_ar && !t->chain_half && k_bb_chain_supported(d, B) && !k_bb_chain_small(d);
     TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->cp_top_p,
                            io->seed, io->steps, nullptr, stream, io->rows.seed, want_tail ? &tl : nullptr));
     if (t->tail_fused) return OMNI_OK;
@@ -947,14 +949,16 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
     const bool do_attn = (parts & 2) != 0, do_rest = (parts & 4) != 0;
     t->head_fused = false;
 #ifdef OMNI_DEBUG_HOOKS
-    if (parts == 6 && k_bb_all_supported(d, io->B, t->has_ar)) {      // A/B arm: the whole stack, attention included, as one persistent launch
+    if (parts == 6 && !t->chain_half && k_bb_all_supported(d, io->B, t->has_ar)) {      // A/B arm: the whole stack, attention included, as one persistent launch
         t->ran |= 2;                                                  // (a split request -- step_part 2 / 4 -- takes the two-launch structure below)
         return k_bb_all(d, t->bb_table, io, t->attn, t->resid, t->part, t->act, t->qkv, t->chain_flags,
                         reinterpret_cast<int32_t*>(t->chain_flags + 320), stream);
     }
 #endif
-    if (k_bb_chain_supported(d, io->B, t->has_ar) && d.layers > 0) {
+    const omni_bb_ar bar{&t->ar_attn, &t->ar_mlp};
+    if (k_bb_chain_supported(d, io->B, t->has_ar ? &t->ar_attn : nullptr, t->chain_half) && d.layers > 0) {
         t->ran |= 2;
+        const bool plain = !t->has_ar && !t->chain_half;      // (a tensor-parallel rank / the half grid: the 64-row stage set, head as its own launch)
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
         const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
         if (do_rest && !t->tail_fused)      // (tail_fused: layer 0's qkv rows were left by the predictor's all-pass launch, cp_chain.hip tail)
@@ -979,9 +983,10 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
             {
                 const bool last = l + 1 == d.layers;
                 const omni_bb_head hd{io->logits, io->last_hidden, io->num_live, mask_fill(t)};
-                const bool with_head = last && fuse_head && g_bb_head && k_bb_chain_head_supported(d);
+                const bool with_head = last && fuse_head && plain && g_bb_head && k_bb_chain_head_supported(d);
                 TRY(k_bb_chain(d, w, last ? nullptr : &t->layer[l + 1], t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
-                               t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, k_bb_chain_small(d), with_head ? &hd : nullptr));
+                               t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, plain && k_bb_chain_small(d), with_head ? &hd : nullptr,
+                               t->has_ar ? &bar : nullptr, t->chain_half));
                 if (with_head) t->head_fused = true;
             }
         }

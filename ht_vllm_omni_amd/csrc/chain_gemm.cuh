@@ -43,6 +43,26 @@
 //        activation load -- they sit in front of the stores in the wave's in-order queue and the flag waits for the whole
 //        slice: measured +0.2 ms per step.)
 struct ChainNoPrefetch { static constexpr int LOADS = 0; __device__ __forceinline__ void operator()() const {} };
+// ---- round 6: the tensor-parallel all-reduce INSIDE a residual stage (bb_chain.hip on a tensor-parallel rank; allreduce.hip is the same
+// exchange as a launch of its own).  The stage's workgroup owns one 16-column x (16 MT)-row tile of the row-parallel GEMM's output on EVERY
+// rank, so the exchange is per tile and needs no stage of its own:
+//   partial   the tile's K-combined sums, rounded to bf16, into this rank's peer-mapped buffer data[rank] (system-scope write-through stores)
+//   arrive    stores drained, workgroup barrier, system-scope release; lane p stores  tflags[p][rank][tile] = epoch  (peer p's flag array)
+//   wait      lane p polls tflags[rank][p][tile] >= epoch (system-scope loads, bounded by wall clock: a peer that never arrives sets every
+//             rank's error word and the launch carries on -- a wrong step, never a hung GPU); system-scope acquire; barrier
+//   reduce    sum over the ranks in RANK ORDER (fp32, one rounding to bf16: the same bits on every rank), then the residual epilogue as ever
+// Tile flags carry allreduce.hip's epoch sequence (o_proj and down_proj calls alternate between two data buffers): a workgroup passes the
+// wait of call e + 1 only after every peer's workgroup of the same tile has finished reading call e, so call e + 2 may overwrite its buffer.
+#define CH_AR_MAX_WORLD 8
+#define CH_AR_TILES 256
+#define CH_AR_WAIT_TICKS 500000000ull        // 5 s of the 100 MHz counter (allreduce.hip's bound)
+#define CH_AUX_SYS 17                        // sc0 | sc1: system-scope coherent access
+struct ChainAr {
+    int world, rank;
+    const uint16_t* data[CH_AR_MAX_WORLD];       // the ranks' partial buffers of this stage, fragment-major bf16 [64][N]
+    uint32_t* tflags[CH_AR_MAX_WORLD];           // rank p's tile flags [world][CH_AR_TILES]
+    int32_t* error[CH_AR_MAX_WORLD];             // every rank's error word (error[rank] = this rank's)
+};
 template <int N, class F>
 struct ChainPrefetch {           // N = loads per wave that F issues
     F& f;
@@ -54,7 +74,8 @@ struct ChainPrefetch {           // N = loads per wave that F issues
 // PS: rows per sum(r^2) slab (64; 128 for the code predictor's two-position pass, whose stream holds 128 rows)
 // WAUX: cache policy of the WEIGHT loads (0 default, OMNI_AUX_NT = non-temporal: MI355X_MICROARCH "nt-weights" -- for slices that exactly
 // one workgroup reads once per launch; round 5 A/B, profiles/r05_ab_table.txt)
-template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false, int PS = 64, int WAUX = 0>
+template <int MT, int NT, int NTW, int PRO, int EPI, int XG = 0, int WSRC = 0, class PF = ChainNoPrefetch, bool ONEPASS = false, int PS = 64, int WAUX = 0,
+          bool AR = false>
 __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ norm_w, const uint16_t* x,
                                            const float* part_in, int np_in, void* out, int ldo, float* part_out, int M, int N, float eps,
                                            int bx, int by, float* lds, ChainGate& g, bool wait, int code,
@@ -62,7 +83,8 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
                                            uint16_t* normed_out = nullptr /* PRO 2: the normalised rows, row-major [M][K] (plain stores:
                                            for the NEXT launch), written by the workgroup columns bx < 8 as gemm_skinny_kernel spreads them */,
                                            const uint8_t* mask = nullptr /* EPI_F32_BF16RND: logit n is `mask_fill` where mask[n] == 0 (the codec mask) */,
-                                           float mask_fill = 0.f, const int32_t* nlive_ptr = nullptr /* normed_out: rows >= *nlive_ptr are not written */) {
+                                           float mask_fill = 0.f, const int32_t* nlive_ptr = nullptr /* normed_out: rows >= *nlive_ptr are not written */,
+                                           const ChainAr* ar = nullptr, uint32_t ar_epoch = 0 /* AR: the exchange's peers and its call number */) {
     const int sidx = ((code & 255) >> 4) * 5 + (code & 15) - 1;
     constexpr int G = (XG == 0 || XG > NTW) ? NTW : XG;
     constexpr bool NORM = PRO == 2 || PRO == 3, DEFER = PRO == 3;
@@ -243,6 +265,74 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
     if (pass == 0) CH_STAMP(stamps, sidx, 4);                            // 4: operands arrived, MFMAs done, partials in LDS
     chain_barrier(g);
     if (pass == 0) CH_STAMP(stamps, sidx, 5);                            // 5: combine barrier passed
+    if constexpr (AR) {
+        static_assert(EPI == OMNI_EPI_RESID && PASSES == 1 && ITEMS <= CH_THREADS, "chain_gemm: the all-reduce rides in the residual epilogue, one item per thread");
+        const int l = threadIdx.x & 63, tl = threadIdx.x >> 6;
+        const int ml = (tl % MT) * 16 + (l & 15);
+        const bool has = (int)threadIdx.x < ITEMS && ml < Mloc;
+        const int m = m_base + ml, n = bx * 16 + 4 * (l >> 4);
+        const uint32_t off = (uint32_t)frag_off(has ? m : m_base, n, N) * 2;
+        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has) {
+#pragma unroll
+            for (int w = 0; w < CH_WAVES; ++w) sum += lds4[(w * TP + tl) * 64 + l];
+        }
+        const u32x2 mine = (u32x2){pack_bf2(sum[0], sum[1]), pack_bf2(sum[2], sum[3])};      // this rank's partial, bf16
+        float acc[4] = {bf_lo(mine[0]), bf_hi(mine[0]), bf_lo(mine[1]), bf_hi(mine[1])};
+        const int world = ar->world, rank = ar->rank;
+        if (world > 1) {
+            const int tile = by * (N >> 4) + bx;
+            if (has) __builtin_amdgcn_raw_buffer_store_b64(mine, coh_rsrc(ar->data[rank]), off, 0, CH_AUX_SYS);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            chain_barrier(g);
+            if (threadIdx.x < 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // system scope: the tile is out before its flag
+                const int p = threadIdx.x;
+                if (p < world && p != rank) {
+                    __hip_atomic_store(ar->tflags[p] + rank * CH_AR_TILES + tile, ar_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // a peer that failed to arrive once is not waited for again (allreduce.hip): one time-out per dead rank, not one per stage
+                    if (!g.dead && __hip_atomic_load(ar->error[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        const uint32_t* f = ar->tflags[rank] + p * CH_AR_TILES + tile;
+                        uint32_t spins = 0;
+                        unsigned long long t0 = 0;
+                        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - ar_epoch) < 0) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 1023u) == 0) {
+                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                                if (spins == 1024u) t0 = now;
+                                else if (now - t0 > CH_AR_WAIT_TICKS) {
+                                    const int ecode = 1 + p + 256 * (rank + 1) + 0x10000;      // 0x10000: raised by a chain stage
+                                    for (int q = 0; q < world; ++q) __hip_atomic_store(ar->error[q], ecode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                      // system scope: the peers' tiles below are fresh
+            chain_barrier(g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = 0.f;
+            if (has) {
+                for (int p = 0; p < world; ++p) {                              // rank order: identical bits on every rank
+                    const u32x2 v = p == rank ? mine : __builtin_amdgcn_raw_buffer_load_b64(coh_rsrc(ar->data[p]), off, 0, CH_AUX_SYS);
+                    acc[0] += bf_lo(v[0]); acc[1] += bf_hi(v[0]); acc[2] += bf_lo(v[1]); acc[3] += bf_hi(v[1]);
+                }
+            }
+        }
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = bfround(acc[e]);               // the all-reduced delta, bf16 (one rank: the partial itself)
+            rv[0] = bfround(bf_lo(r_old[0]) + rv[0]); rv[1] = bfround(bf_hi(r_old[0]) + rv[1]);
+            rv[2] = bfround(bf_lo(r_old[1]) + rv[2]); rv[3] = bfround(bf_hi(r_old[1]) + rv[3]);
+            coh_st8(ors, off, (u32x2){pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3])});
+        }
+        float ss = sq4_sum(rv[0], rv[1], rv[2], rv[3]);
+        ss = xor32_sum(xor16_sum(ss));                                         // (whole waves: rows past Mloc add into lanes nobody stores)
+        if (has && l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * PS + m) * 4, __float_as_uint(ss));
+    } else
     for (int it = threadIdx.x; it < ITEMS; it += CH_THREADS) {
         const int l = it % LN;
         const int tl = it / LN, t = pass * TP + tl;                       // tile index j * MT + i
@@ -289,7 +379,7 @@ __device__ __forceinline__ void chain_gemm(const uint16_t* __restrict__ W, const
             rv[0] = bfround(bf_lo(r_old[0]) + rv[0]); rv[1] = bfround(bf_hi(r_old[0]) + rv[1]);
             rv[2] = bfround(bf_lo(r_old[1]) + rv[2]); rv[3] = bfround(bf_hi(r_old[1]) + rv[3]);
             coh_st8(ors, (uint32_t)frag_off(m, n, N) * 2, (u32x2){pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3])});
-            float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
+            float ss = sq4_sum(rv[0], rv[1], rv[2], rv[3]);
             ss = xor32_sum(xor16_sum(ss));
             if (l < 16) coh_st4(coh_rsrc(part_out), (uint32_t)(bx * PS + m) * 4, __float_as_uint(ss));
         } else if (EPI == OMNI_EPI_F32_BF16RND) {

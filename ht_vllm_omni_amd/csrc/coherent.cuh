@@ -89,6 +89,7 @@ struct EngSync {
 
 struct ChainGate {
     coh_rsrc_t frs;        // flag words [OMNI_CHAIN_WGS]
+    int wg;                // the workgroup this gate speaks for: blockIdx.x, or a VIRTUAL one (bb_chain.hip's half grid: 128 workgroups play 256)
     uint32_t epoch;        // stages this workgroup has completed
     int32_t* err;
     bool dead;             // a spin ran out (here or in an earlier launch): stop waiting
@@ -152,10 +153,11 @@ __device__ __forceinline__ void eng_release(ChainGate& g, int wave, unsigned upt
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g.es->consumed[wave], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, int32_t* err) {
+__device__ __forceinline__ void chain_gate_init(ChainGate& g, uint32_t* flags, int32_t* err, int wg = blockIdx.x) {
     g.frs = coh_rsrc(flags);
     g.err = err;
-    g.epoch = __builtin_amdgcn_readfirstlane(coh_ld4(g.frs, blockIdx.x * 4));
+    g.wg = wg;
+    g.epoch = __builtin_amdgcn_readfirstlane(coh_ld4(g.frs, wg * 4));
     g.dead = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
     g.dom = 8;
     g.nap = 1;
@@ -180,7 +182,7 @@ __device__ __forceinline__ void chain_gate_wait(ChainGate& g, int code) {
     if (threadIdx.x < 64 && !g.dead) {
         for (int i = 0; i < g.ahead * g.skip_units; ++i) __builtin_amdgcn_s_sleep(32);
         // (1 << dom) / 4 lanes x 4 flags each (the other lanes read copies)
-        const uint32_t off = chain_flag_copy() + ((blockIdx.x >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
+        const uint32_t off = chain_flag_copy() + ((g.wg >> g.dom) << (g.dom + 2)) + (threadIdx.x & ((1u << (g.dom - 2)) - 1)) * 16;
         unsigned spins = 0;
         unsigned long long t0 = 0;
         if (g.nap >= 16) {
@@ -241,12 +243,12 @@ __device__ __forceinline__ void chain_gate_arrive(ChainGate& g) {
         chain_barrier(g);
     }
     g.epoch += 1;
-    if (threadIdx.x < 64) chain_flag_publish(g.frs, blockIdx.x, g.epoch);
+    if (threadIdx.x < 64) chain_flag_publish(g.frs, g.wg, g.epoch);
 }
 
 // a stage in which this workgroup has no rows: no wait, no work -- publish it and run ahead (see chain_gate_wait)
 __device__ __forceinline__ void chain_gate_skip(ChainGate& g) {
     g.ahead = g.ahead < 12 ? g.ahead + 1 : 12;
     g.epoch += 1;
-    if (threadIdx.x < 64) chain_flag_publish(g.frs, blockIdx.x, g.epoch);
+    if (threadIdx.x < 64) chain_flag_publish(g.frs, g.wg, g.epoch);
 }

@@ -91,6 +91,9 @@ __device__ __forceinline__ float row16_max(float v) {
 // permlane16_swap leaves {rows 0,0,2,2 of v} in the first result and {rows 1,1,3,3} in the second; permlane32_swap
 // {lanes 0-31 twice} and {lanes 32-63 twice}: their sum / max is the lane ^ 16 / lane ^ 32 butterfly step, and picking the
 // first result on the odd rows (upper half) and the second on the even rows (lower half) is the plain exchange.
+// sum of four squares with the contraction written out (hipcc fuses `a * a + b * b + ...` as it pleases: the residual epilogues of gemm.hip
+// and chain_gemm.cuh and the all-reduce launch must put the SAME bits into a sum(r^2) slab)
+__device__ __forceinline__ float sq4_sum(float a, float b, float c, float d) { return fmaf(d, d, fmaf(c, c, fmaf(b, b, a * a))); }
 __device__ __forceinline__ float xor16_sum(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(const GemmArg
                     rv[2] = bfround(bf_lo(r_old.y) + rv[2]); rv[3] = bfround(bf_hi(r_old.y) + rv[3]);
                 }
                 *reinterpret_cast<uint2*>(rp) = make_uint2(pack_bf2(rv[0], rv[1]), pack_bf2(rv[2], rv[3]));
-                float ss = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2] + rv[3] * rv[3];
+                float ss = sq4_sum(rv[0], rv[1], rv[2], rv[3]);
                 ss = xor32_sum(xor16_sum(ss));       // the 4 lanes (l & 15) + 16 * {0..3} hold the 16 columns of row m
                 if (l < 16) a.part_out[blockIdx.x * a.pstride + m] = ss;   // slabs [n group][pstride rows]
             } else if (EPI == OMNI_EPI_BF16) {

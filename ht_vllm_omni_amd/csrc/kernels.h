@@ -99,14 +99,15 @@ int k_cp_chain(const omni_talker_desc& d, const omni_layer_weights* layers, uint
 // the backbone between two attention launches (o_proj -> gate_up -> down_proj -> next layer's qkv) as one persistent launch
 // (bb_chain.hip); supported = a dense shape whose (q width, hidden, intermediate) triple is instantiated there (BB_SHAPES) and whose tile
 // grids fit 256 workgroups, at 1-64 rows on a single rank; or the 0.6B shape (bb_chain_small_kernel)
-bool k_bb_chain_supported(const omni_talker_desc& d, int B, bool has_ar);
+bool k_bb_chain_supported(const omni_talker_desc& d, int B, const omni_ar_peers* ar = nullptr, bool half = false);
 bool k_bb_chain_small(const omni_talker_desc& d);       // the 0.6B shape: the segment on the code predictor's 16-row stage set, any batch
 // `head` (last layer only, next == NULL): the launch ends in the talker's head -- final norm folded into the lm_head GEMM -> logits, h[t + 1]
 struct omni_bb_head { float* logits; void* last_hidden; const int32_t* num_live; float mask_fill; };
+struct omni_bb_ar { const omni_ar_peers* attn; const omni_ar_peers* mlp; };      // tensor-parallel rank: the peers of the o_proj / down_proj all-reduces
 bool k_bb_chain_head_supported(const omni_talker_desc& d);
 int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omni_layer_weights* next, const void* attn, void* resid, float* part,
                void* act, void* qkv, int B, float eps, uint32_t* flags, int32_t* err, void* stream, bool small = false,
-               const omni_bb_head* head = nullptr);
+               const omni_bb_head* head = nullptr, const omni_bb_ar* ar = nullptr, bool half = false);
 // the sparse-MoE layer between its attention launch and its expert GEMMs (o_proj -> router | shared gate_up -> shared down + routing) as
 // one persistent launch (moe_chain.hip); supported = the Omni talker's shape on a single rank, <= 64 rows
 bool k_moe_chain_supported(const omni_talker_desc& d, int B, bool has_ar);

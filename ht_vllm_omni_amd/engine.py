@@ -853,10 +853,11 @@ class TalkerEngine:
         launch-per-op path -- other shapes, batches below the backbone chain's row range, tensor-parallel ranks, chains off."""
         return int(self.lib.omni_talker_chains_ran(self.handle))
 
-    def set_chains(self, on: bool) -> None:
-        """Turn the persistent chains of this engine on / off (same bits either way).  Captured graphs keep what they recorded:
-        re-capture after a switch."""
-        L.check(self.lib.omni_talker_set_chains(self.handle, int(bool(on))), "omni_talker_set_chains")
+    def set_chains(self, on) -> None:
+        """Turn the persistent chains of this engine on / off (same bits either way); ``on == 2``: the half grid -- the backbone chain on
+        128 workgroups (two engines' launches fit the chip side by side), the code predictor launch per op.  Captured graphs keep what they
+        recorded: re-capture after a switch."""
+        L.check(self.lib.omni_talker_set_chains(self.handle, 2 if on == 2 else int(bool(on))), "omni_talker_set_chains")
         self.persistent_chains = bool(on)
 
     def recover_from_chain_timeout(self) -> None:

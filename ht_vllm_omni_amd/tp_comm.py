@@ -16,7 +16,10 @@ import torch
 
 from . import _lib as L
 
-CTL_BYTES = 256          # uint32 flags[8] | uint32 epoch, ticket | int32 error (64-byte aligned pieces)
+# control block: uint32 flags[8] | uint32 epoch, ticket | int32 error (64-byte aligned pieces) | uint32 tile_flags[8][256] (ABI v5: the
+# arrival flags of the all-reduce inside the backbone's persistent launches, csrc/bb_chain.hip -- [source rank][tile])
+TILE_OFF, TILE_BYTES = 256, 8 * 256 * 4
+CTL_BYTES = TILE_OFF + TILE_BYTES
 FLAGS_OFF, EPOCH_OFF, ERROR_OFF = 0, 64, 128
 
 
@@ -67,13 +70,14 @@ class PeerAllReduce:
 
     @staticmethod
     def link_local(members: list["PeerAllReduce"]) -> None:
-        """All ranks inside ONE process (tests on a single GPU): peers are plain device pointers."""
+        """All ranks inside ONE process (tests on a single GPU): peers are plain device pointers.  The ranks' steps run one after the other
+        there, so the exchange inside a persistent launch (which waits for its peers within the launch) is left unconfigured: launch path."""
         for m in members:
             for o in members:
                 m.data[0][o.rank], m.data[1][o.rank], m.ctl[o.rank] = o._own
-            m._finish()
+            m._finish(in_chain=len(members) == 1)
 
-    def _finish(self) -> "PeerAllReduce":
+    def _finish(self, in_chain: bool = True) -> "PeerAllReduce":
         self.peers = []
         for b in (0, 1):
             s = L.ArPeers()
@@ -81,6 +85,7 @@ class PeerAllReduce:
             for r in range(self.world):
                 s.data[r] = self.data[b][r]
                 s.flags[r] = self.ctl[r] + FLAGS_OFF
+                s.tile_flags[r] = self.ctl[r] + TILE_OFF if in_chain else None
             s.epoch = self.ctl[self.rank] + EPOCH_OFF
             s.error = self.ctl[self.rank] + ERROR_OFF
             self.peers.append(s)

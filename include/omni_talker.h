@@ -316,6 +316,10 @@ typedef struct omni_ar_peers {
     uint32_t* flags[8];
     uint32_t* epoch;
     int32_t* error;
+    /* ABI v5: per-tile arrival flags for the all-reduce INSIDE the backbone's persistent launches (csrc/bb_chain.hip): tile_flags[p] = rank
+     * p's array of world x 256 zero-initialised uint32 (index [source rank][tile]) in the same kind of memory as flags[p].  All NULL: the
+     * tensor-parallel backbone stays on the launch-per-op path with omni_allreduce_resid launches (a one-rank group needs none). */
+    uint32_t* tile_flags[8];
 } omni_ar_peers;
 int omni_allreduce_resid(const omni_ar_peers* peers, void* r_io, int accumulate, float* partials, int pstride, void* out_rowmajor,
                          int M, int H, void* stream);
@@ -432,6 +436,9 @@ int omni_talker_chain_error(omni_talker* t, int reset);
  * what a host does after a chain flag wait timed out (omni_step_io.status) -- reset the words, turn the chains off, re-capture
  * its graphs, redo the step: a degraded stage, not a dead one.  The GPU may be shared with another process then.        */
 int omni_talker_set_chains(omni_talker* t, int on);
+/* ABI v5.  on == 2: the HALF grid -- the backbone's persistent launches run on 128 workgroups (each plays two of the 256 stage workgroups),
+ * so that two engines' launches are co-resident on one GPU (a co-located second stage; two tensor-parallel ranks of a test on one GPU); the
+ * code predictor runs launch per op then.  Same bits as on == 1 and on == 0. */
 /* Which persistent chains the LAST decode-step call of this engine launched (host-side record, no device access):
  * bit 0 the code-predictor chain (cp_chain.hip), bit 1 the backbone chain (bb_chain.hip).  0 = launch-per-op path.      */
 int omni_talker_chains_ran(const omni_talker* t);

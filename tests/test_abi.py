@@ -27,16 +27,17 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.omni_abi_version() == 4
+    assert lib.omni_abi_version() == 5
     assert lib.omni_last_error() is not None
 
 
 def test_struct_layout_matches_c(tmp_path):
     from ht_vllm_omni_amd import _lib
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(omni_talker_desc),sizeof(omni_step_io),sizeof(omni_layer_weights),offsetof(omni_talker_desc,scratch_bytes),'
-                   'offsetof(omni_step_io,advance),offsetof(omni_talker_desc,k_cache));return 0;}\n' % HDR)
+                   'offsetof(omni_step_io,advance),offsetof(omni_talker_desc,k_cache),sizeof(omni_ar_peers),'
+                   'offsetof(omni_ar_peers,tile_flags));return 0;}\n' % HDR)
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -46,6 +47,8 @@ def test_struct_layout_matches_c(tmp_path):
     assert got[3] == _lib.TalkerDesc.scratch_bytes.offset
     assert got[4] == _lib.StepIO.advance.offset
     assert got[5] == _lib.TalkerDesc.k_cache.offset
+    assert got[6] == C.sizeof(_lib.ArPeers)
+    assert got[7] == _lib.ArPeers.tile_flags.offset
 
 
 def test_argument_errors_do_not_abort():
