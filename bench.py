@@ -52,6 +52,10 @@ def build_engine(args, rank, world):
                        device=f"cuda:{torch.cuda.current_device()}", tp_rank=0 if args.parallel == "dp" else rank,
                        tp_size=1 if args.parallel == "dp" else world, allow_eos=False,
                        n_sub=args.sub_batches, tp_force=args.tp_force, peer_allreduce=ar, prefill_gemm=args.prefill_gemm)
+    args.tp_backbone_chain = False
+    if ar is not None and world > 1:      # the all-reduce inside the backbone's persistent launches: one scratch step both ways on every rank first
+        from ht_vllm_omni_amd.tp_comm import check_backbone_chain
+        args.tp_backbone_chain = check_backbone_chain(eng, log=log)
     return d, w, eng
 
 
@@ -562,7 +566,9 @@ def main():
                    "multi_gpu": ("one engine per GPU (replicas, no data-path collective) is the throughput mode of this stage; tensor "
                                  "parallelism divides the backbone's bytes but not the replicated code predictor: latency mode "
                                  "(DESIGN 5)"),
-                   **({"rccl_ranks": world, "rank_error_words": rank_words} if world > 1 or args.tp_force else {}),
+                   **({"rccl_ranks": world, "rank_error_words": rank_words,
+                       "allreduce_in_backbone_launches": bool(chains_ran & 2) and getattr(args, "allreduce_used", "").startswith("oneshot")}
+                      if world > 1 or args.tp_force else {}),
                    "sampling": "greedy" if args.greedy else "T=0.9,top_k=50,rep=1.05,seed=42",
                    "target_ctx": args.target_ctx, "untimed_advance_steps": advance,
                    **({"ctx_extra": args.ctx_extra} if args.ctx_extra else {})},

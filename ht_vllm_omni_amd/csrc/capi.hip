@@ -119,6 +119,7 @@ struct omni_talker {
     omni_ar_peers ar_attn, ar_mlp;      // copies of desc.ar_* (has_ar)
     bool has_ar;
     bool chain_half;                    // omni_talker_set_chains(t, 2): the backbone chain on 128 workgroups, the predictor on the launch path
+    bool bb_ar_off;                     // omni_talker_set_chains(t, 3): a tensor-parallel rank's backbone stays launch per op (all-reduce launches)
     int ran;                            // persistent chains launched by the decode-step call in progress / last made (bit 0 cp, bit 1 bb)
     bool head_fused = false;            // the last backbone launch of the step in progress computed logits + h[t + 1] (run_backbone fuse_head)
     bool tail_fused = false;            // the predictor's all-pass launch of the step in progress assembled the backbone's input and computed layer 0's qkv
@@ -352,6 +353,7 @@ extern "C" int omni_talker_set_chains(omni_talker* t, int on) {
     if (!t) return OMNI_EINVAL;
     t->d.cp_chain = on != 0;            // k_cp_chain_supported / k_bb_chain_supported read it per call
     t->chain_half = on == 2;
+    t->bb_ar_off = on == 3;
     return OMNI_OK;
 }
 extern "C" int omni_talker_chains_ran(const omni_talker* t) { return t ? t->ran : 0; }
@@ -956,7 +958,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
     }
 #endif
     const omni_bb_ar bar{&t->ar_attn, &t->ar_mlp};
-    if (k_bb_chain_supported(d, io->B, t->has_ar ? &t->ar_attn : nullptr, t->chain_half) && d.layers > 0) {
+    if (!(t->has_ar && t->bb_ar_off) && k_bb_chain_supported(d, io->B, t->has_ar ? &t->ar_attn : nullptr, t->chain_half) && d.layers > 0) {
         t->ran |= 2;
         const bool plain = !t->has_ar && !t->chain_half;      // (a tensor-parallel rank / the half grid: the 64-row stage set, head as its own launch)
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv

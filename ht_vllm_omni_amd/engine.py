@@ -856,8 +856,8 @@ class TalkerEngine:
     def set_chains(self, on) -> None:
         """Turn the persistent chains of this engine on / off (same bits either way); ``on == 2``: the half grid -- the backbone chain on
         128 workgroups (two engines' launches fit the chip side by side), the code predictor launch per op.  Captured graphs keep what they
-        recorded: re-capture after a switch."""
-        L.check(self.lib.omni_talker_set_chains(self.handle, 2 if on == 2 else int(bool(on))), "omni_talker_set_chains")
+        recorded: re-capture after a switch.  ``on == 3``: chains on, a tensor-parallel rank's backbone on all-reduce LAUNCHES."""
+        L.check(self.lib.omni_talker_set_chains(self.handle, int(on) if on in (2, 3) and on is not True else int(bool(on))), "omni_talker_set_chains")
         self.persistent_chains = bool(on)
 
     def recover_from_chain_timeout(self) -> None:

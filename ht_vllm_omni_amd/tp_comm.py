@@ -99,6 +99,11 @@ class PeerAllReduce:
     def error(self) -> int:
         return int(_device_tensor(self.ctl[self.rank] + ERROR_OFF, 1, torch.int32).item())
 
+    def clear_error(self) -> None:
+        """Clear this rank's sticky error word (after the group agreed to stop using what timed out; every rank clears its own)."""
+        _device_tensor(self.ctl[self.rank] + ERROR_OFF, 1, torch.int32).zero_()
+        torch.cuda.synchronize()
+
     def all_reduce(self, which: int, *, r_io=None, accumulate=True, partials=None, out=None, M: int) -> None:
         """Launch on the current stream: sum of data[which] over the ranks (+ residual add / slabs / row-major copy)."""
         L.check(self.lib.omni_allreduce_resid(C.byref(self.peers[which]), L.ptr(r_io), int(accumulate), L.ptr(partials),
@@ -185,6 +190,65 @@ def setup_peer_allreduce(hidden: int, rows: int, rank: int, world: int, group=No
     if not agree(ok):
         return fallback(ar)
     return ar
+
+
+def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1) -> bool:
+    """Before a tensor-parallel group trusts the all-reduce INSIDE its backbone's persistent launches (csrc/bb_chain.hip, chain_gemm AR):
+    one scratch decode step both ways on every rank -- all-reduce launches between launch-per-op GEMMs, then the persistent launches -- from
+    the same state; the logits and hidden rows must agree bit for bit on every rank and no peer wait may have timed out.  Any rank's failure
+    (agreed on by an all-reduce(MIN)) leaves every rank on the all-reduce launches (``set_chains(3)``); like setup_peer_allreduce's self-check
+    against RCCL this runs once at start-up, before any request, so the KV slot the scratch step writes belongs to nobody.  Returns whether
+    the persistent launches are in use.  chain_mode = the ``set_chains`` mode under test and left on when it passes (1: the full grid of a
+    rank that owns its GPU; 2: the half grid of ranks that share one).  Called by MI355XARWorker._build_engine and bench.py."""
+    import torch.distributed as dist
+    ar = getattr(engine, "ar", None)
+    if ar is None or engine.tp_size <= 1 or not getattr(engine, "persistent_chains", False):
+        return False
+    B = min(engine.max_batch, 64)
+    if B < 33:
+        return False                                # below the backbone chain's row range: launch per op anyway
+    names = ("input_ids", "positions", "seq_lens", "last_hidden", "steps", "seen", "text_step")
+    keep = {n: getattr(engine, n).clone() for n in names if hasattr(engine, n)}
+    g = torch.Generator().manual_seed(4321)        # the same scratch rows on every rank
+    hid = torch.randn(B, engine.d.hidden, generator=g).to(torch.bfloat16)
+    outs, ran = [], 0
+    ok = True
+    try:
+        for mode in (0, chain_mode):                # 0: launch per op throughout (the predictor's chains do not touch this step's logits)
+            for n, v in keep.items():
+                getattr(engine, n).copy_(v)
+            engine.last_hidden[:B] = hid.to(engine.last_hidden.device)
+            engine.text_step[:B] = hid.flip(0).to(engine.text_step.device)
+            engine.positions[:B] = 0
+            engine.seq_lens[:B] = 1
+            engine.set_chains(mode)
+            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            engine.decode_step(B)
+            torch.cuda.synchronize()
+            outs.append((engine.logits[:B].clone(), engine.last_hidden[:B].clone()))
+            ran = engine.chains_ran()
+        ok = bool(ran & 2) and ar.error() == 0 and engine.chain_error() == 0 and all(torch.equal(a, b) for a, b in zip(*outs))
+    except Exception as e:   # noqa: BLE001
+        log(f"[rank {engine.tp_rank}] backbone chain start-up comparison failed to run: {e!r}")
+        ok = False
+    for n, v in keep.items():
+        getattr(engine, n).copy_(v)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    agreed = int(flag.item()) == 1
+    if not agreed:
+        if engine.tp_rank == 0:
+            log("all-reduce inside the backbone's persistent launches NOT in use (start-up comparison failed or the shape has no stage set): "
+                "all-reduce launches between launch-per-op GEMMs")
+        engine.chain_error(reset=True)
+        engine.set_chains(3)
+        torch.cuda.synchronize()
+        dist.barrier(group=group)                  # nobody is still inside a launch that could raise the word again
+        ar.clear_error()
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    return agreed
 
 
 def _device_tensor(ptr: int, n: int, dtype) -> torch.Tensor:

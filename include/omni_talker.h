@@ -438,7 +438,9 @@ int omni_talker_chain_error(omni_talker* t, int reset);
 int omni_talker_set_chains(omni_talker* t, int on);
 /* ABI v5.  on == 2: the HALF grid -- the backbone's persistent launches run on 128 workgroups (each plays two of the 256 stage workgroups),
  * so that two engines' launches are co-resident on one GPU (a co-located second stage; two tensor-parallel ranks of a test on one GPU); the
- * code predictor runs launch per op then.  Same bits as on == 1 and on == 0. */
+ * code predictor runs launch per op then.  Same bits as on == 1 and on == 0.
+ * on == 3: as 1, but a tensor-parallel rank's backbone keeps omni_allreduce_resid launches between launch-per-op GEMMs instead of the
+ * all-reduce inside its persistent launches (what tp_comm.check_backbone_chain selects when its start-up comparison fails on any rank). */
 /* Which persistent chains the LAST decode-step call of this engine launched (host-side record, no device access):
  * bit 0 the code-predictor chain (cp_chain.hip), bit 1 the backbone chain (bb_chain.hip).  0 = launch-per-op path.      */
 int omni_talker_chains_ran(const omni_talker* t);

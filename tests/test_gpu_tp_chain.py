@@ -115,6 +115,15 @@ def _tp2_proc(rank, world, port, q, B):
     half, ran2, e2 = _run(eng, B, 3, 2, seed=7, sync=dist.barrier)
     dist.barrier()
     ok_bits = all(torch.equal(u, v) for x, y in zip(off, half) for u, v in zip(x, y))
+    # the start-up comparison a worker runs before it trusts the exchange (tp_comm.check_backbone_chain): passes on the half grid; on the
+    # FULL grid two ranks of one GPU cannot be co-resident -- a peer wait runs out, every rank agrees to keep the all-reduce launches, the
+    # error words are cleared and the next steps are right again
+    from ht_vllm_omni_amd.tp_comm import check_backbone_chain
+    chk_half = check_backbone_chain(eng, log=lambda m: None, chain_mode=2)
+    chk_full = check_backbone_chain(eng, log=lambda m: None, chain_mode=1) if B == 40 else False
+    after, ran3, e3 = (_run(eng, B, 3, 0, seed=7, sync=dist.barrier) if B == 40 else (off, 0, 0))
+    ok_bits = ok_bits and chk_half and not chk_full and ran3 == 0 and e3 == 0 and ar.error() == 0 and \
+        all(torch.equal(u, v) for x, y in zip(off, after) for u, v in zip(x, y))
     import hashlib
     digests = [hashlib.sha1(t.cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest() for t in half[-1]]      # (plain data through the queue)
     q.put((rank, ran0, ran2, e2, ar.error(), ok_bits, digests))
