@@ -621,7 +621,7 @@ static int run_code_predictor(omni_talker* t, const int32_t* layer0_ids, const v
         for (int g = pair_chain ? 2 : 1; g < Q; ++g) {
             const bool in_pair = pair && g == 1;          // position 1 was computed by the pair pass
             const uint16_t* head = reinterpret_cast<const uint16_t*>(d.cp_lm_head) + (size_t)(g - 1) * d.codebook * Hc;
-            if (!in_pair && d.cp_chain && k_cp_chain_all_supported(d, g, greedy, top_k, top_p)) {
+            if (!in_pair && d.cp_chain && !t->chain_half && k_cp_chain_all_supported(d, g, greedy, top_k, top_p)) {
                 // passes g .. Q - 1 -- layer stacks, head GEMMs, samplers, input gathers -- as ONE persistent launch
                 omni_chain_head hd{};
                 hd.logits = cp_logits_out ? cp_logits_out : t->cp_logits;

@@ -380,6 +380,9 @@ class TalkerEngine:
                     raise L.OmniError("omni_talker_create(sub): " + self.lib.omni_last_error().decode())
                 self._sub.append((h, sc, dk))
             self._sub_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_sub)]
+            # (round 6: TWO concurrent row ranges CAN keep their backbones' persistent launches on half grids -- set_chains(2), 128 workgroups
+            #  each, co-resident, same bits: tests/test_gpu_tp_chain.py -- but measured slower than launch per op at 2 x 64 rows, 24.3 k against
+            #  25.3 k tokens/s: half the chip per stage and the other range's kernels beside it; so the ranges stay launch per op by default)
 
         # ---- persistent per-step buffers (graph-stable addresses), row r = batch slot r
         Bm, H, Q = max_batch, d.hidden, d.num_code_groups
@@ -846,18 +849,28 @@ class TalkerEngine:
         rc = self.lib.omni_talker_chain_error(self.handle, int(reset))
         if rc < 0:
             L.check(rc, "omni_talker_chain_error")
+        for h, _, _ in self._sub:                   # the concurrent row ranges' engines (half-grid backbone chains)
+            r2 = self.lib.omni_talker_chain_error(h, int(reset))
+            if r2 < 0:
+                L.check(r2, "omni_talker_chain_error(sub)")
+            rc = rc or r2
         return rc
 
     def chains_ran(self) -> int:
         """Which persistent chains the last native decode-step call launched (bit 0: code predictor, bit 1: backbone): 0 on the
         launch-per-op path -- other shapes, batches below the backbone chain's row range, tensor-parallel ranks, chains off."""
-        return int(self.lib.omni_talker_chains_ran(self.handle))
+        ran = int(self.lib.omni_talker_chains_ran(self.handle))
+        for h, _, _ in self._sub:
+            ran |= int(self.lib.omni_talker_chains_ran(h))
+        return ran
 
     def set_chains(self, on) -> None:
         """Turn the persistent chains of this engine on / off (same bits either way); ``on == 2``: the half grid -- the backbone chain on
         128 workgroups (two engines' launches fit the chip side by side), the code predictor launch per op.  Captured graphs keep what they
         recorded: re-capture after a switch.  ``on == 3``: chains on, a tensor-parallel rank's backbone on all-reduce LAUNCHES."""
         L.check(self.lib.omni_talker_set_chains(self.handle, int(on) if on in (2, 3) and on is not True else int(bool(on))), "omni_talker_set_chains")
+        for h, _, _ in self._sub:                   # concurrent row ranges: the half grid or nothing
+            L.check(self.lib.omni_talker_set_chains(h, 2 if on == 2 and on is not True and self.n_sub == 2 else 0), "omni_talker_set_chains(sub)")
         self.persistent_chains = bool(on)
 
     def recover_from_chain_timeout(self) -> None:

@@ -61,7 +61,7 @@ def _same(a, b, what):
 def test_half_grid_backbone_chain_equals_the_full_grid_and_the_launch_path(B):
     """Single rank: 128 workgroups playing the 256 of the stage grid leave the same bits as the 256-workgroup launches and as launch per op."""
     from ht_vllm_omni_amd.engine import TalkerEngine
-    d = get_dims("tts-1.7b").with_(layers=3, cp_layers=1, num_code_groups=3, max_model_len=256)
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
     w = make_weights(d, seed=21, std=0.02)
     eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=B * 3 + 2, block_size=16, max_batch=64)
     eng.set_sampling(greedy=1, cp_greedy=1)
@@ -74,6 +74,36 @@ def test_half_grid_backbone_chain_equals_the_full_grid_and_the_launch_path(B):
     _same(half, off, "half grid vs launch path")
 
 
+def test_two_concurrent_row_ranges_keep_the_backbone_chain_on_half_grids():
+    """128 rows as two concurrent 64-row ranges (parallel graph branches, bench.py --sub-batches 2): each range's backbone runs its persistent
+    launches on a half grid -- the two are co-resident -- and leaves the bits of launch per op; no flag wait times out."""
+    from ht_vllm_omni_amd.engine import TalkerEngine
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
+    w = make_weights(d, seed=21, std=0.02)
+    B = 128
+    eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=B * 3 + 2, block_size=16, max_batch=B, n_sub=2)
+    eng.set_sampling(greedy=1, cp_greedy=1)
+    off, ran0, _ = _run(eng, B, 3, 0, seed=8)
+    g = None
+    eng.chain_error(reset=True)
+    eng.set_chains(2)                        # (opt-in: at 2 x 64 rows the half grids measure slower than launch per op, engine.py)
+    _state(eng, B, 8)
+    eng.decode_step(B)                       # warm-up, then the same three steps as ONE captured graph each (two branches)
+    torch.cuda.synchronize()
+    _state(eng, B, 8)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.decode_step(B)
+    _state(eng, B, 8)
+    half = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        half.append((eng.logits[:B].clone(), eng.last_hidden[:B].clone(), eng.audio_codes[:B].clone(), eng.input_ids[:B].clone()))
+    assert ran0 == 0 and eng.chains_ran() == 2 and eng.chain_error() == 0
+    _same(half, off, "two half-grid ranges vs launch path")
+
+
 @pytest.mark.parametrize("B", [64, 40])
 def test_one_rank_group_runs_the_backbone_chain_with_the_all_reduce_stages(B):
     """The tensor-parallel code path on a group of ONE rank (bench.py --tp-force): the all-reduce instantiation of the backbone launches
@@ -81,7 +111,7 @@ def test_one_rank_group_runs_the_backbone_chain_with_the_all_reduce_stages(B):
     full grid and half grid -- and the all-reduce's epoch word counts two calls per layer either way."""
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
-    d = get_dims("tts-1.7b").with_(layers=3, cp_layers=1, num_code_groups=3, max_model_len=256)
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
     w = make_weights(d, seed=21, std=0.02)
     ar = PeerAllReduce(0, 1, 64, d.hidden)
     PeerAllReduce.link_local([ar])
@@ -105,7 +135,7 @@ def _tp2_proc(rank, world, port, q, B):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
-    d = get_dims("tts-1.7b").with_(layers=3, cp_layers=1, num_code_groups=3, max_model_len=256)
+    d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
     w = make_weights(d, seed=23, std=0.02)
     ar = PeerAllReduce(rank, world, 64, d.hidden).connect()
     eng = TalkerEngine(d, w, kv_dtype="fp8", num_blocks=B * 3 + 2, block_size=16, max_batch=64, tp_rank=rank, tp_size=world, peer_allreduce=ar)
