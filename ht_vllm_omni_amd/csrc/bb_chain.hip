@@ -267,8 +267,8 @@ extern "C" void omni_debug_bb_min_rows(int rows) { g_bb_min_rows = rows; g_bb_b3
 // checkpoint has (hidden 1536, intermediate 4608, 12 q heads: tests/test_gpu_chain.py, tests/test_gpu_engine.py); a new width = one more line
 #define BB_SHAPES(X) X(8, 8, 24) X(6, 6, 18)
 // ... and the triples of a tensor-parallel RANK (the all-reduce instantiations, full and half grid): the 1.7B shape whole (a one-rank group:
-// bench.py --tp-force), over 2 ranks (BASELINE config #4: 8 q / 4 kv heads, intermediate 3072) and over 4
-#define BB_AR_SHAPES(X) X(8, 8, 24) X(4, 8, 12) X(2, 8, 6)
+// bench.py --tp-force), over 2 ranks (8 q / 4 kv heads, intermediate 3072), over 4 and over the 8 GPUs of a node (2 q / 1 kv head, 768)
+#define BB_AR_SHAPES(X) X(8, 8, 24) X(4, 8, 12) X(2, 8, 6) X(1, 8, 3)
 
 // ar: the rank's peer table (NULL = not tensor parallel); half: the 128-workgroup grid (omni_talker_set_chains(t, 2))
 bool k_bb_chain_supported(const omni_talker_desc& d, int B, const omni_ar_peers* ar, bool half) {

@@ -104,14 +104,17 @@ def test_two_concurrent_row_ranges_keep_the_backbone_chain_on_half_grids():
     _same(half, off, "two half-grid ranges vs launch path")
 
 
-@pytest.mark.parametrize("B", [64, 40])
-def test_one_rank_group_runs_the_backbone_chain_with_the_all_reduce_stages(B):
+@pytest.mark.parametrize("B,shard", [(64, 1), (40, 1), (64, 2), (48, 4), (64, 8)])
+def test_one_rank_group_runs_the_backbone_chain_with_the_all_reduce_stages(B, shard):
     """The tensor-parallel code path on a group of ONE rank (bench.py --tp-force): the all-reduce instantiation of the backbone launches
     (partial -> bf16 -> sum over one rank -> residual) leaves the bits of the launch-per-op step with its omni_allreduce_resid launches --
-    full grid and half grid -- and the all-reduce's epoch word counts two calls per layer either way."""
+    full grid and half grid -- and the all-reduce's epoch word counts two calls per layer either way.  shard > 1: a model whose WHOLE
+    backbone has the dimensions of one rank of the 1.7B shape split `shard` ways (heads and intermediate divided): the stage sets that
+    ranks of 2, 4 and 8 run."""
     from ht_vllm_omni_amd.engine import TalkerEngine
     from ht_vllm_omni_amd.tp_comm import PeerAllReduce
     d = get_dims("tts-1.7b").with_(layers=3, max_model_len=256)
+    d = d.with_(q_heads=d.q_heads // shard, kv_heads=d.kv_heads // shard, inter=d.inter // shard)
     w = make_weights(d, seed=21, std=0.02)
     ar = PeerAllReduce(0, 1, 64, d.hidden)
     PeerAllReduce.link_local([ar])
