@@ -562,7 +562,10 @@ def main():
                        (["code-predictor passes 2..15 (layer stacks, heads, samplers) = 1 persistent launch"] if chains_ran & 1
                         else ["code predictor: one launch per op"]) +
                        (["backbone = 1 attention + 1 four-stage persistent launch (o_proj, gate_up, down_proj, next qkv) per layer"]
-                        if chains_ran & 2 else ["backbone: one launch per op"])),
+                        if chains_ran & 2 else ["backbone: one launch per op"]) +
+                       # round 6 (single rank, both chains): the step's small launches ride in the chains
+                       (["final norm + lm_head = last stage of the last backbone launch; input assembly + layer 0's qkv = tail of the predictor launch"]
+                        if chains_ran == 3 and world == 1 and not args.tp_force and args.sub_batches == 1 else [])),
                    "multi_gpu": ("one engine per GPU (replicas, no data-path collective) is the throughput mode of this stage; tensor "
                                  "parallelism divides the backbone's bytes but not the replicated code predictor: latency mode "
                                  "(DESIGN 5)"),
