@@ -26,6 +26,7 @@ struct PAArgs {
     void* k_cache; void* v_cache; float* k_scales; float* v_scales;
     const int32_t* block_table; int bt_stride; const int32_t* seq_lens; const int32_t* req_of_row; int seq_from_pos;
     uint16_t* out; float* partial;
+    unsigned* merge_cnt;           // KV splits merged by the LAST ARRIVER of a (row, virtual kv head) (round 6): its arrival counters, or NULL = paged_attn_merge_kernel
     int q_heads, kv_heads, bs; float k_scale, v_scale, sm_scale; int nsplit;
     int bs_shift;                  // log2(bs): the paged kernels take power-of-two blocks (vLLM's 8 ... 256) -- token -> (block, offset)
                                    // by shift and mask; a runtime division cost every (token group, batch) ~20 quarter-rate instructions
@@ -557,6 +558,15 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
                 const float vs = (KV == OMNI_KV_FP8) ? v_scale : 1.0f;
                 const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
                 a.out[oo] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
+            } else if (a.merge_cnt != nullptr) {
+                // write-through stores ("coherent by access", coherent.cuh): the merging workgroup may sit on another XCD
+                const coh_rsrc_t prs = coh_rsrc(a.partial);
+                const uint32_t ro = (uint32_t)((((size_t)row * a.q_heads + qh) * a.nsplit + sp) * PA_REC) * 4;
+                if (d == 0) {
+                    coh_st4(prs, ro, __float_as_uint(M));
+                    coh_st4(prs, ro + 4, __float_as_uint(L));
+                }
+                coh_st4(prs, ro + (2 + d) * 4, __float_as_uint(A));
             } else {
                 float* rec = a.partial + (((size_t)row * a.q_heads + qh) * a.nsplit + sp) * PA_REC;
                 if (d == 0) {
@@ -564,6 +574,44 @@ __device__ __forceinline__ void pa_decode_body(const PAArgs& a, float* lds, cons
                     rec[1] = L;
                 }
                 rec[2 + d] = A;
+            }
+        }
+    }
+    if (!CHAIN && a.nsplit > 1 && a.merge_cnt != nullptr && active) {          // (workgroup-uniform)
+        // ---- round 6: the splits of this (row, virtual kv head) are merged by whichever of their workgroups arrives LAST -- no merge launch
+        // (5 us + a boundary per layer at 1-32 rows).  Records out (every wave drains its own stores), barrier, one device-scope ticket; the
+        // last arriver resets the counter for the next launch and merges the records in SPLIT order (paged_attn_merge_kernel's arithmetic:
+        // the result does not depend on who arrives last), reading them with sc1 loads.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                      // (also: every thread is done with the wave partials in LDS)
+        int* s_last = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            unsigned* cnt = a.merge_cnt + (size_t)row * (a.kv_heads * a.kv_rep) + vh;
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)a.nsplit - 1u;
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_last = last;
+        }
+        __syncthreads();
+        if (*s_last) {
+            const coh_rsrc_t prs = coh_rsrc(a.partial);
+            const float vs = (KV == OMNI_KV_FP8) ? v_scale : 1.0f;
+            for (int it = tid; it < G * 128; it += PA_THREADS) {
+                const int g = it >> 7, d = it & 127;
+                const int qh = vh * G + g;
+                const uint32_t base = (uint32_t)((((size_t)row * a.q_heads + qh) * a.nsplit) * PA_REC) * 4;
+                float M = -INFINITY;
+                for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, coh_ldf(prs, base + (uint32_t)s * (PA_REC * 4)));
+                float L = 0.f, A = 0.f;
+                for (int s = 0; s < a.nsplit; ++s) {
+                    const uint32_t ro = base + (uint32_t)s * (PA_REC * 4);
+                    const float m = coh_ldf(prs, ro);
+                    const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+                    L = fmaf(w, coh_ldf(prs, ro + 4), L);           // (the shared factor FIRST: see the note on packed FMAs above)
+                    A = fmaf(w, coh_ldf(prs, ro + (2 + d) * 4), A);
+                }
+                const size_t oo = a.out_frag ? frag_off(row, qh * 128 + d, a.q_heads * 128) : ((size_t)row * a.q_heads + qh) * 128 + d;
+                a.out[oo] = f2bf(L > 0.f ? (A / L) * vs : 0.f);
             }
         }
     }

@@ -389,14 +389,21 @@ static int pick_nsplit(int rows, int kv_heads, int max_seq_len) {
     return ns < 1 ? 1 : ns;
 }
 
+// workspace = PA_MERGE_CNT arrival counters (zero when handed over; every launch leaves them zero) + the splits' partial records
+#define PA_MERGE_CNT 512
 extern "C" int64_t omni_paged_attn_workspace_bytes(int B, int q_heads, int head_dim, int max_seq_len) {
     (void)head_dim;
     (void)max_seq_len;
-    return (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
+    return (int64_t)PA_MERGE_CNT * 4 + (int64_t)B * q_heads * 16 * PA_REC * sizeof(float);
 }
 
-OMNI_KNOB g_pa_int8_max_g = 2, g_pa_tail_chunks = 1;
+// g_pa_merge_inkernel (round 6): the KV splits merged by their last arriver inside the attention launch -- built, bit-identical
+// (tests/test_gpu_ops.py), and measured against the merge launch in one process (profiles/r06_ab_kv_merge.txt): 1 row (16 splits) +0.087 ms per
+// step, 16 / 32 rows a tie -- the merge launch spreads (row, head) pairs over 128-thread blocks of its own and costs ~3 us behind an 11 us
+// attention; the last arriver walks its records alone.  Off; the debug library keeps the arm.
+OMNI_KNOB g_pa_int8_max_g = 2, g_pa_tail_chunks = 1, g_pa_merge_inkernel = 0;
 #ifdef OMNI_DEBUG_HOOKS
+extern "C" void omni_debug_pa_merge(int inkernel) { g_pa_merge_inkernel = inkernel; }      // 1: KV splits merged by their last arriver (A/B arm)
 extern "C" void omni_debug_int8_max_g(int g) { g_pa_int8_max_g = g; }
 extern "C" void omni_debug_pa_tail(int on) { g_pa_tail_chunks = on; }      // A/B: the tail round as contiguous chunks (PAArgs::tail_chunks)
 #endif
@@ -410,6 +417,13 @@ static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     const int max_g = (KV == OMNI_KV_INT8) ? g_pa_int8_max_g : 4;
     while (G > max_g && G % 2 == 0) { G /= 2; a.kv_rep *= 2; }
     if (rows * a.kv_heads * a.kv_rep >= 512) a.nsplit = 1;      // the virtual heads already fill the chip: no KV split
+    // the workspace opens with the arrival counters of the in-kernel merge (a split launch has fewer than 512 (row, virtual head) pairs)
+    float* ws = a.partial;
+    a.merge_cnt = nullptr;
+    if (ws != nullptr) {
+        a.partial = ws + PA_MERGE_CNT;
+        if (a.nsplit > 1 && g_pa_merge_inkernel && rows * a.kv_heads * a.kv_rep <= PA_MERGE_CNT) a.merge_cnt = reinterpret_cast<unsigned*>(ws);
+    }
     dim3 grid(a.kv_heads * a.kv_rep, rows, a.nsplit), block(PA_THREADS);
     const size_t lds = (size_t)PA_LDS_FLOATS(G) * sizeof(float);
 #define LAUNCH(GG) hipLaunchKernelGGL((paged_attn_decode_kernel<KV, GG, FUSED>), grid, block, lds, st, a)
@@ -421,7 +435,7 @@ static int launch_pa(const PAArgs& a_in, int rows, hipStream_t st) {
     }
 #undef LAUNCH
     OMNI_CHECK_LAUNCH("omni_paged_attn_decode");
-    if (a.nsplit > 1) {
+    if (a.nsplit > 1 && a.merge_cnt == nullptr) {
         hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(rows * a.q_heads), dim3(128), 0, st, (const float*)a.partial,
                            a.out, a.nsplit, KV == OMNI_KV_FP8 ? a.v_scale : 1.0f, a.q_heads, a.out_frag,
                            KV == OMNI_KV_FP8 ? a.scale_dev : nullptr);

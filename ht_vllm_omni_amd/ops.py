@@ -163,7 +163,7 @@ def attn_decode_fused(qkv, qnorm_w, knorm_w, positions, cos_sin, k_cache, v_cach
     ws = None
     if split:
         nbytes = L.load().omni_paged_attn_workspace_bytes(B, q_heads, head_dim, max_seq_len)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=qkv.device)      # (opens with the split merge's arrival counters: zero)
     L.check(L.load().omni_attn_decode_fused(
         L.ptr(qkv), L.ptr(qnorm_w), L.ptr(knorm_w), L.ptr(positions), L.ptr(cos_sin), float(eps), L.ptr(k_cache),
         L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), L.ptr(block_table), block_table.stride(0), L.ptr(seq_lens),
@@ -220,14 +220,15 @@ def qknorm_rope_kvwrite(qkv, qnorm_w, knorm_w, positions, cos_sin, slots, k_cach
 
 
 def paged_attn_decode(q, k_cache, v_cache, block_table, seq_lens, *, q_heads, kv_heads, head_dim, block_size, kv_dtype,
-                      k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None, max_seq_len=4096, split=True):
+                      k_scale=1.0, v_scale=1.0, k_scales=None, v_scales=None, max_seq_len=4096, split=True, workspace=None):
+    """workspace: a caller-owned fp32 buffer of omni_paged_attn_workspace_bytes, zero-filled once (reused from call to call)."""
     _chk_dev(q, k_cache, v_cache, block_table, seq_lens, k_scales, v_scales)
     B = q.shape[0]
     out = torch.empty_like(q)
-    ws = None
-    if split:
+    ws = workspace
+    if split and ws is None:
         nbytes = L.load().omni_paged_attn_workspace_bytes(B, q_heads, head_dim, max_seq_len)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=q.device)
     L.check(L.load().omni_paged_attn_decode(
         L.ptr(q), L.ptr(k_cache), L.ptr(v_cache), L.ptr(k_scales), L.ptr(v_scales), L.ptr(block_table),
         block_table.stride(0), L.ptr(seq_lens), L.ptr(out), L.ptr(ws), B, q_heads, kv_heads, head_dim, block_size,

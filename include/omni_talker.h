@@ -234,7 +234,9 @@ int omni_slot_mapping(const int32_t* block_table, int bt_stride, const int32_t* 
  * gpu_ar_model_runner.py:299-308; metadata built 246-258).
  *   q : bf16 [B, Hq*D]   out : bf16 [B, Hq*D]   block_table : int32 [B, bt_stride]
  *   seq_lens : int32 [B] (context length INCLUDING the current token)
- *   workspace: fp32, >= omni_paged_attn_workspace_bytes(...)                                  */
+ *   workspace: fp32, >= omni_paged_attn_workspace_bytes(...), or NULL = no KV split.  ABI v5: hand it over ZERO-FILLED -- its first 2 KB
+ *   are reserved for arrival counters (the in-launch merge of KV splits, an A/B arm of the debug library; every launch leaves them
+ *   zero), the rest is scratch                                                                                                        */
 int omni_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
                            const float* k_scales, const float* v_scales,
                            const int32_t* block_table, int bt_stride, const int32_t* seq_lens,

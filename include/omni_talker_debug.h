@@ -25,6 +25,7 @@ void omni_debug_chain_skip(int mode);                      /* code-predictor cha
 void omni_debug_bb_min_rows(int rows);                     /* backbone chain: smallest batch the 64-row stage set takes (33 since round 5; 49: round 4's policy, 33-48 rows launch per op) */
 void omni_debug_moe_chain(int on);                         /* sparse-MoE layer: o_proj -> router | shared gate_up -> shared down + routing as one persistent launch (moe_chain.hip) */
 void omni_debug_pa_tail(int on);                           /* decode attention: the last, partial 128-token round as contiguous 32-token chunks per wave (0: interleaved groups) */
+void omni_debug_pa_merge(int inkernel);                    /* 1: KV splits merged by their last arriver inside the attention launch (round-6 A/B arm; default 0 = the merge launch) */
 void omni_debug_bb_deep(int mode);                         /* backbone chain arms: 1-3 deeper rings, 4 two-pass gate_up combine, 5 gate_up weights ahead of the flags, 6 rstd in the epilogue, 7-9 nt weight loads (gate_up / o+down+qkv / all) */
 void omni_debug_bb_ar(int on);                             /* 0: tensor-parallel ranks keep the launch-per-op backbone with all-reduce launches (round 5) */
 void omni_debug_sample_wave(int on);                       /* row sampler: 1 = one wave per row (smp_pick_wave, round 6) where eligible, 0 = always the 4-wave sample_kernel */

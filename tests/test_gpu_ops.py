@@ -375,6 +375,59 @@ def test_paged_attn_decode(ops, kv, hq, hkv, split):
         assert_bf16_close(out[r].view(1, hq, D), ref, ulps=1, max_mismatch=0.05, what=f"attn row {r} len {n}")
 
 
+@pytest.mark.parametrize("kv", ["fp8", "bf16", "int8"])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2)])
+def test_kv_splits_merged_inside_the_attention_launch_equal_the_merge_launch(ops, kv, hq, hkv):
+    """Round 6 A/B arm (debug library; measured a tie at 16 / 32 rows and a loss at 1 row, so the product keeps the merge launch): at 1-32
+    rows the context of a (row, kv head) is split over several workgroups; the LAST of them to arrive merges the splits inside the attention
+    launch (arrival counters at the head of the workspace, write-through records).  Same arithmetic in split order: bit-identical to the
+    merge launch, whoever arrives last; the counters are zero again after every launch, so one workspace serves call after call."""
+    import ctypes as C
+    from ht_vllm_omni_amd import _lib as L
+    D, bs, nb = 128, 16, 160
+    g = torch.Generator().manual_seed(11 + hkv)
+    k_scale, v_scale = (0.5, 2.0) if kv == "fp8" else (1.0, 1.0)
+    pk = _fill_cache(kv, nb, bs, hkv, D, g, k_scale, v_scale)
+    seq_lens = [700, 1000, 257, 33, 1, 513, 2000]
+    B = len(seq_lens)
+    perm = torch.randperm(nb - 1, generator=g) + 1
+    bt = torch.zeros(B, 128, dtype=torch.int32)
+    ptr = 0
+    for r, n in enumerate(seq_lens):
+        need = (n + bs - 1) // bs
+        bt[r, :need] = perm[(ptr + torch.arange(need)) % (nb - 1)]
+        ptr += 7
+    qs = [_rand(g, B, hq * D, scale=1.0).cuda() for _ in range(3)]
+    store = pk.data.view(torch.uint8) if kv == "fp8" else pk.data
+    cache = store.cuda()
+    sc = pk.scales.cuda() if kv == "int8" else None
+    res = {}
+    with L.debug_library() as lib:
+        lib.omni_debug_pa_merge.argtypes = [C.c_int]; lib.omni_debug_pa_merge.restype = None
+        nbytes = lib.omni_paged_attn_workspace_bytes(B, hq, D, 2048)
+        try:
+            for inkernel in (0, 1):
+                lib.omni_debug_pa_merge(inkernel)
+                ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+                outs = []
+                for q in qs:                 # the same workspace three times: the counters must come back to zero
+                    outs.append(ops.paged_attn_decode(q, cache[0], cache[1], bt.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(),
+                                                      q_heads=hq, kv_heads=hkv, head_dim=D, block_size=bs, kv_dtype=L.KV_CODES[kv],
+                                                      k_scale=k_scale, v_scale=v_scale, k_scales=None if sc is None else sc[0],
+                                                      v_scales=None if sc is None else sc[1], max_seq_len=2048, workspace=ws).clone())
+                torch.cuda.synchronize()
+                assert int(ws[:512].view(torch.int32).abs().sum()) == 0, "arrival counters left non-zero"
+                res[inkernel] = outs
+        finally:
+            lib.omni_debug_pa_merge(0)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for r, n in enumerate(seq_lens):         # ... and both are the oracle's attention
+        kk, vv = pk.gather(bt[r].tolist(), n)
+        ref = O.attention_rows(qs[2][r].cpu().view(1, hq, D), kk, vv, torch.tensor([n - 1]), D ** -0.5)
+        assert_bf16_close(res[1][2][r].cpu().view(1, hq, D), ref, ulps=1, max_mismatch=0.05, what=f"attn row {r} len {n}")
+
+
 @pytest.mark.parametrize("kv", ["bf16", "fp8", "int8"])
 @pytest.mark.parametrize("hq,hkv", [(4, 2), (16, 8), (16, 2)])
 @pytest.mark.parametrize("split", [False, True])
