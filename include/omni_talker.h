@@ -54,7 +54,7 @@ extern "C" {
                                  * finished act columns, so any number of tiles per workgroup divides the chip evenly */
 
 const char* omni_last_error(void);
-int omni_abi_version(void);
+int omni_abi_version(void);   /* 5 (round 6: omni_ar_peers.tile_flags, omni_talker_set_chains modes 2 / 3, a zero-filled attention workspace) */
 
 /* ------------------------------------------------------------------ per-op entry points */
 
