@@ -53,7 +53,7 @@ def build_engine(args, rank, world):
                        tp_size=1 if args.parallel == "dp" else world, allow_eos=False,
                        n_sub=args.sub_batches, tp_force=args.tp_force, peer_allreduce=ar, prefill_gemm=args.prefill_gemm)
     args.tp_backbone_chain = False
-    if ar is not None and world > 1:      # the all-reduce inside the backbone's persistent launches: one scratch step both ways on every rank first
+    if ar is not None and world > 1:      # the all-reduce inside the backbone's persistent launches: four scratch steps both ways on every rank first
         from ht_vllm_omni_amd.tp_comm import check_backbone_chain
         args.tp_backbone_chain = check_backbone_chain(eng, log=log)
     return d, w, eng

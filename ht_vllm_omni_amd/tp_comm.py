@@ -192,9 +192,9 @@ def setup_peer_allreduce(hidden: int, rows: int, rank: int, world: int, group=No
     return ar
 
 
-def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1) -> bool:
+def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1, n_steps: int = 4) -> bool:
     """Before a tensor-parallel group trusts the all-reduce INSIDE its backbone's persistent launches (csrc/bb_chain.hip, chain_gemm AR):
-    one scratch decode step both ways on every rank -- all-reduce launches between launch-per-op GEMMs, then the persistent launches -- from
+    `n_steps` scratch decode steps both ways on every rank -- all-reduce launches between launch-per-op GEMMs, then the persistent launches -- from
     the same state; the logits and hidden rows must agree bit for bit on every rank and no peer wait may have timed out.  Any rank's failure
     (agreed on by an all-reduce(MIN)) leaves every rank on the all-reduce launches (``set_chains(3)``); like setup_peer_allreduce's self-check
     against RCCL this runs once at start-up, before any request, so the KV slot the scratch step writes belongs to nobody.  Returns whether
@@ -209,6 +209,13 @@ def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1) -> 
         return False                                # below the backbone chain's row range: launch per op anyway
     names = ("input_ids", "positions", "seq_lens", "last_hidden", "steps", "seen", "text_step")
     keep = {n: getattr(engine, n).clone() for n in names if hasattr(engine, n)}
+    # consecutive steps read the KV slots the earlier ones wrote: every scratch row needs a block of its own (rows sharing block 0 of a fresh
+    # block table would race for its slots and the two runs would differ for that reason alone); too few blocks: one step (it reads no history)
+    bt_keep = engine.block_table[:B, :1].clone()
+    if engine.num_blocks > B and n_steps <= engine.block_size:
+        engine.block_table[:B, 0] = torch.arange(1, B + 1, dtype=engine.block_table.dtype, device=engine.block_table.device)
+    else:
+        n_steps = 1
     g = torch.Generator().manual_seed(4321)        # the same scratch rows on every rank
     hid = torch.randn(B, engine.d.hidden, generator=g).to(torch.bfloat16)
     outs, ran = [], 0
@@ -224,9 +231,12 @@ def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1) -> 
             engine.set_chains(mode)
             torch.cuda.synchronize()
             dist.barrier(group=group)
-            engine.decode_step(B)
+            got = []
+            for _ in range(n_steps):                # consecutive steps: both data buffers, epochs e + 1 .. e + 2 * layers * n_steps
+                engine.decode_step(B)
+                got += [engine.logits[:B].clone(), engine.last_hidden[:B].clone()]
             torch.cuda.synchronize()
-            outs.append((engine.logits[:B].clone(), engine.last_hidden[:B].clone()))
+            outs.append(got)
             ran = engine.chains_ran()
         ok = bool(ran & 2) and ar.error() == 0 and engine.chain_error() == 0 and all(torch.equal(a, b) for a, b in zip(*outs))
     except Exception as e:   # noqa: BLE001
@@ -234,6 +244,7 @@ def check_backbone_chain(engine, group=None, log=print, chain_mode: int = 1) -> 
         ok = False
     for n, v in keep.items():
         getattr(engine, n).copy_(v)
+    engine.block_table[:B, :1] = bt_keep
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     agreed = int(flag.item()) == 1

@@ -243,7 +243,7 @@ class MI355XARWorker:
                                    block_size=cfg.block_size, max_batch=cfg.max_num_seqs, device=str(self.device),
                                    tp_rank=self.rank, tp_size=self.tp_size, peer_allreduce=self.peer_allreduce,
                                    calculate_kv_scales=bool(getattr(cfg, "calculate_kv_scales", False)))
-        # ... and the all-reduce INSIDE the backbone's persistent launches only after one scratch step both ways agreed on every rank
+        # ... and the all-reduce INSIDE the backbone's persistent launches only after four scratch steps both ways agreed on every rank
         self.tp_backbone_chain = False
         if self.peer_allreduce is not None:
             from .tp_comm import check_backbone_chain
