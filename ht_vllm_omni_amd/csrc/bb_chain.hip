@@ -340,7 +340,13 @@ static int bb_launch_ar(const BbArgs& a, bool half, hipStream_t stream) {
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
+        if (AR) (void)hipFuncSetAttribute((const void*)bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, true, AR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
         attr = true;
+    }
+    if (AR && !half && a.lm_head != nullptr) {      // a tensor-parallel rank's last layer: the (replicated) lm_head as the launch's last stage
+        hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, true, AR, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
+        OMNI_CHECK_LAUNCH("bb_chain(all-reduce, head)");
+        return OMNI_OK;
     }
     if (half) hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, true>), dim3(OMNI_CHAIN_WGS / 2), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((bb_chain_kernel<KO, KH, KI, 2, 4, 4, false, true, false, true, 0, false, AR, false>), dim3(OMNI_CHAIN_WGS), dim3(CH_THREADS), BB_LDS_BYTES, stream, a);
@@ -390,7 +396,7 @@ int k_bb_chain(const omni_talker_desc& d, const omni_layer_weights& w, const omn
     }
     const int ko = d.q_heads * 128 / 256, kh = d.hidden / 256, ki = d.inter / 256;
     if (ar != nullptr || half) {
-        OMNI_CHECK_ARG(!small && B > 32 && a.lm_head == nullptr, "bb_chain: the all-reduce / half-grid launches are the 64-row stage set without a head stage");
+        OMNI_CHECK_ARG(!small && B > 32 && (a.lm_head == nullptr || (ar != nullptr && !half)), "bb_chain: the all-reduce / half-grid launches are the 64-row stage set; the half grid has no head stage");
         if (ar != nullptr) {
             OMNI_CHECK_ARG(ar->attn && ar->mlp && ar->attn->epoch == ar->mlp->epoch, "bb_chain: the two all-reduces share one epoch word");
             bb_fill_ar(a.ar_o, *ar->attn);

@@ -732,7 +732,9 @@ static int mtp_phase(omni_talker* t, const omni_step_io* io, void* stream, bool 
     if (!d.cp_e0_table) TRY(k_embed(io->input_ids, 1, d.embed, t->e0, B, d.hidden, d.vocab, stream));
     const omni_chain_tail tl{io->input_ids, d.embed, d.vocab, d.cp_embed, io->text_step, io->inputs_embeds, t->resid, t->part, io->audio_codes, d.hidden,
                              d.layers > 0 ? t->layer[0].wqkv : nullptr, d.layers > 0 ? t->layer[0].ln1 : nullptr, t->qkv, (d.q_heads + 2 * d.kv_heads) * d.head_dim};
-    const bool want_tail = fuse_tail && d.layers > 0 && !t->has_ar && !t->chain_half && k_bb_chain_supported(d, B) && !k_bb_chain_small(d);
+    // (a tensor-parallel rank too: layer 0's qkv is column-parallel -- this rank's shard, no exchange)
+    const bool want_tail = fuse_tail && d.layers > 0 && !t->chain_half && !(t->has_ar && t->bb_ar_off) &&
+                           k_bb_chain_supported(d, B, t->has_ar ? &t->ar_attn : nullptr, false) && !k_bb_chain_small(d);
     TRY(run_code_predictor(t, io->input_ids, t->e0, io->last_hidden, B, io->cp_greedy, io->cp_temperature, io->cp_top_k, io->cp_top_p,
                            io->seed, io->steps, nullptr, stream, io->rows.seed, want_tail ? &tl : nullptr));
     if (t->tail_fused) return OMNI_OK;
@@ -960,7 +962,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
     const omni_bb_ar bar{&t->ar_attn, &t->ar_mlp};
     if (!(t->has_ar && t->bb_ar_off) && k_bb_chain_supported(d, io->B, t->has_ar ? &t->ar_attn : nullptr, t->chain_half) && d.layers > 0) {
         t->ran |= 2;
-        const bool plain = !t->has_ar && !t->chain_half;      // (a tensor-parallel rank / the half grid: the 64-row stage set, head as its own launch)
+        const bool plain = !t->has_ar && !t->chain_half;      // (a tensor-parallel rank / the half grid: the 64-row stage set only)
         // attention launches alternate with one persistent launch per layer: o_proj -> gate_up -> down_proj -> next qkv
         const int H = d.hidden, hq = d.q_heads, hkv = d.kv_heads, D = d.head_dim, B = io->B;
         if (do_rest && !t->tail_fused)      // (tail_fused: layer 0's qkv rows were left by the predictor's all-pass launch, cp_chain.hip tail)
@@ -985,7 +987,7 @@ static int run_backbone(omni_talker* t, const omni_step_io* io, void* stream, in
             {
                 const bool last = l + 1 == d.layers;
                 const omni_bb_head hd{io->logits, io->last_hidden, io->num_live, mask_fill(t)};
-                const bool with_head = last && fuse_head && plain && g_bb_head && k_bb_chain_head_supported(d);
+                const bool with_head = last && fuse_head && !t->chain_half && g_bb_head && k_bb_chain_head_supported(d);      // (the half grid has no head stage)
                 TRY(k_bb_chain(d, w, last ? nullptr : &t->layer[l + 1], t->attn, t->resid, t->part, t->act, t->qkv, B, d.eps,
                                t->chain_flags, reinterpret_cast<int32_t*>(t->chain_flags + 320), stream, plain && k_bb_chain_small(d), with_head ? &hd : nullptr,
                                t->has_ar ? &bar : nullptr, t->chain_half));
