@@ -131,3 +131,17 @@ def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
         torch.ops.mi355x_omni.silu_mul(torch.zeros(2, 8, dtype=torch.bfloat16))
     with pytest.raises(NotImplementedError):
         torch.ops.mi355x_omni.topk_sample(torch.zeros(2, 8), None, None, True, 1.0, 0, 1.0, 1.0, 0, 1, 0, False)
+
+
+def test_tile_flag_block_matches_the_kernels_indexing():
+    """tp_comm lays the per-tile arrival flags out behind the control block; chain_gemm.cuh indexes them [source rank][CH_AR_TILES]: the two
+    sizes must agree (a host that allocated less would let a rank write past a peer's control block)."""
+    import re
+    from ht_vllm_omni_amd import tp_comm
+    src = open(os.path.join(os.path.dirname(HDR), "..", "ht_vllm_omni_amd", "csrc", "chain_gemm.cuh")).read()
+    tiles = int(re.search(r"#define\s+CH_AR_TILES\s+(\d+)", src).group(1))
+    world = int(re.search(r"#define\s+CH_AR_MAX_WORLD\s+(\d+)", src).group(1))
+    assert tp_comm.TILE_BYTES == world * tiles * 4
+    assert tp_comm.CTL_BYTES == tp_comm.TILE_OFF + tp_comm.TILE_BYTES and tp_comm.TILE_OFF >= tp_comm.ERROR_OFF + 4
+    assert tiles >= 256, "the o_proj / down_proj tile grid of the 64-row stage set: up to 128 column tiles x 2 row tiles"
+

@@ -166,7 +166,7 @@ def _tp2_proc(rank, world, port, q, B):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("B", [64, 40])
+@pytest.mark.parametrize("B", [64, 40, 33])
 def test_two_rank_processes_all_reduce_inside_the_backbone_launches(B):
     """BASELINE config #4's split (tensor parallel over 2 ranks: 8 q / 4 kv heads and intermediate 3072 per rank), one PROCESS per rank, both
     on this box's one GPU: hipIpc-mapped partial buffers and tile flags, the backbone's persistent launches on the half grid so that the
